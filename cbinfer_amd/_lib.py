@@ -1,0 +1,101 @@
+"""ctypes binding of libcbinfer_hip.so (the C ABI declared in include/cbinfer_hip.h).
+
+Replaces the reference's cffi ABI-mode dlopen at import time (pycbinfer/conv2d_cg.py:40-50,
+conv2d_fg.py:13-32).  There is no fallback: if the HIP library has not been built, importing the
+package fails, exactly as the reference fails when its CUDA .so files are missing.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libcbinfer_hip.so")
+
+CB_F32 = 0
+CB_F16 = 1
+
+_vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+
+_SIGNATURES = {
+    # name: (restype, [argtypes])
+    "cbinfer_abi_version": (_i, []),
+    "cbinfer_status_string": (ctypes.c_char_p, [_i]),
+    "cbinfer_mask_words_per_row": (_i, [_i]),
+    "cbinfer_mask_words": (_l, [_i, _i]),
+    "cbinfer_weights_kpad": (_i, [_i]),
+    "cbinfer_weights_ckkpad": (_i, [_i]),
+    "cbinfer_change_detection": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "cbinfer_change_detection_bits": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "cbinfer_change_propagation": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "cbinfer_change_indexes_extr": (_i, [_vp, _l, _vp, _vp, _vp, _vp]),
+    "cbinfer_compact_bits": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "cbinfer_gen_x_matrix": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "cbinfer_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "cbinfer_matrix_mult": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "cbinfer_update_output": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
+    "cbinfer_conv_changed": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
+                                  _vp, _l, _i, _vp]),
+    "cbinfer_cbconv2d_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
+                                      _i, _f, _i, _i, _i, _i, _i, _i, _vp]),
+    "cbinfer_max_pool2d": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "cbinfer_change_detection_fg": (_i, [_vp, _vp, _vp, _vp, _l, _f, _i, _vp]),
+    "cbinfer_update_output_fg": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _vp]),
+    "cbinfer_conv2d_fg_cpu": (None, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "cbinfer_amd: %s not found. Build the HIP kernels first (python -c 'import "
+            "__graft_entry__ as g; g.build()' or make -C cbinfer_amd/csrc). There is no CPU or "
+            "PyTorch fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cbinfer_abi_version() != 1:
+        raise ImportError("cbinfer_amd: libcbinfer_hip.so ABI version mismatch")
+    return lib
+
+
+C = _load()
+
+
+class CBinferError(RuntimeError):
+    pass
+
+
+def check(status):
+    """Raise on a non-zero launcher status (the reference launchers return void and never check)."""
+    if status != 0:
+        raise CBinferError("libcbinfer_hip: %s (status %d)" %
+                           (C.cbinfer_status_string(status).decode(), status))
+
+
+def dtype_code(t):
+    import torch
+    if t.dtype == torch.float32:
+        return CB_F32
+    if t.dtype == torch.float16:
+        return CB_F16
+    raise TypeError("cbinfer_amd supports float32 and float16 tensors, got %s" % t.dtype)
+
+
+def stream_ptr(t=None):
+    import torch
+    return torch.cuda.current_stream(t.device if t is not None else None).cuda_stream
+
+
+def ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise CBinferError(
+                "cbinfer_amd runs on HIP devices only: got a CPU tensor. (The reference's pure-torch "
+                "CPU twins are restated in oracle/ for testing, they are not part of the product.)")

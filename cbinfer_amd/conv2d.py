@@ -1,0 +1,358 @@
+"""CBConv2d / CBPoolMax2d: change-based convolution and pooling modules on MI355X.
+
+Same torch.nn.Module surface as the reference (pycbinfer/conv2d.py): constructor arguments, the
+attribute flags set from outside (threshold, withReLU, saveChangeMap, propChangeIndexes,
+gatherComputationStats, finegrained, copyInput, feedbackLoop), the registered state buffers
+(prevInput, prevOutput, outputState), clearMemory()/getStateTensors(), the
+('changeIndexes', output, indexes) tuple protocol between modules, and the returned tensor aliasing
+the layer state.  What differs is underneath: a frame of a layer is ONE call into libcbinfer_hip.so
+that enqueues detection -> compaction -> fused gather/MFMA/scatter on torch's current stream with the
+changed-pixel count kept on the device, so a whole network frame runs without a host round trip and
+can be captured into a hipGraph (torch.cuda.CUDAGraph).
+
+Two execution modes, chosen per module by `syncIndexes` (default False):
+  False: sync-free.  Change lists travel as `ChangeIndexes` (capacity buffer + device count).
+  True : like the reference, block on the count after compaction; change lists are exact IntTensors
+         and the reference-structured op sequence (changeDetection, changeIndexesExtr, genXMatrix,
+         matrixMult, updateOutput) of conv2d_cg.py is what runs.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import C, check, dtype_code, ptr, require_device, stream_ptr
+from .conv2d_cg import (ChangeIndexes, changeDetection, changeIndexesExtr, genXMatrix, matrixMult,
+                        maxPool2d, prepWeights, updateOutput)
+from .conv2d_fg import cbconvFG, cbconvFG_deterministic
+
+
+def _same_shape(t, shape):
+    return t is not None and tuple(t.size()) == tuple(shape)
+
+
+class CBPoolMax2d(nn.Module):
+    """Change-based 2x2/stride-2 max pooling (reference: conv2d.py:24-84)."""
+
+    def __init__(self, m):
+        super(CBPoolMax2d, self).__init__()
+        ks = m.kernel_size if isinstance(m.kernel_size, tuple) else (m.kernel_size,) * 2
+        st = m.stride if isinstance(m.stride, tuple) else (m.stride,) * 2
+        assert ks == (2, 2) and st == (2, 2)
+        self.stride = st
+        self.kernel_size = ks
+        self.ceil_mode = m.ceil_mode
+        self.propChangeIndexes = False
+        self.register_buffer('outputState', torch.zeros(0))
+        self.clearMemory()
+
+    def clearMemory(self):
+        if not hasattr(self, 'outputState') or 'outputState' not in self._buffers:
+            self.register_buffer('outputState', torch.zeros(0))
+        self.outputState = self.outputState.new_zeros(0)
+
+    def getStateTensors(self):
+        state = []
+        if hasattr(self, 'outputState'):
+            state += [self.outputState]
+        return state
+
+    def forward(self, inp):
+        assert type(inp) == tuple and inp[0] == 'changeIndexes'
+        input = inp[1].detach().contiguous()
+        changeIndexes = inp[2]
+        require_device(input)
+        exact = isinstance(changeIndexes, torch.Tensor)
+        if exact:
+            changeIndexes = changeIndexes.detach().contiguous()
+            assert changeIndexes.dim() == 1
+        if not exact or changeIndexes.numel() != 0:
+            nc, h, w = input.size(-3), input.size(-2), input.size(-1)
+            if self.ceil_mode:
+                oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            else:
+                oh, ow = h // 2, w // 2
+            if (not _same_shape(self.outputState, (1, nc, oh, ow)) or
+                    self.outputState.dtype != input.dtype or self.outputState.device != input.device):
+                self.outputState = torch.full((1, nc, oh, ow), float('inf'), dtype=input.dtype,
+                                              device=input.device)
+            maxPool2d(input, self.outputState, changeIndexes, self.kernel_size, self.stride)
+
+        # a private copy: a following CBConv2d with copyInput=False keeps a reference to it
+        output = self.outputState.clone()
+        if self.propChangeIndexes:
+            return 'changeIndexes', output, inp[2]
+        return output
+
+    def __repr__(self):
+        return ('%s (k=%s, s=%s, ceil_mode=%s, propChgIdxs=%s)' %
+                (self.__class__.__name__, self.kernel_size, self.stride, self.ceil_mode,
+                 self.propChangeIndexes))
+
+
+class CBConv2d(nn.Module):
+    """Change-based 2-D convolution (reference: conv2d.py:87-304)."""
+
+    def __init__(self, m, threshold):
+        super(CBConv2d, self).__init__()
+        assert m.groups == 1 and m.transposed == False
+        assert m.output_padding == (0, 0) and m.padding == (m.kernel_size[-2] // 2,
+                                                             m.kernel_size[-1] // 2)
+        assert m.dilation == (1, 1) and m.stride == (1, 1)
+        self.groups = m.groups
+        self.transposed = m.transposed
+        self.output_padding = m.output_padding
+        self.padding = m.padding
+        self.dilation = m.dilation
+        self.stride = m.stride
+        self.kernel_size = m.kernel_size
+        self.in_channels = m.in_channels
+        self.out_channels = m.out_channels
+
+        assert m.weight is not None and m.bias is not None
+        self.weight = m.weight   # shared with the source module, as in the reference
+        self.bias = m.bias
+
+        self.threshold = threshold
+        self.clearMemory()
+
+        self.withReLU = False
+        self.saveChangeMap = False
+        self.propChangeIndexes = False
+        self.gatherComputationStats = False
+        self.finegrained = False
+        self.copyInput = True
+        self.feedbackLoop = False
+        self._setDefaultValues()
+
+    # ---------------------------------------------------------------- state
+    def clearMemory(self):
+        for name in ('prevInput', 'prevOutput'):
+            if not hasattr(self, name):
+                self.register_buffer(name, self.weight.detach().new_zeros(0))
+            elif name not in self._buffers:
+                tmp = getattr(self, name)
+                delattr(self, name)
+                self.register_buffer(name, tmp)
+        self.prevInput = self.weight.detach().new_zeros(0)
+        self.prevOutput = self.weight.detach().new_zeros(0)
+        if hasattr(self, 'compStats'):
+            self.compStats = None
+        # device work buffers (not part of the module state)
+        self._work = None
+
+    def getStateTensors(self):
+        state = []
+        if hasattr(self, 'prevInput'):
+            state += [self.prevInput]
+        if hasattr(self, 'prevOutput'):
+            state += [self.prevOutput]
+        return state
+
+    def _setDefaultValues(self):
+        # back-fill attributes missing in modules pickled by older versions (conv2d.py:292-304)
+        for name, val in (('saveChangeMap', False), ('propChangeIndexes', False),
+                          ('gatherComputationStats', False), ('finegrained', False),
+                          ('copyInput', True), ('feedbackLoop', False), ('syncIndexes', False),
+                          ('deterministicFG', False), ('_work', None), ('_wprep', None)):
+            if name not in self.__dict__:
+                self.__dict__[name] = val
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d['_work'] = None     # transient device buffers are not serialised
+        d['_wprep'] = None
+        return d
+
+    def _prepared_weights(self):
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.dtype, w.device)
+        if self._wprep is None or self._wprep[0] != key:
+            self._wprep = (key, prepWeights(w))
+        return self._wprep[1]
+
+    def _workspace(self, input):
+        H, W = input.size(-2), input.size(-1)
+        key = (H, W, input.device)
+        if self._work is None or self._work['key'] != key:
+            dev = input.device
+            self._work = dict(
+                key=key,
+                bits=torch.zeros(C.cbinfer_mask_words(H, W), dtype=torch.int64, device=dev),
+                idx=torch.empty(H * W, dtype=torch.int32, device=dev),
+                count=torch.zeros(1, dtype=torch.int32, device=dev),
+                map=None)
+        if self.saveChangeMap and self._work['map'] is None:
+            self._work['map'] = torch.zeros(H, W, dtype=torch.int8, device=input.device)
+        return self._work
+
+    # ---------------------------------------------------------------- fine-grained
+    def forward_fg(self, inp):
+        input = inp.detach()
+        if self.prevInput.size() != input.size():
+            # first frame / size change: dense convolution (conv2d.py:163-167)
+            self.prevOutput = F.conv2d(input, self.weight.detach(),
+                                       padding=tuple(s // 2 for s in self.weight.size()[2:]),
+                                       bias=self.bias.detach())
+        else:
+            po = self.prevOutput.clone()
+            if self.deterministicFG and input.is_cuda:
+                self.prevOutput = cbconvFG_deterministic(input.contiguous(), self.prevInput, po,
+                                                         self.weight.detach(), self.threshold,
+                                                         weightsPrepared=self._prepared_weights())
+            else:
+                self.prevOutput = cbconvFG(input.contiguous(), self.prevInput, po,
+                                           self.weight.detach(), self.threshold)
+        outp = self.prevOutput
+        if self.withReLU:
+            outp = F.relu(outp)
+        self.prevInput = input
+        return outp
+
+    # ---------------------------------------------------------------- coarse-grained
+    def forward_normal(self, inp):
+        # input parsing and checks (conv2d.py:180-190)
+        changeIndexes = None
+        if type(inp) == tuple:
+            assert inp[0] == 'changeIndexes'
+            input = inp[1].detach().contiguous()
+            changeIndexes = inp[2]
+            if isinstance(changeIndexes, torch.Tensor):
+                changeIndexes = changeIndexes.detach().contiguous()
+            assert changeIndexes.dim() == 1
+        else:
+            input = inp.detach().contiguous()
+        assert input.size(-3) == self.in_channels
+        assert input.dim() == 4 and input.size(0) == 1
+        require_device(input)
+        assert input.dtype == self.weight.dtype, "input and weights must have the same dtype"
+
+        # (re)allocate the state, +inf => the first frame is 100 % change (conv2d.py:192-199)
+        if (self.prevInput.size() != input.size() or self.prevInput.dtype != input.dtype or
+                self.prevInput.device != input.device):
+            self.prevInput = torch.full_like(input, float('inf'))
+        outpSize = list(input.size())
+        outpSize[-3] = self.out_channels
+        if (not _same_shape(self.prevOutput, outpSize) or self.prevOutput.dtype != input.dtype or
+                self.prevOutput.device != input.device):
+            self.prevOutput = torch.full(outpSize, float('inf'), dtype=input.dtype,
+                                         device=input.device)
+
+        if self.gatherComputationStats:
+            self._gatherStats(input)
+
+        if self.syncIndexes:
+            changeIndexes = self._forward_ops(input, changeIndexes)
+        else:
+            changeIndexes = self._forward_fused(input, changeIndexes)
+
+        if self.propChangeIndexes:
+            return 'changeIndexes', self.prevOutput, changeIndexes
+        return self.prevOutput
+
+    def _forward_fused(self, input, changeIndexes):
+        """One library call per frame: no host sync (see cbinfer_cbconv2d_forward)."""
+        work = self._workspace(input)
+        K, Cin, kH, kW = self.weight.size()
+        H, W = input.size(-2), input.size(-1)
+        have = changeIndexes is not None
+        if have and self.feedbackLoop:
+            # the reference skips detection here and so never refreshes prevInput (conv2d.py:220-238):
+            # its gather would read the +inf initial state.  Refuse instead of computing garbage.
+            raise _lib.CBinferError("CBConv2d: feedbackLoop=True cannot be combined with propagated "
+                                    "change indexes (the layer state would never be updated)")
+        if have:
+            if isinstance(changeIndexes, ChangeIndexes):
+                idx, count, cap = changeIndexes.buffer, changeIndexes.count, changeIndexes.buffer.numel()
+            else:
+                idx, cap = changeIndexes, changeIndexes.numel()
+                count = None
+            cap = min(cap, H * W)
+            result = changeIndexes
+        else:
+            idx, count, cap = work['idx'], work['count'], H * W
+            result = ChangeIndexes(idx, count)
+        if have and count is None:
+            # exact host-side list: write its length where the kernels look for it
+            count = torch.full((1,), cap, dtype=torch.int32, device=input.device)
+        prev = self.prevInput
+        if not prev.is_contiguous():
+            prev = self.prevInput = prev.contiguous()
+        mapOut = work['map'] if (self.saveChangeMap and not have) else None
+        if cap > 0:
+            check(C.cbinfer_cbconv2d_forward(
+                ptr(input), ptr(prev), ptr(self.prevOutput), None if have else ptr(work['bits']),
+                ptr(idx), ptr(count), ptr(mapOut), ptr(self._prepared_weights()),
+                ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold),
+                int(bool(self.feedbackLoop)), int(bool(self.copyInput)), int(bool(self.withReLU)),
+                int(have), cap, dtype_code(input), stream_ptr(input)))
+        if mapOut is not None:
+            self.changeMap = mapOut
+        if not self.feedbackLoop and not self.copyInput:
+            self.prevInput = input      # alias, conv2d.py:237-238
+        return result
+
+    def _forward_ops(self, input, changeIndexes):
+        """The reference's op sequence (conv2d.py:220-251), one kernel launch per op, blocking on the
+        change count like torch.nonzero does."""
+        if isinstance(changeIndexes, ChangeIndexes):
+            changeIndexes = changeIndexes.tensor()
+        if changeIndexes is None:
+            changeMap = changeDetection(input, self.prevInput, self.kernel_size, self.threshold,
+                                        updateInputState=self.feedbackLoop)
+            if self.saveChangeMap:
+                self.changeMap = changeMap
+            changeIndexes = changeIndexesExtr(changeMap)
+        if not self.feedbackLoop:
+            if self.copyInput:
+                self.prevInput.copy_(input)
+            else:
+                self.prevInput = input
+        if changeIndexes.numel() != 0:
+            Xmatrix = genXMatrix(self.prevInput, changeIndexes, self.kernel_size)
+            Ymatrix = matrixMult(Xmatrix, self.weight.detach(), self.bias.detach(), transposeOut=True,
+                                 weightsPrepared=self._prepared_weights())
+            updateOutput(Ymatrix, changeIndexes, self.prevOutput, withReLU=self.withReLU)
+        return changeIndexes
+
+    def _gatherStats(self, input):
+        """Operation counts behind the 'effective GOp/s' metric (conv2d.py:201-218)."""
+        changeTensor = (input - self.prevInput).abs().gt(self.threshold)
+        nC = changeTensor.size(-3)
+        kH, kW = self.weight.size(2), self.weight.size(3)
+        proped = F.conv2d(changeTensor.float(),
+                          torch.ones(nC, 1, kH, kW, device=input.device), groups=nC).gt(0)
+        opsPerValue = self.weight.size(0) * kH * kW * 2
+        self.compStats = dict(
+            numInputChangesPerFeatureMap=changeTensor.sum() * opsPerValue,
+            numInputChanges=changeTensor.sum(-3).gt(0).sum() * nC * opsPerValue,
+            numInputPropedChangesPerFeatureMap=proped.sum() * opsPerValue,
+            numInputPropedChanges=proped.sum(-3).gt(0).sum() * nC * opsPerValue,
+            totalInputValues=changeTensor.size(-1) * changeTensor.size(-2) * nC * opsPerValue)
+
+    def forward(self, inp):
+        self._setDefaultValues()
+        if self.finegrained:
+            assert self.feedbackLoop == False
+            return self.forward_fg(inp)
+        return self.forward_normal(inp)
+
+    def __repr__(self):
+        self._setDefaultValues()
+        s = '%s (th=%s, %s->%s, k=%s, s=%s, copyInput=%s' % (
+            self.__class__.__name__, self.threshold, self.in_channels, self.out_channels,
+            self.kernel_size, self.stride, self.copyInput)
+        if self.padding != (0,) * len(self.padding):
+            s += ', pad=%s' % (self.padding,)
+        if self.dilation != (1,) * len(self.dilation):
+            s += ', dilation=%s' % (self.dilation,)
+        if self.output_padding != (0,) * len(self.output_padding):
+            s += ', outpad=%s' % (self.output_padding,)
+        if self.groups != 1:
+            s += ', grp=%s' % (self.groups,)
+        if self.bias is None:
+            s += ', bias=False'
+        if self.withReLU:
+            s += ', withReLU=%s' % (self.withReLU,)
+        s += ', propChgIdxs=%s)' % (self.propChangeIndexes,)
+        return s

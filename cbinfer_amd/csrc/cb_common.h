@@ -1,0 +1,52 @@
+// Shared definitions for the gfx950 kernels of libcbinfer_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cbinfer_hip.h"
+
+#define CB_WAVE 64
+
+typedef _Float16 cb_half;
+
+// MFMA tile geometry of the contraction kernels (cb_conv.hip).  The prepared weight matrix is
+// padded to these so the k-loop and the m-tiles need no bounds checks.
+#define CB_MFMA_M 32      // out-channel rows per MFMA tile
+#define CB_BK 16          // k-depth staged in LDS per step (fp32); fp16 uses 32
+#define CB_BK_H 32
+
+static inline int cb_div_up(long a, long b) { return (int)((a + b - 1) / b); }
+
+static inline int cb_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CB_OK : (int)e;
+}
+
+#define CB_REQUIRE(cond)                 \
+    do {                                 \
+        if (!(cond)) return CB_ERR_BADARG; \
+    } while (0)
+
+template <typename T>
+struct cb_traits;
+template <>
+struct cb_traits<float> {
+    static constexpr int dtype = CB_F32;
+};
+template <>
+struct cb_traits<cb_half> {
+    static constexpr int dtype = CB_F16;
+};
+
+// change predicate, one channel value
+//   fp32: fabs(state - in) > th                                  (cbconv2d_cg_backend.cu:22,56)
+//   fp16: d = __hsub(state, in); d > th16 | d < -th16            (cbconv2d_cg_half_backend.cu:27-28)
+__device__ __forceinline__ bool cb_changed(float s, float x, float th) {
+    return fabsf(s - x) > th;
+}
+__device__ __forceinline__ bool cb_changed(cb_half s, cb_half x, cb_half th) {
+    cb_half d = s - x;  // v_sub_f16: one rounding, like __hsub
+    return (d > th) | (d < -th);
+}
+__device__ __forceinline__ float cb_threshold(float th, float*) { return th; }
+__device__ __forceinline__ cb_half cb_threshold(float th, cb_half*) { return (cb_half)th; }  // RNE

@@ -1,0 +1,570 @@
+// Gather -> im2col, the dense contraction on MFMA, scatter-back, and the fused
+// gather->MFMA->bias/ReLU->scatter kernel for gfx950.  Reference behaviour restated from
+// cbconv2d_cg_backend.cu:138-197 and conv2d_cg.py:342-349; entry-point contracts in
+// include/cbinfer_hip.h.
+//
+// Contraction layout: D[m][n] = sum_k A[m][k] * B[k][n] with m = output channel, n = position in the
+// changed-pixel list, k = (c*kH+ky)*kW+kx.  The pixel index sits on the MFMA *lane* (C/D column), the
+// output channel in the accumulator registers, so the scatter epilogue writes 32 (mostly consecutive)
+// pixels of one output-channel plane per store instruction.
+//   fp32: v_mfma_f32_32x32x2_f32 (exact f32 fma chain, k-ordered) -- operands A[k][m], B[k][n] in LDS
+//   fp16: v_mfma_f32_32x32x16_f16, f32 accumulation             -- operands A[m][k], B[n][k] in LDS
+#include "cb_common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+
+// n / d by multiply-high with magic = ceil(2^32/d) (exact while n*d < 2^32); magic 0 encodes d == 1
+__device__ __forceinline__ unsigned cb_fastdiv(unsigned n, unsigned magic) {
+    return magic ? __umulhi(n, magic) : n;
+}
+__device__ __forceinline__ float cb_relu(float v) { return v <= 0.f ? 0.f : v; }
+__device__ __forceinline__ cb_half cb_relu(cb_half v) { return v <= (cb_half)0 ? (cb_half)0 : v; }
+
+// ---------------------------------------------------------------------------------------------
+// weight preparation: pad to the MFMA tile grid (zeros), fp32 additionally transposed to k-major
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cb_prep_w_f32_kernel(const float* __restrict__ w,
+                                                           float* __restrict__ wt, int K, int Ckk,
+                                                           int KP, int CkkP) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)KP * CkkP) return;
+    const int m = (int)(e % KP), k = (int)(e / KP);
+    wt[e] = (m < K && k < Ckk) ? w[(long)m * Ckk + k] : 0.f;
+}
+__global__ __launch_bounds__(256) void cb_prep_w_f16_kernel(const cb_half* __restrict__ w,
+                                                           cb_half* __restrict__ wp, int K, int Ckk,
+                                                           int KP, int CkkP) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)KP * CkkP) return;
+    const int k = (int)(e % CkkP), m = (int)(e / CkkP);
+    wp[e] = (m < K && k < Ckk) ? w[(long)m * Ckk + k] : (cb_half)0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a5 genXMatrix (materialising form, API parity): one thread per X element, writes coalesced
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cb_genx_kernel(T* __restrict__ X, const T* __restrict__ in,
+                                                     const int32_t* __restrict__ list, int kW, int kH,
+                                                     int C, int W, int H, int nHost,
+                                                     const int32_t* __restrict__ countDev) {
+    const int N = countDev ? min(*countDev, nHost) : nHost;
+    const int Ckk = C * kH * kW;
+    const long total = (long)N * Ckk;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(e / Ckk), j = (int)(e % Ckk);
+        const int c = j / (kH * kW), r = j % (kH * kW);
+        const int ky = r / kW, kx = r % kW;
+        const int pos = list[n];
+        const int ix = pos % W + kx - (kW - 1) / 2;
+        const int iy = pos / W + ky - (kH - 1) / 2;
+        const bool inside = ix >= 0 && ix < W && iy >= 0 && iy < H;
+        X[e] = inside ? in[((long)c * H + iy) * W + ix] : (T)0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a8 updateOutput (API parity): one thread per Yt element
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cb_scatter_kernel(const T* __restrict__ Yt, T* out,
+                                                        const int32_t* __restrict__ list, int HW,
+                                                        int nHost, const int32_t* __restrict__ countDev,
+                                                        int K, int relu) {
+    // Yt is [K, nHost] (row length = the HOST count the matrix was allocated with)
+    const int N = countDev ? min(*countDev, nHost) : nHost;
+    const long total = (long)K * N;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(e / N), n = (int)(e % N);
+        T v = Yt[(long)k * nHost + n];
+        if (relu) v = cb_relu(v);
+        out[(long)k * HW + list[n]] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the MFMA contraction
+// ---------------------------------------------------------------------------------------------
+struct ConvParams {
+    const void* A;     // prepared weights
+    const void* B;     // MODE 0: X [N, Ckk];  MODE 1: layer state [C,H,W]
+    const void* bias;  // [K] or null
+    void* out;         // EPI 0: Y [N,K]; 1: Yt [K,N]; 2/3: output planes [K,H,W]
+    const int32_t* list;
+    const int32_t* countDev;
+    int nHost;
+    int K, KP, Ckk, CkkP;
+    int C, H, W, kH, kW;
+    unsigned magicKHW, magicKW;  // ceil(2^32/d) for d = kH*kW and d = kW
+    int relu;
+    unsigned long long* clearBits;  // optional: change bit mask to zero for the next frame
+    long clearWords;
+};
+
+// The fused kernel is the last consumer of the frame's change mask, so it re-zeroes it (before any
+// early exit): the next frame's detection can atomicOr into a clean mask without a memset node.
+__device__ __forceinline__ void cb_clear_mask(const ConvParams& p) {
+    if (p.clearBits && blockIdx.y == 0)
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.clearWords;
+             i += (long)gridDim.x * blockDim.x)
+            p.clearBits[i] = 0ull;
+}
+
+#define CB_MODE_MATRIX 0
+#define CB_MODE_GATHER 1
+#define CB_EPI_Y 0
+#define CB_EPI_YT 1
+#define CB_EPI_SCATTER 2
+#define CB_EPI_SCATTER_ACC 3
+
+// fp32: WM waves along m (BM = 32*WM), 4/WM waves along n (BN = 32*4/WM), BK = 16 per LDS stage.
+// Global loads for stage s+1 are issued into registers before the MFMAs of stage s (one barrier pair
+// per stage); the gather computes its (c,ky,kx) decode with multiply-high by precomputed reciprocals.
+template <int WM, int MODE, int EPI>
+__global__ __launch_bounds__(256) void cb_mfma_f32_kernel(ConvParams p) {
+    constexpr int BM = 32 * WM;
+    constexpr int WN = 4 / WM;
+    constexpr int BN = 32 * WN;
+    constexpr int BK = CB_BK;
+    constexpr int LDB = BN + 2;
+    constexpr int A_F4 = BK * BM / 4;           // float4s per A stage
+    constexpr int A_PER_T = (A_F4 + 255) / 256;  // 1 (BM<=64) or 2 (BM=128)
+    constexpr int B_PER_T = BK * BN / 256;       // 8 / 4 / 2
+
+    if (MODE == CB_MODE_GATHER) cb_clear_mask(p);
+    const int N = p.countDev ? min(*p.countDev, p.nHost) : p.nHost;
+    const int n0 = blockIdx.x * BN;
+    if (n0 >= N) return;
+    const int m0 = blockIdx.y * BM;
+
+    __shared__ __attribute__((aligned(16))) float As[BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const float* __restrict__ Ag = (const float*)p.A;
+    const float* __restrict__ Bg = (const float*)p.B;
+    const int HW = p.H * p.W;
+
+    // per-thread B-load coordinates
+    int bj, br;             // column (pixel slot) and first k-row this thread loads
+    int py = 0, px = 0;     // gather: pixel coordinates
+    bool pvalid = false;
+    if (MODE == CB_MODE_GATHER) {
+        bj = t % BN;
+        br = t / BN;  // rows br + i*(256/BN)
+        const int n = n0 + bj;
+        pvalid = n < N;
+        if (pvalid) {
+            const int pos = p.list[n];
+            py = pos / p.W;
+            px = pos - py * p.W;
+        }
+    } else {
+        bj = t / BK;  // pixel slots bj + i*(256/BK)
+        br = t % BK;  // k within the stage
+    }
+    const int ph = (p.kH - 1) / 2, pw = (p.kW - 1) / 2;
+    const int KHW = p.kH * p.kW;
+
+    float4 areg[A_PER_T];
+    float breg[B_PER_T];
+
+    auto load_stage = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) {
+            const int f = t + i * 256;
+            if (A_F4 >= 256 || f < A_F4) {
+                const int row = f / (BM / 4), c4 = f % (BM / 4);
+                areg[i] = *(const float4*)(Ag + (long)(k0 + row) * p.KP + m0 + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_T; ++i) {
+            float v = 0.f;
+            if (MODE == CB_MODE_GATHER) {
+                const unsigned kg = (unsigned)(k0 + br + i * (256 / BN));
+                const unsigned c = cb_fastdiv(kg, p.magicKHW);
+                const unsigned r = kg - c * KHW;
+                const unsigned ky = cb_fastdiv(r, p.magicKW);
+                const unsigned kx = r - ky * p.kW;
+                const int iy = py + (int)ky - ph, ix = px + (int)kx - pw;
+                const bool ok = pvalid && (int)kg < p.Ckk && (unsigned)iy < (unsigned)p.H &&
+                                (unsigned)ix < (unsigned)p.W;
+                if (ok) v = Bg[(long)c * HW + iy * p.W + ix];
+            } else {
+                const int n = n0 + bj + i * (256 / BK);
+                const int kg = k0 + br;
+                if (n < N && kg < p.Ckk) v = Bg[(long)n * p.Ckk + kg];
+            }
+            breg[i] = v;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) {
+            const int f = t + i * 256;
+            if (A_F4 >= 256 || f < A_F4) *(float4*)(As + f * 4) = areg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_T; ++i) {
+            if (MODE == CB_MODE_GATHER)
+                Bs[(br + i * (256 / BN)) * LDB + bj] = breg[i];
+            else
+                Bs[br * LDB + bj + i * (256 / BK)] = breg[i];
+        }
+    };
+
+    floatx16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    load_stage(0);
+    for (int k0 = 0; k0 < p.CkkP; k0 += BK) {
+        store_stage();
+        __syncthreads();
+        if (k0 + BK < p.CkkP) load_stage(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = As[(kk + h) * BM + wm * 32 + l31];
+            const float b = Bs[(kk + h) * LDB + wn * 32 + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int n = n0 + wn * 32 + l31;
+    if (n >= N) return;
+    float* __restrict__ out = (float*)p.out;
+    const float* __restrict__ bias = (const float*)p.bias;
+    int pix = 0;
+    if (EPI >= CB_EPI_SCATTER) pix = p.list[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= p.K) continue;
+        float v = acc[r];
+        if (EPI != CB_EPI_SCATTER_ACC) {
+            if (bias) v += bias[m];
+            if (p.relu) v = cb_relu(v);
+        }
+        if (EPI == CB_EPI_Y)
+            out[(long)n * p.K + m] = v;
+        else if (EPI == CB_EPI_YT)
+            out[(long)m * p.nHost + n] = v;
+        else if (EPI == CB_EPI_SCATTER)
+            out[(long)m * HW + pix] = v;
+        else
+            out[(long)m * HW + pix] += v;
+    }
+}
+
+// fp16: same decomposition; LDS operands are k-contiguous rows (A[m][k], B[n][k]) padded to an
+// 80-byte stride so the 16-byte fragment reads of a 16-lane group cover all 64 banks once.
+template <int WM, int MODE, int EPI>
+__global__ __launch_bounds__(256) void cb_mfma_f16_kernel(ConvParams p) {
+    constexpr int BM = 32 * WM;
+    constexpr int WN = 4 / WM;
+    constexpr int BN = 32 * WN;
+    constexpr int BK = CB_BK_H;   // 32 halfs = 64 B per row per stage
+    constexpr int LDH = 40;       // row stride in halfs (80 B)
+    constexpr int A_V = BM * 4;   // 16-byte vectors per A stage
+    constexpr int A_PER_T = (A_V + 255) / 256;
+    constexpr int B_PER_T = BK * BN / 256;
+
+    if (MODE == CB_MODE_GATHER) cb_clear_mask(p);
+    const int N = p.countDev ? min(*p.countDev, p.nHost) : p.nHost;
+    const int n0 = blockIdx.x * BN;
+    if (n0 >= N) return;
+    const int m0 = blockIdx.y * BM;
+
+    __shared__ __attribute__((aligned(16))) cb_half As[BM * LDH];
+    __shared__ __attribute__((aligned(16))) cb_half Bs[BN * LDH];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const cb_half* __restrict__ Ag = (const cb_half*)p.A;
+    const cb_half* __restrict__ Bg = (const cb_half*)p.B;
+    const int HW = p.H * p.W;
+
+    int bj, br;
+    int py = 0, px = 0;
+    bool pvalid = false;
+    if (MODE == CB_MODE_GATHER) {
+        bj = t % BN;
+        br = t / BN;
+        const int n = n0 + bj;
+        pvalid = n < N;
+        if (pvalid) {
+            const int pos = p.list[n];
+            py = pos / p.W;
+            px = pos - py * p.W;
+        }
+    } else {
+        bj = t / BK;
+        br = t % BK;
+    }
+    const int ph = (p.kH - 1) / 2, pw = (p.kW - 1) / 2;
+    const int KHW = p.kH * p.kW;
+
+    uint4 areg[A_PER_T];
+    cb_half breg[B_PER_T];
+
+    auto load_stage = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) {
+            const int f = t + i * 256;
+            if (A_V >= 256 || f < A_V) {
+                const int row = f / 4, q = f % 4;
+                areg[i] = *(const uint4*)(Ag + (long)(m0 + row) * p.CkkP + k0 + q * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_T; ++i) {
+            cb_half v = (cb_half)0;
+            if (MODE == CB_MODE_GATHER) {
+                const unsigned kg = (unsigned)(k0 + br + i * (256 / BN));
+                const unsigned c = cb_fastdiv(kg, p.magicKHW);
+                const unsigned r = kg - c * KHW;
+                const unsigned ky = cb_fastdiv(r, p.magicKW);
+                const unsigned kx = r - ky * p.kW;
+                const int iy = py + (int)ky - ph, ix = px + (int)kx - pw;
+                const bool ok = pvalid && (int)kg < p.Ckk && (unsigned)iy < (unsigned)p.H &&
+                                (unsigned)ix < (unsigned)p.W;
+                if (ok) v = Bg[(long)c * HW + iy * p.W + ix];
+            } else {
+                const int n = n0 + bj + i * (256 / BK);
+                const int kg = k0 + br;
+                if (n < N && kg < p.Ckk) v = Bg[(long)n * p.Ckk + kg];
+            }
+            breg[i] = v;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) {
+            const int f = t + i * 256;
+            if (A_V >= 256 || f < A_V) {
+                const int row = f / 4, q = f % 4;
+                *(uint4*)(As + row * LDH + q * 8) = areg[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_T; ++i) {
+            if (MODE == CB_MODE_GATHER)
+                Bs[bj * LDH + br + i * (256 / BN)] = breg[i];
+            else
+                Bs[(bj + i * (256 / BK)) * LDH + br] = breg[i];
+        }
+    };
+
+    floatx16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    load_stage(0);
+    for (int k0 = 0; k0 < p.CkkP; k0 += BK) {
+        store_stage();
+        __syncthreads();
+        if (k0 + BK < p.CkkP) load_stage(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            // lane holds A[row l31][k = kk + 8h + 0..7] and B[k = kk + 8h + 0..7][col l31]
+            const halfx8 a = *(const halfx8*)(As + (wm * 32 + l31) * LDH + kk + 8 * h);
+            const halfx8 b = *(const halfx8*)(Bs + (wn * 32 + l31) * LDH + kk + 8 * h);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const int n = n0 + wn * 32 + l31;
+    if (n >= N) return;
+    cb_half* __restrict__ out = (cb_half*)p.out;
+    const cb_half* __restrict__ bias = (const cb_half*)p.bias;
+    int pix = 0;
+    if (EPI >= CB_EPI_SCATTER) pix = p.list[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= p.K) continue;
+        float v = acc[r];
+        if (EPI != CB_EPI_SCATTER_ACC) {
+            if (bias) v += (float)bias[m];
+            if (p.relu) v = cb_relu(v);
+        }
+        if (EPI == CB_EPI_Y)
+            out[(long)n * p.K + m] = (cb_half)v;
+        else if (EPI == CB_EPI_YT)
+            out[(long)m * p.nHost + n] = (cb_half)v;
+        else if (EPI == CB_EPI_SCATTER)
+            out[(long)m * HW + pix] = (cb_half)v;
+        else
+            out[(long)m * HW + pix] = (cb_half)((float)out[(long)m * HW + pix] + v);
+    }
+}
+
+unsigned magic_u32(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
+
+template <int MODE, int EPI>
+int launch_mfma(const ConvParams& p, int dtype, hipStream_t s) {
+    // tile choice: KP == 32 -> one m-tile, 128 pixels per workgroup; otherwise 64 x 64
+    const bool narrow = p.KP <= 32;
+    const int BM = narrow ? 32 : 64, BN = narrow ? 128 : 64;
+    dim3 grid(cb_div_up(p.nHost, BN), p.KP / BM), block(256);
+    if (grid.x == 0) return CB_OK;
+    if (dtype == CB_F32) {
+        if (narrow)
+            hipLaunchKernelGGL((cb_mfma_f32_kernel<1, MODE, EPI>), grid, block, 0, s, p);
+        else
+            hipLaunchKernelGGL((cb_mfma_f32_kernel<2, MODE, EPI>), grid, block, 0, s, p);
+    } else {
+        if (narrow)
+            hipLaunchKernelGGL((cb_mfma_f16_kernel<1, MODE, EPI>), grid, block, 0, s, p);
+        else
+            hipLaunchKernelGGL((cb_mfma_f16_kernel<2, MODE, EPI>), grid, block, 0, s, p);
+    }
+    return cb_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int cbinfer_weights_kpad(int K) { return (K + CB_MFMA_M - 1) / CB_MFMA_M * CB_MFMA_M; }
+int cbinfer_weights_ckkpad(int Ckk) { return (Ckk + CB_BK_H - 1) / CB_BK_H * CB_BK_H; }
+
+int cbinfer_prep_weights(const void* weight, void* weightsPrepared, int K, int Ckk, int dtype,
+                         cbStream_t stream) {
+    CB_REQUIRE(weight && weightsPrepared && K > 0 && Ckk > 0);
+    const int KP = cbinfer_weights_kpad(K), CkkP = cbinfer_weights_ckkpad(Ckk);
+    const long total = (long)KP * CkkP;
+    dim3 grid(cb_div_up(total, 256)), block(256);
+    if (dtype == CB_F32)
+        hipLaunchKernelGGL(cb_prep_w_f32_kernel, grid, block, 0, (hipStream_t)stream,
+                           (const float*)weight, (float*)weightsPrepared, K, Ckk, KP, CkkP);
+    else if (dtype == CB_F16)
+        hipLaunchKernelGGL(cb_prep_w_f16_kernel, grid, block, 0, (hipStream_t)stream,
+                           (const cb_half*)weight, (cb_half*)weightsPrepared, K, Ckk, KP, CkkP);
+    else
+        return CB_ERR_BADARG;
+    return cb_launch_status();
+}
+
+int cbinfer_gen_x_matrix(void* columns, const void* input, const int32_t* changeList, int kW, int kH,
+                         int C, int W, int H, int numChanges, const int32_t* countDev, int dtype,
+                         cbStream_t stream) {
+    CB_REQUIRE(columns && input && changeList && kW > 0 && kH > 0 && C > 0 && W > 0 && H > 0 &&
+               numChanges >= 0);
+    if (numChanges == 0) return CB_OK;
+    const long total = (long)numChanges * C * kH * kW;
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == CB_F32)
+        hipLaunchKernelGGL((cb_genx_kernel<float>), grid, block, 0, (hipStream_t)stream,
+                           (float*)columns, (const float*)input, changeList, kW, kH, C, W, H,
+                           numChanges, countDev);
+    else if (dtype == CB_F16)
+        hipLaunchKernelGGL((cb_genx_kernel<cb_half>), grid, block, 0, (hipStream_t)stream,
+                           (cb_half*)columns, (const cb_half*)input, changeList, kW, kH, C, W, H,
+                           numChanges, countDev);
+    else
+        return CB_ERR_BADARG;
+    return cb_launch_status();
+}
+
+int cbinfer_matrix_mult(const void* X, const void* weightsPrepared, const void* bias, void* Y, int N,
+                        const int32_t* countDev, int Ckk, int K, int transposeOut, int dtype,
+                        cbStream_t stream) {
+    CB_REQUIRE(X && weightsPrepared && Y && N >= 0 && Ckk > 0 && K > 0);
+    CB_REQUIRE(dtype == CB_F32 || dtype == CB_F16);
+    if (N == 0) return CB_OK;
+    ConvParams p = {};
+    p.A = weightsPrepared;
+    p.B = X;
+    p.bias = bias;
+    p.out = Y;
+    p.countDev = countDev;
+    p.nHost = N;
+    p.K = K;
+    p.KP = cbinfer_weights_kpad(K);
+    p.Ckk = Ckk;
+    p.CkkP = cbinfer_weights_ckkpad(Ckk);
+    p.H = p.W = p.kH = p.kW = 1;
+    if (transposeOut) return launch_mfma<CB_MODE_MATRIX, CB_EPI_YT>(p, dtype, (hipStream_t)stream);
+    return launch_mfma<CB_MODE_MATRIX, CB_EPI_Y>(p, dtype, (hipStream_t)stream);
+}
+
+int cbinfer_update_output(const void* Yt, void* output, const int32_t* changeList,
+                          int numOutputPixel, int numChanges, const int32_t* countDev,
+                          int nOutputPlane, int relu, int dtype, cbStream_t stream) {
+    CB_REQUIRE(Yt && output && changeList && numOutputPixel > 0 && numChanges >= 0 &&
+               nOutputPlane > 0);
+    if (numChanges == 0) return CB_OK;
+    const long total = (long)numChanges * nOutputPlane;
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    dim3 grid((unsigned)blocks), block(256);
+    if (dtype == CB_F32)
+        hipLaunchKernelGGL((cb_scatter_kernel<float>), grid, block, 0, (hipStream_t)stream,
+                           (const float*)Yt, (float*)output, changeList, numOutputPixel, numChanges,
+                           countDev, nOutputPlane, relu);
+    else if (dtype == CB_F16)
+        hipLaunchKernelGGL((cb_scatter_kernel<cb_half>), grid, block, 0, (hipStream_t)stream,
+                           (const cb_half*)Yt, (cb_half*)output, changeList, numOutputPixel,
+                           numChanges, countDev, nOutputPlane, relu);
+    else
+        return CB_ERR_BADARG;
+    return cb_launch_status();
+}
+
+int cbinfer_conv_changed(const void* input, const int32_t* changeList, int numChanges,
+                         const int32_t* countDev, const void* weightsPrepared, const void* bias,
+                         void* output, int C, int H, int W, int K, int kH, int kW, int relu,
+                         int accumulate, uint64_t* clearBits, long clearWords, int dtype,
+                         cbStream_t stream) {
+    CB_REQUIRE(input && changeList && weightsPrepared && output && C > 0 && H > 0 && W > 0 && K > 0 &&
+               kH > 0 && kW > 0 && numChanges >= 0);
+    CB_REQUIRE(dtype == CB_F32 || dtype == CB_F16);
+    if ((long)C * kH * kW > 65535 || (long)C * H * W >= (1l << 31)) return CB_ERR_UNSUPPORTED;
+    if (numChanges == 0) return CB_OK;
+    ConvParams p = {};
+    p.A = weightsPrepared;
+    p.B = input;
+    p.bias = bias;
+    p.out = output;
+    p.list = changeList;
+    p.countDev = countDev;
+    p.nHost = numChanges;
+    p.K = K;
+    p.KP = cbinfer_weights_kpad(K);
+    p.Ckk = C * kH * kW;
+    p.CkkP = cbinfer_weights_ckkpad(p.Ckk);
+    p.C = C;
+    p.H = H;
+    p.W = W;
+    p.kH = kH;
+    p.kW = kW;
+    p.magicKHW = magic_u32((unsigned)(kH * kW));
+    p.magicKW = magic_u32((unsigned)kW);
+    p.relu = relu;
+    p.clearBits = (unsigned long long*)clearBits;
+    p.clearWords = clearBits ? clearWords : 0;
+    if (accumulate)
+        return launch_mfma<CB_MODE_GATHER, CB_EPI_SCATTER_ACC>(p, dtype, (hipStream_t)stream);
+    return launch_mfma<CB_MODE_GATHER, CB_EPI_SCATTER>(p, dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,287 @@
+// Change detection (+dilation, +feedback update), mask dilation and changed-index compaction for
+// gfx950.  HBM-bound byte/flag work: coalesced 256-B row segments per wave over the channel axis,
+// wave64 ballots instead of per-pixel flags, dilation on 64-bit words, order-preserving compaction by
+// popcount prefix.  Reference behaviour restated from cbconv2d_cg_backend.cu:6-136 and
+// conv2d_cg.py:200-209; see include/cbinfer_hip.h for the entry-point contracts.
+#include "cb_common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned long long cb_valid_mask(int W, int tile) {
+    const int rem = W - tile * 64;
+    return rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+}
+
+// One workgroup = one 64-pixel row segment x all channels.  blockDim.x = 64*G: wave g scans channels
+// g, g+G, ... (each wave-load is one coalesced 256-B (fp32) / 128-B (fp16) segment of a channel row),
+// the per-wave ballots are OR-reduced through LDS, and the resulting 64-bit word is dilated with
+// shifts.  BITS=true : atomicOr of the dilated words into the row-padded bit mask;
+// BITS=false: byte stores of 1 into the (pre-zeroed) [H,W] map -- same-value races are benign, as in
+// the reference (cbconv2d_cg_backend.cu:69).
+template <typename T, bool BITS>
+__global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ in, T* state,
+                                                        int8_t* __restrict__ map,
+                                                        unsigned long long* __restrict__ bits, int W,
+                                                        int H, int C, int kHH, int kWH, float thf,
+                                                        int update, int wpr) {
+    const int lane = threadIdx.x & 63;
+    const int g = threadIdx.x >> 6;
+    const int G = blockDim.x >> 6;
+    const int tx = blockIdx.x;
+    const int y = blockIdx.y;
+    const int x = tx * 64 + lane;
+    const bool valid = x < W;
+    const long HW = (long)H * W;
+    const long p = (long)y * W + x;
+    const T th = cb_threshold(thf, (T*)nullptr);
+
+    bool chg = false;
+    if (valid) {
+        int c = g;
+#pragma unroll 1
+        for (; c + 3 * G < C; c += 4 * G) {  // 8 independent loads in flight per lane
+            const T s0 = state[(long)c * HW + p], x0 = in[(long)c * HW + p];
+            const T s1 = state[(long)(c + G) * HW + p], x1 = in[(long)(c + G) * HW + p];
+            const T s2 = state[(long)(c + 2 * G) * HW + p], x2 = in[(long)(c + 2 * G) * HW + p];
+            const T s3 = state[(long)(c + 3 * G) * HW + p], x3 = in[(long)(c + 3 * G) * HW + p];
+            chg |= cb_changed(s0, x0, th) | cb_changed(s1, x1, th) | cb_changed(s2, x2, th) |
+                   cb_changed(s3, x3, th);
+        }
+        for (; c < C; c += G) chg |= cb_changed(state[(long)c * HW + p], in[(long)c * HW + p], th);
+    }
+
+    __shared__ unsigned long long sm[16];
+    const unsigned long long b = __ballot(chg);
+    if (lane == 0) sm[g] = b;
+    __syncthreads();
+    unsigned long long m = 0;
+    for (int i = 0; i < G; ++i) m |= sm[i];
+    if (m == 0) return;  // uniform over the workgroup
+
+    // feedback: refresh the state at the (pre-dilation) changed pixels only (.cu:74-80)
+    if (update && ((m >> lane) & 1ull)) {
+        for (int c = g; c < C; c += G) state[(long)c * HW + p] = in[(long)c * HW + p];
+    }
+
+    // horizontal dilation of the 64-pixel word, with the parts spilling into the neighbour words
+    unsigned long long D = m, SR = 0, SL = 0;
+    for (int d = 1; d <= kWH; ++d) {
+        D |= (m << d) | (m >> d);
+        SR |= m >> (64 - d);
+        SL |= m << (64 - d);
+    }
+    D &= cb_valid_mask(W, tx);
+    SR = (tx + 1 < wpr) ? (SR & cb_valid_mask(W, tx + 1)) : 0ull;
+    if (tx == 0) SL = 0;
+
+    if (BITS) {
+        if (g == 0) {
+            const int items = 3 * (2 * kHH + 1);
+            for (int i = lane; i < items; i += 64) {
+                const int yy = y + i / 3 - kHH;
+                const int which = i % 3;
+                if (yy < 0 || yy >= H) continue;
+                const unsigned long long v = which == 0 ? D : (which == 1 ? SR : SL);
+                const int t2 = which == 0 ? tx : (which == 1 ? tx + 1 : tx - 1);
+                if (v) atomicOr(&bits[(long)yy * wpr + t2], v);
+            }
+        }
+    } else {
+        for (int r = g; r <= 2 * kHH; r += G) {
+            const int yy = y + r - kHH;
+            if (yy < 0 || yy >= H) continue;
+            int8_t* row = map + (long)yy * W;
+            if ((D >> lane) & 1ull) row[x] = 1;
+            if (lane < kWH) {
+                if ((SR >> lane) & 1ull) row[(tx + 1) * 64 + lane] = 1;
+                if ((SL >> (64 - kWH + lane)) & 1ull) row[tx * 64 - kWH + lane] = 1;
+            }
+        }
+    }
+}
+
+// Stand-alone gather-form dilation of a byte map (cbconv2d_cg_backend.cu:101-124).
+__global__ __launch_bounds__(256) void cb_propagate_kernel(const int8_t* __restrict__ in,
+                                                          int8_t* __restrict__ out, int W, int H,
+                                                          int kHH, int kWH) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long)H * W) return;
+    const int xo = (int)(p % W), yo = (int)(p / W);
+    bool change = false;
+    for (int k = -kHH; k <= kHH; ++k) {
+        const int yi = yo + k;
+        if (yi < 0 || yi >= H) continue;
+        for (int l = -kWH; l <= kWH; ++l) {
+            const int xi = xo + l;
+            if (xi >= 0 && xi < W) change |= in[(long)yi * W + xi] != 0;
+        }
+    }
+    out[p] = change;
+}
+
+// bytes -> flat bit words (one ballot per 64 map bytes)
+__global__ __launch_bounds__(256) void cb_bytes_to_bits_kernel(const int8_t* __restrict__ map,
+                                                              long numel,
+                                                              unsigned long long* __restrict__ words) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool v = i < numel && map[i] != 0;
+    const unsigned long long b = __ballot(v);
+    if ((threadIdx.x & 63) == 0 && (i >> 6) < ((numel + 63) >> 6)) words[i >> 6] = b;
+}
+
+__device__ __forceinline__ int cb_wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Order-preserving compaction of a bit mask into ascending pixel indices.  Each workgroup owns
+// CB_CW consecutive words; its output offset is the popcount of every word before them, which it
+// recomputes itself from the (L2-resident, <=32 KB) mask -- no inter-workgroup hand-off, no second
+// launch.  Inside the workgroup a wave turns one word into indices with ballot-free rank
+// arithmetic: rank(lane) = popcount(word & lanemask_lt).
+#define CB_CW 64
+__global__ __launch_bounds__(256) void cb_compact_kernel(
+    const unsigned long long* __restrict__ bits, long nWords, int wpr, int W, int H,
+    int32_t* __restrict__ idx, int32_t* __restrict__ count, unsigned long long* __restrict__ clearBits,
+    int8_t* __restrict__ mapOut) {
+    const int lane = threadIdx.x & 63;
+    const int g = threadIdx.x >> 6;
+    const long w0 = (long)blockIdx.x * CB_CW;
+
+    __shared__ int red[4];
+    __shared__ unsigned long long sw[CB_CW];
+    __shared__ int soff[CB_CW + 1];
+
+    int part = 0;
+    for (long i = threadIdx.x; i < w0; i += 256) part += __popcll(bits[i]);
+    part = cb_wave_sum(part);
+    if (lane == 0) red[g] = part;
+
+    if (g == 0) {
+        const long wi = w0 + lane;
+        const unsigned long long word = wi < nWords ? bits[wi] : 0ull;
+        const int pc = __popcll(word);
+        int incl = pc;  // inclusive scan over the 64 lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        sw[lane] = word;
+        soff[lane] = incl - pc;
+        if (lane == 63) soff[CB_CW] = incl;
+    }
+    __syncthreads();
+    const int base = red[0] + red[1] + red[2] + red[3];
+
+    for (int j = g; j < CB_CW; j += 4) {
+        const long wi = w0 + j;
+        if (wi >= nWords) break;
+        const unsigned long long word = sw[j];
+        const int row = (int)(wi / wpr), tile = (int)(wi % wpr);
+        const int x = tile * 64 + lane;
+        const bool bit = (word >> lane) & 1ull;
+        if (bit) {
+            const int rank = __popcll(word & ((1ull << lane) - 1ull));
+            idx[base + soff[j] + rank] = row * W + x;
+        }
+        if (mapOut && x < W) mapOut[(long)row * W + x] = bit;
+        if (clearBits && lane == 0) clearBits[wi] = 0ull;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) count[0] = base + soff[CB_CW];
+}
+
+int detect_groups(int C) {
+    int G = C / 8;
+    if (G < 1) G = 1;
+    if (G > 16) G = 16;
+    return G;
+}
+
+template <typename T, bool BITS>
+int launch_detect(const void* input, void* state, int8_t* map, uint64_t* bits, int W, int H, int C,
+                  int kHH, int kWH, float th, int update, hipStream_t s) {
+    const int wpr = cbinfer_mask_words_per_row(W);
+    const int G = detect_groups(C);
+    dim3 grid(wpr, H), block(64 * G);
+    hipLaunchKernelGGL((cb_detect_kernel<T, BITS>), grid, block, 0, s, (const T*)input, (T*)state, map,
+                       (unsigned long long*)bits, W, H, C, kHH, kWH, th, update, wpr);
+    return cb_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int cbinfer_mask_words_per_row(int W) { return (W + 63) / 64; }
+long cbinfer_mask_words(int H, int W) { return (long)H * ((W + 63) / 64); }
+
+int cbinfer_change_detection(const void* input, void* state, int8_t* changeMap, int W, int H, int C,
+                             int kHHalf, int kWHalf, float threshold, int updateInputState,
+                             int dtype, cbStream_t stream) {
+    CB_REQUIRE(input && state && changeMap && W > 0 && H > 0 && C > 0 && kHHalf >= 0 && kWHalf >= 0);
+    if (kWHalf > 63 || H > 65535) return CB_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(changeMap, 0, (size_t)H * W, s);
+    if (e != hipSuccess) return (int)e;
+    if (dtype == CB_F32)
+        return launch_detect<float, false>(input, state, changeMap, nullptr, W, H, C, kHHalf, kWHalf,
+                                           threshold, updateInputState, s);
+    if (dtype == CB_F16)
+        return launch_detect<cb_half, false>(input, state, changeMap, nullptr, W, H, C, kHHalf, kWHalf,
+                                             threshold, updateInputState, s);
+    return CB_ERR_BADARG;
+}
+
+int cbinfer_change_detection_bits(const void* input, void* state, uint64_t* bitsOut, int W, int H,
+                                  int C, int kHHalf, int kWHalf, float threshold,
+                                  int updateInputState, int dtype, cbStream_t stream) {
+    CB_REQUIRE(input && state && bitsOut && W > 0 && H > 0 && C > 0 && kHHalf >= 0 && kWHalf >= 0);
+    if (kWHalf > 63 || H > 65535) return CB_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CB_F32)
+        return launch_detect<float, true>(input, state, nullptr, bitsOut, W, H, C, kHHalf, kWHalf,
+                                          threshold, updateInputState, s);
+    if (dtype == CB_F16)
+        return launch_detect<cb_half, true>(input, state, nullptr, bitsOut, W, H, C, kHHalf, kWHalf,
+                                            threshold, updateInputState, s);
+    return CB_ERR_BADARG;
+}
+
+int cbinfer_change_propagation(const int8_t* mapIn, int8_t* mapOut, int W, int H, int kHHalf,
+                               int kWHalf, cbStream_t stream) {
+    CB_REQUIRE(mapIn && mapOut && W > 0 && H > 0 && kHHalf >= 0 && kWHalf >= 0);
+    const long n = (long)H * W;
+    hipLaunchKernelGGL(cb_propagate_kernel, dim3(cb_div_up(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, mapIn, mapOut, W, H, kHHalf, kWHalf);
+    return cb_launch_status();
+}
+
+int cbinfer_change_indexes_extr(const int8_t* changeMap, long numel, uint64_t* scratchWords,
+                                int32_t* idxOut, int32_t* countDev, cbStream_t stream) {
+    CB_REQUIRE(changeMap && scratchWords && idxOut && countDev && numel > 0 && numel < (1l << 31));
+    hipStream_t s = (hipStream_t)stream;
+    const long nWords = (numel + 63) / 64;
+    hipLaunchKernelGGL(cb_bytes_to_bits_kernel, dim3(cb_div_up(nWords * 64, 256)), dim3(256), 0, s,
+                       changeMap, numel, (unsigned long long*)scratchWords);
+    // flat layout: a single "row" of numel pixels
+    hipLaunchKernelGGL(cb_compact_kernel, dim3(cb_div_up(nWords, CB_CW)), dim3(256), 0, s,
+                       (const unsigned long long*)scratchWords, nWords, (int)nWords, (int)numel, 1,
+                       idxOut, countDev, (unsigned long long*)nullptr, (int8_t*)nullptr);
+    return cb_launch_status();
+}
+
+int cbinfer_compact_bits(const uint64_t* bits, int W, int H, int32_t* idxOut, int32_t* countDev,
+                         uint64_t* clearBits, int8_t* mapOut, cbStream_t stream) {
+    CB_REQUIRE(bits && idxOut && countDev && W > 0 && H > 0);
+    CB_REQUIRE((const void*)clearBits != (const void*)bits);
+    const int wpr = cbinfer_mask_words_per_row(W);
+    const long nWords = (long)H * wpr;
+    hipLaunchKernelGGL(cb_compact_kernel, dim3(cb_div_up(nWords, CB_CW)), dim3(256), 0,
+                       (hipStream_t)stream, (const unsigned long long*)bits, nWords, wpr, W, H, idxOut,
+                       countDev, (unsigned long long*)clearBits, mapOut);
+    return cb_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+// One-call-per-layer frame pipeline: the host side of CBConv2d.forward_normal (conv2d.py:178-259)
+// expressed as a fixed sequence of launches on one stream, with the changed-pixel count kept on the
+// device (the reference blocks on torch.nonzero at this point, conv2d_cg.py:202).  Safe under
+// hipGraph capture: no allocation, no synchronisation, no memset node.
+#include "cb_common.h"
+
+extern "C" int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void* prevOutput,
+                                        uint64_t* bits, int32_t* idx, int32_t* countDev,
+                                        int8_t* mapOut, const void* weightsPrepared, const void* bias,
+                                        int C, int H, int W, int K, int kH, int kW, float threshold,
+                                        int feedbackLoop, int copyInput, int relu, int haveIndexes,
+                                        int capN, int dtype, cbStream_t stream) {
+    CB_REQUIRE(input && prevInput && prevOutput && idx && countDev && weightsPrepared);
+    CB_REQUIRE(dtype == CB_F32 || dtype == CB_F16);
+    CB_REQUIRE(capN >= 0 && capN <= H * W);
+    int st;
+    if (!haveIndexes) {
+        CB_REQUIRE(bits != nullptr);
+        st = cbinfer_change_detection_bits(input, prevInput, bits, W, H, C, (kH - 1) / 2, (kW - 1) / 2,
+                                           threshold, feedbackLoop, dtype, stream);
+        if (st != CB_OK) return st;
+        st = cbinfer_compact_bits(bits, W, H, idx, countDev, nullptr, mapOut, stream);
+        if (st != CB_OK) return st;
+    }
+    if (!feedbackLoop && copyInput && prevInput != input) {
+        const size_t bytes = (size_t)C * H * W * (dtype == CB_F16 ? 2 : 4);
+        hipError_t e = hipMemcpyAsync(prevInput, input, bytes, hipMemcpyDeviceToDevice,
+                                      (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    // The gather reads the layer STATE (conv2d.py:242).  With copyInput=0 (and no feedback loop) the
+    // reference re-points the state at the caller's tensor (:237-238), i.e. the gather reads `input`.
+    const void* src = (feedbackLoop || copyInput) ? prevInput : input;
+    return cbinfer_conv_changed(src, idx, capN, countDev, weightsPrepared, bias, prevOutput, C, H, W, K,
+                                kH, kW, relu, 0, bits, bits ? cbinfer_mask_words(H, W) : 0, dtype,
+                                stream);
+}

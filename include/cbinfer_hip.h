@@ -1,0 +1,181 @@
+/*
+ * cbinfer_hip.h -- C ABI of libcbinfer_hip.so: hand-written HIP (gfx950 / MI355X) kernels for
+ * CBinfer's change-based convolution hot path.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one native launcher (or one torch op) of
+ * the reference; the reference interface it replaces is cited as file:line relative to
+ * /root/reference/pycbinfer.  Conventions (the reference has none of these):
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise;
+ *   - the library allocates nothing and keeps no global state: every buffer is caller-owned;
+ *   - every launcher takes the HIP stream to enqueue on (cbStream_t = hipStream_t, NULL = default
+ *     stream) and never synchronises; it is safe to call while the stream is being graph-captured;
+ *   - return value: 0 on success, a positive hipError_t if the launch failed, a negative CB_ERR_* for
+ *     rejected arguments.  cbinfer_status_string() turns either into text;
+ *   - launch geometry is chosen inside the library (the reference computes it in Python and passes
+ *     six ints, conv2d_cg.py:106-111);
+ *   - dtype: CB_F32 (cbconv2d_cg_backend.cu) or CB_F16 (cbconv2d_cg_half_backend.cu);
+ *   - tensors are NCHW, batch 1, contiguous.  Index lists are int32 flat pixel indices y*W+x in
+ *     ascending order.  "count" pointers are device int32 scalars holding the list length N, so that
+ *     a whole frame can be enqueued without a host round trip; where a launcher takes both a host
+ *     `numChanges` and a device `countDev`, countDev (if non-NULL) wins and numChanges is only the
+ *     capacity the grid is sized for.
+ *
+ * The same library also exports the reference's own symbol names and signatures
+ * (cbconv2d_{cg,cg_half,fg}_backend compat shims, cbinfer_amd/csrc/cb_compat.cpp) so the reference's cffi
+ * cdef/dlopen (conv2d_cg.py:6-50, conv2d_fg.py:13-32) binds without change.
+ */
+#ifndef CBINFER_HIP_H
+#define CBINFER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cbStream_t; /* hipStream_t */
+
+#define CB_F32 0
+#define CB_F16 1
+
+#define CB_OK 0
+#define CB_ERR_BADARG (-1)      /* null pointer, non-positive size, unsupported dtype */
+#define CB_ERR_UNSUPPORTED (-2) /* shape outside what the kernels implement (e.g. kWHalf > 63) */
+
+#define CBINFER_ABI_VERSION 1
+
+int cbinfer_abi_version(void);
+const char* cbinfer_status_string(int status);
+
+/* ---- geometry helpers (host, pure) --------------------------------------------------------- */
+/* Row-padded bit mask layout used by the sync-free path: one uint64 word per 64 pixels of a row,
+ * rows padded to whole words.  Returns words per row / total words for an H x W map. */
+int cbinfer_mask_words_per_row(int W);
+long cbinfer_mask_words(int H, int W);
+/* Padded sizes of the prepared weight matrix (see cbinfer_prep_weights). */
+int cbinfer_weights_kpad(int K);
+int cbinfer_weights_ckkpad(int Ckk);
+
+/* ---- a1: change detection + dilation (+ feedback state update) ------------------------------
+ * replaces changeDetection, conv2d_cg.py:100-122 -> cbconv2d_cg_backend.cu:83-100 (kernels :6-81),
+ * half: cbconv2d_cg_half_backend.cu:10-88.
+ * change(p) = OR_c |state[c,p] - in[c,p]| > th (strict; half: compared in half precision after one
+ * rounding of the difference).  A changed pixel marks its (2kHHalf+1)x(2kWHalf+1) neighbourhood in
+ * changeMap [H,W] int8 and, if updateInputState, gets in[:,p] copied into state[:,p].
+ * The map is zeroed by the library (the reference's caller does it, conv2d_cg.py:105). */
+int cbinfer_change_detection(const void* input, void* state, int8_t* changeMap, int W, int H, int C,
+                             int kHHalf, int kWHalf, float threshold, int updateInputState,
+                             int dtype, cbStream_t stream);
+
+/* Same computation, emitting the dilated mask as a row-padded BIT mask (wave ballot -> one word per
+ * 64 pixels; bitsOut must be zero on entry, cbinfer_compact_bits re-zeroes a buffer for the next
+ * frame).  This is the form the sync-free frame pipeline uses. */
+int cbinfer_change_detection_bits(const void* input, void* state, uint64_t* bitsOut, int W, int H,
+                                  int C, int kHHalf, int kWHalf, float threshold,
+                                  int updateInputState, int dtype, cbStream_t stream);
+
+/* ---- a2: stand-alone mask dilation ------------------------------------------------------------
+ * replaces changePropagation, conv2d_cg.py:159-177 -> cbconv2d_cg_backend.cu:126-136 (kernel :101). */
+int cbinfer_change_propagation(const int8_t* mapIn, int8_t* mapOut, int W, int H, int kHHalf,
+                               int kWHalf, cbStream_t stream);
+
+/* ---- a3: changed-index extraction (stream compaction) ----------------------------------------
+ * replaces changeIndexesExtr[_python], conv2d_cg.py:200-213 (torch.nonzero(map.view(-1)).int()).
+ * idxOut (capacity numel) receives the ascending flat indices of the non-zero bytes, countDev the
+ * number of them.  scratchWords: caller-owned uint64 scratch of ceil(numel/64) words. */
+int cbinfer_change_indexes_extr(const int8_t* changeMap, long numel, uint64_t* scratchWords,
+                                int32_t* idxOut, int32_t* countDev, cbStream_t stream);
+
+/* Compaction of a row-padded bit mask (from cbinfer_change_detection_bits) into flat indices y*W+x.
+ * If clearBits is non-NULL that (other) mask buffer of the same geometry is zeroed for the next
+ * frame.  If mapOut is non-NULL the mask is also expanded to an int8 [H,W] map (saveChangeMap). */
+int cbinfer_compact_bits(const uint64_t* bits, int W, int H, int32_t* idxOut, int32_t* countDev,
+                         uint64_t* clearBits, int8_t* mapOut, cbStream_t stream);
+
+/* ---- a5: gather -> im2col rows of the changed pixels ------------------------------------------
+ * replaces genXMatrix, conv2d_cg.py:239-261 -> cbconv2d_cg_backend.cu:163-173 (kernel :138-161).
+ * columns [N, C*kH*kW] row-major, column (c*kH+ky)*kW+kx; zero outside the image. */
+int cbinfer_gen_x_matrix(void* columns, const void* input, const int32_t* changeList, int kW, int kH,
+                         int C, int W, int H, int numChanges, const int32_t* countDev, int dtype,
+                         cbStream_t stream);
+
+/* ---- a6/a7: the dense contraction ------------------------------------------------------------
+ * replaces matrixMult_python, conv2d_cg.py:342-349 (torch matmul -> cuBLAS) and, with
+ * transposeOut=1, also the transpose+contiguous of conv2d.py:247 / conv2d_cg.py:305.
+ * Y = X[N,Ckk] . W[K,Ckk]^T + bias; Y is [N,K] (transposeOut=0) or [K,N] (transposeOut=1).
+ * fp32: exact-f32 MFMA (v_mfma_f32_32x32x2_f32); fp16: f16 MFMA with f32 accumulation.
+ * weightsPrepared is the matrix produced by cbinfer_prep_weights. */
+int cbinfer_prep_weights(const void* weight, void* weightsPrepared, int K, int Ckk, int dtype,
+                         cbStream_t stream);
+int cbinfer_matrix_mult(const void* X, const void* weightsPrepared, const void* bias, void* Y,
+                        int N, const int32_t* countDev, int Ckk, int K, int transposeOut, int dtype,
+                        cbStream_t stream);
+
+/* ---- a8: scatter-back -------------------------------------------------------------------------
+ * replaces updateOutput, conv2d_cg.py:292-313 -> cbconv2d_cg_backend.cu:191-197 (kernel :175-189).
+ * output[k*HW + changeList[n]] = relu ? (v <= 0 ? 0 : v) : v with v = Yt[k*N + n]. */
+int cbinfer_update_output(const void* Yt, void* output, const int32_t* changeList,
+                          int numOutputPixel, int numChanges, const int32_t* countDev,
+                          int nOutputPlane, int relu, int dtype, cbStream_t stream);
+
+/* ---- a5+a6+a7+a8 fused: gather -> MFMA -> bias/ReLU -> scatter, no X / Y in HBM --------------
+ * One launch replaces conv2d.py:240-251 (genXMatrix, matrixMult_python, transpose, updateOutput).
+ * input is the layer state the gather reads from (conv2d.py:242 reads self.prevInput).
+ * accumulate=1 adds to output instead of overwriting (no bias/ReLU): used by the deterministic
+ * fine-grained variant (a12) where `input` holds the masked deltas.
+ * clearBits (optional, clearWords words): a change bit mask this launch zeroes on the way, so the
+ * next frame's cbinfer_change_detection_bits finds it clean (keeps the frame free of memset nodes). */
+int cbinfer_conv_changed(const void* input, const int32_t* changeList, int numChanges,
+                         const int32_t* countDev, const void* weightsPrepared, const void* bias,
+                         void* output, int C, int H, int W, int K, int kH, int kW, int relu,
+                         int accumulate, uint64_t* clearBits, long clearWords, int dtype,
+                         cbStream_t stream);
+
+/* ---- a14 in one call: CBConv2d.forward_normal (conv2d.py:178-259) enqueued without a host sync --
+ * detection(+dilation,+feedback) -> compaction -> [state copy] -> fused gather/MFMA/scatter.
+ *   bits      : row-padded change mask (cbinfer_mask_words(H,W) words), zero on first use; left zero
+ *               (may be NULL when haveIndexes=1)
+ *   idx/count : capacity H*W int32 / one int32; on return (stream order) the frame's change list
+ *   mapOut    : optional int8 [H,W] copy of the dilated mask (saveChangeMap)
+ *   haveIndexes=1: idx/count were produced upstream (propChangeIndexes protocol): skip detection
+ *   feedbackLoop=1: prevInput refreshed at changed pixels only; else, if copyInput, prevInput <- input
+ *                   (copyInput=0: the gather reads `input` and the caller re-points its state at it,
+ *                   conv2d.py:237-238)
+ *   capN      : grid capacity for the fused kernel (H*W, or the exact N if the caller synchronised) */
+int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void* prevOutput, uint64_t* bits,
+                             int32_t* idx, int32_t* countDev, int8_t* mapOut,
+                             const void* weightsPrepared, const void* bias, int C, int H, int W,
+                             int K, int kH, int kW, float threshold, int feedbackLoop,
+                             int copyInput, int relu, int haveIndexes, int capN, int dtype,
+                             cbStream_t stream);
+
+/* ---- a9: change-based 2x2/stride-2 max pooling -----------------------------------------------
+ * replaces maxPool2d, conv2d_cg.py:58-82 -> cbconv2d_cg_backend.cu:229-240 (kernel :199-227).
+ * changeIndexes are INPUT-resolution pixel indices.  Unlike the reference, windows with
+ * yo >= oH or xo >= oW (odd size, floor mode) are skipped instead of written out of bounds. */
+int cbinfer_max_pool2d(const void* input, void* output, const int32_t* changeIndexes, int numChanges,
+                       const int32_t* countDev, int C, int iH, int iW, int oH, int oW, int dtype,
+                       cbStream_t stream);
+
+/* ---- a10-a12: fine-grained path ---------------------------------------------------------------
+ * replaces changeDetectionFG, conv2d_fg.py:34-46 -> cbconv2d_fg_backend.cu:25-35 (kernel :7-23):
+ * d = in - prev; changeMap = |d| > th; diffs = d where changed.  zeroUnchanged=1 additionally writes
+ * diffs = 0 elsewhere (the reference leaves it uninitialised). */
+int cbinfer_change_detection_fg(const float* input, const float* prevInput, float* diffs,
+                                int8_t* changeMap, long numVals, float threshold, int zeroUnchanged,
+                                cbStream_t stream);
+/* replaces updateOutputFG, conv2d_fg.py:48-72 -> cbconv2d_fg_backend.cu:68-79 (kernel :37-66):
+ * atomicAdd of w[:,ci,ky,kx]*d into the K*kH*kW outputs each changed value touches.
+ * changeCoords: int64 flat coordinates into [C,H,W] (torch.nonzero, conv2d_fg.py:82). */
+int cbinfer_update_output_fg(const float* diffs, const float* weight, float* output,
+                             const int64_t* changeCoords, int K, int C, int H, int W, int kH, int kW,
+                             long numChanges, cbStream_t stream);
+/* replaces conv2d_fg_cpu, cbconv2d_fg_backend.cu:81-112: HOST pointers, host code, race-free. */
+void cbinfer_conv2d_fg_cpu(const float* input, const float* prevInput, float* output,
+                           const float* weight, float threshold, int no, int ni, int h, int w,
+                           int kh, int kw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CBINFER_HIP_H */

@@ -1,0 +1,162 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol, the compat shims export
+the reference's names, and the host-side model surgery (convert & friends) behaves like the
+reference's (pycbinfer/__init__.py).  No kernel is launched here."""
+import ctypes
+import io
+import os
+import re
+
+import pytest
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "cbinfer_hip.h")).read()
+    declared = set(re.findall(r"\b(cbinfer_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(os.path.join(REPO, "cbinfer_amd", "libcbinfer_hip.so"))
+    for name in declared:
+        assert hasattr(lib, name), name
+    from cbinfer_amd import _lib
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    assert lib.cbinfer_abi_version() == 1
+    lib.cbinfer_mask_words.restype = ctypes.c_long
+    assert lib.cbinfer_mask_words_per_row(480) == 8 and lib.cbinfer_mask_words(320, 480) == 2560
+    assert lib.cbinfer_weights_kpad(8) == 32 and lib.cbinfer_weights_ckkpad(147) == 160
+
+
+def test_compat_shims_export_reference_symbols():
+    import platform
+    d = os.path.join(REPO, "cbinfer_amd", "compat")
+    cg = ["changeDetection", "changePropagation", "genXMatrix", "updateOutput", "maxPool2d"]
+    fg = ["changeDetectionFG", "updateOutputFG", "conv2d_fg_cpu"]
+    for fname, names in (("cbconv2d_cg_backend_%s.so", cg), ("cbconv2d_cg_half_backend_%s.so", cg),
+                         ("cbconv2d_fg_backend_%s.so", fg)):
+        lib = ctypes.CDLL(os.path.join(d, fname % platform.machine()))
+        for n in names:
+            assert hasattr(lib, n), (fname, n)
+
+
+def test_host_fg_routine_matches_golden(golden_dir):
+    import numpy as np
+    from cbinfer_amd import conv2d_fg
+    for name in ("fg_test1.npz", "fg_case1.npz"):
+        d = dict(np.load(os.path.join(golden_dir, name)))
+        out = conv2d_fg.cbconvFG(torch.from_numpy(d["input"]), torch.from_numpy(d["prevInput"]),
+                                 torch.from_numpy(d["prevOutput"].copy()), torch.from_numpy(d["weight"]),
+                                 float(d["threshold"]))
+        np.testing.assert_allclose(out.numpy(), d["output"], rtol=0, atol=1e-5)
+
+
+def _baseline():
+    return nn.Sequential(
+        nn.Conv2d(3, 16, 7, padding=3), nn.ReLU(), nn.MaxPool2d(2, 2),
+        nn.Conv2d(16, 64, 7, padding=3), nn.ReLU(), nn.MaxPool2d(2, 2),
+        nn.Conv2d(64, 256, 7, padding=3), nn.ReLU(),
+        nn.Conv2d(256, 64, 1), nn.ReLU(),
+        nn.Conv2d(64, 8, 1))
+
+
+def test_convert_structure():
+    import pycbinfer
+    base = _baseline()
+    cb = pycbinfer.convert(base, threshold=0.07)
+    # names preserved, ReLUs merged: children 0,2,3,5,6,8,10
+    assert [n for n, _ in cb.named_children()] == ['0', '2', '3', '5', '6', '8', '10']
+    convs = [m for m in cb if type(m) is pycbinfer.CBConv2d]
+    assert len(convs) == 5 and type(cb[1]) is nn.MaxPool2d
+    assert [m.withReLU for m in convs] == [True, True, True, True, False]
+    assert all(m.threshold == 0.07 for m in convs)
+    # weights are SHARED with the source module (conv2d.py:105-106)
+    assert convs[0].weight is base[0].weight and convs[0].bias is base[0].bias
+    # flags' defaults (conv2d.py:108-118)
+    m = convs[0]
+    assert (m.saveChangeMap, m.propChangeIndexes, m.gatherComputationStats, m.finegrained, m.copyInput,
+            m.feedbackLoop) == (False, False, False, False, True, False)
+    assert pycbinfer.conv2d.CBConv2d is pycbinfer.CBConv2d
+    r = repr(convs[0])
+    assert r.startswith("CBConv2d (th=0.07, 3->16, k=(7, 7), s=(1, 1), copyInput=True, pad=(3, 3)")
+    assert "withReLU=True" in r and r.endswith("propChgIdxs=False)")
+
+
+def test_convert_nested_dropout_ignorelist():
+    import pycbinfer
+
+    class Lambda(nn.Module):
+        def forward(self, x):
+            return x
+
+    net = nn.Sequential(nn.Sequential(nn.Conv2d(3, 4, 3, padding=1), nn.ReLU(), nn.Dropout()),
+                        Lambda(), nn.Conv2d(4, 2, 1))
+    cb = pycbinfer.convert(net, ignoreList=[Lambda])
+    assert [n for n, _ in cb.named_children()] == ['0', '2']
+    inner = cb[0]
+    assert [n for n, _ in inner.named_children()] == ['0'] and inner[0].withReLU
+    assert type(cb[1]) is pycbinfer.CBConv2d and not cb[1].withReLU
+
+
+def test_constructor_asserts():
+    import pycbinfer
+    for bad in (nn.Conv2d(4, 4, 3, padding=1, groups=2), nn.Conv2d(3, 4, 3, padding=0),
+                nn.Conv2d(3, 4, 3, padding=1, stride=2), nn.Conv2d(3, 4, 3, padding=2, dilation=2),
+                nn.Conv2d(3, 4, 3, padding=1, bias=False)):
+        with pytest.raises(AssertionError):
+            pycbinfer.CBConv2d(bad, 0.1)
+    with pytest.raises(AssertionError):
+        pycbinfer.CBPoolMax2d(nn.MaxPool2d(3, 3))
+    p = pycbinfer.CBPoolMax2d(nn.MaxPool2d(2, 2, ceil_mode=True))
+    assert p.ceil_mode and p.kernel_size == (2, 2)
+
+
+def test_prop_change_indexes_of_1x1():
+    import pycbinfer
+    cb = pycbinfer.propChangeIndexesOf1x1(pycbinfer.convert(_baseline()))
+    convs = [m for m in cb if type(m) is pycbinfer.CBConv2d]
+    assert [m.propChangeIndexes for m in convs] == [False, False, True, True, False]
+
+
+def test_pickle_roundtrip_and_state_buffers():
+    import pycbinfer
+    cb = pycbinfer.convert(_baseline())
+    pycbinfer.clearMemory(cb)
+    buf = io.BytesIO()
+    torch.save(cb, buf)
+    buf.seek(0)
+    cb2 = torch.load(buf, weights_only=False)
+    conv = cb2[0]
+    assert type(conv) is pycbinfer.CBConv2d
+    assert set(dict(conv.named_buffers())) == {'prevInput', 'prevOutput'}
+    assert all(t.numel() == 0 for t in pycbinfer.getStateTensors(cb2))
+    # attributes missing in old pickles are back-filled (conv2d.py:292-304)
+    del conv.__dict__['feedbackLoop'], conv.__dict__['copyInput']
+    conv._setDefaultValues()
+    assert conv.feedbackLoop is False and conv.copyInput is True
+
+
+def test_experiment_presets_structure():
+    import pycbinfer
+    from cbinfer_amd import workloads
+    base = workloads.sceneLabelingBaseline()
+    assert len(base) == 11
+    assert workloads.denseOps(workloads.SCENE_LABELING_SPEC, 320, 480) == 20314521600
+    t6 = workloads.configureExperiment(base, pycbinfer.convert(base), 6)
+    kinds = [type(m).__name__ for m in t6]
+    assert kinds == ['CBConv2d', 'CBPoolMax2d', 'CBConv2d', 'CBPoolMax2d', 'CBConv2d', 'Conv2d', 'ReLU',
+                     'Conv2d']
+    assert t6[0].propChangeIndexes and t6[2].propChangeIndexes and not t6[4].propChangeIndexes
+    assert all(m.feedbackLoop for m in t6 if type(m) is pycbinfer.CBConv2d)
+    t7 = workloads.configureExperiment(base, pycbinfer.convert(base), 7)
+    assert all(m.finegrained for m in t7 if type(m) is pycbinfer.CBConv2d)
+
+
+def test_synthetic_video_change_ratio():
+    from cbinfer_amd import workloads
+    vid = workloads.SyntheticVideo(H=64, W=96, ratio=0.10, block=16, seed=1, device='cpu')
+    assert vid.cells == 24 and vid.nblocks == 2
+    f0 = vid.frame
+    f1 = vid.next()
+    changed = (f0 != f1).any(dim=1)
+    assert changed.float().mean().item() == pytest.approx(vid.ratio, abs=1e-3)

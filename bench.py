@@ -1,0 +1,331 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s (+ effective GFLOP/s vs dense) of the change-based scene-labeling CNN
+on synthetic 480x320 video at a fixed change ratio (BASELINE.json configs[1]) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one video frame through the converted network (reference experiment 6: CBConv2d with
+feedback loop + CBPoolMax2d for the three 7x7 layers, dense 1x1 tail; sceneLabeling/modelLoader.py:62-78).
+Every rank owns one independent sequence (weak scaling); the only collective is the final
+MAX(elapsed) reduction.  Frames are resident in HBM before the timed region starts.
+
+Rank 0 prints ONE JSON line (see the keys below).  `roofline` is measured live with HIP events on the
+launch stream for the dominant kernel; `cpu_baseline` times the oracle port (test infrastructure) of the
+same path on the host cores over a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+H, W = 320, 480
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--ratio", type=float, default=0.10)
+    ap.add_argument("--block", type=int, default=32)
+    ap.add_argument("--experiment", type=int, default=6)
+    ap.add_argument("--threshold", type=float, default=0.05)
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-kernel table to stderr")
+    return ap.parse_args()
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+class FrameRunner(object):
+    """Runs model(frame) either eagerly or as a replayed hipGraph with a static input buffer."""
+
+    def __init__(self, model, example, mode):
+        self.model, self.mode = model, mode
+        self.static_in = example.clone()
+        self.graph = None
+        self.out = None
+
+    def prime(self, frames):
+        """Process `frames` eagerly (allocates state/workspaces); in graph mode capture afterwards."""
+        with torch.no_grad():
+            for f in frames:
+                self.static_in.copy_(f)
+                self.out = self.model(self.static_in)
+            if self.mode == "graph":
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self.out = self.model(self.static_in)      # same frame again: no change
+                torch.cuda.current_stream().wait_stream(s)
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.out = self.model(self.static_in)
+
+    def step(self, frame):
+        self.static_in.copy_(frame)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            with torch.no_grad():
+                self.out = self.model(self.static_in)
+        return self.out
+
+
+def timed_loop(runner, frames, steps, barrier):
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        runner.step(frames[i % len(frames)])
+    torch.cuda.synchronize()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def event_time_ms(fn, reps):
+    """Average duration of fn() (which enqueues on torch's current stream) over reps launches."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def kernel_breakdown(test, frames, reps=50):
+    """Per-layer, per-kernel time of the change-based layers on the state left by the timed sequence,
+    by re-launching each kernel stand-alone through the C ABI (idempotent: same inputs, same outputs).
+    Returns a list of dicts with the algorithmic bytes / flops of SURVEY 8d."""
+    import pycbinfer
+    from cbinfer_amd import conv2d_cg as cg
+    from cbinfer_amd._lib import C as lib, check, stream_ptr, ptr
+    rows = []
+    # feed one more frame layer by layer, keeping each CB layer's input
+    x = frames[0]
+    with torch.no_grad():
+        for m in test.children():
+            xin = x
+            x = m(x)
+            if type(m) is pycbinfer.CBConv2d and not m.finegrained:
+                inp = xin[1] if isinstance(xin, tuple) else xin
+                K, C, kH, kW = m.weight.shape
+                Hh, Ww = inp.shape[-2:]
+                s = 4 if inp.dtype == torch.float32 else 2
+                ci = cg.ChangeIndexes(m._work['idx'], m._work['count'])
+                N = ci.numel()
+                bits = torch.zeros_like(m._work['bits'])
+                cnt = torch.zeros(1, dtype=torch.int32, device=inp.device)
+                idx = torch.empty_like(m._work['idx'])
+                dt = 0 if s == 4 else 1
+                t_det = event_time_ms(lambda: (bits.zero_(), check(lib.cbinfer_change_detection_bits(
+                    ptr(inp), ptr(m.prevInput), ptr(bits), Ww, Hh, C, (kH - 1) // 2, (kW - 1) // 2,
+                    float(m.threshold), 0, dt, stream_ptr()))), reps)
+                t_zero = event_time_ms(lambda: bits.zero_(), reps)
+                t_cmp = event_time_ms(lambda: check(lib.cbinfer_compact_bits(
+                    ptr(m._work['bits']), Ww, Hh, ptr(idx), ptr(cnt), None, None, stream_ptr())), reps)
+                wp = m._prepared_weights()
+                t_conv = event_time_ms(lambda: check(lib.cbinfer_conv_changed(
+                    ptr(m.prevInput), ptr(ci.buffer), Hh * Ww, ptr(ci.count), ptr(wp), ptr(m.bias.detach()),
+                    ptr(m.prevOutput), C, Hh, Ww, K, kH, kW, int(m.withReLU), 0, None, 0, dt,
+                    stream_ptr())), reps)
+                HW = Hh * Ww
+                rows.append(dict(layer="conv %d->%d k%d @%dx%d" % (C, K, kH, Hh, Ww), N=N,
+                                 ratio=N / float(HW),
+                                 detect_ms=max(t_det - t_zero, 0.0), detect_bytes=2 * C * HW * s + HW // 8,
+                                 compact_ms=t_cmp, compact_bytes=HW // 8 + 4 * N,
+                                 conv_ms=t_conv, conv_flops=2.0 * N * C * kH * kW * K,
+                                 conv_bytes=(N * C * kH * kW + K * C * kH * kW + N * K) * s))
+            elif type(m) is pycbinfer.CBPoolMax2d:
+                inp, ci = xin[1], xin[2]
+                N = ci.numel()
+                C = inp.shape[1]
+                s = 4 if inp.dtype == torch.float32 else 2
+                t_pool = event_time_ms(lambda: cg.maxPool2d(inp, m.outputState, ci, (2, 2), (2, 2)), reps)
+                rows.append(dict(layer="pool C%d @%dx%d" % (C, inp.shape[-2], inp.shape[-1]), N=N,
+                                 pool_ms=t_pool, pool_bytes=N * C * 5 * s + 4 * N))
+    return rows
+
+
+def cpu_baseline(test, video_kw, budget_frames=4):
+    """The oracle's port of the reference CPU path (C loops for detect/gather/scatter/pool, torch CPU
+    matmul for the contraction as conv2d_cg.py:346 does), timed on the host cores.  Sample: frame 0
+    (100 % change) untimed, then `budget_frames` steady-state frames."""
+    import numpy as np
+    import pycbinfer
+    from cbinfer_amd import workloads
+    from oracle import cb_oracle as orc          # checker / baseline only
+
+    class TorchGemmConv(orc.OracleCBConv2d):
+        pass
+
+    def matmul(X, weight, bias, accMode=0):
+        K = weight.shape[0]
+        Y = torch.from_numpy(X).matmul(torch.from_numpy(np.ascontiguousarray(weight.reshape(K, -1))).t())
+        return (Y + torch.from_numpy(bias)).numpy()
+
+    orc_matmul, orc.matrixMult = orc.matrixMult, matmul
+    try:
+        layers = []
+        for m in test.children():
+            if type(m) is pycbinfer.CBConv2d:
+                layers.append(orc.OracleCBConv2d(m.weight.detach().cpu().numpy(),
+                                                 m.bias.detach().cpu().numpy(), m.threshold,
+                                                 withReLU=m.withReLU, feedbackLoop=m.feedbackLoop,
+                                                 propChangeIndexes=m.propChangeIndexes,
+                                                 copyInput=m.copyInput))
+            elif type(m) is pycbinfer.CBPoolMax2d:
+                layers.append(orc.OracleCBPoolMax2d(m.ceil_mode, m.propChangeIndexes))
+            elif type(m) is torch.nn.ReLU:
+                layers.append(orc.OracleReLU())
+            elif type(m) is torch.nn.Conv2d:
+                mc = torch.nn.Conv2d(m.in_channels, m.out_channels, m.kernel_size, padding=m.padding)
+                mc.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+                layers.append(type("DenseTorch", (), {
+                    "forward": lambda self, x, mc=mc: mc(torch.from_numpy(x)).detach().numpy(),
+                    "clearMemory": lambda self: None})())
+            else:
+                raise AssertionError(type(m))
+        net = orc.OracleSequential(layers)
+        vid = workloads.SyntheticVideo(device="cpu", **video_kw)
+        frames = [f.numpy() for f in vid.frames(budget_frames + 1)]
+        with torch.no_grad():
+            net.forward(frames[0])
+            t0 = time.perf_counter()
+            for f in frames[1:]:
+                net.forward(f)
+            dt = time.perf_counter() - t0
+    finally:
+        orc.matrixMult = orc_matmul
+    return dict(value=budget_frames / dt, unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d steady-state frames of the same 480x320 sequence after an untimed 100%%-change "
+                       "first frame; oracle C ops + torch CPU matmul" % budget_frames)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_.init_process_group("nccl")      # RCCL on ROCm
+        dist = dist_
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    import pycbinfer
+    from cbinfer_amd import workloads
+
+    base, test = workloads.sceneLabelingModels(experimentIdx=args.experiment, threshold=args.threshold)
+    video_kw = dict(H=H, W=W, ratio=args.ratio, block=args.block, seed=1234 + rank)
+    vid = workloads.SyntheticVideo(**video_kw)
+    n_frames = min(max(args.steps, 8), 256) + 2
+    frames = vid.frames(n_frames)                    # resident in HBM
+    prime, frames = frames[:2], frames[2:]
+
+    runner = FrameRunner(test, frames[0], args.mode)
+    runner.prime(prime)
+    for i in range(args.warmup):
+        runner.step(frames[i % len(frames)])
+    elapsed = timed_loop(runner, frames, args.steps, barrier)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_frames = args.steps * world
+    fps = total_frames / elapsed
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    dense_ops = workloads.denseOps(workloads.SCENE_LABELING_SPEC, H, W)
+    result = {
+        "metric": "frames/sec + effective GFLOP/s vs dense, scene-labeling CNN 480x320 @10% change",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "sceneLabeling CBConv2d coarse-grained fp32, synthetic 480x320 seq @%g%% "
+                               "change (%dx%d re-drawn blocks), experiment %d, one sequence per GPU"
+                               % (100 * vid.ratio, args.block, args.block, args.experiment),
+                   "launch": args.mode, "threshold": args.threshold},
+        "effective_gflops": fps * dense_ops / 1e9,
+    }
+
+    # dense network on the same GPU, timed the same way (eval01.py:68)
+    if not args.no_dense and world == 1:
+        drunner = FrameRunner(base, frames[0], args.mode)
+        drunner.prime(prime)
+        for i in range(min(args.warmup, 5)):
+            drunner.step(frames[i % len(frames)])
+        dsteps = max(10, args.steps // 4)
+        delapsed = timed_loop(drunner, frames, dsteps, lambda: None)
+        result["dense_fps"] = dsteps / delapsed
+        result["speedup_vs_dense"] = fps / result["dense_fps"]
+        result["dense_tflops"] = result["dense_fps"] * dense_ops / 1e12
+
+    # per-kernel measurement (HIP events on the launch stream) -> roofline of the dominant kernel
+    if world == 1:
+        test_rows = kernel_breakdown(test, frames)
+        result["layers"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()}
+                            for r in test_rows]
+        best = None
+        for r in test_rows:
+            for kname in ("detect", "compact", "conv", "pool"):
+                if kname + "_ms" in r and (best is None or r[kname + "_ms"] > best[2]):
+                    best = (r, kname, r[kname + "_ms"])
+        r, kname, ms = best
+        if kname == "conv":
+            ach = r["conv_flops"] / (ms * 1e-3) / 1e12
+            result["roofline"] = {"kernel": "cb_mfma_f32_kernel (fused gather->MFMA->scatter), " + r["layer"],
+                                  "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                                  "avg_duration_us": ms * 1e3, "units_per_launch": r["N"]}
+        else:
+            ach = r[kname + "_bytes"] / (ms * 1e-3) / 1e9
+            result["roofline"] = {"kernel": kname + ", " + r["layer"], "bound": "hbm", "achieved": ach,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                  "traffic": None, "avg_duration_us": ms * 1e3, "units_per_launch": r["N"]}
+        if args.breakdown:
+            for r in test_rows:
+                log(json.dumps(r))
+
+    if not args.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = cpu_baseline(test, dict(H=H, W=W, ratio=args.ratio, block=args.block,
+                                                         seed=1234))
+
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -214,7 +214,8 @@ def test_half_network(pkg):
     from cbinfer_amd import workloads
     base, test = workloads.sceneLabelingModels(experimentIdx=6, threshold=0.05, dtype=torch.float16)
     vid = workloads.SyntheticVideo(H=64, W=96, ratio=0.1, block=16, seed=3, dtype=torch.float16)
-    ref = base.float()
+    import copy
+    ref = copy.deepcopy(base).float()      # base shares its Parameters with the test model
     with torch.no_grad():
         for fr in vid.frames(3):
             y = test(fr)

@@ -29,7 +29,8 @@ _SIGNATURES = {
     "cbinfer_change_indexes_extr": (_i, [_vp, _l, _vp, _vp, _vp, _vp]),
     "cbinfer_compact_bits": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cbinfer_gen_x_matrix": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
-    "cbinfer_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "cbinfer_prepared_weights_bytes": (_l, [_i, _i, _i, _i, _i]),
+    "cbinfer_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cbinfer_matrix_mult": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "cbinfer_update_output": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "cbinfer_conv_changed": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,

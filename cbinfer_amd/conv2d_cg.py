@@ -158,10 +158,13 @@ def prepWeights(weights):
     require_device(weights)
     w = weights.detach().contiguous()
     K = w.size(0)
-    Ckk = w.numel() // K
-    KP, CkkP = C.cbinfer_weights_kpad(K), C.cbinfer_weights_ckkpad(Ckk)
-    wp = w.new_empty(KP * CkkP)
-    check(C.cbinfer_prep_weights(ptr(w), ptr(wp), K, Ckk, dtype_code(w), stream_ptr(w)))
+    if w.dim() == 4:
+        Cin, kH, kW = w.size(1), w.size(2), w.size(3)
+    else:
+        Cin, kH, kW = w.numel() // K, 1, 1
+    nbytes = C.cbinfer_prepared_weights_bytes(K, Cin, kH, kW, dtype_code(w))
+    wp = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    check(C.cbinfer_prep_weights(ptr(w), ptr(wp), K, Cin, kH, kW, dtype_code(w), stream_ptr(w)))
     return wp
 
 

@@ -9,12 +9,15 @@
 // pixels of one output-channel plane per store instruction.
 //   fp32: v_mfma_f32_32x32x2_f32 (exact f32 fma chain, k-ordered) -- operands A[k][m], B[k][n] in LDS
 //   fp16: v_mfma_f32_32x32x16_f16, f32 accumulation             -- operands A[m][k], B[n][k] in LDS
+#include <stdlib.h>
+
 #include "cb_common.h"
 
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(4))) int cb_const_int;   // constant address space: scalar loads
 
 // n / d by multiply-high with magic = ceil(2^32/d) (exact while n*d < 2^32); magic 0 encodes d == 1
 __device__ __forceinline__ unsigned cb_fastdiv(unsigned n, unsigned magic) {
@@ -26,18 +29,27 @@ __device__ __forceinline__ cb_half cb_relu(cb_half v) { return v <= (cb_half)0 ?
 // ---------------------------------------------------------------------------------------------
 // weight preparation: pad to the MFMA tile grid (zeros), fp32 additionally transposed to k-major
 // ---------------------------------------------------------------------------------------------
+// k -> (c, ky, kx) table appended to the prepared weights: (c << 16) | (ky << 8) | kx, or a negative
+// word for the zero-padded tail k >= Ckk.
+__device__ __forceinline__ int cb_pack_k(int k, int Ckk, int kH, int kW) {
+    if (k >= Ckk) return (int)0x80000000;
+    const int c = k / (kH * kW), r = k % (kH * kW);
+    return (c << 16) | ((r / kW) << 8) | (r % kW);
+}
 __global__ __launch_bounds__(256) void cb_prep_w_f32_kernel(const float* __restrict__ w,
                                                            float* __restrict__ wt, int K, int Ckk,
-                                                           int KP, int CkkP) {
+                                                           int KP, int CkkP, int kH, int kW) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < CkkP) ((int*)(wt + (long)KP * CkkP))[e] = cb_pack_k((int)e, Ckk, kH, kW);
     if (e >= (long)KP * CkkP) return;
     const int m = (int)(e % KP), k = (int)(e / KP);
     wt[e] = (m < K && k < Ckk) ? w[(long)m * Ckk + k] : 0.f;
 }
 __global__ __launch_bounds__(256) void cb_prep_w_f16_kernel(const cb_half* __restrict__ w,
                                                            cb_half* __restrict__ wp, int K, int Ckk,
-                                                           int KP, int CkkP) {
+                                                           int KP, int CkkP, int kH, int kW) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < CkkP) ((int*)(wp + (long)KP * CkkP))[e] = cb_pack_k((int)e, Ckk, kH, kW);
     if (e >= (long)KP * CkkP) return;
     const int k = (int)(e % CkkP), m = (int)(e / CkkP);
     wp[e] = (m < K && k < Ckk) ? w[(long)m * Ckk + k] : (cb_half)0;
@@ -122,19 +134,31 @@ __device__ __forceinline__ void cb_clear_mask(const ConvParams& p) {
 #define CB_EPI_SCATTER 2
 #define CB_EPI_SCATTER_ACC 3
 
-// fp32: WM waves along m (BM = 32*WM), 4/WM waves along n (BN = 32*4/WM), BK = 16 per LDS stage.
-// Global loads for stage s+1 are issued into registers before the MFMAs of stage s (one barrier pair
-// per stage); the gather computes its (c,ky,kx) decode with multiply-high by precomputed reciprocals.
-template <int WM, int MODE, int EPI>
-__global__ __launch_bounds__(256) void cb_mfma_f32_kernel(ConvParams p) {
+// fp32 contraction kernel.
+//   workgroup tile  BM x BN = (32*WM) x (32*WN) outputs, one 32x32 MFMA tile per wave, KS wave groups
+//   splitting the k-depth of every LDS stage between them (in-block split-K: more waves per CU for
+//   the small grids a 10-40 % change list gives, partial tiles summed through LDS at the end);
+//   BK = 32 per stage, two LDS buffers, two register staging sets: the global loads of stage s+2 are
+//   issued before the MFMAs of stage s, one barrier per stage.
+//   Gather: a k-row of the stage is wave-uniform (BN is a multiple of 64), so its (c,ky,kx) decode is a
+//   scalar load from the table built by cbinfer_prep_weights plus scalar arithmetic; per lane only the
+//   pixel offset add and the image-bounds test remain.
+template <int WM, int WN, int KS, int MODE, int EPI>
+__global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvParams p) {
+    constexpr int NT = 64 * WM * WN * KS;
     constexpr int BM = 32 * WM;
-    constexpr int WN = 4 / WM;
     constexpr int BN = 32 * WN;
-    constexpr int BK = CB_BK;
+    constexpr int BK = 32;
     constexpr int LDB = BN + 2;
-    constexpr int A_F4 = BK * BM / 4;           // float4s per A stage
-    constexpr int A_PER_T = (A_F4 + 255) / 256;  // 1 (BM<=64) or 2 (BM=128)
-    constexpr int B_PER_T = BK * BN / 256;       // 8 / 4 / 2
+    constexpr int A_F4 = BK * BM / 4;
+    constexpr int A_PER_T = (A_F4 + NT - 1) / NT;
+    constexpr int B_PER_T = BK * BN / NT;
+    constexpr int NPP = NT / BK;        // matrix: pixel slots covered by one pass
+    constexpr int KSTEP = BK / KS;      // k-depth one wave group handles per stage
+    constexpr int A_STAGE = BK * BM, B_STAGE = BK * LDB;
+    static_assert(BN % 64 == 0, "gather rows must be wave-uniform");
+    static_assert(BK * BN % NT == 0 && KSTEP % 2 == 0, "bad decomposition");
+    static_assert(KS == 1 || 2 * (A_STAGE + B_STAGE) >= WM * WN * 64 * 16, "reduce buffer");
 
     if (MODE == CB_MODE_GATHER) cb_clear_mask(p);
     const int N = p.countDev ? min(*p.countDev, p.nHost) : p.nHost;
@@ -142,47 +166,63 @@ __global__ __launch_bounds__(256) void cb_mfma_f32_kernel(ConvParams p) {
     if (n0 >= N) return;
     const int m0 = blockIdx.y * BM;
 
-    __shared__ __attribute__((aligned(16))) float As[BK * BM];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_STAGE + B_STAGE)];
+    float* const As = smem;                  // [2][BK][BM]
+    float* const Bs = smem + 2 * A_STAGE;    // [2][BK][LDB]
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int wm = wave % WM, wn = wave / WM;
+    const int ks = wave / (WM * WN), wq = wave % (WM * WN);
+    const int wm = wq % WM, wn = wq / WM;
     const int l31 = lane & 31, h = lane >> 5;
 
     const float* __restrict__ Ag = (const float*)p.A;
     const float* __restrict__ Bg = (const float*)p.B;
+    const int* __restrict__ ktab = (const int*)(Ag + (long)p.KP * p.CkkP);
     const int HW = p.H * p.W;
+    const int ph = (p.kH - 1) / 2, pw = (p.kW - 1) / 2;
 
     // per-thread B-load coordinates
-    int bj, br;             // column (pixel slot) and first k-row this thread loads
-    int py = 0, px = 0;     // gather: pixel coordinates
-    bool pvalid = false;
+    int bj, br;
+    int py = -(1 << 20), px = 0, pbase4 = 0;   // gather: a slot past the list is "outside the image"
     if (MODE == CB_MODE_GATHER) {
         bj = t % BN;
-        br = t / BN;  // rows br + i*(256/BN)
+        br = __builtin_amdgcn_readfirstlane(t / BN) * B_PER_T;   // wave-uniform first k-row
         const int n = n0 + bj;
-        pvalid = n < N;
-        if (pvalid) {
+        if (n < N) {
             const int pos = p.list[n];
             py = pos / p.W;
             px = pos - py * p.W;
+            pbase4 = pos * 4;
         }
     } else {
-        bj = t / BK;  // pixel slots bj + i*(256/BK)
-        br = t % BK;  // k within the stage
+        bj = t / BK;
+        br = t % BK;
     }
-    const int ph = (p.kH - 1) / 2, pw = (p.kW - 1) / 2;
-    const int KHW = p.kH * p.kW;
+    // The gather goes through a raw buffer descriptor over the layer state: a lane whose tap falls
+    // outside the image (or past the list / past Ckk) gets an out-of-range offset and the hardware
+    // returns 0 -- no divergent branch, no select after the load.
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.B, 0, MODE == CB_MODE_GATHER ? p.C * HW * 4 : 0, 0x00020000);
+    const cb_const_int* ktab_c = (const cb_const_int*)ktab;
+    int pk[B_PER_T];   // (c,ky,kx) words of the NEXT stage to load: scalar registers
+    auto fetch_pk = [&](int k0) {
+        if (MODE == CB_MODE_GATHER) {
+#pragma unroll
+            for (int i = 0; i < B_PER_T; ++i) pk[i] = ktab_c[k0 + br + i];
+        }
+    };
+    fetch_pk(0);
+    const int kLast = p.CkkP - BK;   // CkkP is a multiple of 2*BK: the stage count is even
 
-    float4 areg[A_PER_T];
-    float breg[B_PER_T];
+    float4 a0[A_PER_T], a1[A_PER_T];
+    float b0[B_PER_T], b1[B_PER_T];
 
-    auto load_stage = [&](int k0) {
+    auto load_stage = [&](int k0, float4(&areg)[A_PER_T], float(&breg)[B_PER_T]) {
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
-            const int f = t + i * 256;
-            if (A_F4 >= 256 || f < A_F4) {
+            const int f = t + i * NT;
+            if (A_F4 % NT == 0 || f < A_F4) {
                 const int row = f / (BM / 4), c4 = f % (BM / 4);
                 areg[i] = *(const float4*)(Ag + (long)(k0 + row) * p.KP + m0 + c4 * 4);
             }
@@ -191,35 +231,36 @@ __global__ __launch_bounds__(256) void cb_mfma_f32_kernel(ConvParams p) {
         for (int i = 0; i < B_PER_T; ++i) {
             float v = 0.f;
             if (MODE == CB_MODE_GATHER) {
-                const unsigned kg = (unsigned)(k0 + br + i * (256 / BN));
-                const unsigned c = cb_fastdiv(kg, p.magicKHW);
-                const unsigned r = kg - c * KHW;
-                const unsigned ky = cb_fastdiv(r, p.magicKW);
-                const unsigned kx = r - ky * p.kW;
-                const int iy = py + (int)ky - ph, ix = px + (int)kx - pw;
-                const bool ok = pvalid && (int)kg < p.Ckk && (unsigned)iy < (unsigned)p.H &&
-                                (unsigned)ix < (unsigned)p.W;
-                if (ok) v = Bg[(long)c * HW + iy * p.W + ix];
+                const int w = pk[i];                              // scalar
+                const int dy = ((w >> 8) & 0xff) - ph, dx = (w & 0xff) - pw;
+                const int koff4 = (((w >> 16) & 0x7fff) * HW + dy * p.W + dx) * 4;
+                const int iy = py + dy, ix = px + dx;
+                const bool ok = (w >= 0) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                const int voff = ok ? pbase4 + koff4 : (1 << 30);
+                v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, voff, 0, 0));
             } else {
-                const int n = n0 + bj + i * (256 / BK);
+                const int n = n0 + bj + i * NPP;
                 const int kg = k0 + br;
                 if (n < N && kg < p.Ckk) v = Bg[(long)n * p.Ckk + kg];
             }
             breg[i] = v;
         }
+        fetch_pk(min(k0 + BK, kLast));   // consecutive calls load consecutive stages
     };
-    auto store_stage = [&]() {
+    auto store_stage = [&](int buf, const float4(&areg)[A_PER_T], const float(&breg)[B_PER_T]) {
+        float* as = As + buf * A_STAGE;
+        float* bs = Bs + buf * B_STAGE;
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
-            const int f = t + i * 256;
-            if (A_F4 >= 256 || f < A_F4) *(float4*)(As + f * 4) = areg[i];
+            const int f = t + i * NT;
+            if (A_F4 % NT == 0 || f < A_F4) *(float4*)(as + f * 4) = areg[i];
         }
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) {
             if (MODE == CB_MODE_GATHER)
-                Bs[(br + i * (256 / BN)) * LDB + bj] = breg[i];
+                bs[(br + i) * LDB + bj] = breg[i];
             else
-                Bs[br * LDB + bj + i * (256 / BK)] = breg[i];
+                bs[br * LDB + bj + i * NPP] = breg[i];
         }
     };
 
@@ -227,18 +268,49 @@ __global__ __launch_bounds__(256) void cb_mfma_f32_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    load_stage(0);
-    for (int k0 = 0; k0 < p.CkkP; k0 += BK) {
-        store_stage();
-        __syncthreads();
-        if (k0 + BK < p.CkkP) load_stage(k0 + BK);
+    auto compute = [&](int buf) {
+        const float* as = As + buf * A_STAGE + wm * 32 + l31;
+        const float* bs = Bs + buf * B_STAGE + wn * 32 + l31;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float a = As[(kk + h) * BM + wm * 32 + l31];
-            const float b = Bs[(kk + h) * LDB + wn * 32 + l31];
+        for (int kk = ks * KSTEP; kk < (ks + 1) * KSTEP; kk += 2) {
+            const float a = as[(kk + h) * BM];
+            const float b = bs[(kk + h) * LDB];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
+    };
+
+    // Every iteration issues the same number of loads (past the end they re-load the last stage and
+    // are never stored), so the compiler's counted vmcnt waits only for the set being stored.
+    load_stage(0, a0, b0);
+    load_stage(BK, a1, b1);
+    for (int k0 = 0; k0 < p.CkkP; k0 += 2 * BK) {
+        store_stage(0, a0, b0);
         __syncthreads();
+        load_stage(min(k0 + 2 * BK, kLast), a0, b0);
+        compute(0);
+        store_stage(1, a1, b1);
+        __syncthreads();
+        load_stage(min(k0 + 3 * BK, kLast), a1, b1);
+        compute(1);
+    }
+
+    if (KS > 1) {   // sum the wave groups' partial tiles through LDS (fixed order: deterministic)
+        __syncthreads();
+        float* red = smem + (wq * 16) * 64 + lane;
+#pragma unroll
+        for (int g = 1; g < KS; ++g) {
+            if (ks == g) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[r * 64] = acc[r];
+            }
+            __syncthreads();
+            if (ks == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += red[r * 64];
+            }
+            if (g + 1 < KS) __syncthreads();
+        }
+        if (ks != 0) return;
     }
 
     // epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -417,24 +489,48 @@ __global__ __launch_bounds__(256) void cb_mfma_f16_kernel(ConvParams p) {
 
 unsigned magic_u32(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 
+// Tile configuration.  cfg = 100*WM + 10*WN + KS; the CBINFER_CONV_CFG environment variable overrides
+// the heuristic (tuning aid).  KP == 32 (K <= 32): one m-tile, 128 pixels per workgroup; otherwise
+// 64 x 64.  KS (in-block split-K): 2 unless the k-depth is a single stage.
+template <int WM, int WN, int KS, int MODE, int EPI>
+int launch_f32(const ConvParams& p, hipStream_t s) {
+    dim3 grid(cb_div_up(p.nHost, 32 * WN), p.KP / (32 * WM)), block(64 * WM * WN * KS);
+    if (grid.x == 0) return CB_OK;
+    hipLaunchKernelGGL((cb_mfma_f32_kernel<WM, WN, KS, MODE, EPI>), grid, block, 0, s, p);
+    return cb_launch_status();
+}
+
+int conv_cfg_override() {
+    const char* e = getenv("CBINFER_CONV_CFG");
+    return e ? atoi(e) : 0;
+}
+
 template <int MODE, int EPI>
 int launch_mfma(const ConvParams& p, int dtype, hipStream_t s) {
-    // tile choice: KP == 32 -> one m-tile, 128 pixels per workgroup; otherwise 64 x 64
     const bool narrow = p.KP <= 32;
+    if (dtype == CB_F32) {
+        int cfg = conv_cfg_override();
+        if (cfg == 0) cfg = narrow ? 142 : 224;
+        if (narrow && cfg / 100 != 1) cfg = 142;
+        switch (cfg) {
+            case 141: return launch_f32<1, 4, 1, MODE, EPI>(p, s);
+            case 142: return launch_f32<1, 4, 2, MODE, EPI>(p, s);
+            case 121: return launch_f32<1, 2, 1, MODE, EPI>(p, s);
+            case 122: return launch_f32<1, 2, 2, MODE, EPI>(p, s);
+            case 124: return launch_f32<1, 2, 4, MODE, EPI>(p, s);
+            case 221: return launch_f32<2, 2, 1, MODE, EPI>(p, s);
+            case 222: return launch_f32<2, 2, 2, MODE, EPI>(p, s);
+            case 224: return launch_f32<2, 2, 4, MODE, EPI>(p, s);
+            default: return CB_ERR_BADARG;
+        }
+    }
     const int BM = narrow ? 32 : 64, BN = narrow ? 128 : 64;
     dim3 grid(cb_div_up(p.nHost, BN), p.KP / BM), block(256);
     if (grid.x == 0) return CB_OK;
-    if (dtype == CB_F32) {
-        if (narrow)
-            hipLaunchKernelGGL((cb_mfma_f32_kernel<1, MODE, EPI>), grid, block, 0, s, p);
-        else
-            hipLaunchKernelGGL((cb_mfma_f32_kernel<2, MODE, EPI>), grid, block, 0, s, p);
-    } else {
-        if (narrow)
-            hipLaunchKernelGGL((cb_mfma_f16_kernel<1, MODE, EPI>), grid, block, 0, s, p);
-        else
-            hipLaunchKernelGGL((cb_mfma_f16_kernel<2, MODE, EPI>), grid, block, 0, s, p);
-    }
+    if (narrow)
+        hipLaunchKernelGGL((cb_mfma_f16_kernel<1, MODE, EPI>), grid, block, 0, s, p);
+    else
+        hipLaunchKernelGGL((cb_mfma_f16_kernel<2, MODE, EPI>), grid, block, 0, s, p);
     return cb_launch_status();
 }
 
@@ -443,20 +539,27 @@ int launch_mfma(const ConvParams& p, int dtype, hipStream_t s) {
 extern "C" {
 
 int cbinfer_weights_kpad(int K) { return (K + CB_MFMA_M - 1) / CB_MFMA_M * CB_MFMA_M; }
-int cbinfer_weights_ckkpad(int Ckk) { return (Ckk + CB_BK_H - 1) / CB_BK_H * CB_BK_H; }
+int cbinfer_weights_ckkpad(int Ckk) { return (Ckk + 63) / 64 * 64; }
 
-int cbinfer_prep_weights(const void* weight, void* weightsPrepared, int K, int Ckk, int dtype,
-                         cbStream_t stream) {
-    CB_REQUIRE(weight && weightsPrepared && K > 0 && Ckk > 0);
+long cbinfer_prepared_weights_bytes(int K, int C, int kH, int kW, int dtype) {
+    const long KP = cbinfer_weights_kpad(K), CkkP = cbinfer_weights_ckkpad(C * kH * kW);
+    return KP * CkkP * (dtype == CB_F16 ? 2 : 4) + CkkP * 4;
+}
+
+int cbinfer_prep_weights(const void* weight, void* weightsPrepared, int K, int C, int kH, int kW,
+                         int dtype, cbStream_t stream) {
+    CB_REQUIRE(weight && weightsPrepared && K > 0 && C > 0 && kH > 0 && kW > 0);
+    if (C >= 32768 || kH > 255 || kW > 255) return CB_ERR_UNSUPPORTED;
+    const int Ckk = C * kH * kW;
     const int KP = cbinfer_weights_kpad(K), CkkP = cbinfer_weights_ckkpad(Ckk);
     const long total = (long)KP * CkkP;
     dim3 grid(cb_div_up(total, 256)), block(256);
     if (dtype == CB_F32)
         hipLaunchKernelGGL(cb_prep_w_f32_kernel, grid, block, 0, (hipStream_t)stream,
-                           (const float*)weight, (float*)weightsPrepared, K, Ckk, KP, CkkP);
+                           (const float*)weight, (float*)weightsPrepared, K, Ckk, KP, CkkP, kH, kW);
     else if (dtype == CB_F16)
         hipLaunchKernelGGL(cb_prep_w_f16_kernel, grid, block, 0, (hipStream_t)stream,
-                           (const cb_half*)weight, (cb_half*)weightsPrepared, K, Ckk, KP, CkkP);
+                           (const cb_half*)weight, (cb_half*)weightsPrepared, K, Ckk, KP, CkkP, kH, kW);
     else
         return CB_ERR_BADARG;
     return cb_launch_status();

@@ -104,9 +104,13 @@ int cbinfer_gen_x_matrix(void* columns, const void* input, const int32_t* change
  * transposeOut=1, also the transpose+contiguous of conv2d.py:247 / conv2d_cg.py:305.
  * Y = X[N,Ckk] . W[K,Ckk]^T + bias; Y is [N,K] (transposeOut=0) or [K,N] (transposeOut=1).
  * fp32: exact-f32 MFMA (v_mfma_f32_32x32x2_f32); fp16: f16 MFMA with f32 accumulation.
- * weightsPrepared is the matrix produced by cbinfer_prep_weights. */
-int cbinfer_prep_weights(const void* weight, void* weightsPrepared, int K, int Ckk, int dtype,
-                         cbStream_t stream);
+ * weightsPrepared is the buffer produced by cbinfer_prep_weights from the [K,C,kH,kW] filter bank:
+ * the matrix padded to the MFMA tile grid (fp32: transposed to k-major) followed by a k->(c,ky,kx)
+ * table; cbinfer_prepared_weights_bytes gives its size.  For a plain [K,Ckk] matrix pass C=Ckk,
+ * kH=kW=1. */
+long cbinfer_prepared_weights_bytes(int K, int C, int kH, int kW, int dtype);
+int cbinfer_prep_weights(const void* weight, void* weightsPrepared, int K, int C, int kH, int kW,
+                         int dtype, cbStream_t stream);
 int cbinfer_matrix_mult(const void* X, const void* weightsPrepared, const void* bias, void* Y,
                         int N, const int32_t* countDev, int Ckk, int K, int transposeOut, int dtype,
                         cbStream_t stream);

@@ -141,10 +141,11 @@ def kernel_breakdown(test, frames, reps=50):
                 t_zero = event_time_ms(lambda: bits.zero_(), reps)
                 t_cmp = event_time_ms(lambda: check(lib.cbinfer_compact_bits(
                     ptr(m._work['bits']), Ww, Hh, ptr(idx), ptr(cnt), None, None, stream_ptr())), reps)
-                wp = m._prepared_weights()
+                wp = m._prepared_weights(Hh, Ww)
+                ws = cg.convWorkspace(inp.device)
                 t_conv = event_time_ms(lambda: check(lib.cbinfer_conv_changed(
                     ptr(m.prevInput), ptr(ci.buffer), Hh * Ww, ptr(ci.count), ptr(wp), ptr(m.bias.detach()),
-                    ptr(m.prevOutput), C, Hh, Ww, K, kH, kW, int(m.withReLU), 0, None, 0, dt,
+                    ptr(m.prevOutput), C, Hh, Ww, K, kH, kW, int(m.withReLU), 0, None, 0, ptr(ws), dt,
                     stream_ptr())), reps)
                 HW = Hh * Ww
                 rows.append(dict(layer="conv %d->%d k%d @%dx%d" % (C, K, kH, Hh, Ww), N=N,

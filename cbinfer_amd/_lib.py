@@ -30,13 +30,14 @@ _SIGNATURES = {
     "cbinfer_compact_bits": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cbinfer_gen_x_matrix": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "cbinfer_prepared_weights_bytes": (_l, [_i, _i, _i, _i, _i]),
-    "cbinfer_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "cbinfer_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "cbinfer_conv_workspace_bytes": (_l, []),
     "cbinfer_matrix_mult": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "cbinfer_update_output": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "cbinfer_conv_changed": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
-                                  _vp, _l, _i, _vp]),
+                                  _vp, _l, _vp, _i, _vp]),
     "cbinfer_cbconv2d_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
-                                      _i, _f, _i, _i, _i, _i, _i, _i, _vp]),
+                                      _i, _f, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "cbinfer_max_pool2d": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cbinfer_change_detection_fg": (_i, [_vp, _vp, _vp, _vp, _l, _f, _i, _vp]),
     "cbinfer_update_output_fg": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _vp]),

@@ -22,8 +22,8 @@ import torch.nn.functional as F
 
 from . import _lib
 from ._lib import C, check, dtype_code, ptr, require_device, stream_ptr
-from .conv2d_cg import (ChangeIndexes, changeDetection, changeIndexesExtr, genXMatrix, matrixMult,
-                        maxPool2d, prepWeights, updateOutput)
+from .conv2d_cg import (ChangeIndexes, changeDetection, changeIndexesExtr, convWorkspace, genXMatrix,
+                        matrixMult, maxPool2d, prepWeights, updateOutput)
 from .conv2d_fg import cbconvFG, cbconvFG_deterministic
 
 
@@ -164,11 +164,11 @@ class CBConv2d(nn.Module):
         d['_wprep'] = None
         return d
 
-    def _prepared_weights(self):
+    def _prepared_weights(self, H=1, W=1):
         w = self.weight
-        key = (w.data_ptr(), w._version, w.dtype, w.device)
+        key = (w.data_ptr(), w._version, w.dtype, w.device, H, W)
         if self._wprep is None or self._wprep[0] != key:
-            self._wprep = (key, prepWeights(w))
+            self._wprep = (key, prepWeights(w, H, W))
         return self._wprep[1]
 
     def _workspace(self, input):
@@ -197,9 +197,9 @@ class CBConv2d(nn.Module):
         else:
             po = self.prevOutput.clone()
             if self.deterministicFG and input.is_cuda:
-                self.prevOutput = cbconvFG_deterministic(input.contiguous(), self.prevInput, po,
-                                                         self.weight.detach(), self.threshold,
-                                                         weightsPrepared=self._prepared_weights())
+                self.prevOutput = cbconvFG_deterministic(
+                    input.contiguous(), self.prevInput, po, self.weight.detach(), self.threshold,
+                    weightsPrepared=self._prepared_weights(input.size(-2), input.size(-1)))
             else:
                 self.prevOutput = cbconvFG(input.contiguous(), self.prevInput, po,
                                            self.weight.detach(), self.threshold)
@@ -282,10 +282,11 @@ class CBConv2d(nn.Module):
         if cap > 0:
             check(C.cbinfer_cbconv2d_forward(
                 ptr(input), ptr(prev), ptr(self.prevOutput), None if have else ptr(work['bits']),
-                ptr(idx), ptr(count), ptr(mapOut), ptr(self._prepared_weights()),
+                ptr(idx), ptr(count), ptr(mapOut), ptr(self._prepared_weights(H, W)),
                 ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold),
                 int(bool(self.feedbackLoop)), int(bool(self.copyInput)), int(bool(self.withReLU)),
-                int(have), cap, dtype_code(input), stream_ptr(input)))
+                int(have), cap, ptr(convWorkspace(input.device)), dtype_code(input),
+                stream_ptr(input)))
         if mapOut is not None:
             self.changeMap = mapOut
         if not self.feedbackLoop and not self.copyInput:

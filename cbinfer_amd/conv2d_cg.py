@@ -153,8 +153,25 @@ def genXMatrix(input, changeIndexes, filtSize, useHalf=False):
 # ------------------------------------------------------------------------------------------------
 # a6/a7 the contraction
 # ------------------------------------------------------------------------------------------------
-def prepWeights(weights):
-    """Pad (and for fp32 transpose to k-major) the [K,C,kH,kW] filter bank for the MFMA kernels."""
+_workspaces = {}
+
+
+def convWorkspace(device):
+    """Zero-initialised split-K workspace of the persistent contraction kernel, one per device.
+    The kernels leave it zero; it is shared by all launches on the device, which is safe as long as
+    they are ordered (one stream, or one graph) -- modules running on several streams at once own
+    private ones (CBConv2d.privateWorkspace)."""
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = torch.zeros(C.cbinfer_conv_workspace_bytes(), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def prepWeights(weights, H=1, W=1):
+    """Pad (and for fp32 transpose to k-major) the [K,C,kH,kW] filter bank for the MFMA kernels and
+    append the tap table for an H x W feature map."""
     require_device(weights)
     w = weights.detach().contiguous()
     K = w.size(0)
@@ -164,7 +181,7 @@ def prepWeights(weights):
         Cin, kH, kW = w.numel() // K, 1, 1
     nbytes = C.cbinfer_prepared_weights_bytes(K, Cin, kH, kW, dtype_code(w))
     wp = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    check(C.cbinfer_prep_weights(ptr(w), ptr(wp), K, Cin, kH, kW, dtype_code(w), stream_ptr(w)))
+    check(C.cbinfer_prep_weights(ptr(w), ptr(wp), K, Cin, kH, kW, H, W, dtype_code(w), stream_ptr(w)))
     return wp
 
 
@@ -233,11 +250,11 @@ def convChanged(input, changeIndexes, weights, bias, prevOutput, withReLU=False,
     idx, count, cap = _split_indexes(changeIndexes)
     if cap == 0:
         return prevOutput
-    wp = weightsPrepared if weightsPrepared is not None else prepWeights(weights)
+    wp = weightsPrepared if weightsPrepared is not None else prepWeights(weights, H, W)
     b = bias.detach().contiguous() if bias is not None else None
     check(C.cbinfer_conv_changed(ptr(inp), ptr(idx), cap, ptr(count), ptr(wp), ptr(b), ptr(prevOutput),
                                  Cin, H, W, K, kH, kW, int(bool(withReLU)), int(bool(accumulate)), None,
-                                 0, dtype_code(inp), stream_ptr(inp)))
+                                 0, ptr(convWorkspace(inp.device)), dtype_code(inp), stream_ptr(inp)))
     return prevOutput
 
 
@@ -262,6 +279,6 @@ def maxPool2d(input, outputState, changeIndexes, kernelSize, stride, useHalf=Fal
     return outputState
 
 
-__all__ = ['ChangeIndexes', 'changeDetection', 'changePropagation', 'changeIndexesExtr',
+__all__ = ['ChangeIndexes', 'convWorkspace', 'changeDetection', 'changePropagation', 'changeIndexesExtr',
            'changeIndexesExtrAsync', 'genXMatrix', 'prepWeights', 'matrixMult', 'matrixMult_python',
            'updateOutput', 'convChanged', 'maxPool2d', 'CBinferError']

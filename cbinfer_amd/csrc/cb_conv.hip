@@ -18,6 +18,8 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(4))) int cb_const_int;   // constant address space: scalar loads
+typedef int cb_i2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(4))) cb_i2 cb_const_int2;
 
 // n / d by multiply-high with magic = ceil(2^32/d) (exact while n*d < 2^32); magic 0 encodes d == 1
 __device__ __forceinline__ unsigned cb_fastdiv(unsigned n, unsigned magic) {
@@ -29,27 +31,32 @@ __device__ __forceinline__ cb_half cb_relu(cb_half v) { return v <= (cb_half)0 ?
 // ---------------------------------------------------------------------------------------------
 // weight preparation: pad to the MFMA tile grid (zeros), fp32 additionally transposed to k-major
 // ---------------------------------------------------------------------------------------------
-// k -> (c, ky, kx) table appended to the prepared weights: (c << 16) | (ky << 8) | kx, or a negative
-// word for the zero-padded tail k >= Ckk.
-__device__ __forceinline__ int cb_pack_k(int k, int Ckk, int kH, int kW) {
-    if (k >= Ckk) return (int)0x80000000;
+// k -> tap table appended to the prepared weights, two words per k:
+//   .x = byte offset of the tap relative to the output pixel in a [C,H,W] tensor of elemSize bytes,
+//   .y = (dx << 16) | (dy & 0xffff)   (signed 16-bit each)
+// The zero-padded tail k >= Ckk gets dy = -32768, i.e. always outside the image.
+__device__ __forceinline__ int2 cb_pack_k(int k, int Ckk, int kH, int kW, int H, int W, int elemSize) {
+    if (k >= Ckk) return make_int2(1 << 30, 0x8000);
     const int c = k / (kH * kW), r = k % (kH * kW);
-    return (c << 16) | ((r / kW) << 8) | (r % kW);
+    const int dy = r / kW - (kH - 1) / 2, dx = r % kW - (kW - 1) / 2;
+    return make_int2((c * H * W + dy * W + dx) * elemSize, (dx << 16) | (dy & 0xffff));
 }
 __global__ __launch_bounds__(256) void cb_prep_w_f32_kernel(const float* __restrict__ w,
                                                            float* __restrict__ wt, int K, int Ckk,
-                                                           int KP, int CkkP, int kH, int kW) {
+                                                           int KP, int CkkP, int kH, int kW, int H,
+                                                           int W) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < CkkP) ((int*)(wt + (long)KP * CkkP))[e] = cb_pack_k((int)e, Ckk, kH, kW);
+    if (e < CkkP) ((int2*)(wt + (long)KP * CkkP))[e] = cb_pack_k((int)e, Ckk, kH, kW, H, W, 4);
     if (e >= (long)KP * CkkP) return;
     const int m = (int)(e % KP), k = (int)(e / KP);
     wt[e] = (m < K && k < Ckk) ? w[(long)m * Ckk + k] : 0.f;
 }
 __global__ __launch_bounds__(256) void cb_prep_w_f16_kernel(const cb_half* __restrict__ w,
                                                            cb_half* __restrict__ wp, int K, int Ckk,
-                                                           int KP, int CkkP, int kH, int kW) {
+                                                           int KP, int CkkP, int kH, int kW, int H,
+                                                           int W) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < CkkP) ((int*)(wp + (long)KP * CkkP))[e] = cb_pack_k((int)e, Ckk, kH, kW);
+    if (e < CkkP) ((int2*)(wp + (long)KP * CkkP))[e] = cb_pack_k((int)e, Ckk, kH, kW, H, W, 2);
     if (e >= (long)KP * CkkP) return;
     const int k = (int)(e % CkkP), m = (int)(e / CkkP);
     wp[e] = (m < K && k < Ckk) ? w[(long)m * Ckk + k] : (cb_half)0;
@@ -116,17 +123,20 @@ struct ConvParams {
     int relu;
     unsigned long long* clearBits;  // optional: change bit mask to zero for the next frame
     long clearWords;
+    float* slabs;   // optional split-K workspace: gridDim.x partial tiles of 64x64 floats ...
+    int* tickets;   // ... and gridDim.x arrival counters (zero between launches)
 };
 
 // The fused kernel is the last consumer of the frame's change mask, so it re-zeroes it (before any
 // early exit): the next frame's detection can atomicOr into a clean mask without a memset node.
 __device__ __forceinline__ void cb_clear_mask(const ConvParams& p) {
-    if (p.clearBits && blockIdx.y == 0)
+    if (p.clearBits && blockIdx.y == 0)   // (the fp32 kernel's grid is 1-D)
         for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.clearWords;
              i += (long)gridDim.x * blockDim.x)
             p.clearBits[i] = 0ull;
 }
 
+#define CB_CONV_GRID_PER_CU 2
 #define CB_MODE_MATRIX 0
 #define CB_MODE_GATHER 1
 #define CB_EPI_Y 0
@@ -134,15 +144,26 @@ __device__ __forceinline__ void cb_clear_mask(const ConvParams& p) {
 #define CB_EPI_SCATTER 2
 #define CB_EPI_SCATTER_ACC 3
 
-// fp32 contraction kernel.
-//   workgroup tile  BM x BN = (32*WM) x (32*WN) outputs, one 32x32 MFMA tile per wave, KS wave groups
-//   splitting the k-depth of every LDS stage between them (in-block split-K: more waves per CU for
-//   the small grids a 10-40 % change list gives, partial tiles summed through LDS at the end);
-//   BK = 32 per stage, two LDS buffers, two register staging sets: the global loads of stage s+2 are
-//   issued before the MFMAs of stage s, one barrier per stage.
-//   Gather: a k-row of the stage is wave-uniform (BN is a multiple of 64), so its (c,ky,kx) decode is a
-//   scalar load from the table built by cbinfer_prep_weights plus scalar arithmetic; per lane only the
-//   pixel offset add and the image-bounds test remain.
+// fp32 contraction kernel (persistent, load-balanced).
+//   tile      BM x BN = (32*WM) x (32*WN) outputs, one 32x32 MFMA tile per wave; KS wave groups split the
+//             k-depth of every LDS stage between them (partials summed through LDS at the end).
+//   schedule  a FIXED grid (2 workgroups per CU) walks the work items (tile, k-slice) computed from the
+//             device-side list length N: the host never needs N, idle workgroups exit at once, and a
+//             short list is split along k (SK slices per tile) so that it still fills the chip.  The SK
+//             partial tiles of a tile go to a workspace slab; the workgroup whose ticket is last sums
+//             them in slice order (deterministic) and runs the epilogue -- agent-scope release by every
+//             writer, one acquire by the reducer, nobody ever waits.
+//   pipeline  BK = 32 per stage, two LDS buffers, two register staging sets: the loads of stage s+2 are
+//             issued during stage s, one barrier per stage, every stage issues the same number of loads
+//             so the compiler's counted vmcnt only waits for the set being stored.  Odd wave groups
+//             run [MFMA, issue loads], even ones [issue loads, MFMA], so the address arithmetic of one
+//             half overlaps the matrix work of the other.
+//   gather    a k-row of a stage is wave-uniform: its tap (byte offset, dy, dx) comes from the table
+//             built by cbinfer_prep_weights via scalar loads one stage ahead; per lane there remain two
+//             adds, the image-bounds test and a select.  The load goes through a raw buffer descriptor
+//             over the layer state: an out-of-image tap gets an out-of-range offset, for which the
+//             hardware returns 0.
+#define CB_SKMAX 8
 template <int WM, int WN, int KS, int MODE, int EPI>
 __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvParams p) {
     constexpr int NT = 64 * WM * WN * KS;
@@ -156,17 +177,28 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
     constexpr int NPP = NT / BK;        // matrix: pixel slots covered by one pass
     constexpr int KSTEP = BK / KS;      // k-depth one wave group handles per stage
     constexpr int A_STAGE = BK * BM, B_STAGE = BK * LDB;
+    constexpr int TILE = BM * BN;
     static_assert(BN % 64 == 0, "gather rows must be wave-uniform");
     static_assert(BK * BN % NT == 0 && KSTEP % 2 == 0, "bad decomposition");
     static_assert(KS == 1 || 2 * (A_STAGE + B_STAGE) >= WM * WN * 64 * 16, "reduce buffer");
 
     if (MODE == CB_MODE_GATHER) cb_clear_mask(p);
     const int N = p.countDev ? min(*p.countDev, p.nHost) : p.nHost;
-    const int n0 = blockIdx.x * BN;
-    if (n0 >= N) return;
-    const int m0 = blockIdx.y * BM;
+    const int MT = p.KP / BM;
+    const int T = ((N + BN - 1) / BN) * MT;                  // output tiles
+    const int P = p.CkkP / (2 * BK);                         // stage pairs along k
+    // Split along k only while whole CUs would otherwise idle (T below the CU count) and the k-depth is
+    // long enough to pay for the slab round trip: the reducer costs ~4 us of fences + ~1 us per slab,
+    // a stage pair ~1.7 us, so the best slice count is ~sqrt(1.7 P).
+    int SK = 1;
+    const int cus = (int)gridDim.x / CB_CONV_GRID_PER_CU;
+    if (p.slabs && T > 0 && T < cus && P >= 8)
+        SK = max(1, min(min(CB_SKMAX, cus / T), (int)sqrtf(1.7f * (float)P)));
+    const int items = T * SK;
+    if ((int)blockIdx.x >= items) return;
 
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_STAGE + B_STAGE)];
+    __shared__ int s_last;
     float* const As = smem;                  // [2][BK][BM]
     float* const Bs = smem + 2 * A_STAGE;    // [2][BK][LDB]
 
@@ -178,165 +210,211 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
 
     const float* __restrict__ Ag = (const float*)p.A;
     const float* __restrict__ Bg = (const float*)p.B;
-    const int* __restrict__ ktab = (const int*)(Ag + (long)p.KP * p.CkkP);
+    const cb_const_int2* ktab_c = (const cb_const_int2*)(Ag + (long)p.KP * p.CkkP);
     const int HW = p.H * p.W;
-    const int ph = (p.kH - 1) / 2, pw = (p.kW - 1) / 2;
-
-    // per-thread B-load coordinates
-    int bj, br;
-    int py = -(1 << 20), px = 0, pbase4 = 0;   // gather: a slot past the list is "outside the image"
-    if (MODE == CB_MODE_GATHER) {
-        bj = t % BN;
-        br = __builtin_amdgcn_readfirstlane(t / BN) * B_PER_T;   // wave-uniform first k-row
-        const int n = n0 + bj;
-        if (n < N) {
-            const int pos = p.list[n];
-            py = pos / p.W;
-            px = pos - py * p.W;
-            pbase4 = pos * 4;
-        }
-    } else {
-        bj = t / BK;
-        br = t % BK;
-    }
-    // The gather goes through a raw buffer descriptor over the layer state: a lane whose tap falls
-    // outside the image (or past the list / past Ckk) gets an out-of-range offset and the hardware
-    // returns 0 -- no divergent branch, no select after the load.
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.B, 0, MODE == CB_MODE_GATHER ? p.C * HW * 4 : 0, 0x00020000);
-    const cb_const_int* ktab_c = (const cb_const_int*)ktab;
-    int pk[B_PER_T];   // (c,ky,kx) words of the NEXT stage to load: scalar registers
-    auto fetch_pk = [&](int k0) {
-        if (MODE == CB_MODE_GATHER) {
-#pragma unroll
-            for (int i = 0; i < B_PER_T; ++i) pk[i] = ktab_c[k0 + br + i];
-        }
-    };
-    fetch_pk(0);
-    const int kLast = p.CkkP - BK;   // CkkP is a multiple of 2*BK: the stage count is even
-
-    float4 a0[A_PER_T], a1[A_PER_T];
-    float b0[B_PER_T], b1[B_PER_T];
-
-    auto load_stage = [&](int k0, float4(&areg)[A_PER_T], float(&breg)[B_PER_T]) {
-#pragma unroll
-        for (int i = 0; i < A_PER_T; ++i) {
-            const int f = t + i * NT;
-            if (A_F4 % NT == 0 || f < A_F4) {
-                const int row = f / (BM / 4), c4 = f % (BM / 4);
-                areg[i] = *(const float4*)(Ag + (long)(k0 + row) * p.KP + m0 + c4 * 4);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_PER_T; ++i) {
-            float v = 0.f;
-            if (MODE == CB_MODE_GATHER) {
-                const int w = pk[i];                              // scalar
-                const int dy = ((w >> 8) & 0xff) - ph, dx = (w & 0xff) - pw;
-                const int koff4 = (((w >> 16) & 0x7fff) * HW + dy * p.W + dx) * 4;
-                const int iy = py + dy, ix = px + dx;
-                const bool ok = (w >= 0) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-                const int voff = ok ? pbase4 + koff4 : (1 << 30);
-                v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, voff, 0, 0));
-            } else {
-                const int n = n0 + bj + i * NPP;
-                const int kg = k0 + br;
-                if (n < N && kg < p.Ckk) v = Bg[(long)n * p.Ckk + kg];
-            }
-            breg[i] = v;
-        }
-        fetch_pk(min(k0 + BK, kLast));   // consecutive calls load consecutive stages
-    };
-    auto store_stage = [&](int buf, const float4(&areg)[A_PER_T], const float(&breg)[B_PER_T]) {
-        float* as = As + buf * A_STAGE;
-        float* bs = Bs + buf * B_STAGE;
-#pragma unroll
-        for (int i = 0; i < A_PER_T; ++i) {
-            const int f = t + i * NT;
-            if (A_F4 % NT == 0 || f < A_F4) *(float4*)(as + f * 4) = areg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_PER_T; ++i) {
-            if (MODE == CB_MODE_GATHER)
-                bs[(br + i) * LDB + bj] = breg[i];
-            else
-                bs[br * LDB + bj + i * NPP] = breg[i];
-        }
-    };
-
-    floatx16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-
-    auto compute = [&](int buf) {
-        const float* as = As + buf * A_STAGE + wm * 32 + l31;
-        const float* bs = Bs + buf * B_STAGE + wn * 32 + l31;
-#pragma unroll
-        for (int kk = ks * KSTEP; kk < (ks + 1) * KSTEP; kk += 2) {
-            const float a = as[(kk + h) * BM];
-            const float b = bs[(kk + h) * LDB];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-    };
-
-    // Every iteration issues the same number of loads (past the end they re-load the last stage and
-    // are never stored), so the compiler's counted vmcnt waits only for the set being stored.
-    load_stage(0, a0, b0);
-    load_stage(BK, a1, b1);
-    for (int k0 = 0; k0 < p.CkkP; k0 += 2 * BK) {
-        store_stage(0, a0, b0);
-        __syncthreads();
-        load_stage(min(k0 + 2 * BK, kLast), a0, b0);
-        compute(0);
-        store_stage(1, a1, b1);
-        __syncthreads();
-        load_stage(min(k0 + 3 * BK, kLast), a1, b1);
-        compute(1);
-    }
-
-    if (KS > 1) {   // sum the wave groups' partial tiles through LDS (fixed order: deterministic)
-        __syncthreads();
-        float* red = smem + (wq * 16) * 64 + lane;
-#pragma unroll
-        for (int g = 1; g < KS; ++g) {
-            if (ks == g) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[r * 64] = acc[r];
-            }
-            __syncthreads();
-            if (ks == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] += red[r * 64];
-            }
-            if (g + 1 < KS) __syncthreads();
-        }
-        if (ks != 0) return;
-    }
-
-    // epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int n = n0 + wn * 32 + l31;
-    if (n >= N) return;
     float* __restrict__ out = (float*)p.out;
     const float* __restrict__ bias = (const float*)p.bias;
-    int pix = 0;
-    if (EPI >= CB_EPI_SCATTER) pix = p.list[n];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= p.K) continue;
-        float v = acc[r];
-        if (EPI != CB_EPI_SCATTER_ACC) {
-            if (bias) v += bias[m];
-            if (p.relu) v = cb_relu(v);
+
+    const int bj = MODE == CB_MODE_GATHER ? t % BN : t / BK;
+    const int br = MODE == CB_MODE_GATHER ? __builtin_amdgcn_readfirstlane(t / BN) * B_PER_T : t % BK;
+
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int tile = item / SK, slice = item - tile * SK;
+        const int n0 = (tile / MT) * BN, m0 = (tile % MT) * BM;
+        const int kBeg = (P * slice / SK) * 2 * BK, kEnd = (P * (slice + 1) / SK) * 2 * BK;
+        const int kLast = kEnd - BK;
+
+        // per-thread B-load coordinates; a slot past the list is "outside the image"
+        int py = -(1 << 20), px = 0, pbase4 = 0;
+        if (MODE == CB_MODE_GATHER) {
+            const int n = n0 + bj;
+            if (n < N) {
+                const int pos = p.list[n];
+                py = pos / p.W;
+                px = pos - py * p.W;
+                pbase4 = pos * 4;
+            }
         }
-        if (EPI == CB_EPI_Y)
-            out[(long)n * p.K + m] = v;
-        else if (EPI == CB_EPI_YT)
-            out[(long)m * p.nHost + n] = v;
-        else if (EPI == CB_EPI_SCATTER)
-            out[(long)m * HW + pix] = v;
-        else
-            out[(long)m * HW + pix] += v;
+        cb_i2 pk[B_PER_T];   // taps of the NEXT stage to load: scalar registers
+        auto fetch_pk = [&](int k0) {
+            if (MODE == CB_MODE_GATHER) {
+#pragma unroll
+                for (int i = 0; i < B_PER_T; ++i) pk[i] = ktab_c[k0 + br + i];
+            }
+        };
+        fetch_pk(kBeg);
+
+        float4 a0[A_PER_T], a1[A_PER_T];
+        float b0[B_PER_T], b1[B_PER_T];
+
+        auto load_stage = [&](int k0, float4(&areg)[A_PER_T], float(&breg)[B_PER_T]) {
+#pragma unroll
+            for (int i = 0; i < A_PER_T; ++i) {
+                const int f = t + i * NT;
+                if (A_F4 % NT == 0 || f < A_F4) {
+                    const int row = f / (BM / 4), c4 = f % (BM / 4);
+                    areg[i] = *(const float4*)(Ag + (long)(k0 + row) * p.KP + m0 + c4 * 4);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < B_PER_T; ++i) {
+                float v = 0.f;
+                if (MODE == CB_MODE_GATHER) {
+                    const int koff4 = pk[i].x;                       // scalar
+                    const int dy = (pk[i].y << 16) >> 16, dx = pk[i].y >> 16;
+                    const int iy = py + dy, ix = px + dx;
+                    const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                    const int voff = ok ? pbase4 + koff4 : (1 << 30);
+                    v = __builtin_bit_cast(float,
+                                           __builtin_amdgcn_raw_buffer_load_b32(brsrc, voff, 0, 0));
+                } else {
+                    const int n = n0 + bj + i * NPP;
+                    const int kg = k0 + br;
+                    if (n < N && kg < p.Ckk) v = Bg[(long)n * p.Ckk + kg];
+                }
+                breg[i] = v;
+            }
+            fetch_pk(min(k0 + BK, kLast));   // consecutive calls load consecutive stages
+        };
+        auto store_stage = [&](int buf, const float4(&areg)[A_PER_T], const float(&breg)[B_PER_T]) {
+            float* as = As + buf * A_STAGE;
+            float* bs = Bs + buf * B_STAGE;
+#pragma unroll
+            for (int i = 0; i < A_PER_T; ++i) {
+                const int f = t + i * NT;
+                if (A_F4 % NT == 0 || f < A_F4) *(float4*)(as + f * 4) = areg[i];
+            }
+#pragma unroll
+            for (int i = 0; i < B_PER_T; ++i) {
+                if (MODE == CB_MODE_GATHER)
+                    bs[(br + i) * LDB + bj] = breg[i];
+                else
+                    bs[br * LDB + bj + i * NPP] = breg[i];
+            }
+        };
+
+        floatx16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+        auto compute = [&](int buf) {
+            const float* as = As + buf * A_STAGE + wm * 32 + l31;
+            const float* bs = Bs + buf * B_STAGE + wn * 32 + l31;
+#pragma unroll
+            for (int kk = ks * KSTEP; kk < (ks + 1) * KSTEP; kk += 2) {
+                const float a = as[(kk + h) * BM];
+                const float b = bs[(kk + h) * LDB];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+        };
+
+        // Every stage issues the same number of loads (past the slice end they re-load its last stage
+        // and are never stored).
+        load_stage(kBeg, a0, b0);
+        load_stage(kBeg + BK, a1, b1);
+        const bool mfmaFirst = (KS > 1) && (ks & 1);
+        for (int k0 = kBeg; k0 < kEnd; k0 += 2 * BK) {
+            store_stage(0, a0, b0);
+            __syncthreads();
+            if (mfmaFirst) {
+                compute(0);
+                load_stage(min(k0 + 2 * BK, kLast), a0, b0);
+            } else {
+                load_stage(min(k0 + 2 * BK, kLast), a0, b0);
+                compute(0);
+            }
+            store_stage(1, a1, b1);
+            __syncthreads();
+            if (mfmaFirst) {
+                compute(1);
+                load_stage(min(k0 + 3 * BK, kLast), a1, b1);
+            } else {
+                load_stage(min(k0 + 3 * BK, kLast), a1, b1);
+                compute(1);
+            }
+        }
+        __syncthreads();   // all LDS stage reads done: smem may be reused
+
+        if (KS > 1) {   // sum the wave groups' partial tiles through LDS (fixed order: deterministic)
+            float* red = smem + (wq * 16) * 64 + lane;
+#pragma unroll
+            for (int g = 1; g < KS; ++g) {
+                if (ks == g) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[r * 64] = acc[r];
+                }
+                __syncthreads();
+                if (ks == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] += red[r * 64];
+                }
+                __syncthreads();
+            }
+        }
+
+        if (SK > 1) {
+            // publish this slice's partial tile, take a ticket; the last arriver reduces
+            float* slab = p.slabs + (long)item * TILE + (wq * 16) * 64 + lane;
+            if (ks == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[r * 64] = acc[r];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int ticket = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+                const int last = ticket == SK - 1;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(p.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                s_last = last;
+            }
+            __syncthreads();
+            const bool last = s_last != 0;
+            __syncthreads();   // s_last may be rewritten by the next item
+            if (!last) continue;
+            if (ks == 0) {
+                const float* sl = p.slabs + (long)tile * SK * TILE + (wq * 16) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int j = 0; j < SK; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] += sl[(long)j * TILE + r * 64];
+                }
+            }
+        }
+
+        // epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        const int n = n0 + wn * 32 + l31;
+        if (ks == 0 && n < N) {
+            int pix = 0;
+            if (EPI >= CB_EPI_SCATTER) pix = p.list[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= p.K) continue;
+                float v = acc[r];
+                if (EPI != CB_EPI_SCATTER_ACC) {
+                    if (bias) v += bias[m];
+                    if (p.relu) v = cb_relu(v);
+                }
+                if (EPI == CB_EPI_Y)
+                    out[(long)n * p.K + m] = v;
+                else if (EPI == CB_EPI_YT)
+                    out[(long)m * p.nHost + n] = v;
+                else if (EPI == CB_EPI_SCATTER)
+                    out[(long)m * HW + pix] = v;
+                else
+                    out[(long)m * HW + pix] += v;
+            }
+        }
     }
 }
 
@@ -492,10 +570,28 @@ unsigned magic_u32(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) +
 // Tile configuration.  cfg = 100*WM + 10*WN + KS; the CBINFER_CONV_CFG environment variable overrides
 // the heuristic (tuning aid).  KP == 32 (K <= 32): one m-tile, 128 pixels per workgroup; otherwise
 // 64 x 64.  KS (in-block split-K): 2 unless the k-depth is a single stage.
+int cb_num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        else
+            cus = 256;
+    }
+    return cus;
+}
+
 template <int WM, int WN, int KS, int MODE, int EPI>
 int launch_f32(const ConvParams& p, hipStream_t s) {
-    dim3 grid(cb_div_up(p.nHost, 32 * WN), p.KP / (32 * WM)), block(64 * WM * WN * KS);
-    if (grid.x == 0) return CB_OK;
+    const long tilesCap = (long)cb_div_up(p.nHost, 32 * WN) * (p.KP / (32 * WM));
+    if (tilesCap == 0) return CB_OK;
+    // persistent grid: 2 workgroups per CU (fewer only if the capacity itself is smaller and there is
+    // no split-K workspace to spread it with)
+    long g = CB_CONV_GRID_PER_CU * (long)cb_num_cus();
+    if (!p.slabs && tilesCap < g) g = tilesCap;
+    dim3 grid((unsigned)g), block(64 * WM * WN * KS);
     hipLaunchKernelGGL((cb_mfma_f32_kernel<WM, WN, KS, MODE, EPI>), grid, block, 0, s, p);
     return cb_launch_status();
 }
@@ -510,7 +606,7 @@ int launch_mfma(const ConvParams& p, int dtype, hipStream_t s) {
     const bool narrow = p.KP <= 32;
     if (dtype == CB_F32) {
         int cfg = conv_cfg_override();
-        if (cfg == 0) cfg = narrow ? 142 : 224;
+        if (cfg == 0) cfg = narrow ? 142 : 222;
         if (narrow && cfg / 100 != 1) cfg = 142;
         switch (cfg) {
             case 141: return launch_f32<1, 4, 1, MODE, EPI>(p, s);
@@ -541,25 +637,29 @@ extern "C" {
 int cbinfer_weights_kpad(int K) { return (K + CB_MFMA_M - 1) / CB_MFMA_M * CB_MFMA_M; }
 int cbinfer_weights_ckkpad(int Ckk) { return (Ckk + 63) / 64 * 64; }
 
+long cbinfer_conv_workspace_bytes(void) {
+    return 4096 + (long)CB_CONV_GRID_PER_CU * cb_num_cus() * 64 * 64 * 4;
+}
+
 long cbinfer_prepared_weights_bytes(int K, int C, int kH, int kW, int dtype) {
     const long KP = cbinfer_weights_kpad(K), CkkP = cbinfer_weights_ckkpad(C * kH * kW);
-    return KP * CkkP * (dtype == CB_F16 ? 2 : 4) + CkkP * 4;
+    return KP * CkkP * (dtype == CB_F16 ? 2 : 4) + CkkP * 8;
 }
 
 int cbinfer_prep_weights(const void* weight, void* weightsPrepared, int K, int C, int kH, int kW,
-                         int dtype, cbStream_t stream) {
-    CB_REQUIRE(weight && weightsPrepared && K > 0 && C > 0 && kH > 0 && kW > 0);
-    if (C >= 32768 || kH > 255 || kW > 255) return CB_ERR_UNSUPPORTED;
+                         int H, int W, int dtype, cbStream_t stream) {
+    CB_REQUIRE(weight && weightsPrepared && K > 0 && C > 0 && kH > 0 && kW > 0 && H > 0 && W > 0);
+    if (kH > 255 || kW > 255 || (long)C * H * W * 4 >= (1l << 30)) return CB_ERR_UNSUPPORTED;
     const int Ckk = C * kH * kW;
     const int KP = cbinfer_weights_kpad(K), CkkP = cbinfer_weights_ckkpad(Ckk);
     const long total = (long)KP * CkkP;
     dim3 grid(cb_div_up(total, 256)), block(256);
     if (dtype == CB_F32)
         hipLaunchKernelGGL(cb_prep_w_f32_kernel, grid, block, 0, (hipStream_t)stream,
-                           (const float*)weight, (float*)weightsPrepared, K, Ckk, KP, CkkP, kH, kW);
+                           (const float*)weight, (float*)weightsPrepared, K, Ckk, KP, CkkP, kH, kW, H, W);
     else if (dtype == CB_F16)
         hipLaunchKernelGGL(cb_prep_w_f16_kernel, grid, block, 0, (hipStream_t)stream,
-                           (const cb_half*)weight, (cb_half*)weightsPrepared, K, Ckk, KP, CkkP, kH, kW);
+                           (const cb_half*)weight, (cb_half*)weightsPrepared, K, Ckk, KP, CkkP, kH, kW, H, W);
     else
         return CB_ERR_BADARG;
     return cb_launch_status();
@@ -636,12 +736,12 @@ int cbinfer_update_output(const void* Yt, void* output, const int32_t* changeLis
 int cbinfer_conv_changed(const void* input, const int32_t* changeList, int numChanges,
                          const int32_t* countDev, const void* weightsPrepared, const void* bias,
                          void* output, int C, int H, int W, int K, int kH, int kW, int relu,
-                         int accumulate, uint64_t* clearBits, long clearWords, int dtype,
-                         cbStream_t stream) {
+                         int accumulate, uint64_t* clearBits, long clearWords, void* workspace,
+                         int dtype, cbStream_t stream) {
     CB_REQUIRE(input && changeList && weightsPrepared && output && C > 0 && H > 0 && W > 0 && K > 0 &&
                kH > 0 && kW > 0 && numChanges >= 0);
     CB_REQUIRE(dtype == CB_F32 || dtype == CB_F16);
-    if ((long)C * kH * kW > 65535 || (long)C * H * W >= (1l << 31)) return CB_ERR_UNSUPPORTED;
+    if ((long)C * kH * kW > 65535 || (long)C * H * W * 4 >= (1l << 30)) return CB_ERR_UNSUPPORTED;
     if (numChanges == 0) return CB_OK;
     ConvParams p = {};
     p.A = weightsPrepared;
@@ -665,6 +765,10 @@ int cbinfer_conv_changed(const void* input, const int32_t* changeList, int numCh
     p.relu = relu;
     p.clearBits = (unsigned long long*)clearBits;
     p.clearWords = clearBits ? clearWords : 0;
+    if (workspace && dtype == CB_F32) {   // [tickets: grid ints, padded to 4 KB][slabs: grid x 64x64 floats]
+        p.tickets = (int*)workspace;
+        p.slabs = (float*)((char*)workspace + 4096);
+    }
     if (accumulate)
         return launch_mfma<CB_MODE_GATHER, CB_EPI_SCATTER_ACC>(p, dtype, (hipStream_t)stream);
     return launch_mfma<CB_MODE_GATHER, CB_EPI_SCATTER>(p, dtype, (hipStream_t)stream);

@@ -9,7 +9,7 @@ extern "C" int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void
                                         int8_t* mapOut, const void* weightsPrepared, const void* bias,
                                         int C, int H, int W, int K, int kH, int kW, float threshold,
                                         int feedbackLoop, int copyInput, int relu, int haveIndexes,
-                                        int capN, int dtype, cbStream_t stream) {
+                                        int capN, void* workspace, int dtype, cbStream_t stream) {
     CB_REQUIRE(input && prevInput && prevOutput && idx && countDev && weightsPrepared);
     CB_REQUIRE(dtype == CB_F32 || dtype == CB_F16);
     CB_REQUIRE(capN >= 0 && capN <= H * W);
@@ -32,6 +32,6 @@ extern "C" int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void
     // reference re-points the state at the caller's tensor (:237-238), i.e. the gather reads `input`.
     const void* src = (feedbackLoop || copyInput) ? prevInput : input;
     return cbinfer_conv_changed(src, idx, capN, countDev, weightsPrepared, bias, prevOutput, C, H, W, K,
-                                kH, kW, relu, 0, bits, bits ? cbinfer_mask_words(H, W) : 0, dtype,
-                                stream);
+                                kH, kW, relu, 0, bits, bits ? cbinfer_mask_words(H, W) : 0, workspace,
+                                dtype, stream);
 }

@@ -106,11 +106,12 @@ int cbinfer_gen_x_matrix(void* columns, const void* input, const int32_t* change
  * fp32: exact-f32 MFMA (v_mfma_f32_32x32x2_f32); fp16: f16 MFMA with f32 accumulation.
  * weightsPrepared is the buffer produced by cbinfer_prep_weights from the [K,C,kH,kW] filter bank:
  * the matrix padded to the MFMA tile grid (fp32: transposed to k-major) followed by a k->(c,ky,kx)
- * table; cbinfer_prepared_weights_bytes gives its size.  For a plain [K,Ckk] matrix pass C=Ckk,
- * kH=kW=1. */
+ * tap table (byte offset, dy, dx per k, which depends on the H x W of the feature map the layer runs
+ * on); cbinfer_prepared_weights_bytes gives its size.  For a plain [K,Ckk] matrix pass C=Ckk,
+ * kH=kW=H=W=1. */
 long cbinfer_prepared_weights_bytes(int K, int C, int kH, int kW, int dtype);
 int cbinfer_prep_weights(const void* weight, void* weightsPrepared, int K, int C, int kH, int kW,
-                         int dtype, cbStream_t stream);
+                         int H, int W, int dtype, cbStream_t stream);
 int cbinfer_matrix_mult(const void* X, const void* weightsPrepared, const void* bias, void* Y,
                         int N, const int32_t* countDev, int Ckk, int K, int transposeOut, int dtype,
                         cbStream_t stream);
@@ -128,12 +129,16 @@ int cbinfer_update_output(const void* Yt, void* output, const int32_t* changeLis
  * accumulate=1 adds to output instead of overwriting (no bias/ReLU): used by the deterministic
  * fine-grained variant (a12) where `input` holds the masked deltas.
  * clearBits (optional, clearWords words): a change bit mask this launch zeroes on the way, so the
- * next frame's cbinfer_change_detection_bits finds it clean (keeps the frame free of memset nodes). */
+ * next frame's cbinfer_change_detection_bits finds it clean (keeps the frame free of memset nodes).
+ * workspace (optional, cbinfer_conv_workspace_bytes() bytes, ZERO on first use and left zero): lets the
+ * persistent kernel split a short change list along k across workgroups (deterministic slab
+ * reduction).  One workspace must not be used by two launches that can run concurrently. */
+long cbinfer_conv_workspace_bytes(void);
 int cbinfer_conv_changed(const void* input, const int32_t* changeList, int numChanges,
                          const int32_t* countDev, const void* weightsPrepared, const void* bias,
                          void* output, int C, int H, int W, int K, int kH, int kW, int relu,
-                         int accumulate, uint64_t* clearBits, long clearWords, int dtype,
-                         cbStream_t stream);
+                         int accumulate, uint64_t* clearBits, long clearWords, void* workspace,
+                         int dtype, cbStream_t stream);
 
 /* ---- a14 in one call: CBConv2d.forward_normal (conv2d.py:178-259) enqueued without a host sync --
  * detection(+dilation,+feedback) -> compaction -> [state copy] -> fused gather/MFMA/scatter.
@@ -145,13 +150,14 @@ int cbinfer_conv_changed(const void* input, const int32_t* changeList, int numCh
  *   feedbackLoop=1: prevInput refreshed at changed pixels only; else, if copyInput, prevInput <- input
  *                   (copyInput=0: the gather reads `input` and the caller re-points its state at it,
  *                   conv2d.py:237-238)
- *   capN      : grid capacity for the fused kernel (H*W, or the exact N if the caller synchronised) */
+ *   capN      : capacity of idx the fused kernel may assume (H*W, or the exact N if the caller
+ *               synchronised);  workspace: see cbinfer_conv_changed */
 int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void* prevOutput, uint64_t* bits,
                              int32_t* idx, int32_t* countDev, int8_t* mapOut,
                              const void* weightsPrepared, const void* bias, int C, int H, int W,
                              int K, int kH, int kW, float threshold, int feedbackLoop,
-                             int copyInput, int relu, int haveIndexes, int capN, int dtype,
-                             cbStream_t stream);
+                             int copyInput, int relu, int haveIndexes, int capN, void* workspace,
+                             int dtype, cbStream_t stream);
 
 /* ---- a9: change-based 2x2/stride-2 max pooling -----------------------------------------------
  * replaces maxPool2d, conv2d_cg.py:58-82 -> cbconv2d_cg_backend.cu:229-240 (kernel :199-227).

@@ -343,4 +343,4 @@ def test_c_abi_rejects_bad_arguments(cb):
         check(lib.cbinfer_change_detection(None, None, None, 4, 4, 1, 0, 0, 0.1, 0, 0, None))
     with pytest.raises(CBinferError):
         check(lib.cbinfer_conv_changed(None, None, 1, None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, None,
-                                       0, 0, None))
+                                       0, None, 0, None))

@@ -58,13 +58,17 @@ def main():
                     os.environ["CBINFER_CONV_CFG"] = str(cfg)
                 else:
                     os.environ.pop("CBINFER_CONV_CFG", None)
+                buf = torch.zeros(H * W, dtype=torch.int32, device="cuda")
+                buf[:N] = idx
+                ci = cg.ChangeIndexes(buf, torch.tensor([N], dtype=torch.int32, device="cuda"))
                 try:
                     ms = time_ms(lambda: cg.convChanged(x, idx, w, b, out, withReLU=True, weightsPrepared=wp))
+                    ms_cap = time_ms(lambda: cg.convChanged(x, ci, w, b, out, withReLU=True, weightsPrepared=wp))
                 except Exception as e:  # config not valid for this shape
                     print("conv %d->%d k%d %dx%d N=%d cfg=%d: %s" % (C, K, k, H, W, N, cfg, e))
                     continue
-                print("conv %3d->%3d k%d %3dx%3d ratio=%.2f N=%6d cfg=%3d: %8.2f us  %6.2f TFLOP/s"
-                      % (C, K, k, H, W, ratio, N, cfg, ms * 1e3, flops / ms / 1e9), flush=True)
+                print("conv %3d->%3d k%d %3dx%3d ratio=%.2f N=%6d cfg=%3d: %8.2f us  %6.2f TFLOP/s | worst-case grid %8.2f us"
+                      % (C, K, k, H, W, ratio, N, cfg, ms * 1e3, flops / ms / 1e9, ms_cap * 1e3), flush=True)
 
 
 if __name__ == "__main__":

@@ -222,27 +222,19 @@ def cpu_baseline(test, video_kw, budget_frames=4):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from cbinfer_amd.shard import SequenceShard
+    shard = SequenceShard()
+    world, rank = shard.world, shard.rank
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
-    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_.init_process_group("nccl")      # RCCL on ROCm
-        dist = dist_
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    shard.device()
+    dist = shard.dist
+    barrier = shard.barrier
 
     import pycbinfer
     from cbinfer_amd import workloads
 
     base, test = workloads.sceneLabelingModels(experimentIdx=args.experiment, threshold=args.threshold)
-    video_kw = dict(H=H, W=W, ratio=args.ratio, block=args.block, seed=1234 + rank)
+    video_kw = dict(H=H, W=W, ratio=args.ratio, block=args.block, seed=shard.sequence_seed(1234))
     vid = workloads.SyntheticVideo(**video_kw)
     # one long non-repeating sequence: 2 priming frames, W warm-up frames, K timed frames, and a few
     # spare ones for the per-kernel measurement -- all resident in HBM (1.8 MB each)
@@ -258,17 +250,11 @@ def main():
         runner.step(f)
     elapsed = timed_loop(runner, frames, args.steps, barrier)
 
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    total_frames = args.steps * world
+    total_frames, elapsed = shard.aggregate(args.steps, elapsed, device="cuda")
     fps = total_frames / elapsed
 
     if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        shard.finish()
         return
 
     dense_ops = workloads.denseOps(workloads.SCENE_LABELING_SPEC, H, W)
@@ -327,9 +313,7 @@ def main():
                                                          seed=1234))
 
     print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    shard.finish()
 
 
 if __name__ == "__main__":

@@ -192,8 +192,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
     // a stage pair ~1.7 us, so the best slice count is ~sqrt(1.7 P).
     int SK = 1;
     const int cus = (int)gridDim.x / CB_CONV_GRID_PER_CU;
-    if (p.slabs && T > 0 && T < cus && P >= 8)
-        SK = max(1, min(min(CB_SKMAX, cus / T), (int)sqrtf(1.7f * (float)P)));
+#ifndef CB_SK_TARGET
+#define CB_SK_TARGET 2
+#endif
+    if (p.slabs && T > 0 && T < CB_SK_TARGET * cus && P >= 8)
+        SK = max(1, min(min(CB_SKMAX, (CB_SK_TARGET * cus) / T), (int)sqrtf(1.7f * (float)P)));
     const int items = T * SK;
     if ((int)blockIdx.x >= items) return;
 

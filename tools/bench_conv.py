@@ -11,6 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cbinfer_amd import conv2d_cg as cg  # noqa: E402
 
 LAYERS = [(3, 16, 7, 320, 480), (16, 64, 7, 160, 240), (64, 256, 7, 80, 120), (256, 64, 1, 80, 120)]
+if os.environ.get('CBINFER_BENCH_LAYER'):
+    LAYERS = [LAYERS[int(os.environ['CBINFER_BENCH_LAYER'])]]
 
 
 def time_ms(fn, reps=30):

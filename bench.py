@@ -64,8 +64,11 @@ class FrameRunner(object):
         """Process `frames` eagerly (allocates state/workspaces); in graph mode capture afterwards."""
         with torch.no_grad():
             for f in frames:
-                self.static_in.copy_(f)
-                self.out = self.model(self.static_in)
+                if self.mode == "graph":
+                    self.static_in.copy_(f)
+                    self.out = self.model(self.static_in)
+                else:
+                    self.out = self.model(f)
             if self.mode == "graph":
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
@@ -77,12 +80,15 @@ class FrameRunner(object):
                     self.out = self.model(self.static_in)
 
     def step(self, frame):
-        self.static_in.copy_(frame)
         if self.graph is not None:
+            self.static_in.copy_(frame)
             self.graph.replay()
         else:
+            # eager: hand the module the frame tensor itself.  Modules that alias their input as state
+            # (copyInput=False without feedback loop, fine-grained; conv2d.py:175,237-238) need a NEW
+            # tensor per frame -- which also means such configurations cannot be graph-captured.
             with torch.no_grad():
-                self.out = self.model(self.static_in)
+                self.out = self.model(frame)
         return self.out
 
 

@@ -131,3 +131,87 @@ class SyntheticVideo(object):
         for _ in range(T - 1):
             out.append(self.next())
         return out
+
+
+# ------------------------------------------------------------------------------------------------
+# OpenPose (BASELINE.json configs[3]): network SHAPE of poseDetection/openPose/PoseModel.py:34-68 with
+# T refinement stages, random weights.  Each entry is (C_in, C_out, k); 'P' is a 2x2/2 max pool.
+# ------------------------------------------------------------------------------------------------
+OPENPOSE_FRONT = [(3, 64, 3), (64, 64, 3), 'P', (64, 128, 3), (128, 128, 3), 'P',
+                  (128, 256, 3), (256, 256, 3), (256, 256, 3), (256, 256, 3), 'P',
+                  (256, 512, 3), (512, 512, 3), (512, 256, 3), (256, 128, 3)]
+
+
+def _openpose_stage(stage, nOut):
+    if stage == 1:
+        return [(128, 128, 3), (128, 128, 3), (128, 128, 3), (128, 512, 1), (512, nOut, 1)]
+    return [(185, 128, 7)] + [(128, 128, 7)] * 4 + [(128, 128, 1), (128, nOut, 1)]
+
+
+def _seq(spec, relu_after_last):
+    layers = []
+    convs = [i for i, e in enumerate(spec) if e != 'P']
+    for i, e in enumerate(spec):
+        if e == 'P':
+            layers.append(nn.MaxPool2d(2, 2, 0))
+        else:
+            ci, co, k = e
+            layers.append(nn.Conv2d(ci, co, k, 1, k // 2))
+            if relu_after_last or i != convs[-1]:
+                layers.append(nn.ReLU(inplace=True))
+    return nn.Sequential(*layers)
+
+
+class OpenPoseModel(nn.Module):
+    """Feature extractor `model0` + per stage t two branches `model{t}_1` (38 PAF maps) and
+    `model{t}_2` (19 confidence maps); stages t >= 2 see cat(branch1, branch2, features) = 185
+    channels (PoseModel.py:122-137)."""
+
+    def __init__(self, T=2, seed=0):
+        super(OpenPoseModel, self).__init__()
+        state = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        self.T = T
+        self.model0 = _seq(OPENPOSE_FRONT, relu_after_last=True)
+        for t in range(1, T + 1):
+            setattr(self, 'model%d_1' % t, _seq(_openpose_stage(t, 38), relu_after_last=False))
+            setattr(self, 'model%d_2' % t, _seq(_openpose_stage(t, 19), relu_after_last=False))
+        torch.random.set_rng_state(state)
+        self.eval()
+
+    def forward(self, x):
+        feat = self.model0(x)
+        cur = feat
+        for t in range(1, self.T + 1):
+            outL = getattr(self, 'model%d_1' % t)(cur)
+            outS = getattr(self, 'model%d_2' % t)(cur)
+            if t != self.T:
+                cur = torch.cat([outL, outS, feat], 1)
+        return outL, outS
+
+    def submodelNames(self):
+        return ['model0'] + ['model%d_%d' % (t, b) for t in range(1, self.T + 1) for b in (1, 2)]
+
+
+def convertOpenPose(model, threshold=1e-2):
+    """Convert every sub-model with pycbinfer.convert(), as poseDetection/modelConverter.py:20-24 does
+    (only nn.Sequential containers are traversed by convert, so the custom module is converted per
+    sub-model).  Returns the same module object with its children replaced."""
+    for name in model.submodelNames():
+        setattr(model, name, convert(getattr(model, name), threshold=threshold))
+    return model
+
+
+def openPoseDenseOps(T, H, W):
+    total = 0
+    h, w = H, W
+    for e in OPENPOSE_FRONT:
+        if e == 'P':
+            h, w = h // 2, w // 2
+        else:
+            total += 2 * e[0] * e[1] * e[2] * e[2] * h * w
+    for t in range(1, T + 1):
+        for nOut in (38, 19):
+            for (ci, co, k) in _openpose_stage(t, nOut):
+                total += 2 * ci * co * k * k * h * w
+    return total

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2] and [3] on one MI355X: frames/s of the change-based scene-labeling net over
+change ratios (coarse-grained experiment 6, fine-grained experiment 7 with atomics and with the
+deterministic MFMA variant) and of the OpenPose T=2 net in fp16 (cg_half path), each next to the dense
+network timed the same way.  Prints markdown tables."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import pycbinfer  # noqa: E402
+from cbinfer_amd import workloads  # noqa: E402
+
+
+def measure(model, frames, steps, warm, mode):
+    runner = bench.FrameRunner(model, frames[0], mode)
+    runner.prime(frames[:2])
+    for f in frames[2:2 + warm]:
+        runner.step(f)
+    seq = frames[2 + warm:2 + warm + steps]
+    dt = bench.timed_loop(runner, seq, len(seq), lambda: None)
+    return len(seq) / dt
+
+
+def layer_ratios(model):
+    out = []
+    for m in model.modules():
+        if type(m) is pycbinfer.CBConv2d and m._work is not None:
+            out.append(int(m._work['count'].item()) / float(m._work['idx'].numel()))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--skip-fg", action="store_true")
+    ap.add_argument("--skip-pose", action="store_true")
+    args = ap.parse_args()
+    n = 2 + args.warmup + args.steps
+
+    print("## scene labeling 480x320 fp32, 16x16 re-drawn blocks (config 3 sweep)\n")
+    print("| change | dense f/s | CG exp6 f/s (graph) | speed-up | post-dilation ratio per CB layer | "
+          "FG exp7 atomics f/s (eager) | FG deterministic f/s (eager) |")
+    print("|---|---|---|---|---|---|---|")
+    for ratio in (0.01, 0.02, 0.05, 0.10, 0.20, 0.30, 0.50):
+        vid = workloads.SyntheticVideo(H=320, W=480, ratio=ratio, block=16, seed=7)
+        frames = vid.frames(n)
+        base, cg = workloads.sceneLabelingModels(experimentIdx=6, threshold=0.05)
+        dense = measure(base, frames, args.steps, args.warmup, "graph")
+        fcg = measure(cg, frames, args.steps, args.warmup, "graph")
+        ratios = ", ".join("%.0f%%" % (100 * r) for r in layer_ratios(cg))
+        ffg = ffd = float("nan")
+        if not args.skip_fg:
+            _, fg = workloads.sceneLabelingModels(experimentIdx=7, threshold=0.05)
+            nfg = min(len(frames), 2 + 2 + 12)
+            ffg = measure(fg, frames[:nfg], 12, 2, "eager")
+            _, fd = workloads.sceneLabelingModels(experimentIdx=7, threshold=0.05)
+            for m in fd.modules():
+                if type(m) is pycbinfer.CBConv2d:
+                    m.deterministicFG = True
+            ffd = measure(fd, frames[:nfg], 12, 2, "eager")
+        print("| %.0f%% | %.0f | %.0f | %.2fx | %s | %.1f | %.1f |" %
+              (100 * vid.ratio, dense, fcg, fcg / dense, ratios, ffg, ffd), flush=True)
+
+    if not args.skip_pose:
+        print("\n## OpenPose T=2 368x654 fp16, coarse-grained (config 4), 10 % change in 46x... blocks\n")
+        H, W = 368, 654
+        # synthetic video at the preprocess range x*255/256-0.5 (PoseDetector.py:72); blocks of 46x... do
+        # not tile 654, so use a padded generator and crop
+        vid = workloads.SyntheticVideo(H=368, W=672, ratio=0.10, block=16, seed=3)
+        frames = [(f[:, :, :, :W] * (255.0 / 256.0) - 0.5).half().contiguous() for f in vid.frames(n)]
+        base = workloads.OpenPoseModel(T=2).cuda().half()
+        test = workloads.convertOpenPose(workloads.OpenPoseModel(T=2).cuda().half(), threshold=0.02)
+        dense = measure(base, frames, min(args.steps, 20), 3, "graph")
+        cb = measure(test, frames, min(args.steps, 20), 3, "graph")
+        rs = layer_ratios(test)
+        print("| dense f/s | CB f/s | speed-up | mean post-dilation ratio over 36 layers |")
+        print("|---|---|---|---|")
+        print("| %.1f | %.1f | %.2fx | %.0f%% |" % (dense, cb, cb / dense, 100 * sum(rs) / max(1, len(rs))))
+
+
+if __name__ == "__main__":
+    main()

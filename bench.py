@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel table to stderr")
+    ap.add_argument("--pool-clone", action="store_true",
+                    help="CBPoolMax2d returns a fresh copy of its state every frame like the reference "
+                         "(default: the state tensor itself; identical results, one copy kernel less)")
     return ap.parse_args()
 
 
@@ -212,6 +215,17 @@ def cpu_baseline(test, video_kw, budget_frames=4):
                 raise AssertionError(type(m))
         net = orc.OracleSequential(layers)
         vid = workloads.SyntheticVideo(device="cpu", **video_kw)
+        # the dense baseline CNN on the same host cores (torch CPU conv2d), min of 3 (evalTools.py:33)
+        dense_cpu = workloads.sceneLabelingBaseline()
+        xin = vid.frame.clone()
+        with torch.no_grad():
+            dense_cpu(xin)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                dense_cpu(xin)
+                ts.append(time.perf_counter() - t0)
+        dense_cpu_fps = 1.0 / min(ts)
         frames = [f.numpy() for f in vid.frames(budget_frames + 1)]
         with torch.no_grad():
             net.forward(frames[0])
@@ -222,6 +236,7 @@ def cpu_baseline(test, video_kw, budget_frames=4):
     finally:
         orc.matrixMult = orc_matmul
     return dict(value=budget_frames / dt, unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                dense_cpu_fps=dense_cpu_fps,
                 sample="%d steady-state frames of the same 480x320 sequence after an untimed 100%%-change "
                        "first frame; oracle C ops + torch CPU matmul" % budget_frames)
 
@@ -240,6 +255,9 @@ def main():
     from cbinfer_amd import workloads
 
     base, test = workloads.sceneLabelingModels(experimentIdx=args.experiment, threshold=args.threshold)
+    for m in test.modules():
+        if type(m) is pycbinfer.CBPoolMax2d:
+            m.cloneOutput = bool(args.pool_clone)
     video_kw = dict(H=H, W=W, ratio=args.ratio, block=args.block, seed=shard.sequence_seed(1234))
     vid = workloads.SyntheticVideo(**video_kw)
     # one long non-repeating sequence: 2 priming frames, W warm-up frames, K timed frames, and a few
@@ -272,7 +290,7 @@ def main():
         "config": {"workload": "sceneLabeling CBConv2d coarse-grained fp32, synthetic 480x320 seq @%g%% "
                                "change (%dx%d re-drawn blocks), experiment %d, one sequence per GPU"
                                % (100 * vid.ratio, args.block, args.block, args.experiment),
-                   "launch": args.mode, "threshold": args.threshold},
+                   "launch": args.mode, "threshold": args.threshold, "pool_clone": bool(args.pool_clone)},
         "effective_gflops": fps * dense_ops / 1e9,
     }
 
@@ -299,17 +317,24 @@ def main():
                 if kname + "_ms" in r and (best is None or r[kname + "_ms"] > best[2]):
                     best = (r, kname, r[kname + "_ms"])
         r, kname, ms = best
+        traffic = None
+        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (see the file's _note)
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
+            key = ("cb_mfma_f32_kernel " if kname == "conv" else "cb_%s_kernel " % kname) + r["layer"]
+            traffic = pmc.get(key, {}).get("bytes_per_launch")
+        except Exception:
+            traffic = None
         if kname == "conv":
             ach = r["conv_flops"] / (ms * 1e-3) / 1e12
             result["roofline"] = {"kernel": "cb_mfma_f32_kernel (fused gather->MFMA->scatter), " + r["layer"],
                                   "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                                  "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                                   "avg_duration_us": ms * 1e3, "units_per_launch": r["N"]}
         else:
             ach = r[kname + "_bytes"] / (ms * 1e-3) / 1e9
             result["roofline"] = {"kernel": kname + ", " + r["layer"], "bound": "hbm", "achieved": ach,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                  "traffic": None, "avg_duration_us": ms * 1e3, "units_per_launch": r["N"]}
+                                  "traffic": traffic, "avg_duration_us": ms * 1e3, "units_per_launch": r["N"]}
         if args.breakdown:
             for r in test_rows:
                 log(json.dumps(r))

@@ -43,6 +43,11 @@ class CBPoolMax2d(nn.Module):
         self.kernel_size = ks
         self.ceil_mode = m.ceil_mode
         self.propChangeIndexes = False
+        # reference behaviour (conv2d.py:73): hand out a private copy of the state every frame.  With
+        # cloneOutput=False the state tensor itself is returned (tagged, so that a consumer about to
+        # keep a reference to it -- CBConv2d with copyInput=False -- takes its copy then); this removes
+        # one full-tensor copy per frame when the consumer copies or feeds back anyway.
+        self.cloneOutput = True
         self.register_buffer('outputState', torch.zeros(0))
         self.clearMemory()
 
@@ -78,8 +83,12 @@ class CBPoolMax2d(nn.Module):
                                               device=input.device)
             maxPool2d(input, self.outputState, changeIndexes, self.kernel_size, self.stride)
 
-        # a private copy: a following CBConv2d with copyInput=False keeps a reference to it
-        output = self.outputState.clone()
+        if getattr(self, 'cloneOutput', True):
+            # a private copy: a following CBConv2d with copyInput=False keeps a reference to it
+            output = self.outputState.clone()
+        else:
+            output = self.outputState
+            output._cbinfer_inplace_state = True
         if self.propChangeIndexes:
             return 'changeIndexes', output, inp[2]
         return output
@@ -154,7 +163,8 @@ class CBConv2d(nn.Module):
         for name, val in (('saveChangeMap', False), ('propChangeIndexes', False),
                           ('gatherComputationStats', False), ('finegrained', False),
                           ('copyInput', True), ('feedbackLoop', False), ('syncIndexes', False),
-                          ('deterministicFG', False), ('_work', None), ('_wprep', None)):
+                          ('deterministicFG', False), ('_work', None), ('_wprep', None),
+                          ('_inputIsLiveState', False)):
             if name not in self.__dict__:
                 self.__dict__[name] = val
 
@@ -213,6 +223,9 @@ class CBConv2d(nn.Module):
     def forward_normal(self, inp):
         # input parsing and checks (conv2d.py:180-190)
         changeIndexes = None
+        src = inp[1] if type(inp) == tuple else inp
+        # a producer that hands out its in-place-updated state (CBPoolMax2d.cloneOutput=False) tags it
+        self._inputIsLiveState = bool(getattr(src, '_cbinfer_inplace_state', False))
         if type(inp) == tuple:
             assert inp[0] == 'changeIndexes'
             input = inp[1].detach().contiguous()
@@ -290,7 +303,8 @@ class CBConv2d(nn.Module):
         if mapOut is not None:
             self.changeMap = mapOut
         if not self.feedbackLoop and not self.copyInput:
-            self.prevInput = input      # alias, conv2d.py:237-238
+            # alias, conv2d.py:237-238 (a producer's in-place-updated state is copied first)
+            self.prevInput = input.clone() if self._inputIsLiveState else input
         return result
 
     def _forward_ops(self, input, changeIndexes):
@@ -308,7 +322,7 @@ class CBConv2d(nn.Module):
             if self.copyInput:
                 self.prevInput.copy_(input)
             else:
-                self.prevInput = input
+                self.prevInput = input.clone() if self._inputIsLiveState else input
         if changeIndexes.numel() != 0:
             Xmatrix = genXMatrix(self.prevInput, changeIndexes, self.kernel_size)
             Ymatrix = matrixMult(Xmatrix, self.weight.detach(), self.bias.detach(), transposeOut=True,

@@ -246,3 +246,25 @@ def test_openpose_half(pkg):
             err = max((L.float() - Lr).abs().max().item(), (S.float() - Sr).abs().max().item())
             assert L.shape == (1, 38, 8, 12) and S.shape == (1, 19, 8, 12)
             assert err <= (0.02 if t == 0 else 0.1) * scale, (t, err, scale)
+
+
+def test_pool_without_clone_is_equivalent(pkg):
+    """CBPoolMax2d.cloneOutput=False returns the state tensor itself; results are unchanged, also when
+    the consumer aliases its input (copyInput=False, no feedback): it then takes the copy itself."""
+    from cbinfer_amd import workloads
+    for exp, feedback in ((6, True), (6, False)):
+        _, a = workloads.sceneLabelingModels(experimentIdx=exp, threshold=0.05, seed=2)
+        _, b = workloads.sceneLabelingModels(experimentIdx=exp, threshold=0.05, seed=2)
+        for net in (a, b):
+            for m in net.modules():
+                if type(m) is pkg.CBConv2d:
+                    m.feedbackLoop = feedback
+                    m.copyInput = False
+        for m in b.modules():
+            if type(m) is pkg.CBPoolMax2d:
+                m.cloneOutput = False
+        vid = workloads.SyntheticVideo(H=64, W=96, ratio=0.125, block=16, seed=9)
+        with torch.no_grad():
+            for f in vid.frames(4):
+                ya, yb = a(f.clone()), b(f.clone())
+                assert torch.equal(ya, yb)

@@ -31,22 +31,28 @@ __device__ __forceinline__ cb_half cb_relu(cb_half v) { return v <= (cb_half)0 ?
 // ---------------------------------------------------------------------------------------------
 // weight preparation: pad to the MFMA tile grid (zeros), fp32 additionally transposed to k-major
 // ---------------------------------------------------------------------------------------------
-// k -> tap table appended to the prepared weights, two words per k:
-//   .x = byte offset of the tap relative to the output pixel in a [C,H,W] tensor of elemSize bytes,
-//   .y = (dx << 16) | (dy & 0xffff)   (signed 16-bit each)
-// The zero-padded tail k >= Ckk gets dy = -32768, i.e. always outside the image.
-__device__ __forceinline__ int2 cb_pack_k(int k, int Ckk, int kH, int kW, int H, int W, int elemSize) {
-    if (k >= Ckk) return make_int2(1 << 30, 0x8000);
+// k -> tap table appended to the prepared weights, two int arrays of CkkP entries each:
+//   off[k]  = byte offset of the tap relative to the output pixel in a [C,H,W] tensor of elemSize bytes
+//   dydx[k] = (dx << 16) | (dy & 0xffff)   (signed 16-bit each)
+// The zero-padded tail k >= Ckk gets offset 2^30 and dy = -32768, i.e. always outside the image.
+__device__ __forceinline__ void cb_pack_k(int* tab, int k, int Ckk, int CkkP, int kH, int kW, int H, int W,
+                                          int elemSize) {
+    if (k >= Ckk) {
+        tab[k] = 1 << 30;
+        tab[CkkP + k] = 0x8000;
+        return;
+    }
     const int c = k / (kH * kW), r = k % (kH * kW);
     const int dy = r / kW - (kH - 1) / 2, dx = r % kW - (kW - 1) / 2;
-    return make_int2((c * H * W + dy * W + dx) * elemSize, (dx << 16) | (dy & 0xffff));
+    tab[k] = (c * H * W + dy * W + dx) * elemSize;
+    tab[CkkP + k] = (dx << 16) | (dy & 0xffff);
 }
 __global__ __launch_bounds__(256) void cb_prep_w_f32_kernel(const float* __restrict__ w,
                                                            float* __restrict__ wt, int K, int Ckk,
                                                            int KP, int CkkP, int kH, int kW, int H,
                                                            int W) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < CkkP) ((int2*)(wt + (long)KP * CkkP))[e] = cb_pack_k((int)e, Ckk, kH, kW, H, W, 4);
+    if (e < CkkP) cb_pack_k((int*)(wt + (long)KP * CkkP), (int)e, Ckk, CkkP, kH, kW, H, W, 4);
     if (e >= (long)KP * CkkP) return;
     const int m = (int)(e % KP), k = (int)(e / KP);
     wt[e] = (m < K && k < Ckk) ? w[(long)m * Ckk + k] : 0.f;
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(256) void cb_prep_w_f16_kernel(const cb_half* __res
                                                            int KP, int CkkP, int kH, int kW, int H,
                                                            int W) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < CkkP) ((int2*)(wp + (long)KP * CkkP))[e] = cb_pack_k((int)e, Ckk, kH, kW, H, W, 2);
+    if (e < CkkP) cb_pack_k((int*)(wp + (long)KP * CkkP), (int)e, Ckk, CkkP, kH, kW, H, W, 2);
     if (e >= (long)KP * CkkP) return;
     const int k = (int)(e % CkkP), m = (int)(e / CkkP);
     wp[e] = (m < K && k < Ckk) ? w[(long)m * Ckk + k] : (cb_half)0;
@@ -213,7 +219,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
 
     const float* __restrict__ Ag = (const float*)p.A;
     const float* __restrict__ Bg = (const float*)p.B;
-    const cb_const_int2* ktab_c = (const cb_const_int2*)(Ag + (long)p.KP * p.CkkP);
+    const cb_const_int* koff_c = (const cb_const_int*)(Ag + (long)p.KP * p.CkkP);
+    const cb_const_int* kdyx_c = koff_c + p.CkkP;
     const int HW = p.H * p.W;
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.B, 0, MODE == CB_MODE_GATHER ? p.C * HW * 4 : 0, 0x00020000);
@@ -240,11 +247,18 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
                 pbase4 = pos * 4;
             }
         }
-        cb_i2 pk[B_PER_T];   // taps of the NEXT stage to load: scalar registers
+        // taps of the NEXT stage to load, B_PER_T consecutive table entries per array: ONE scalar load
+        // each (s_load_dwordx4), kept in scalar registers across the stage
+        typedef int ivec __attribute__((ext_vector_type(B_PER_T)));
+        typedef __attribute__((address_space(4))) ivec cb_const_ivec;
+        ivec pkOff, pkDyx;
         auto fetch_pk = [&](int k0) {
             if (MODE == CB_MODE_GATHER) {
 #pragma unroll
-                for (int i = 0; i < B_PER_T; ++i) pk[i] = ktab_c[k0 + br + i];
+                for (int i = 0; i < 1; ++i) {
+                    pkOff = *(const cb_const_ivec*)(koff_c + k0 + br);
+                    pkDyx = *(const cb_const_ivec*)(kdyx_c + k0 + br);
+                }
             }
         };
         fetch_pk(kBeg);
@@ -265,8 +279,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
             for (int i = 0; i < B_PER_T; ++i) {
                 float v = 0.f;
                 if (MODE == CB_MODE_GATHER) {
-                    const int koff4 = pk[i].x;                       // scalar
-                    const int dy = (pk[i].y << 16) >> 16, dx = pk[i].y >> 16;
+                    const int koff4 = pkOff[i];                       // scalar
+                    const int dy = (pkDyx[i] << 16) >> 16, dx = pkDyx[i] >> 16;
                     const int iy = py + dy, ix = px + dx;
                     const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
                     const int voff = ok ? pbase4 + koff4 : (1 << 30);

@@ -37,7 +37,12 @@ _SIGNATURES = {
     "cbinfer_conv_changed": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                                   _vp, _l, _vp, _i, _vp]),
     "cbinfer_cbconv2d_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
-                                      _i, _f, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+                                      _i, _f, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "cbinfer_frame_mask_bytes": (_l, [_i, _i]),
+    "cbinfer_frame_mask_max_words": (_i, []),
+    "cbinfer_change_detection_frame": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "cbinfer_conv_changed_from_mask": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
+                                            _i, _vp, _i, _vp]),
     "cbinfer_max_pool2d": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cbinfer_change_detection_fg": (_i, [_vp, _vp, _vp, _vp, _l, _f, _i, _vp]),
     "cbinfer_update_output_fg": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _vp]),

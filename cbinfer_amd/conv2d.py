@@ -16,6 +16,8 @@ Two execution modes, chosen per module by `syncIndexes` (default False):
          and the reference-structured op sequence (changeDetection, changeIndexesExtr, genXMatrix,
          matrixMult, updateOutput) of conv2d_cg.py is what runs.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -183,12 +185,18 @@ class CBConv2d(nn.Module):
 
     def _workspace(self, input):
         H, W = input.size(-2), input.size(-1)
-        key = (H, W, input.device)
+        # self-compacting frame pipeline (detection + fused kernel, no compaction launch): fp32, mask
+        # small enough for the kernel's LDS prefix, and no int8 copy of the mask requested
+        selfc = (input.dtype == torch.float32 and not self.saveChangeMap and
+                 C.cbinfer_mask_words(H, W) <= C.cbinfer_frame_mask_max_words() and
+                 os.environ.get('CBINFER_NO_SELFCOMPACT', '0') != '1')
+        key = (H, W, input.device, selfc)
         if self._work is None or self._work['key'] != key:
             dev = input.device
+            nbytes = C.cbinfer_frame_mask_bytes(H, W) if selfc else 8 * C.cbinfer_mask_words(H, W)
             self._work = dict(
-                key=key,
-                bits=torch.zeros(C.cbinfer_mask_words(H, W), dtype=torch.int64, device=dev),
+                key=key, selfc=selfc,
+                bits=torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=dev),
                 idx=torch.empty(H * W, dtype=torch.int32, device=dev),
                 count=torch.zeros(1, dtype=torch.int32, device=dev),
                 map=None)
@@ -298,8 +306,8 @@ class CBConv2d(nn.Module):
                 ptr(idx), ptr(count), ptr(mapOut), ptr(self._prepared_weights(H, W)),
                 ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold),
                 int(bool(self.feedbackLoop)), int(bool(self.copyInput)), int(bool(self.withReLU)),
-                int(have), cap, ptr(convWorkspace(input.device)), dtype_code(input),
-                stream_ptr(input)))
+                int(have), cap, ptr(convWorkspace(input.device)),
+                int(work['selfc'] and not have), dtype_code(input), stream_ptr(input)))
         if mapOut is not None:
             self.changeMap = mapOut
         if not self.feedbackLoop and not self.copyInput:

@@ -131,7 +131,29 @@ struct ConvParams {
     long clearWords;
     float* slabs;   // optional split-K workspace: gridDim.x partial tiles of 64x64 floats ...
     int* tickets;   // ... and gridDim.x arrival counters (zero between launches)
+    // self-compacting mode (SELFC): the kernel derives the change list from the frame's bit mask itself
+    unsigned long long* frameMasks;   // [2][maskWords] masks + {parity, done} ints behind them
+    int maskWords, wpr;
+    int32_t* listOut;                 // the list and its length are written out as a by-product
+    int32_t* countOut;
 };
+
+#define CB_SELFC_MAXW 4096
+
+// r-th (0-based) set bit of w, r < popcount(w)
+__device__ __forceinline__ int cb_select_bit(unsigned long long w, int r) {
+    int pos = 0;
+#pragma unroll
+    for (int width = 32; width >= 1; width >>= 1) {
+        const unsigned long long lowmask = ((1ull << width) - 1ull) << pos;
+        const int c = __popcll(w & lowmask);
+        if (r >= c) {
+            r -= c;
+            pos += width;
+        }
+    }
+    return pos;
+}
 
 // The fused kernel is the last consumer of the frame's change mask, so it re-zeroes it (before any
 // early exit): the next frame's detection can atomicOr into a clean mask without a memset node.
@@ -170,7 +192,7 @@ __device__ __forceinline__ void cb_clear_mask(const ConvParams& p) {
 //             over the layer state: an out-of-image tap gets an out-of-range offset, for which the
 //             hardware returns 0.
 #define CB_SKMAX 8
-template <int WM, int WN, int KS, int MODE, int EPI>
+template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false>
 __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvParams p) {
     constexpr int NT = 64 * WM * WN * KS;
     constexpr int BM = 32 * WM;
@@ -188,14 +210,66 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
     static_assert(BK * BN % NT == 0 && KSTEP % 2 == 0, "bad decomposition");
     static_assert(KS == 1 || 2 * (A_STAGE + B_STAGE) >= WM * WN * 64 * 16, "reduce buffer");
 
-    if (MODE == CB_MODE_GATHER) cb_clear_mask(p);
-    const int N = p.countDev ? min(*p.countDev, p.nHost) : p.nHost;
+    const int t = threadIdx.x;
+    // ---- SELFC: stream compaction folded into this kernel -------------------------------------------
+    // Every workgroup rebuilds the exclusive popcount prefix of the frame's change mask (<= 32 KB, L2
+    // resident) in LDS; a tile's pixels are then found by rank (binary search over the prefix + select
+    // of the r-th set bit).  No compaction launch, and no hand-off between workgroups.  Two masks
+    // alternate by a device-side parity so that this launch can zero the one the NEXT frame's detection
+    // will fill while every workgroup still reads the current one; the last workgroup to finish flips
+    // the parity.
+    __shared__ int s_pre[SELFC ? CB_SELFC_MAXW + 1 : 1];
+    __shared__ int s_wsum[SELFC ? NT / 64 : 1];
+    __shared__ int s_tilePix[SELFC ? BN : 1];
+    const unsigned long long* mask = nullptr;
+    int par = 0;
+    int N;
+    if (SELFC) {
+        int* ctl = (int*)(p.frameMasks + 2 * (long)p.maskWords);   // {parity, done}
+        par = ctl[0];
+        mask = p.frameMasks + (par ? p.maskWords : 0);
+        unsigned long long* other = p.frameMasks + (par ? 0 : p.maskWords);
+        for (int i = blockIdx.x * NT + t; i < p.maskWords; i += gridDim.x * NT) other[i] = 0ull;
+        // exclusive prefix of per-word popcounts: thread t owns CH consecutive words
+        const int CH = (p.maskWords + NT - 1) / NT;
+        const int wb = t * CH;
+        int loc = 0;
+        for (int u = 0; u < CH; ++u) {
+            const int w = wb + u;
+            if (w < p.maskWords) loc += __popcll(mask[w]);
+        }
+        int incl = loc;   // inclusive scan over the wave, then over the waves
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if ((t & 63) >= o) incl += v;
+        }
+        if ((t & 63) == 63) s_wsum[t >> 6] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (t >> 6); ++w) base += s_wsum[w];
+        int run = base + incl - loc;
+        for (int u = 0; u < CH; ++u) {
+            const int w = wb + u;
+            if (w < p.maskWords) {
+                s_pre[w] = run;
+                run += __popcll(mask[w]);
+            }
+        }
+        if (t == NT - 1) s_pre[p.maskWords] = base + incl;   // the last thread's chunk ends the mask
+        __syncthreads();
+        N = min(s_pre[p.maskWords], p.nHost);
+        if (blockIdx.x == 0 && t == 0) p.countOut[0] = N;
+    } else {
+        if (MODE == CB_MODE_GATHER) cb_clear_mask(p);
+        N = p.countDev ? min(*p.countDev, p.nHost) : p.nHost;
+    }
     const int MT = p.KP / BM;
     const int T = ((N + BN - 1) / BN) * MT;                  // output tiles
     const int P = p.CkkP / (2 * BK);                         // stage pairs along k
-    // Split along k only while whole CUs would otherwise idle (T below the CU count) and the k-depth is
-    // long enough to pay for the slab round trip: the reducer costs ~4 us of fences + ~1 us per slab,
-    // a stage pair ~1.7 us, so the best slice count is ~sqrt(1.7 P).
+    // Split along k only while whole CUs would otherwise idle (T below CB_SK_TARGET x the CU count) and
+    // the k-depth is long enough to pay for the slab round trip: the reducer costs ~4 us of fences +
+    // ~1 us per slab, a stage pair ~1.7 us, so the best slice count is ~sqrt(1.7 P).
     int SK = 1;
     const int cus = (int)gridDim.x / CB_CONV_GRID_PER_CU;
 #ifndef CB_SK_TARGET
@@ -204,14 +278,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
     if (p.slabs && T > 0 && T < CB_SK_TARGET * cus && P >= 8)
         SK = max(1, min(min(CB_SKMAX, (CB_SK_TARGET * cus) / T), (int)sqrtf(1.7f * (float)P)));
     const int items = T * SK;
-    if ((int)blockIdx.x >= items) return;
+    if (!SELFC && (int)blockIdx.x >= items) return;
 
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_STAGE + B_STAGE)];
     __shared__ int s_last;
     float* const As = smem;                  // [2][BK][BM]
     float* const Bs = smem + 2 * A_STAGE;    // [2][BK][LDB]
 
-    const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int ks = wave / (WM * WN), wq = wave % (WM * WN);
     const int wm = wq % WM, wn = wq / WM;
@@ -238,7 +311,36 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
 
         // per-thread B-load coordinates; a slot past the list is "outside the image"
         int py = -(1 << 20), px = 0, pbase4 = 0;
-        if (MODE == CB_MODE_GATHER) {
+        if (SELFC) {
+            // pixel of slot j of this tile = the (n0+j)-th set bit of the mask
+            __syncthreads();   // s_tilePix of the previous item is no longer read
+            if (t < BN) {
+                const int r = n0 + t;
+                int pos = -1;
+                if (r < N) {
+                    int lo = 0, hi = p.maskWords;   // largest w with s_pre[w] <= r
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_pre[mid] <= r)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
+                    const int bit = cb_select_bit(mask[lo], r - s_pre[lo]);
+                    const int row = lo / p.wpr;
+                    pos = row * p.W + (lo - row * p.wpr) * 64 + bit;
+                    if (m0 == 0 && slice == 0) p.listOut[r] = pos;
+                }
+                s_tilePix[t] = pos;
+            }
+            __syncthreads();
+            const int pos = s_tilePix[bj];
+            if (pos >= 0) {
+                py = pos / p.W;
+                px = pos - py * p.W;
+                pbase4 = pos * 4;
+            }
+        } else if (MODE == CB_MODE_GATHER) {
             const int n = n0 + bj;
             if (n < N) {
                 const int pos = p.list[n];
@@ -412,7 +514,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
         const int n = n0 + wn * 32 + l31;
         if (ks == 0 && n < N) {
             int pix = 0;
-            if (EPI >= CB_EPI_SCATTER) pix = p.list[n];
+            if (EPI >= CB_EPI_SCATTER) pix = SELFC ? s_tilePix[wn * 32 + l31] : p.list[n];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -430,6 +532,19 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
                     out[(long)m * HW + pix] = v;
                 else
                     out[(long)m * HW + pix] += v;
+            }
+        }
+    }
+
+    if (SELFC) {
+        // every workgroup has read the mask: the last one to get here flips the parity for the next frame
+        __syncthreads();
+        if (t == 0) {
+            int* ctl = (int*)(p.frameMasks + 2 * (long)p.maskWords);
+            const int d = __hip_atomic_fetch_add(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == (int)gridDim.x - 1) {
+                __hip_atomic_store(ctl + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ctl, par ^ 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -600,16 +715,16 @@ int cb_num_cus() {
     return cus;
 }
 
-template <int WM, int WN, int KS, int MODE, int EPI>
+template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false>
 int launch_f32(const ConvParams& p, hipStream_t s) {
     const long tilesCap = (long)cb_div_up(p.nHost, 32 * WN) * (p.KP / (32 * WM));
     if (tilesCap == 0) return CB_OK;
     // persistent grid: 2 workgroups per CU (fewer only if the capacity itself is smaller and there is
     // no split-K workspace to spread it with)
     long g = CB_CONV_GRID_PER_CU * (long)cb_num_cus();
-    if (!p.slabs && tilesCap < g) g = tilesCap;
+    if (!p.slabs && tilesCap < g && !SELFC) g = tilesCap;
     dim3 grid((unsigned)g), block(64 * WM * WN * KS);
-    hipLaunchKernelGGL((cb_mfma_f32_kernel<WM, WN, KS, MODE, EPI>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((cb_mfma_f32_kernel<WM, WN, KS, MODE, EPI, SELFC>), grid, block, 0, s, p);
     return cb_launch_status();
 }
 
@@ -625,6 +740,11 @@ int launch_mfma(const ConvParams& p, int dtype, hipStream_t s) {
         int cfg = conv_cfg_override();
         if (cfg == 0) cfg = narrow ? 142 : 222;
         if (narrow && cfg / 100 != 1) cfg = 142;
+        if (p.frameMasks) {   // self-compacting frame pipeline: only the default configurations
+            if (MODE != CB_MODE_GATHER || EPI != CB_EPI_SCATTER) return CB_ERR_BADARG;
+            if (narrow) return launch_f32<1, 4, 2, CB_MODE_GATHER, CB_EPI_SCATTER, true>(p, s);
+            return launch_f32<2, 2, 2, CB_MODE_GATHER, CB_EPI_SCATTER, true>(p, s);
+        }
         switch (cfg) {
             case 141: return launch_f32<1, 4, 1, MODE, EPI>(p, s);
             case 142: return launch_f32<1, 4, 2, MODE, EPI>(p, s);
@@ -790,5 +910,48 @@ int cbinfer_conv_changed(const void* input, const int32_t* changeList, int numCh
         return launch_mfma<CB_MODE_GATHER, CB_EPI_SCATTER_ACC>(p, dtype, (hipStream_t)stream);
     return launch_mfma<CB_MODE_GATHER, CB_EPI_SCATTER>(p, dtype, (hipStream_t)stream);
 }
+
+// Self-compacting form of cbinfer_conv_changed (used by cbinfer_cbconv2d_forward): the change list is
+// derived inside the kernel from the frame's bit mask; idxOut/countOut receive it as a by-product.
+int cbinfer_conv_changed_from_mask(const void* input, uint64_t* frameMasks, int32_t* idxOut,
+                                   int32_t* countOut, const void* weightsPrepared, const void* bias,
+                                   void* output, int C, int H, int W, int K, int kH, int kW, int relu,
+                                   void* workspace, int dtype, cbStream_t stream) {
+    CB_REQUIRE(input && frameMasks && idxOut && countOut && weightsPrepared && output && C > 0 && H > 0 &&
+               W > 0 && K > 0 && kH > 0 && kW > 0);
+    if (dtype != CB_F32) return CB_ERR_UNSUPPORTED;
+    const long words = cbinfer_mask_words(H, W);
+    if (words > CB_SELFC_MAXW || (long)C * kH * kW > 65535 || (long)C * H * W * 4 >= (1l << 30))
+        return CB_ERR_UNSUPPORTED;
+    ConvParams p = {};
+    p.A = weightsPrepared;
+    p.B = input;
+    p.bias = bias;
+    p.out = output;
+    p.nHost = H * W;
+    p.K = K;
+    p.KP = cbinfer_weights_kpad(K);
+    p.Ckk = C * kH * kW;
+    p.CkkP = cbinfer_weights_ckkpad(p.Ckk);
+    p.C = C;
+    p.H = H;
+    p.W = W;
+    p.kH = kH;
+    p.kW = kW;
+    p.relu = relu;
+    p.frameMasks = (unsigned long long*)frameMasks;
+    p.maskWords = (int)words;
+    p.wpr = cbinfer_mask_words_per_row(W);
+    p.listOut = idxOut;
+    p.countOut = countOut;
+    if (workspace) {
+        p.tickets = (int*)workspace;
+        p.slabs = (float*)((char*)workspace + 4096);
+    }
+    return launch_mfma<CB_MODE_GATHER, CB_EPI_SCATTER>(p, dtype, (hipStream_t)stream);
+}
+
+long cbinfer_frame_mask_bytes(int H, int W) { return 2 * cbinfer_mask_words(H, W) * 8 + 16; }
+int cbinfer_frame_mask_max_words(void) { return CB_SELFC_MAXW; }
 
 }  // extern "C"

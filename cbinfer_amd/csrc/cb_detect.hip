@@ -23,7 +23,10 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
                                                         int8_t* __restrict__ map,
                                                         unsigned long long* __restrict__ bits, int W,
                                                         int H, int C, int kHH, int kWH, float thf,
-                                                        int update, int wpr) {
+                                                        int update, int wpr,
+                                                        const int* __restrict__ parity, long altWords) {
+    // frame pipeline: two masks alternate by a device-side parity (flipped by the consumer kernel)
+    if (BITS && parity && *parity) bits += altWords;
     const int lane = threadIdx.x & 63;
     const int g = threadIdx.x >> 6;
     const int G = blockDim.x >> 6;
@@ -153,8 +156,19 @@ __global__ __launch_bounds__(256) void cb_compact_kernel(
     __shared__ unsigned long long sw[CB_CW];
     __shared__ int soff[CB_CW + 1];
 
+    // popcount of every earlier word: independent loads, 8 in flight per thread
     int part = 0;
-    for (long i = threadIdx.x; i < w0; i += 256) part += __popcll(bits[i]);
+    {
+        long i = threadIdx.x;
+        for (; i + 7 * 256 < w0; i += 8 * 256) {
+            unsigned long long w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = bits[i + u * 256];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part += __popcll(w[u]);
+        }
+        for (; i < w0; i += 256) part += __popcll(bits[i]);
+    }
     part = cb_wave_sum(part);
     if (lane == 0) red[g] = part;
 
@@ -201,12 +215,13 @@ int detect_groups(int C) {
 
 template <typename T, bool BITS>
 int launch_detect(const void* input, void* state, int8_t* map, uint64_t* bits, int W, int H, int C,
-                  int kHH, int kWH, float th, int update, hipStream_t s) {
+                  int kHH, int kWH, float th, int update, hipStream_t s, const int* parity = nullptr,
+                  long altWords = 0) {
     const int wpr = cbinfer_mask_words_per_row(W);
     const int G = detect_groups(C);
     dim3 grid(wpr, H), block(64 * G);
     hipLaunchKernelGGL((cb_detect_kernel<T, BITS>), grid, block, 0, s, (const T*)input, (T*)state, map,
-                       (unsigned long long*)bits, W, H, C, kHH, kWH, th, update, wpr);
+                       (unsigned long long*)bits, W, H, C, kHH, kWH, th, update, wpr, parity, altWords);
     return cb_launch_status();
 }
 
@@ -246,6 +261,25 @@ int cbinfer_change_detection_bits(const void* input, void* state, uint64_t* bits
     if (dtype == CB_F16)
         return launch_detect<cb_half, true>(input, state, nullptr, bitsOut, W, H, C, kHHalf, kWHalf,
                                             threshold, updateInputState, s);
+    return CB_ERR_BADARG;
+}
+
+// Frame-pipeline form: frameMasks = [2][words] masks followed by {parity, done}; the detection ORs into
+// the mask the parity selects (cbinfer_conv_changed_from_mask consumes it and flips the parity).
+int cbinfer_change_detection_frame(const void* input, void* state, uint64_t* frameMasks, int W, int H,
+                                   int C, int kHHalf, int kWHalf, float threshold,
+                                   int updateInputState, int dtype, cbStream_t stream) {
+    CB_REQUIRE(input && state && frameMasks && W > 0 && H > 0 && C > 0 && kHHalf >= 0 && kWHalf >= 0);
+    if (kWHalf > 63 || H > 65535) return CB_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const long words = cbinfer_mask_words(H, W);
+    const int* parity = (const int*)(frameMasks + 2 * words);
+    if (dtype == CB_F32)
+        return launch_detect<float, true>(input, state, nullptr, frameMasks, W, H, C, kHHalf, kWHalf,
+                                          threshold, updateInputState, s, parity, words);
+    if (dtype == CB_F16)
+        return launch_detect<cb_half, true>(input, state, nullptr, frameMasks, W, H, C, kHHalf, kWHalf,
+                                            threshold, updateInputState, s, parity, words);
     return CB_ERR_BADARG;
 }
 

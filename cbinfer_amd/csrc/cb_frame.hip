@@ -9,11 +9,29 @@ extern "C" int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void
                                         int8_t* mapOut, const void* weightsPrepared, const void* bias,
                                         int C, int H, int W, int K, int kH, int kW, float threshold,
                                         int feedbackLoop, int copyInput, int relu, int haveIndexes,
-                                        int capN, void* workspace, int dtype, cbStream_t stream) {
+                                        int capN, void* workspace, int selfCompact, int dtype,
+                                        cbStream_t stream) {
     CB_REQUIRE(input && prevInput && prevOutput && idx && countDev && weightsPrepared);
     CB_REQUIRE(dtype == CB_F32 || dtype == CB_F16);
     CB_REQUIRE(capN >= 0 && capN <= H * W);
     int st;
+    if (selfCompact) {
+        // detection -> [state copy] -> self-compacting fused kernel: 2 launches per layer and frame.
+        // `bits` is a cbinfer_frame_mask_bytes(H,W) buffer (two alternating masks + parity).
+        CB_REQUIRE(!haveIndexes && bits && !mapOut && dtype == CB_F32);
+        st = cbinfer_change_detection_frame(input, prevInput, bits, W, H, C, (kH - 1) / 2, (kW - 1) / 2,
+                                            threshold, feedbackLoop, dtype, stream);
+        if (st != CB_OK) return st;
+        if (!feedbackLoop && copyInput && prevInput != input) {
+            const size_t bytes = (size_t)C * H * W * 4;
+            hipError_t e = hipMemcpyAsync(prevInput, input, bytes, hipMemcpyDeviceToDevice,
+                                          (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
+        const void* src = (feedbackLoop || copyInput) ? prevInput : input;
+        return cbinfer_conv_changed_from_mask(src, bits, idx, countDev, weightsPrepared, bias, prevOutput,
+                                              C, H, W, K, kH, kW, relu, workspace, dtype, stream);
+    }
     if (!haveIndexes) {
         CB_REQUIRE(bits != nullptr);
         st = cbinfer_change_detection_bits(input, prevInput, bits, W, H, C, (kH - 1) / 2, (kW - 1) / 2,

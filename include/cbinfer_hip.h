@@ -157,7 +157,22 @@ int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void* prevOutpu
                              const void* weightsPrepared, const void* bias, int C, int H, int W,
                              int K, int kH, int kW, float threshold, int feedbackLoop,
                              int copyInput, int relu, int haveIndexes, int capN, void* workspace,
-                             int dtype, cbStream_t stream);
+                             int selfCompact, int dtype, cbStream_t stream);
+
+/* selfCompact=1 (fp32, no mapOut, no upstream indexes, cbinfer_mask_words(H,W) <=
+ * cbinfer_frame_mask_max_words()): `bits` is a zero-initialised buffer of cbinfer_frame_mask_bytes(H,W)
+ * bytes holding two alternating masks and a device-side parity; the compaction launch disappears, the
+ * fused kernel derives the change list from the mask by itself and still writes idx/countDev.
+ * The two launches are also available on their own: */
+long cbinfer_frame_mask_bytes(int H, int W);
+int cbinfer_frame_mask_max_words(void);
+int cbinfer_change_detection_frame(const void* input, void* state, uint64_t* frameMasks, int W, int H,
+                                   int C, int kHHalf, int kWHalf, float threshold,
+                                   int updateInputState, int dtype, cbStream_t stream);
+int cbinfer_conv_changed_from_mask(const void* input, uint64_t* frameMasks, int32_t* idxOut,
+                                   int32_t* countOut, const void* weightsPrepared, const void* bias,
+                                   void* output, int C, int H, int W, int K, int kH, int kW, int relu,
+                                   void* workspace, int dtype, cbStream_t stream);
 
 /* ---- a9: change-based 2x2/stride-2 max pooling -----------------------------------------------
  * replaces maxPool2d, conv2d_cg.py:58-82 -> cbconv2d_cg_backend.cu:229-240 (kernel :199-227).

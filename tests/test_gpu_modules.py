@@ -268,3 +268,49 @@ def test_pool_without_clone_is_equivalent(pkg):
             for f in vid.frames(4):
                 ya, yb = a(f.clone()), b(f.clone())
                 assert torch.equal(ya, yb)
+
+
+def test_self_compacting_pipeline_matches_op_sequence(pkg):
+    """The default frame pipeline (detection + self-compacting fused kernel, two alternating masks with a
+    device-side parity) against the reference-structured op sequence (syncIndexes=True) over a sequence
+    with partial changes: identical change lists every frame, states within 1e-5; also across a
+    clearMemory() in the middle and with an empty change list (repeated frame)."""
+    from cbinfer_amd import workloads
+    from cbinfer_amd.conv2d_cg import ChangeIndexes
+    _, a = workloads.sceneLabelingModels(experimentIdx=6, threshold=0.05, seed=5)
+    _, b = workloads.sceneLabelingModels(experimentIdx=6, threshold=0.05, seed=5)
+    pkg.setSyncIndexes(b, True)
+    ca = [m for m in a.modules() if type(m) is pkg.CBConv2d]
+    cb_ = [m for m in b.modules() if type(m) is pkg.CBConv2d]
+    vid = workloads.SyntheticVideo(H=96, W=160, ratio=0.1, block=16, seed=11)
+    frames = vid.frames(7)
+    frames.insert(3, frames[2].clone())          # a frame without any change
+    with torch.no_grad():
+        for t, f in enumerate(frames):
+            if t == 5:
+                pkg.clearMemory(a)
+                pkg.clearMemory(b)
+            ya, yb = a(f.clone()), b(f.clone())
+            for ma, mb in zip(ca, cb_):
+                assert ma._work['selfc'], "self-compacting path not taken"
+                ia = ChangeIndexes(ma._work['idx'], ma._work['count']).tensor()
+                # the op-sequence twin re-derives its list from its own (bit-identical) state
+                assert torch.allclose(ma.prevOutput, mb.prevOutput, rtol=0, atol=1e-5), (t,)
+                assert torch.allclose(ma.prevInput, mb.prevInput, rtol=0, atol=1e-5), (t,)
+                if t == 3:
+                    assert ia.numel() == 0
+            assert torch.allclose(ya, yb, rtol=0, atol=1e-5)
+    # index lists: compare against the detection op on a fresh pair of inputs
+    from cbinfer_amd import conv2d_cg as cg
+    x0 = torch.rand(1, 3, 96, 160, device="cuda")
+    conv = pkg.CBConv2d(torch.nn.Conv2d(3, 16, 7, padding=3).cuda(), 0.05)
+    conv.feedbackLoop = True
+    with torch.no_grad():
+        conv(x0)
+        x1 = x0.clone()
+        x1[:, :, 10:30, 40:90] += 0.5
+        st = conv.prevInput.clone()
+        conv(x1)
+    expect = cg.changeIndexesExtr(cg.changeDetection(x1, st, (7, 7), 0.05))
+    got = ChangeIndexes(conv._work['idx'], conv._work['count']).tensor()
+    assert torch.equal(got, expect)

@@ -17,7 +17,10 @@ class SequenceShard(object):
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # RCCL ("nccl") on GPUs; CBINFER_DIST_BACKEND=gloo lets the N>1 control flow be rehearsed
+                # with several ranks on one GPU, where RCCL refuses duplicate devices
+                backend = os.environ.get("CBINFER_DIST_BACKEND") or (
+                    "nccl" if torch.cuda.is_available() else "gloo")
             if not dist.is_initialized():
                 dist.init_process_group(backend)
             self.dist = dist
@@ -42,6 +45,8 @@ class SequenceShard(object):
         """(total frames over all ranks, MAX elapsed over ranks): whole-job throughput is their ratio."""
         if self.dist is None:
             return steps, elapsed
+        if self.backend == "gloo":
+            device = "cpu"
         t = torch.tensor([float(elapsed)], dtype=torch.float64, device=device)
         n = torch.tensor([float(steps)], dtype=torch.float64, device=device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)

@@ -314,3 +314,24 @@ def test_self_compacting_pipeline_matches_op_sequence(pkg):
     expect = cg.changeIndexesExtr(cg.changeDetection(x1, st, (7, 7), 0.05))
     got = ChangeIndexes(conv._work['idx'], conv._work['count']).tensor()
     assert torch.equal(got, expect)
+
+
+def test_fullsize_threshold_zero_tracks_dense(pkg):
+    """Size-independent property at BASELINE size (480x320): with threshold 0 every non-zero change is
+    detected (strict >), so after any number of frames the change-based network equals the dense network
+    on the last frame within the fp32 tolerance -- coarse-grained with feedback loop + change-based
+    pooling (experiment 6) -- and a repeated frame leaves every change list empty."""
+    from cbinfer_amd import workloads
+    from cbinfer_amd.conv2d_cg import ChangeIndexes
+    base, test = workloads.sceneLabelingModels(experimentIdx=6, threshold=0.0, seed=3)
+    vid = workloads.SyntheticVideo(H=320, W=480, ratio=0.10, block=32, seed=21)
+    with torch.no_grad():
+        for f in vid.frames(5):
+            y = test(f)
+        ref = base(vid.frame)
+        assert (y - ref).abs().max().item() <= 1e-4
+        y2 = test(vid.frame.clone())
+        assert torch.equal(y, y2)
+        for m in test.modules():
+            if type(m) is pkg.CBConv2d:
+                assert ChangeIndexes(m._work['idx'], m._work['count']).numel() == 0

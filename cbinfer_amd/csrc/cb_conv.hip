@@ -285,7 +285,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
     float* const As = smem;                  // [2][BK][BM]
     float* const Bs = smem + 2 * A_STAGE;    // [2][BK][LDB]
 
-    const int lane = t & 63, wave = t >> 6;
+    // the wave index is wave-uniform, but only readfirstlane lets the compiler know: roles derived from
+    // it (k-group, tile position, MFMA-first stagger) then stay in scalar registers and real branches
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int ks = wave / (WM * WN), wq = wave % (WM * WN);
     const int wm = wq % WM, wn = wq / WM;
     const int l31 = lane & 31, h = lane >> 5;

@@ -163,7 +163,8 @@ def tuneThresholdParameters(vidSeqReader, evalSequences, numFramesPerSeq, target
             m.threshold *= thresholdIncrFactor
             loss = evaluateModel()
             _log('. (%f < %f + %f)' % (loss, prevLoss, lossToleranceList[i]))
-            if loss - prevLoss > lossToleranceList[i]:
+            # (guard absent in the reference: a tolerance that is never exceeded would loop forever)
+            if loss - prevLoss > lossToleranceList[i] or not (m.threshold < 1e30):
                 m.threshold /= thresholdIncrFactor
                 break
         prevLoss = evaluateModel()

@@ -1,0 +1,170 @@
+"""Evaluation harness with the reference's protocol (poseDetection/evalTools.py, symlinked into
+sceneLabeling/): run a model over a frame list, time the LAST frame after priming on the others
+(min of 3 repeats), list the change-based layers, write result tables.  Power logging, Tegra-specific in
+the reference (tx2power.py), reads the amdgpu hwmon sensor here."""
+import csv
+import glob
+import math
+import os
+import threading
+import time
+import timeit
+
+import torch
+
+from . import CBConv2d, CBPoolMax2d, clearMemory
+
+
+def inferFramesetBenchmark(m, frameset, cuda=True, numIter=3, preprocessor=None):
+    """Seconds for the last frame of `frameset` (reference: evalTools.py:7-35): state cleared, frames
+    [:-1] run untimed, device synchronised, then the last frame + synchronise is timed; repeated numIter
+    times, minimum returned.  Frames are moved to the device before timing."""
+    if preprocessor is not None:
+        frameset = list(map(preprocessor, frameset))
+    if cuda:
+        frameset = [frm.cuda() for frm in frameset]
+
+    def prepBenchm():
+        clearMemory(m)
+        with torch.no_grad():
+            for frame in frameset[:-1]:
+                m(frame)
+        if cuda:
+            torch.cuda.synchronize()
+
+    def coreBenchm():
+        with torch.no_grad():
+            m(frameset[-1])
+        if cuda:
+            torch.cuda.synchronize()
+
+    tmr = timeit.Timer(stmt=coreBenchm, setup=prepBenchm)
+    return min(tmr.repeat(repeat=numIter, number=1))
+
+
+def inferFrameset(m, frameset, cuda=True, preprocessor=None, postproc=None):
+    """Output for the last frame after feeding the whole list (reference: evalTools.py:37-49)."""
+    if preprocessor is not None:
+        frameset = list(map(preprocessor, frameset))
+    if cuda:
+        frameset = [frm.cuda() for frm in frameset]
+    clearMemory(m)
+    y = None
+    with torch.no_grad():
+        for frame in frameset:
+            y = m(frame)
+    if postproc is not None:
+        y = postproc(y)
+    return y
+
+
+class PowerLogger(object):
+    """Samples the GPU board power (amdgpu hwmon `power1_average`, microwatts) in a thread."""
+
+    def __init__(self, interval=0.05, device=0):
+        self.interval = interval
+        paths = sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*/power1_average'))
+        self.path = paths[device] if device < len(paths) else None
+        self.samples = []     # (time, watts)
+        self.events = []
+        self._stop = threading.Event()
+        self._thread = None
+
+    def _read(self):
+        try:
+            with open(self.path) as f:
+                return int(f.read().strip()) * 1e-6
+        except Exception:
+            return float('nan')
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append((time.time(), self._read()))
+            time.sleep(self.interval)
+
+    def start(self):
+        self._stop.clear()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def recordEvent(self, name):
+        self.events.append((time.time(), name))
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join()
+
+    def getTotalEnergy(self):
+        """Joules, trapezoidal over the samples."""
+        e = 0.0
+        for (t0, p0), (t1, p1) in zip(self.samples[:-1], self.samples[1:]):
+            if not (math.isnan(p0) or math.isnan(p1)):
+                e += 0.5 * (p0 + p1) * (t1 - t0)
+        return e
+
+    def getAveragePower(self):
+        vals = [p for _, p in self.samples if not math.isnan(p)]
+        return sum(vals) / len(vals) if vals else float('nan')
+
+
+def inferFramesetPowerMeasurement(m, frameset, cuda=True, numFrames=0, preprocessor=None):
+    """Run a (back-and-forth extended) sequence under a PowerLogger (reference: evalTools.py:54-83)."""
+    if preprocessor is not None:
+        frameset = list(map(preprocessor, frameset))
+    if cuda:
+        frameset = [frm.cuda() for frm in frameset]
+    if numFrames > 0:
+        frameset = frameset + frameset[-2:0:-1]
+        frameset = int(math.ceil(numFrames / float(len(frameset)))) * frameset
+        frameset = frameset[:numFrames]
+    clearMemory(m)
+    with torch.no_grad():
+        m(frameset[0])
+        if cuda:
+            torch.cuda.synchronize()
+        pl = PowerLogger()
+        pl.start()
+        for frame in frameset[1:]:
+            m(frame)
+        if cuda:
+            torch.cuda.synchronize()
+        pl.stop()
+    return pl
+
+
+def _submodels(model):
+    return [m for _, m in sorted(model.named_children(), key=lambda kv: kv[0])]
+
+
+def getCBconvLayers(model):
+    """CBConv2d modules of a two-level model (sub-models sorted by name), reference: evalTools.py:85-93."""
+    out = []
+    for sub in _submodels(model):
+        mods = sub if isinstance(sub, torch.nn.Sequential) else [sub]
+        for m in mods:
+            if type(m) is CBConv2d:
+                out.append(m)
+    return out
+
+
+def getCBpoolLayers(model):
+    out = []
+    for sub in _submodels(model):
+        mods = sub if isinstance(sub, torch.nn.Sequential) else [sub]
+        for m in mods:
+            if type(m) is CBPoolMax2d:
+                out.append(m)
+    return out
+
+
+def writeTable(table, appName='poseDet', seqName='sampleSequence', evalName='evalXX', resultsDir='./results'):
+    """Write a list of rows (first row = header) as ./results/<app>-<seq>-<eval>.csv
+    (reference: evalTools.py:105-125)."""
+    os.makedirs(resultsDir, exist_ok=True)
+    path = os.path.join(resultsDir, '%s-%s-%s.csv' % (appName, seqName, evalName))
+    with open(path, 'w', newline='') as f:
+        w = csv.writer(f)
+        for row in table:
+            w.writerow(row)
+    return path

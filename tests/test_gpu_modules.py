@@ -335,3 +335,40 @@ def test_fullsize_threshold_zero_tracks_dense(pkg):
         for m in test.modules():
             if type(m) is pkg.CBConv2d:
                 assert ChangeIndexes(m._work['idx'], m._work['count']).numel() == 0
+
+
+def test_eval_harness_and_threshold_tuner(pkg, tmp_path):
+    """The reference's measurement protocol (evalTools.inferFramesetBenchmark: last frame timed after
+    priming, min of 3) and its greedy threshold tuner with the callback protocol of __init__.py:98-149."""
+    from cbinfer_amd import evalTools, workloads
+    base, test = workloads.sceneLabelingModels(experimentIdx=4, threshold=0.02, seed=1)
+    vid = workloads.SyntheticVideo(H=64, W=96, ratio=0.125, block=16, seed=2)
+    frames = [f.cpu() for f in vid.frames(4)]
+    t_cb = evalTools.inferFramesetBenchmark(test, frames)
+    t_dense = evalTools.inferFramesetBenchmark(base, frames[-1:])
+    assert t_cb > 0 and t_dense > 0
+    y = evalTools.inferFrameset(test, frames)
+    ref = evalTools.inferFrameset(base, frames[-1:])
+    assert (y - ref).abs().max().item() < 0.2
+    wrapped = torch.nn.Sequential()
+    wrapped.add_module('model0', test)
+    assert len(evalTools.getCBconvLayers(wrapped)) == 3 and evalTools.getCBpoolLayers(wrapped) == []
+    path = evalTools.writeTable([['layer', 'th'], ['0', 0.1]], resultsDir=str(tmp_path))
+    assert open(path).read().splitlines() == ['layer,th', '0,0.1']
+
+    class Reader(object):
+        def getDataFrames(self, seqName, numFrames):
+            return frames[:numFrames], None
+
+    cbs = [m for m in test.modules() if type(m) is pkg.CBConv2d]
+    with torch.no_grad():
+        target = base(frames[-1].cuda())
+    scale = float(target.pow(2).mean())
+    pkg.tuneThresholdParameters(Reader(), ['s'], 4, lambda fr: target, lambda fr: fr, base, test,
+                                lambda out, tgt: float((out - tgt).pow(2).mean()), cbs,
+                                lossToleranceList=1e-4 * scale, initThreshold=1e-3,
+                                thresholdIncrFactor=4.0)
+    assert all(1e-3 <= m.threshold < 10 for m in cbs), [m.threshold for m in cbs]
+    # the tuned network still tracks the dense one: every module stopped before its tolerance was spent
+    y2 = evalTools.inferFrameset(test, frames)
+    assert float((y2 - ref).pow(2).mean()) <= 4 * 1e-4 * scale

@@ -185,9 +185,9 @@ class CBConv2d(nn.Module):
 
     def _workspace(self, input):
         H, W = input.size(-2), input.size(-1)
-        # self-compacting frame pipeline (detection + fused kernel, no compaction launch): fp32, mask
-        # small enough for the kernel's LDS prefix, and no int8 copy of the mask requested
-        selfc = (input.dtype == torch.float32 and not self.saveChangeMap and
+        # self-compacting frame pipeline (detection + fused kernel, no compaction launch): mask small
+        # enough for the kernel's LDS prefix, and no int8 copy of the mask requested
+        selfc = (not self.saveChangeMap and
                  C.cbinfer_mask_words(H, W) <= C.cbinfer_frame_mask_max_words() and
                  os.environ.get('CBINFER_NO_SELFCOMPACT', '0') != '1')
         key = (H, W, input.device, selfc)

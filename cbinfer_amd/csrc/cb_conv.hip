@@ -18,13 +18,7 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(4))) int cb_const_int;   // constant address space: scalar loads
-typedef int cb_i2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(4))) cb_i2 cb_const_int2;
 
-// n / d by multiply-high with magic = ceil(2^32/d) (exact while n*d < 2^32); magic 0 encodes d == 1
-__device__ __forceinline__ unsigned cb_fastdiv(unsigned n, unsigned magic) {
-    return magic ? __umulhi(n, magic) : n;
-}
 __device__ __forceinline__ float cb_relu(float v) { return v <= 0.f ? 0.f : v; }
 __device__ __forceinline__ cb_half cb_relu(cb_half v) { return v <= (cb_half)0 ? (cb_half)0 : v; }
 
@@ -125,7 +119,6 @@ struct ConvParams {
     int nHost;
     int K, KP, Ckk, CkkP;
     int C, H, W, kH, kW;
-    unsigned magicKHW, magicKW;  // ceil(2^32/d) for d = kH*kW and d = kW
     int relu;
     unsigned long long* clearBits;  // optional: change bit mask to zero for the next frame
     long clearWords;
@@ -552,154 +545,390 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
     }
 }
 
-// fp16: same decomposition; LDS operands are k-contiguous rows (A[m][k], B[n][k]) padded to an
-// 80-byte stride so the 16-byte fragment reads of a 16-lane group cover all 64 banks once.
-template <int WM, int MODE, int EPI>
-__global__ __launch_bounds__(256) void cb_mfma_f16_kernel(ConvParams p) {
+// fp16 contraction kernel (cg_half path): the schedule, pipeline, split-K, in-kernel compaction and
+// gather of cb_mfma_f32_kernel with v_mfma_f32_32x32x16_f16 (f32 accumulation).  A lane's MFMA fragment is
+// 8 consecutive k, so both LDS operands are k-contiguous rows -- A[m][k], B[n][k], 144-byte row stride so
+// that the 16-byte fragment reads of a 16-lane group cover all 64 banks once -- which is exactly what
+// the gather produces: a thread owns B_PER_T consecutive k of one pixel and stores them with one (or
+// two) 16-byte LDS writes.  BK = 64 halfs per stage.  With only 2-4 MFMAs per wave and stage this
+// kernel is bound by the gather/issue stream, not by the matrix pipe.
+template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false>
+__global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvParams p) {
+    constexpr int NT = 64 * WM * WN * KS;
     constexpr int BM = 32 * WM;
-    constexpr int WN = 4 / WM;
     constexpr int BN = 32 * WN;
-    constexpr int BK = CB_BK_H;   // 32 halfs = 64 B per row per stage
-    constexpr int LDH = 40;       // row stride in halfs (80 B)
-    constexpr int A_V = BM * 4;   // 16-byte vectors per A stage
-    constexpr int A_PER_T = (A_V + 255) / 256;
-    constexpr int B_PER_T = BK * BN / 256;
-
-    if (MODE == CB_MODE_GATHER) cb_clear_mask(p);
-    const int N = p.countDev ? min(*p.countDev, p.nHost) : p.nHost;
-    const int n0 = blockIdx.x * BN;
-    if (n0 >= N) return;
-    const int m0 = blockIdx.y * BM;
-
-    __shared__ __attribute__((aligned(16))) cb_half As[BM * LDH];
-    __shared__ __attribute__((aligned(16))) cb_half Bs[BN * LDH];
+    constexpr int BK = 64;              // halfs per stage
+    constexpr int LDH = 72;             // LDS row stride in halfs (144 B)
+    constexpr int A_V = BK * BM / 8;    // 16-byte chunks per A stage
+    constexpr int A_PER_T = (A_V + NT - 1) / NT;
+    constexpr int B_PER_T = BK * BN / NT;
+    constexpr int NPP = NT / BK;        // matrix: pixel slots covered by one pass
+    constexpr int KSTEP = BK / KS;      // k-depth one wave group handles per stage
+    constexpr int A_STAGE = BM * LDH, B_STAGE = BN * LDH;   // in halfs
+    constexpr int TILE = BM * BN;
+    static_assert(BN % 64 == 0, "gather rows must be wave-uniform");
+    static_assert(BK * BN % NT == 0 && KSTEP % 16 == 0 && B_PER_T % 8 == 0, "bad decomposition");
+    static_assert(KS == 1 || 2 * (A_STAGE + B_STAGE) * 2 >= WM * WN * 64 * 16 * 4, "reduce buffer");
 
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    const int wm = wave % WM, wn = wave / WM;
+    // ---- SELFC: stream compaction folded into this kernel -------------------------------------------
+    // Every workgroup rebuilds the exclusive popcount prefix of the frame's change mask (<= 32 KB, L2
+    // resident) in LDS; a tile's pixels are then found by rank (binary search over the prefix + select
+    // of the r-th set bit).  No compaction launch, and no hand-off between workgroups.  Two masks
+    // alternate by a device-side parity so that this launch can zero the one the NEXT frame's detection
+    // will fill while every workgroup still reads the current one; the last workgroup to finish flips
+    // the parity.
+    __shared__ int s_pre[SELFC ? CB_SELFC_MAXW + 1 : 1];
+    __shared__ int s_wsum[SELFC ? NT / 64 : 1];
+    __shared__ int s_tilePix[SELFC ? BN : 1];
+    const unsigned long long* mask = nullptr;
+    int par = 0;
+    int N;
+    if (SELFC) {
+        int* ctl = (int*)(p.frameMasks + 2 * (long)p.maskWords);   // {parity, done}
+        par = ctl[0];
+        mask = p.frameMasks + (par ? p.maskWords : 0);
+        unsigned long long* other = p.frameMasks + (par ? 0 : p.maskWords);
+        for (int i = blockIdx.x * NT + t; i < p.maskWords; i += gridDim.x * NT) other[i] = 0ull;
+        // exclusive prefix of per-word popcounts: thread t owns CH consecutive words
+        const int CH = (p.maskWords + NT - 1) / NT;
+        const int wb = t * CH;
+        int loc = 0;
+        for (int u = 0; u < CH; ++u) {
+            const int w = wb + u;
+            if (w < p.maskWords) loc += __popcll(mask[w]);
+        }
+        int incl = loc;   // inclusive scan over the wave, then over the waves
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if ((t & 63) >= o) incl += v;
+        }
+        if ((t & 63) == 63) s_wsum[t >> 6] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (t >> 6); ++w) base += s_wsum[w];
+        int run = base + incl - loc;
+        for (int u = 0; u < CH; ++u) {
+            const int w = wb + u;
+            if (w < p.maskWords) {
+                s_pre[w] = run;
+                run += __popcll(mask[w]);
+            }
+        }
+        if (t == NT - 1) s_pre[p.maskWords] = base + incl;   // the last thread's chunk ends the mask
+        __syncthreads();
+        N = min(s_pre[p.maskWords], p.nHost);
+        if (blockIdx.x == 0 && t == 0) p.countOut[0] = N;
+    } else {
+        if (MODE == CB_MODE_GATHER) cb_clear_mask(p);
+        N = p.countDev ? min(*p.countDev, p.nHost) : p.nHost;
+    }
+    const int MT = p.KP / BM;
+    const int T = ((N + BN - 1) / BN) * MT;                  // output tiles
+    const int P = p.CkkP / (2 * BK);                         // stage pairs along k
+    // Split along k only while whole CUs would otherwise idle (T below CB_SK_TARGET x the CU count) and
+    // the k-depth is long enough to pay for the slab round trip: the reducer costs ~4 us of fences +
+    // ~1 us per slab, a stage pair ~1.7 us, so the best slice count is ~sqrt(1.7 P).
+    int SK = 1;
+    const int cus = (int)gridDim.x / CB_CONV_GRID_PER_CU;
+#ifndef CB_SK_TARGET
+#define CB_SK_TARGET 2
+#endif
+    if (p.slabs && T > 0 && T < CB_SK_TARGET * cus && P >= 8)
+        SK = max(1, min(min(CB_SKMAX, (CB_SK_TARGET * cus) / T), (int)sqrtf(1.7f * (float)P)));
+    const int items = T * SK;
+    if (!SELFC && (int)blockIdx.x >= items) return;
+
+    __shared__ __attribute__((aligned(16))) cb_half smemh[2 * (A_STAGE + B_STAGE)];
+    __shared__ int s_last;
+    cb_half* const As = smemh;                  // [2][BM][LDH]
+    cb_half* const Bs = smemh + 2 * A_STAGE;    // [2][BN][LDH]
+    float* const smem = (float*)smemh;          // reduce buffer view
+
+    // the wave index is wave-uniform, but only readfirstlane lets the compiler know: roles derived from
+    // it (k-group, tile position, MFMA-first stagger) then stay in scalar registers and real branches
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ks = wave / (WM * WN), wq = wave % (WM * WN);
+    const int wm = wq % WM, wn = wq / WM;
     const int l31 = lane & 31, h = lane >> 5;
 
     const cb_half* __restrict__ Ag = (const cb_half*)p.A;
     const cb_half* __restrict__ Bg = (const cb_half*)p.B;
+    const cb_const_int* koff_c = (const cb_const_int*)(Ag + (long)p.KP * p.CkkP);
+    const cb_const_int* kdyx_c = koff_c + p.CkkP;
     const int HW = p.H * p.W;
-
-    int bj, br;
-    int py = 0, px = 0;
-    bool pvalid = false;
-    if (MODE == CB_MODE_GATHER) {
-        bj = t % BN;
-        br = t / BN;
-        const int n = n0 + bj;
-        pvalid = n < N;
-        if (pvalid) {
-            const int pos = p.list[n];
-            py = pos / p.W;
-            px = pos - py * p.W;
-        }
-    } else {
-        bj = t / BK;
-        br = t % BK;
-    }
-    const int ph = (p.kH - 1) / 2, pw = (p.kW - 1) / 2;
-    const int KHW = p.kH * p.kW;
-
-    uint4 areg[A_PER_T];
-    cb_half breg[B_PER_T];
-
-    auto load_stage = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < A_PER_T; ++i) {
-            const int f = t + i * 256;
-            if (A_V >= 256 || f < A_V) {
-                const int row = f / 4, q = f % 4;
-                areg[i] = *(const uint4*)(Ag + (long)(m0 + row) * p.CkkP + k0 + q * 8);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_PER_T; ++i) {
-            cb_half v = (cb_half)0;
-            if (MODE == CB_MODE_GATHER) {
-                const unsigned kg = (unsigned)(k0 + br + i * (256 / BN));
-                const unsigned c = cb_fastdiv(kg, p.magicKHW);
-                const unsigned r = kg - c * KHW;
-                const unsigned ky = cb_fastdiv(r, p.magicKW);
-                const unsigned kx = r - ky * p.kW;
-                const int iy = py + (int)ky - ph, ix = px + (int)kx - pw;
-                const bool ok = pvalid && (int)kg < p.Ckk && (unsigned)iy < (unsigned)p.H &&
-                                (unsigned)ix < (unsigned)p.W;
-                if (ok) v = Bg[(long)c * HW + iy * p.W + ix];
-            } else {
-                const int n = n0 + bj + i * (256 / BK);
-                const int kg = k0 + br;
-                if (n < N && kg < p.Ckk) v = Bg[(long)n * p.Ckk + kg];
-            }
-            breg[i] = v;
-        }
-    };
-    auto store_stage = [&]() {
-#pragma unroll
-        for (int i = 0; i < A_PER_T; ++i) {
-            const int f = t + i * 256;
-            if (A_V >= 256 || f < A_V) {
-                const int row = f / 4, q = f % 4;
-                *(uint4*)(As + row * LDH + q * 8) = areg[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_PER_T; ++i) {
-            if (MODE == CB_MODE_GATHER)
-                Bs[bj * LDH + br + i * (256 / BN)] = breg[i];
-            else
-                Bs[(bj + i * (256 / BK)) * LDH + br] = breg[i];
-        }
-    };
-
-    floatx16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-
-    load_stage(0);
-    for (int k0 = 0; k0 < p.CkkP; k0 += BK) {
-        store_stage();
-        __syncthreads();
-        if (k0 + BK < p.CkkP) load_stage(k0 + BK);
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 16) {
-            // lane holds A[row l31][k = kk + 8h + 0..7] and B[k = kk + 8h + 0..7][col l31]
-            const halfx8 a = *(const halfx8*)(As + (wm * 32 + l31) * LDH + kk + 8 * h);
-            const halfx8 b = *(const halfx8*)(Bs + (wn * 32 + l31) * LDH + kk + 8 * h);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-
-    const int n = n0 + wn * 32 + l31;
-    if (n >= N) return;
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.B, 0, MODE == CB_MODE_GATHER ? p.C * HW * 2 : 0, 0x00020000);
     cb_half* __restrict__ out = (cb_half*)p.out;
     const cb_half* __restrict__ bias = (const cb_half*)p.bias;
-    int pix = 0;
-    if (EPI >= CB_EPI_SCATTER) pix = p.list[n];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= p.K) continue;
-        float v = acc[r];
-        if (EPI != CB_EPI_SCATTER_ACC) {
-            if (bias) v += (float)bias[m];
-            if (p.relu) v = cb_relu(v);
+
+    const int bj = MODE == CB_MODE_GATHER ? t % BN : t / BK;
+    const int br = MODE == CB_MODE_GATHER ? __builtin_amdgcn_readfirstlane(t / BN) * B_PER_T : t % BK;
+
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int tile = item / SK, slice = item - tile * SK;
+        const int n0 = (tile / MT) * BN, m0 = (tile % MT) * BM;
+        const int kBeg = (P * slice / SK) * 2 * BK, kEnd = (P * (slice + 1) / SK) * 2 * BK;
+        const int kLast = kEnd - BK;
+
+        // per-thread B-load coordinates; a slot past the list is "outside the image"
+        int py = -(1 << 20), px = 0, pbase4 = 0;
+        if (SELFC) {
+            // pixel of slot j of this tile = the (n0+j)-th set bit of the mask
+            __syncthreads();   // s_tilePix of the previous item is no longer read
+            if (t < BN) {
+                const int r = n0 + t;
+                int pos = -1;
+                if (r < N) {
+                    int lo = 0, hi = p.maskWords;   // largest w with s_pre[w] <= r
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_pre[mid] <= r)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
+                    const int bit = cb_select_bit(mask[lo], r - s_pre[lo]);
+                    const int row = lo / p.wpr;
+                    pos = row * p.W + (lo - row * p.wpr) * 64 + bit;
+                    if (m0 == 0 && slice == 0) p.listOut[r] = pos;
+                }
+                s_tilePix[t] = pos;
+            }
+            __syncthreads();
+            const int pos = s_tilePix[bj];
+            if (pos >= 0) {
+                py = pos / p.W;
+                px = pos - py * p.W;
+                pbase4 = pos * 2;
+            }
+        } else if (MODE == CB_MODE_GATHER) {
+            const int n = n0 + bj;
+            if (n < N) {
+                const int pos = p.list[n];
+                py = pos / p.W;
+                px = pos - py * p.W;
+                pbase4 = pos * 2;
+            }
         }
-        if (EPI == CB_EPI_Y)
-            out[(long)n * p.K + m] = (cb_half)v;
-        else if (EPI == CB_EPI_YT)
-            out[(long)m * p.nHost + n] = (cb_half)v;
-        else if (EPI == CB_EPI_SCATTER)
-            out[(long)m * HW + pix] = (cb_half)v;
-        else
-            out[(long)m * HW + pix] = (cb_half)((float)out[(long)m * HW + pix] + v);
+        // taps of the NEXT stage to load, B_PER_T consecutive table entries per array: ONE scalar load
+        // each (s_load_dwordx4), kept in scalar registers across the stage
+        typedef int ivec __attribute__((ext_vector_type(B_PER_T)));
+        typedef __attribute__((address_space(4))) ivec cb_const_ivec;
+        ivec pkOff, pkDyx;
+        auto fetch_pk = [&](int k0) {
+            if (MODE == CB_MODE_GATHER) {
+#pragma unroll
+                for (int i = 0; i < 1; ++i) {
+                    pkOff = *(const cb_const_ivec*)(koff_c + k0 + br);
+                    pkDyx = *(const cb_const_ivec*)(kdyx_c + k0 + br);
+                }
+            }
+        };
+        fetch_pk(kBeg);
+
+        // staging registers as vector types (arrays passed by reference may end up in scratch)
+        typedef unsigned avec __attribute__((ext_vector_type(4 * A_PER_T)));
+        typedef _Float16 bvec __attribute__((ext_vector_type(B_PER_T)));
+        avec a0, a1;
+        bvec b0, b1;
+
+        auto load_stage = [&](int k0, avec& areg, bvec& breg) {
+#pragma unroll
+            for (int i = 0; i < A_PER_T; ++i) {
+                const int f = t + i * NT;
+                if (A_V % NT == 0 || f < A_V) {
+                    const int row = f / (BK / 8), c8 = f % (BK / 8);
+                    const uint4 v4 = *(const uint4*)(Ag + (long)(m0 + row) * p.CkkP + k0 + c8 * 8);
+                    areg[4 * i + 0] = v4.x;
+                    areg[4 * i + 1] = v4.y;
+                    areg[4 * i + 2] = v4.z;
+                    areg[4 * i + 3] = v4.w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < B_PER_T; ++i) {
+                cb_half v = (cb_half)0;
+                if (MODE == CB_MODE_GATHER) {
+                    const int koff4 = pkOff[i];                       // scalar
+                    const int dy = (pkDyx[i] << 16) >> 16, dx = pkDyx[i] >> 16;
+                    const int iy = py + dy, ix = px + dx;
+                    const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                    const int voff = ok ? pbase4 + koff4 : (1 << 30);
+                    v = __builtin_bit_cast(cb_half, __builtin_amdgcn_raw_buffer_load_b16(brsrc, voff, 0, 0));
+                } else {
+                    const int n = n0 + bj + i * NPP;
+                    const int kg = k0 + br;
+                    if (n < N && kg < p.Ckk) v = Bg[(long)n * p.Ckk + kg];
+                }
+                breg[i] = v;
+            }
+            fetch_pk(min(k0 + BK, kLast));   // consecutive calls load consecutive stages
+        };
+        auto store_stage = [&](int buf, const avec& areg, const bvec& breg) {
+            cb_half* as = As + buf * A_STAGE;
+            cb_half* bs = Bs + buf * B_STAGE;
+#pragma unroll
+            for (int i = 0; i < A_PER_T; ++i) {
+                const int f = t + i * NT;
+                if (A_V % NT == 0 || f < A_V) {
+                    const int row = f / (BK / 8), c8 = f % (BK / 8);
+                    *(uint4*)(as + row * LDH + c8 * 8) =
+                        make_uint4(areg[4 * i + 0], areg[4 * i + 1], areg[4 * i + 2], areg[4 * i + 3]);
+                }
+            }
+            if (MODE == CB_MODE_GATHER) {
+                // this thread's B_PER_T consecutive k of pixel slot bj: 16-byte LDS writes
+#pragma unroll
+                for (int q = 0; q < B_PER_T / 8; ++q) {
+                    halfx8 v8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v8[e] = breg[8 * q + e];
+                    *(halfx8*)(bs + bj * LDH + br + 8 * q) = v8;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < B_PER_T; ++i) bs[(bj + i * NPP) * LDH + br] = breg[i];
+            }
+        };
+
+        floatx16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+        auto compute = [&](int buf) {
+            // lane holds A[row l31][k = kk + 8h + 0..7] and B[k = kk + 8h + 0..7][col l31]
+            const cb_half* as = As + buf * A_STAGE + (wm * 32 + l31) * LDH + 8 * h;
+            const cb_half* bs = Bs + buf * B_STAGE + (wn * 32 + l31) * LDH + 8 * h;
+#pragma unroll
+            for (int kk = ks * KSTEP; kk < (ks + 1) * KSTEP; kk += 16) {
+                const halfx8 a = *(const halfx8*)(as + kk);
+                const halfx8 b = *(const halfx8*)(bs + kk);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+            }
+        };
+
+        // Every stage issues the same number of loads (past the slice end they re-load its last stage
+        // and are never stored).
+        load_stage(kBeg, a0, b0);
+        load_stage(kBeg + BK, a1, b1);
+        const bool mfmaFirst = (KS > 1) && (ks & 1);
+        for (int k0 = kBeg; k0 < kEnd; k0 += 2 * BK) {
+            store_stage(0, a0, b0);
+            __syncthreads();
+            if (mfmaFirst) {
+                compute(0);
+                load_stage(min(k0 + 2 * BK, kLast), a0, b0);
+            } else {
+                load_stage(min(k0 + 2 * BK, kLast), a0, b0);
+                compute(0);
+            }
+            store_stage(1, a1, b1);
+            __syncthreads();
+            if (mfmaFirst) {
+                compute(1);
+                load_stage(min(k0 + 3 * BK, kLast), a1, b1);
+            } else {
+                load_stage(min(k0 + 3 * BK, kLast), a1, b1);
+                compute(1);
+            }
+        }
+        __syncthreads();   // all LDS stage reads done: smem may be reused
+
+        if (KS > 1) {   // sum the wave groups' partial tiles through LDS (fixed order: deterministic)
+            float* red = smem + (wq * 16) * 64 + lane;
+#pragma unroll
+            for (int g = 1; g < KS; ++g) {
+                if (ks == g) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[r * 64] = acc[r];
+                }
+                __syncthreads();
+                if (ks == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] += red[r * 64];
+                }
+                __syncthreads();
+            }
+        }
+
+        if (SK > 1) {
+            // publish this slice's partial tile, take a ticket; the last arriver reduces
+            float* slab = p.slabs + (long)item * TILE + (wq * 16) * 64 + lane;
+            if (ks == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[r * 64] = acc[r];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int ticket = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+                const int last = ticket == SK - 1;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(p.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                s_last = last;
+            }
+            __syncthreads();
+            const bool last = s_last != 0;
+            __syncthreads();   // s_last may be rewritten by the next item
+            if (!last) continue;
+            if (ks == 0) {
+                const float* sl = p.slabs + (long)tile * SK * TILE + (wq * 16) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int j = 0; j < SK; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] += sl[(long)j * TILE + r * 64];
+                }
+            }
+        }
+
+        // epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        const int n = n0 + wn * 32 + l31;
+        if (ks == 0 && n < N) {
+            int pix = 0;
+            if (EPI >= CB_EPI_SCATTER) pix = SELFC ? s_tilePix[wn * 32 + l31] : p.list[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= p.K) continue;
+                float v = acc[r];
+                if (EPI != CB_EPI_SCATTER_ACC) {
+                    if (bias) v += (float)bias[m];
+                    if (p.relu) v = cb_relu(v);
+                }
+                if (EPI == CB_EPI_Y)
+                    out[(long)n * p.K + m] = (cb_half)v;
+                else if (EPI == CB_EPI_YT)
+                    out[(long)m * p.nHost + n] = (cb_half)v;
+                else if (EPI == CB_EPI_SCATTER)
+                    out[(long)m * HW + pix] = (cb_half)v;
+                else
+                    out[(long)m * HW + pix] = (cb_half)((float)out[(long)m * HW + pix] + v);
+            }
+        }
+    }
+
+    if (SELFC) {
+        // every workgroup has read the mask: the last one to get here flips the parity for the next frame
+        __syncthreads();
+        if (t == 0) {
+            int* ctl = (int*)(p.frameMasks + 2 * (long)p.maskWords);
+            const int d = __hip_atomic_fetch_add(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == (int)gridDim.x - 1) {
+                __hip_atomic_store(ctl + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ctl, par ^ 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
-
-unsigned magic_u32(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 
 // Tile configuration.  cfg = 100*WM + 10*WN + KS; the CBINFER_CONV_CFG environment variable overrides
 // the heuristic (tuning aid).  KP == 32 (K <= 32): one m-tile, 128 pixels per workgroup; otherwise
@@ -728,6 +957,23 @@ int launch_f32(const ConvParams& p, hipStream_t s) {
     dim3 grid((unsigned)g), block(64 * WM * WN * KS);
     hipLaunchKernelGGL((cb_mfma_f32_kernel<WM, WN, KS, MODE, EPI, SELFC>), grid, block, 0, s, p);
     return cb_launch_status();
+}
+
+template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false>
+int launch_f16(const ConvParams& p, hipStream_t s) {
+    const long tilesCap = (long)cb_div_up(p.nHost, 32 * WN) * (p.KP / (32 * WM));
+    if (tilesCap == 0) return CB_OK;
+    long g = CB_CONV_GRID_PER_CU * (long)cb_num_cus();
+    if (!p.slabs && tilesCap < g && !SELFC) g = tilesCap;
+    dim3 grid((unsigned)g), block(64 * WM * WN * KS);
+    hipLaunchKernelGGL((cb_mfma_f16_kernel<WM, WN, KS, MODE, EPI, SELFC>), grid, block, 0, s, p);
+    return cb_launch_status();
+}
+
+// k-depth padding of the prepared weights: a whole number of stage pairs (fp32: 2 x 32, fp16: 2 x 64)
+int cb_ckkpad(int Ckk, int dtype) {
+    const int q = dtype == CB_F16 ? 128 : 64;
+    return (Ckk + q - 1) / q * q;
 }
 
 int conv_cfg_override() {
@@ -759,14 +1005,13 @@ int launch_mfma(const ConvParams& p, int dtype, hipStream_t s) {
             default: return CB_ERR_BADARG;
         }
     }
-    const int BM = narrow ? 32 : 64, BN = narrow ? 128 : 64;
-    dim3 grid(cb_div_up(p.nHost, BN), p.KP / BM), block(256);
-    if (grid.x == 0) return CB_OK;
-    if (narrow)
-        hipLaunchKernelGGL((cb_mfma_f16_kernel<1, MODE, EPI>), grid, block, 0, s, p);
-    else
-        hipLaunchKernelGGL((cb_mfma_f16_kernel<2, MODE, EPI>), grid, block, 0, s, p);
-    return cb_launch_status();
+    if (p.frameMasks) {
+        if (MODE != CB_MODE_GATHER || EPI != CB_EPI_SCATTER) return CB_ERR_BADARG;
+        if (narrow) return launch_f16<1, 4, 2, CB_MODE_GATHER, CB_EPI_SCATTER, true>(p, s);
+        return launch_f16<2, 2, 2, CB_MODE_GATHER, CB_EPI_SCATTER, true>(p, s);
+    }
+    if (narrow) return launch_f16<1, 4, 2, MODE, EPI>(p, s);
+    return launch_f16<2, 2, 2, MODE, EPI>(p, s);
 }
 
 }  // namespace
@@ -781,7 +1026,7 @@ long cbinfer_conv_workspace_bytes(void) {
 }
 
 long cbinfer_prepared_weights_bytes(int K, int C, int kH, int kW, int dtype) {
-    const long KP = cbinfer_weights_kpad(K), CkkP = cbinfer_weights_ckkpad(C * kH * kW);
+    const long KP = cbinfer_weights_kpad(K), CkkP = cb_ckkpad(C * kH * kW, dtype);
     return KP * CkkP * (dtype == CB_F16 ? 2 : 4) + CkkP * 8;
 }
 
@@ -790,7 +1035,7 @@ int cbinfer_prep_weights(const void* weight, void* weightsPrepared, int K, int C
     CB_REQUIRE(weight && weightsPrepared && K > 0 && C > 0 && kH > 0 && kW > 0 && H > 0 && W > 0);
     if (kH > 255 || kW > 255 || (long)C * H * W * 4 >= (1l << 30)) return CB_ERR_UNSUPPORTED;
     const int Ckk = C * kH * kW;
-    const int KP = cbinfer_weights_kpad(K), CkkP = cbinfer_weights_ckkpad(Ckk);
+    const int KP = cbinfer_weights_kpad(K), CkkP = cb_ckkpad(Ckk, dtype);
     const long total = (long)KP * CkkP;
     dim3 grid(cb_div_up(total, 256)), block(256);
     if (dtype == CB_F32)
@@ -843,7 +1088,7 @@ int cbinfer_matrix_mult(const void* X, const void* weightsPrepared, const void* 
     p.K = K;
     p.KP = cbinfer_weights_kpad(K);
     p.Ckk = Ckk;
-    p.CkkP = cbinfer_weights_ckkpad(Ckk);
+    p.CkkP = cb_ckkpad(Ckk, dtype);
     p.H = p.W = p.kH = p.kW = 1;
     if (transposeOut) return launch_mfma<CB_MODE_MATRIX, CB_EPI_YT>(p, dtype, (hipStream_t)stream);
     return launch_mfma<CB_MODE_MATRIX, CB_EPI_Y>(p, dtype, (hipStream_t)stream);
@@ -893,18 +1138,16 @@ int cbinfer_conv_changed(const void* input, const int32_t* changeList, int numCh
     p.K = K;
     p.KP = cbinfer_weights_kpad(K);
     p.Ckk = C * kH * kW;
-    p.CkkP = cbinfer_weights_ckkpad(p.Ckk);
+    p.CkkP = cb_ckkpad(p.Ckk, dtype);
     p.C = C;
     p.H = H;
     p.W = W;
     p.kH = kH;
     p.kW = kW;
-    p.magicKHW = magic_u32((unsigned)(kH * kW));
-    p.magicKW = magic_u32((unsigned)kW);
     p.relu = relu;
     p.clearBits = (unsigned long long*)clearBits;
     p.clearWords = clearBits ? clearWords : 0;
-    if (workspace && dtype == CB_F32) {   // [tickets: grid ints, padded to 4 KB][slabs: grid x 64x64 floats]
+    if (workspace) {   // [tickets: grid ints, padded to 4 KB][slabs: grid x 64x64 floats]
         p.tickets = (int*)workspace;
         p.slabs = (float*)((char*)workspace + 4096);
     }
@@ -921,7 +1164,7 @@ int cbinfer_conv_changed_from_mask(const void* input, uint64_t* frameMasks, int3
                                    void* workspace, int dtype, cbStream_t stream) {
     CB_REQUIRE(input && frameMasks && idxOut && countOut && weightsPrepared && output && C > 0 && H > 0 &&
                W > 0 && K > 0 && kH > 0 && kW > 0);
-    if (dtype != CB_F32) return CB_ERR_UNSUPPORTED;
+    if (dtype != CB_F32 && dtype != CB_F16) return CB_ERR_BADARG;
     const long words = cbinfer_mask_words(H, W);
     if (words > CB_SELFC_MAXW || (long)C * kH * kW > 65535 || (long)C * H * W * 4 >= (1l << 30))
         return CB_ERR_UNSUPPORTED;
@@ -934,7 +1177,7 @@ int cbinfer_conv_changed_from_mask(const void* input, uint64_t* frameMasks, int3
     p.K = K;
     p.KP = cbinfer_weights_kpad(K);
     p.Ckk = C * kH * kW;
-    p.CkkP = cbinfer_weights_ckkpad(p.Ckk);
+    p.CkkP = cb_ckkpad(p.Ckk, dtype);
     p.C = C;
     p.H = H;
     p.W = W;

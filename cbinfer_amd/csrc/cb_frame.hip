@@ -18,12 +18,12 @@ extern "C" int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void
     if (selfCompact) {
         // detection -> [state copy] -> self-compacting fused kernel: 2 launches per layer and frame.
         // `bits` is a cbinfer_frame_mask_bytes(H,W) buffer (two alternating masks + parity).
-        CB_REQUIRE(!haveIndexes && bits && !mapOut && dtype == CB_F32);
+        CB_REQUIRE(!haveIndexes && bits && !mapOut);
         st = cbinfer_change_detection_frame(input, prevInput, bits, W, H, C, (kH - 1) / 2, (kW - 1) / 2,
                                             threshold, feedbackLoop, dtype, stream);
         if (st != CB_OK) return st;
         if (!feedbackLoop && copyInput && prevInput != input) {
-            const size_t bytes = (size_t)C * H * W * 4;
+            const size_t bytes = (size_t)C * H * W * (dtype == CB_F16 ? 2 : 4);
             hipError_t e = hipMemcpyAsync(prevInput, input, bytes, hipMemcpyDeviceToDevice,
                                           (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;

@@ -43,11 +43,12 @@ def main():
     cfgs = [int(c) for c in sys.argv[1:]] or [0]
     gen = torch.Generator().manual_seed(0)
     for (C, K, k, H, W) in LAYERS:
-        x = torch.randn(1, C, H, W, device="cuda")
-        w = torch.randn(K, C, k, k, device="cuda") / (C * k * k) ** 0.5
-        b = torch.randn(K, device="cuda")
-        out = torch.zeros(1, K, H, W, device="cuda")
-        wp = cg.prepWeights(w)
+        dt = torch.float16 if os.environ.get("CBINFER_BENCH_HALF") else torch.float32
+        x = torch.randn(1, C, H, W, device="cuda").to(dt)
+        w = (torch.randn(K, C, k, k, device="cuda") / (C * k * k) ** 0.5).to(dt)
+        b = torch.randn(K, device="cuda").to(dt)
+        out = torch.zeros(1, K, H, W, device="cuda", dtype=dt)
+        wp = cg.prepWeights(w, H, W)
         for ratio in (0.1, 0.2, 0.36, 1.0):
             idx = blocks_list(H, W, ratio, 8, gen)
             N = idx.numel()

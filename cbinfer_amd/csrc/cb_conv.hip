@@ -223,13 +223,17 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
         mask = p.frameMasks + (par ? p.maskWords : 0);
         unsigned long long* other = p.frameMasks + (par ? 0 : p.maskWords);
         for (int i = blockIdx.x * NT + t; i < p.maskWords; i += gridDim.x * NT) other[i] = 0ull;
-        // exclusive prefix of per-word popcounts: thread t owns CH consecutive words
+        // Exclusive prefix of the per-word popcounts.  Pass 1: coalesced, independent loads (word t,
+        // t+NT, ...) -> counts in LDS; pass 2 (LDS only): thread t owns CH consecutive words.
         const int CH = (p.maskWords + NT - 1) / NT;
+#pragma unroll 4
+        for (int w = t; w < p.maskWords; w += NT) s_pre[w] = __popcll(mask[w]);
+        __syncthreads();
         const int wb = t * CH;
         int loc = 0;
         for (int u = 0; u < CH; ++u) {
             const int w = wb + u;
-            if (w < p.maskWords) loc += __popcll(mask[w]);
+            if (w < p.maskWords) loc += s_pre[w];
         }
         int incl = loc;   // inclusive scan over the wave, then over the waves
 #pragma unroll
@@ -245,8 +249,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
         for (int u = 0; u < CH; ++u) {
             const int w = wb + u;
             if (w < p.maskWords) {
+                const int c = s_pre[w];   // count -> exclusive prefix, in place (this thread's chunk only)
                 s_pre[w] = run;
-                run += __popcll(mask[w]);
+                run += c;
             }
         }
         if (t == NT - 1) s_pre[p.maskWords] = base + incl;   // the last thread's chunk ends the mask
@@ -590,13 +595,17 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
         mask = p.frameMasks + (par ? p.maskWords : 0);
         unsigned long long* other = p.frameMasks + (par ? 0 : p.maskWords);
         for (int i = blockIdx.x * NT + t; i < p.maskWords; i += gridDim.x * NT) other[i] = 0ull;
-        // exclusive prefix of per-word popcounts: thread t owns CH consecutive words
+        // Exclusive prefix of the per-word popcounts.  Pass 1: coalesced, independent loads (word t,
+        // t+NT, ...) -> counts in LDS; pass 2 (LDS only): thread t owns CH consecutive words.
         const int CH = (p.maskWords + NT - 1) / NT;
+#pragma unroll 4
+        for (int w = t; w < p.maskWords; w += NT) s_pre[w] = __popcll(mask[w]);
+        __syncthreads();
         const int wb = t * CH;
         int loc = 0;
         for (int u = 0; u < CH; ++u) {
             const int w = wb + u;
-            if (w < p.maskWords) loc += __popcll(mask[w]);
+            if (w < p.maskWords) loc += s_pre[w];
         }
         int incl = loc;   // inclusive scan over the wave, then over the waves
 #pragma unroll
@@ -612,8 +621,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
         for (int u = 0; u < CH; ++u) {
             const int w = wb + u;
             if (w < p.maskWords) {
+                const int c = s_pre[w];   // count -> exclusive prefix, in place (this thread's chunk only)
                 s_pre[w] = run;
-                run += __popcll(mask[w]);
+                run += c;
             }
         }
         if (t == NT - 1) s_pre[p.maskWords] = base + incl;   // the last thread's chunk ends the mask

@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--ratio", type=float, default=0.10)
     ap.add_argument("--block", type=int, default=32)
+    ap.add_argument("--pattern", choices=["blocks", "region"], default="blocks",
+                    help="blocks: BASELINE.md config 2 (scattered re-drawn blocks); region: one moving rectangle")
     ap.add_argument("--experiment", type=int, default=6)
     ap.add_argument("--threshold", type=float, default=0.05)
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
@@ -258,7 +260,8 @@ def main():
     for m in test.modules():
         if type(m) is pycbinfer.CBPoolMax2d:
             m.cloneOutput = bool(args.pool_clone)
-    video_kw = dict(H=H, W=W, ratio=args.ratio, block=args.block, seed=shard.sequence_seed(1234))
+    video_kw = dict(H=H, W=W, ratio=args.ratio, block=args.block, seed=shard.sequence_seed(1234),
+                    pattern=args.pattern)
     vid = workloads.SyntheticVideo(**video_kw)
     # one long non-repeating sequence: 2 priming frames, W warm-up frames, K timed frames, and a few
     # spare ones for the per-kernel measurement -- all resident in HBM (1.8 MB each)
@@ -288,8 +291,10 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "sceneLabeling CBConv2d coarse-grained fp32, synthetic 480x320 seq @%g%% "
-                               "change (%dx%d re-drawn blocks), experiment %d, one sequence per GPU"
-                               % (100 * vid.ratio, args.block, args.block, args.experiment),
+                               "change (%s), experiment %d, one sequence per GPU"
+                               % (100 * vid.ratio, ("%dx%d re-drawn blocks" % (args.block, args.block))
+                                  if args.pattern == "blocks" else "one moving re-drawn rectangle",
+                                  args.experiment),
                    "launch": args.mode, "threshold": args.threshold, "pool_clone": bool(args.pool_clone)},
         "effective_gflops": fps * dense_ops / 1e9,
     }
@@ -341,7 +346,7 @@ def main():
 
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(test, dict(H=H, W=W, ratio=args.ratio, block=args.block,
-                                                         seed=1234))
+                                                         seed=1234, pattern=args.pattern))
 
     print(json.dumps(result), flush=True)
     shard.finish()

@@ -102,12 +102,19 @@ class SyntheticVideo(object):
     fraction of pixels is exactly nblocks*block^2/(H*W) every frame."""
 
     def __init__(self, H=320, W=480, C=3, ratio=0.10, block=32, seed=1234, device='cuda',
-                 dtype=torch.float32):
+                 dtype=torch.float32, pattern='blocks'):
         assert H % block == 0 and W % block == 0
         self.H, self.W, self.C, self.block = H, W, C, block
+        self.pattern = pattern
         self.cells = (H // block) * (W // block)
         self.nblocks = max(0, int(round(ratio * self.cells)))
         self.ratio = self.nblocks / float(self.cells)
+        if pattern == 'region':
+            # ONE rectangle with the frame's aspect ratio covering `ratio` of the pixels, moving to a new
+            # random position every frame (a single moving object instead of scattered blocks)
+            self.rh = max(1, int(round(H * ratio ** 0.5)))
+            self.rw = max(1, int(round(ratio * H * W / self.rh)))
+            self.ratio = self.rh * self.rw / float(H * W)
         self.device, self.dtype = device, dtype
         self.gen = torch.Generator(device='cpu')
         self.gen.manual_seed(seed)
@@ -116,6 +123,13 @@ class SyntheticVideo(object):
     def next(self):
         """Advance by one frame; returns a NEW tensor (the previous frame is left intact)."""
         f = self.frame.clone()
+        if self.pattern == 'region':
+            y0 = int(torch.randint(0, self.H - self.rh + 1, (1,), generator=self.gen))
+            x0 = int(torch.randint(0, self.W - self.rw + 1, (1,), generator=self.gen))
+            patch = torch.rand(1, self.C, self.rh, self.rw, generator=self.gen)
+            f[:, :, y0:y0 + self.rh, x0:x0 + self.rw] = patch.to(device=self.device, dtype=self.dtype)
+            self.frame = f
+            return f
         b = self.block
         gw = self.W // b
         cells = torch.randperm(self.cells, generator=self.gen)[:self.nblocks].tolist()

@@ -349,6 +349,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
                 pbase4 = pos * 4;
             }
         }
+        // wave-uniform: every tap of every pixel of this wave lies inside the image -> no bounds test
+        bool fast = false;
+        if (MODE == CB_MODE_GATHER) {
+            const int phh = (p.kH - 1) / 2, pww = (p.kW - 1) / 2;
+            fast = __all(py >= phh && py + (p.kH - 1 - phh) < p.H && px >= pww &&
+                         px + (p.kW - 1 - pww) < p.W);
+        }
         // taps of the NEXT stage to load, B_PER_T consecutive table entries per array: ONE scalar load
         // each (s_load_dwordx4), kept in scalar registers across the stage
         typedef int ivec __attribute__((ext_vector_type(B_PER_T)));
@@ -377,6 +384,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
                     areg[i] = *(const float4*)(Ag + (long)(k0 + row) * p.KP + m0 + c4 * 4);
                 }
             }
+            if (MODE == CB_MODE_GATHER && fast) {
+#pragma unroll
+                for (int i = 0; i < B_PER_T; ++i)   // (a padded k-row has offset 2^30 -> reads 0)
+                    breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                            brsrc, pbase4 + pkOff[i], 0, 0));
+            } else
 #pragma unroll
             for (int i = 0; i < B_PER_T; ++i) {
                 float v = 0.f;
@@ -722,6 +735,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
                 pbase4 = pos * 2;
             }
         }
+        // wave-uniform: every tap of every pixel of this wave lies inside the image -> no bounds test
+        bool fast = false;
+        if (MODE == CB_MODE_GATHER) {
+            const int phh = (p.kH - 1) / 2, pww = (p.kW - 1) / 2;
+            fast = __all(py >= phh && py + (p.kH - 1 - phh) < p.H && px >= pww &&
+                         px + (p.kW - 1 - pww) < p.W);
+        }
         // taps of the NEXT stage to load, B_PER_T consecutive table entries per array: ONE scalar load
         // each (s_load_dwordx4), kept in scalar registers across the stage
         typedef int ivec __attribute__((ext_vector_type(B_PER_T)));
@@ -757,6 +777,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
                     areg[4 * i + 3] = v4.w;
                 }
             }
+            if (MODE == CB_MODE_GATHER && fast) {
+#pragma unroll
+                for (int i = 0; i < B_PER_T; ++i)   // (a padded k-row has offset 2^30 -> reads 0)
+                    breg[i] = __builtin_bit_cast(cb_half, __builtin_amdgcn_raw_buffer_load_b16(
+                                                              brsrc, pbase4 + pkOff[i], 0, 0));
+            } else
 #pragma unroll
             for (int i = 0; i < B_PER_T; ++i) {
                 cb_half v = (cb_half)0;

@@ -1054,7 +1054,8 @@ int launch_mfma(const ConvParams& p, int dtype, hipStream_t s) {
 
 extern "C" {
 
-int cbinfer_weights_kpad(int K) { return (K + CB_MFMA_M - 1) / CB_MFMA_M * CB_MFMA_M; }
+// K <= 32 uses the 32-row workgroup tile, anything larger the 64-row one: pad to whole tiles
+int cbinfer_weights_kpad(int K) { return K <= CB_MFMA_M ? CB_MFMA_M : (K + 63) / 64 * 64; }
 int cbinfer_weights_ckkpad(int Ckk) { return (Ckk + 63) / 64 * 64; }
 
 long cbinfer_conv_workspace_bytes(void) {

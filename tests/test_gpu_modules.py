@@ -372,3 +372,46 @@ def test_eval_harness_and_threshold_tuner(pkg, tmp_path):
     # the tuned network still tracks the dense one: every module stopped before its tolerance was spent
     y2 = evalTools.inferFrameset(test, frames)
     assert float((y2 - ref).pow(2).mean()) <= 4 * 1e-4 * scale
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_fuzz_shapes_track_dense(pkg, dtype):
+    """Randomised layer shapes (odd sizes, W around the 64-pixel word boundary, K around the 32-row MFMA
+    tile, non-square filters, C=1) through the default frame pipeline: with threshold 0 the layer must
+    reproduce the dense convolution of the current frame after every frame, and its change list must be
+    the dilation of the pixels that actually changed."""
+    from cbinfer_amd import conv2d_cg as cg
+    from cbinfer_amd.conv2d_cg import ChangeIndexes
+    rng = np.random.default_rng(17)
+    shapes = [(1, 1, 1, 1, 5, 9), (3, 7, 3, 3, 17, 63), (2, 33, 3, 3, 9, 64), (5, 32, 5, 5, 11, 65),
+              (4, 65, 7, 7, 23, 129), (20, 100, 3, 1, 13, 200), (3, 8, 1, 5, 31, 37), (16, 64, 7, 7, 40, 96),
+              (7, 3, 3, 3, 64, 64), (1, 16, 7, 7, 8, 300)]
+    tol = 1e-4 if dtype == torch.float32 else None
+    for (C, K, kH, kW, H, W) in shapes:
+        conv = torch.nn.Conv2d(C, K, (kH, kW), padding=(kH // 2, kW // 2)).cuda().to(dtype)
+        cbm = pkg.CBConv2d(conv, 0.0)
+        cbm.feedbackLoop = bool(rng.integers(0, 2))
+        cbm.withReLU = bool(rng.integers(0, 2))
+        x = torch.rand(1, C, H, W, device="cuda").to(dtype)
+        with torch.no_grad():
+            for t in range(4):
+                if t:
+                    x = x.clone()
+                    n = int(rng.integers(1, 4))
+                    changed = torch.zeros(H, W, dtype=torch.bool, device="cuda")
+                    for _ in range(n):
+                        y0, x0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+                        hh, ww = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+                        x[:, :, y0:y0 + hh, x0:x0 + ww] += 0.5
+                        changed[y0:y0 + hh, x0:x0 + ww] = True
+                y = cbm(x.clone())
+                ref = conv(x)
+                if cbm.withReLU:
+                    ref = torch.relu(ref)
+                err = (y.float() - ref.float()).abs().max().item()
+                bound = tol if tol else 4 * 2.0 ** -10 * max(1.0, ref.float().abs().max().item())
+                assert err <= bound, (C, K, kH, kW, H, W, t, err)
+                if t:
+                    got = ChangeIndexes(cbm._work['idx'], cbm._work['count']).tensor()
+                    expect = cg.changeIndexesExtr(cg.changePropagation(changed.to(torch.int8), (kH, kW)))
+                    assert torch.equal(got, expect), (C, K, kH, kW, H, W, t)

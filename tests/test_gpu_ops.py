@@ -188,6 +188,8 @@ def test_detection_half(cb, oracle):
     (64, 8, 80, 120, (1, 1), 0.10),
     (5, 7, 23, 41, (3, 5), 0.2),
     (3, 33, 19, 67, (3, 3), 1.0),           # K just above one MFMA tile, every pixel changed
+    (4, 65, 21, 70, (5, 5), 0.5),           # K just above the 64-row workgroup tile
+    (2, 100, 9, 33, (1, 1), 1.0),           # K between tiles, 1x1 filter, narrow map
 ])
 def test_gather_gemm_scatter_fullsize(cb, oracle, C, K, H, W, filt, frac):
     """BASELINE-size layers: X exact, Y and the fused kernel within 1e-4 of the oracle (double

@@ -7,11 +7,12 @@
 // changed-pixel list, k = (c*kH+ky)*kW+kx.  The pixel index sits on the MFMA *lane* (C/D column), the
 // output channel in the accumulator registers, so the scatter epilogue writes 32 (mostly consecutive)
 // pixels of one output-channel plane per store instruction.
-//   fp32: v_mfma_f32_32x32x2_f32 (exact f32 fma chain, k-ordered) -- operands A[k][m], B[k][n] in LDS
+//   fp32: v_mfma_f32_32x32x2_f32 (exact f32 fma chain)            -- operands A[m][k], B[n][k] in LDS
 //   fp16: v_mfma_f32_32x32x16_f16, f32 accumulation             -- operands A[m][k], B[n][k] in LDS
 #include <stdlib.h>
 
 #include "cb_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -23,7 +24,7 @@ __device__ __forceinline__ float cb_relu(float v) { return v <= 0.f ? 0.f : v; }
 __device__ __forceinline__ cb_half cb_relu(cb_half v) { return v <= (cb_half)0 ? (cb_half)0 : v; }
 
 // ---------------------------------------------------------------------------------------------
-// weight preparation: pad to the MFMA tile grid (zeros), fp32 additionally transposed to k-major
+// weight preparation: pad to the MFMA tile grid (zeros), W[KP][CkkP] (k contiguous)
 // ---------------------------------------------------------------------------------------------
 // k -> tap table appended to the prepared weights, two int arrays of CkkP entries each:
 //   off[k]  = byte offset of the tap relative to the output pixel in a [C,H,W] tensor of elemSize bytes
@@ -42,14 +43,14 @@ __device__ __forceinline__ void cb_pack_k(int* tab, int k, int Ckk, int CkkP, in
     tab[CkkP + k] = (dx << 16) | (dy & 0xffff);
 }
 __global__ __launch_bounds__(256) void cb_prep_w_f32_kernel(const float* __restrict__ w,
-                                                           float* __restrict__ wt, int K, int Ckk,
+                                                           float* __restrict__ wp, int K, int Ckk,
                                                            int KP, int CkkP, int kH, int kW, int H,
                                                            int W) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < CkkP) cb_pack_k((int*)(wt + (long)KP * CkkP), (int)e, Ckk, CkkP, kH, kW, H, W, 4);
+    if (e < CkkP) cb_pack_k((int*)(wp + (long)KP * CkkP), (int)e, Ckk, CkkP, kH, kW, H, W, 4);
     if (e >= (long)KP * CkkP) return;
-    const int m = (int)(e % KP), k = (int)(e / KP);
-    wt[e] = (m < K && k < Ckk) ? w[(long)m * Ckk + k] : 0.f;
+    const int k = (int)(e % CkkP), m = (int)(e / CkkP);
+    wp[e] = (m < K && k < Ckk) ? w[(long)m * Ckk + k] : 0.f;
 }
 __global__ __launch_bounds__(256) void cb_prep_w_f16_kernel(const cb_half* __restrict__ w,
                                                            cb_half* __restrict__ wp, int K, int Ckk,
@@ -174,35 +175,60 @@ __device__ __forceinline__ void cb_clear_mask(const ConvParams& p) {
 //             partial tiles of a tile go to a workspace slab; the workgroup whose ticket is last sums
 //             them in slice order (deterministic) and runs the epilogue -- agent-scope release by every
 //             writer, one acquire by the reducer, nobody ever waits.
-//   pipeline  BK = 32 per stage, two LDS buffers, two register staging sets: the loads of stage s+2 are
-//             issued during stage s, one barrier per stage, every stage issues the same number of loads
-//             so the compiler's counted vmcnt only waits for the set being stored.  Odd wave groups
-//             run [MFMA, issue loads], even ones [issue loads, MFMA], so the address arithmetic of one
-//             half overlaps the matrix work of the other.
+//   pipeline  BK = 32 per stage, two LDS buffers, FOUR register staging sets: the loads of stage s+4 are
+//             issued during stage s, and stage s+1 is written to the idle LDS buffer while the MFMA
+//             chain of stage s runs; one barrier per stage.  Every stage issues the same number of loads
+//             and the loop body is branch-free (instantiated per fast-path / wave role), so the
+//             compiler's counted vmcnt only waits for the set being stored.  Odd wave groups run
+//             [MFMA, store, issue loads], even ones [store, issue loads, MFMA].
+//   LDS       both operands as rows of the stage's 32 k (A[m][k], B[n][k], 144-byte row stride): a
+//             lane's 8 k-slots per operand are contiguous -> 2 + 2 ds_read_b128 per wave and stage for
+//             8 MFMAs, one ds_write_b128 per operand and thread.  MFMA step s pairs k-slot s of the
+//             wave group's half with slot 16 + s (any pairing is valid as long as A and B agree).
 //   gather    a k-row of a stage is wave-uniform: its tap (byte offset, dy, dx) comes from the table
 //             built by cbinfer_prep_weights via scalar loads one stage ahead; per lane there remain two
 //             adds, the image-bounds test and a select.  The load goes through a raw buffer descriptor
 //             over the layer state: an out-of-image tap gets an out-of-range offset, for which the
 //             hardware returns 0.
+#ifdef CB_STAMP
+// diagnostic build only (make EXTRA=-DCB_STAMP): per-workgroup phase time stamps (100 MHz constant clock)
+__device__ unsigned long long cb_stamp_buf[1024 * 8];
+__device__ unsigned long long cb_stamp_clk[1024 * 2];   // s_memtime (shader clock) at entry / exit
+#define CB_STAMP_AT(i)                                                                        \
+    do {                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < 1024 && cb_stamp_first)                          \
+            cb_stamp_buf[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();            \
+    } while (0)
+#else
+#define CB_STAMP_AT(i)
+#endif
 #define CB_SKMAX 8
 template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false>
-__global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WN * KS)
+    __attribute__((amdgpu_waves_per_eu((WM * WN * KS >= 8 ? 4 : WM * WN * KS >= 4 ? 2 : 1)))) void cb_mfma_f32_kernel(
+        ConvParams p) {
     constexpr int NT = 64 * WM * WN * KS;
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * WN;
     constexpr int BK = 32;
-    constexpr int LDB = BN + 2;
+    constexpr int LDK = BK + 4;         // LDS row = the stage's 32 k of one m / one pixel + 16 B pad
     constexpr int A_F4 = BK * BM / 4;
     constexpr int A_PER_T = (A_F4 + NT - 1) / NT;
     constexpr int B_PER_T = BK * BN / NT;
     constexpr int NPP = NT / BK;        // matrix: pixel slots covered by one pass
-    constexpr int KSTEP = BK / KS;      // k-depth one wave group handles per stage
-    constexpr int A_STAGE = BK * BM, B_STAGE = BK * LDB;
+    constexpr int KSTEP = BK / KS;     // k-depth one wave group handles per stage
+    constexpr int S = KSTEP / 2;        // ... = MFMA steps per wave and stage (two k per step)
+    constexpr int A_STAGE = BM * LDK, B_STAGE = BN * LDK;
     constexpr int TILE = BM * BN;
     static_assert(BN % 64 == 0, "gather rows must be wave-uniform");
-    static_assert(BK * BN % NT == 0 && KSTEP % 2 == 0, "bad decomposition");
+    static_assert(BK * BN % NT == 0 && S % 4 == 0, "bad decomposition");
     static_assert(KS == 1 || 2 * (A_STAGE + B_STAGE) >= WM * WN * 64 * 16, "reduce buffer");
 
+#ifdef CB_STAMP
+    bool cb_stamp_first = true;
+    if (threadIdx.x == 0 && blockIdx.x < 1024) cb_stamp_clk[blockIdx.x * 2] = __builtin_amdgcn_s_memtime();
+#endif
+    CB_STAMP_AT(0);
     const int t = threadIdx.x;
     // ---- SELFC: stream compaction folded into this kernel -------------------------------------------
     // Every workgroup rebuilds the exclusive popcount prefix of the frame's change mask (<= 32 KB, L2
@@ -264,7 +290,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
     }
     const int MT = p.KP / BM;
     const int T = ((N + BN - 1) / BN) * MT;                  // output tiles
-    const int P = p.CkkP / (2 * BK);                         // stage pairs along k
+    const int P = p.CkkP / (4 * BK);                         // groups of four stages along k
     // Split along k only while whole CUs would otherwise idle (T below CB_SK_TARGET x the CU count) and
     // the k-depth is long enough to pay for the slab round trip: the reducer costs ~4 us of fences +
     // ~1 us per slab, a stage pair ~1.7 us, so the best slice count is ~sqrt(1.7 P).
@@ -273,15 +299,15 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
 #ifndef CB_SK_TARGET
 #define CB_SK_TARGET 2
 #endif
-    if (p.slabs && T > 0 && T < CB_SK_TARGET * cus && P >= 8)
-        SK = max(1, min(min(CB_SKMAX, (CB_SK_TARGET * cus) / T), (int)sqrtf(1.7f * (float)P)));
+    if (p.slabs && T > 0 && T < CB_SK_TARGET * cus && P >= 4)
+        SK = max(1, min(min(CB_SKMAX, (CB_SK_TARGET * cus) / T), min(P, (int)sqrtf(3.4f * (float)P))));
     const int items = T * SK;
     if (!SELFC && (int)blockIdx.x >= items) return;
 
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_STAGE + B_STAGE)];
     __shared__ int s_last;
-    float* const As = smem;                  // [2][BK][BM]
-    float* const Bs = smem + 2 * A_STAGE;    // [2][BK][LDB]
+    float* const As = smem;                  // [2][BM][LDK]
+    float* const Bs = smem + 2 * A_STAGE;    // [2][BN][LDK]
 
     // the wave index is wave-uniform, but only readfirstlane lets the compiler know: roles derived from
     // it (k-group, tile position, MFMA-first stagger) then stay in scalar registers and real branches
@@ -303,10 +329,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
     const int bj = MODE == CB_MODE_GATHER ? t % BN : t / BK;
     const int br = MODE == CB_MODE_GATHER ? __builtin_amdgcn_readfirstlane(t / BN) * B_PER_T : t % BK;
 
+    CB_STAMP_AT(1);
     for (int item = blockIdx.x; item < items; item += gridDim.x) {
         const int tile = item / SK, slice = item - tile * SK;
         const int n0 = (tile / MT) * BN, m0 = (tile % MT) * BM;
-        const int kBeg = (P * slice / SK) * 2 * BK, kEnd = (P * (slice + 1) / SK) * 2 * BK;
+        const int kBeg = (P * slice / SK) * 4 * BK, kEnd = (P * (slice + 1) / SK) * 4 * BK;
         const int kLast = kEnd - BK;
 
         // per-thread B-load coordinates; a slot past the list is "outside the image"
@@ -372,19 +399,29 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
         };
         fetch_pk(kBeg);
 
-        float4 a0[A_PER_T], a1[A_PER_T];
-        float b0[B_PER_T], b1[B_PER_T];
+        // FOUR register staging sets: the loads of stage s+4 are issued during stage s (3-6 % over two
+        // sets; the waits stay counted, vmcnt(15..19), never a drain)
+        // (vector types, not arrays: arrays handed to the lambdas by reference end up in scratch)
+        typedef float avec __attribute__((ext_vector_type(4 * A_PER_T)));
+        typedef float bvec __attribute__((ext_vector_type(B_PER_T < 2 ? 2 : B_PER_T)));
+        avec a0, a1, a2, a3;
+        bvec b0, b1, b2, b3;
 
-        auto load_stage = [&](int k0, float4(&areg)[A_PER_T], float(&breg)[B_PER_T]) {
+        auto load_stage = [&](auto FASTC, int k0, avec& areg, bvec& breg) {
+            constexpr bool FAST = decltype(FASTC)::value;
 #pragma unroll
             for (int i = 0; i < A_PER_T; ++i) {
                 const int f = t + i * NT;
                 if (A_F4 % NT == 0 || f < A_F4) {
-                    const int row = f / (BM / 4), c4 = f % (BM / 4);
-                    areg[i] = *(const float4*)(Ag + (long)(k0 + row) * p.KP + m0 + c4 * 4);
+                    const int row = f / (BK / 4), c4 = f % (BK / 4);
+                    const float4 v = *(const float4*)(Ag + (long)(m0 + row) * p.CkkP + k0 + c4 * 4);
+                    areg[4 * i] = v.x;
+                    areg[4 * i + 1] = v.y;
+                    areg[4 * i + 2] = v.z;
+                    areg[4 * i + 3] = v.w;
                 }
             }
-            if (MODE == CB_MODE_GATHER && fast) {
+            if (MODE == CB_MODE_GATHER && FAST) {
 #pragma unroll
                 for (int i = 0; i < B_PER_T; ++i)   // (a padded k-row has offset 2^30 -> reads 0)
                     breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
@@ -410,20 +447,29 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
             }
             fetch_pk(min(k0 + BK, kLast));   // consecutive calls load consecutive stages
         };
-        auto store_stage = [&](int buf, const float4(&areg)[A_PER_T], const float(&breg)[B_PER_T]) {
+        auto store_stage = [&](int buf, const avec& areg, const bvec& breg) {
             float* as = As + buf * A_STAGE;
             float* bs = Bs + buf * B_STAGE;
 #pragma unroll
             for (int i = 0; i < A_PER_T; ++i) {
                 const int f = t + i * NT;
-                if (A_F4 % NT == 0 || f < A_F4) *(float4*)(as + f * 4) = areg[i];
+                if (A_F4 % NT == 0 || f < A_F4)
+                    *(float4*)(as + (f / (BK / 4)) * LDK + (f % (BK / 4)) * 4) =
+                        make_float4(areg[4 * i], areg[4 * i + 1], areg[4 * i + 2], areg[4 * i + 3]);
             }
+            if (MODE == CB_MODE_GATHER && B_PER_T % 4 == 0) {   // the thread's taps are k-consecutive
 #pragma unroll
-            for (int i = 0; i < B_PER_T; ++i) {
-                if (MODE == CB_MODE_GATHER)
-                    bs[(br + i) * LDB + bj] = breg[i];
-                else
-                    bs[br * LDB + bj + i * NPP] = breg[i];
+                for (int q = 0; q < B_PER_T / 4; ++q)
+                    *(float4*)(bs + bj * LDK + br + q * 4) =
+                        make_float4(breg[q * 4], breg[q * 4 + 1], breg[q * 4 + 2], breg[q * 4 + 3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < B_PER_T; ++i) {
+                    if (MODE == CB_MODE_GATHER)
+                        bs[bj * LDK + br + i] = breg[i];
+                    else
+                        bs[(bj + i * NPP) * LDK + br] = breg[i];
+                }
             }
         };
 
@@ -431,43 +477,90 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
+        // MFMA step s of wave group ks multiplies k-slots {ks*S + s, BK/2 + ks*S + s} of the stage (lane
+        // half h takes the second); any pairing works as long as both operands use it, and this one
+        // makes a lane's S values per operand contiguous: S/4 ds_read_b128 instead of S ds_read_b32.
         auto compute = [&](int buf) {
-            const float* as = As + buf * A_STAGE + wm * 32 + l31;
-            const float* bs = Bs + buf * B_STAGE + wn * 32 + l31;
+            const float* ap = As + buf * A_STAGE + (wm * 32 + l31) * LDK + h * (BK / 2) + ks * S;
+            const float* bp = Bs + buf * B_STAGE + (wn * 32 + l31) * LDK + h * (BK / 2) + ks * S;
+            float4 av[S / 4], bv[S / 4];
 #pragma unroll
-            for (int kk = ks * KSTEP; kk < (ks + 1) * KSTEP; kk += 2) {
-                const float a = as[(kk + h) * BM];
-                const float b = bs[(kk + h) * LDB];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            for (int q = 0; q < S / 4; ++q) {
+                av[q] = *(const float4*)(ap + q * 4);
+                bv[q] = *(const float4*)(bp + q * 4);
+            }
+#pragma unroll
+            for (int q = 0; q < S / 4; ++q) {
+                float a[4] = {av[q].x, av[q].y, av[q].z, av[q].w};
+                float b[4] = {bv[q].x, bv[q].y, bv[q].z, bv[q].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+                }
             }
         };
 
-        // Every stage issues the same number of loads (past the slice end they re-load its last stage
-        // and are never stored).
-        load_stage(kBeg, a0, b0);
-        load_stage(kBeg + BK, a1, b1);
-        const bool mfmaFirst = (KS > 1) && (ks & 1);
-        for (int k0 = kBeg; k0 < kEnd; k0 += 2 * BK) {
+        // Every stage issues the same number of loads (past the slice end they re-load its last stage;
+        // that copy lands in the idle LDS buffer and is never multiplied).  The loop is instantiated per (interior-fast-path, wave role) so that
+        // its body is branch-free: the compiler's vmcnt bookkeeping stays exact (counted waits that
+        // leave the three younger stages in flight) only without control flow between the loads.
+        CB_STAMP_AT(2);
+        auto main_loop = [&](auto FASTC, auto MFC) {
+            constexpr bool MF = decltype(MFC)::value;
+            // (scheduling fences: the prologue must issue the sets in ring order, otherwise the loop
+            // header inherits "set 0 is the youngest" and drains the queue every iteration)
+            load_stage(FASTC, kBeg, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_stage(FASTC, kBeg + BK, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_stage(FASTC, kBeg + 2 * BK, a2, b2);
+            __builtin_amdgcn_sched_barrier(0);
+            load_stage(FASTC, kBeg + 3 * BK, a3, b3);
+            __builtin_amdgcn_sched_barrier(0);
+            // LDS stage 0 <- set 0, which is then re-armed with stage 4
             store_stage(0, a0, b0);
+            load_stage(FASTC, min(kBeg + 4 * BK, kLast), a0, b0);
             __syncthreads();
-            if (mfmaFirst) {
-                compute(0);
-                load_stage(min(k0 + 2 * BK, kLast), a0, b0);
-            } else {
-                load_stage(min(k0 + 2 * BK, kLast), a0, b0);
-                compute(0);
-            }
-            store_stage(1, a1, b1);
+            // One barrier per stage.  While a wave's MFMA chain on LDS buffer BUF runs it also writes the
+            // NEXT stage into the other buffer (free since the barrier just passed: every wave finished
+            // reading it) and re-arms that register set four stages ahead -- the LDS write and the load
+            // issue hide under the 8 x 64-cycle MFMAs instead of sitting between two compute phases.
+#define CB_STAGE(BUF, AREG, BREG, KNEXT)                          \
+            if (MF) {                                             \
+                compute(BUF);                                     \
+                store_stage((BUF) ^ 1, AREG, BREG);               \
+                load_stage(FASTC, min(KNEXT, kLast), AREG, BREG); \
+            } else {                                              \
+                store_stage((BUF) ^ 1, AREG, BREG);               \
+                load_stage(FASTC, min(KNEXT, kLast), AREG, BREG); \
+                compute(BUF);                                     \
+            }                                                     \
             __syncthreads();
-            if (mfmaFirst) {
-                compute(1);
-                load_stage(min(k0 + 3 * BK, kLast), a1, b1);
-            } else {
-                load_stage(min(k0 + 3 * BK, kLast), a1, b1);
-                compute(1);
+            for (int k0 = kBeg; k0 < kEnd; k0 += 4 * BK) {
+                CB_STAGE(0, a1, b1, k0 + 5 * BK)
+                CB_STAGE(1, a2, b2, k0 + 6 * BK)
+                CB_STAGE(0, a3, b3, k0 + 7 * BK)
+                CB_STAGE(1, a0, b0, k0 + 8 * BK)
             }
+#undef CB_STAGE
+        };
+        typedef std::integral_constant<bool, true> cb_true;
+        typedef std::integral_constant<bool, false> cb_false;
+        const bool mfmaFirst = (KS > 1) && (__builtin_amdgcn_readfirstlane(ks) & 1);
+        const bool fastU = __builtin_amdgcn_readfirstlane((int)fast) != 0;
+        if (fastU) {
+            if (mfmaFirst)
+                main_loop(cb_true(), cb_true());
+            else
+                main_loop(cb_true(), cb_false());
+        } else {
+            if (mfmaFirst)
+                main_loop(cb_false(), cb_true());
+            else
+                main_loop(cb_false(), cb_false());
         }
-        __syncthreads();   // all LDS stage reads done: smem may be reused
+        // (the loop ends on a barrier: all LDS stage reads are done and smem may be reused)
+        CB_STAMP_AT(3);
 
         if (KS > 1) {   // sum the wave groups' partial tiles through LDS (fixed order: deterministic)
             float* red = smem + (wq * 16) * 64 + lane;
@@ -486,6 +579,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
             }
         }
 
+        CB_STAMP_AT(4);
         if (SK > 1) {
             // publish this slice's partial tile, take a ticket; the last arriver reduces
             float* slab = p.slabs + (long)item * TILE + (wq * 16) * 64 + lane;
@@ -511,6 +605,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
             __syncthreads();
             const bool last = s_last != 0;
             __syncthreads();   // s_last may be rewritten by the next item
+            CB_STAMP_AT(5);
+#ifdef CB_STAMP
+            if (!last) cb_stamp_first = false;
+#endif
             if (!last) continue;
             if (ks == 0) {
                 const float* sl = p.slabs + (long)tile * SK * TILE + (wq * 16) * 64 + lane;
@@ -547,7 +645,16 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f32_kernel(ConvPara
                     out[(long)m * HW + pix] += v;
             }
         }
+        CB_STAMP_AT(6);
+#ifdef CB_STAMP
+        cb_stamp_first = false;
+#endif
     }
+#ifdef CB_STAMP
+    cb_stamp_first = true;
+    if (threadIdx.x == 0 && blockIdx.x < 1024) cb_stamp_clk[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
+#endif
+    CB_STAMP_AT(7);
 
     if (SELFC) {
         // every workgroup has read the mask: the last one to get here flips the parity for the next frame
@@ -1008,7 +1115,8 @@ int launch_f16(const ConvParams& p, hipStream_t s) {
 
 // k-depth padding of the prepared weights: a whole number of stage pairs (fp32: 2 x 32, fp16: 2 x 64)
 int cb_ckkpad(int Ckk, int dtype) {
-    const int q = dtype == CB_F16 ? 128 : 64;
+    const int q = 128;   // fp32: 4 x 32, fp16: 2 x 64
+    (void)dtype;
     return (Ckk + q - 1) / q * q;
 }
 
@@ -1056,7 +1164,7 @@ extern "C" {
 
 // K <= 32 uses the 32-row workgroup tile, anything larger the 64-row one: pad to whole tiles
 int cbinfer_weights_kpad(int K) { return K <= CB_MFMA_M ? CB_MFMA_M : (K + 63) / 64 * 64; }
-int cbinfer_weights_ckkpad(int Ckk) { return (Ckk + 63) / 64 * 64; }
+int cbinfer_weights_ckkpad(int Ckk) { return (Ckk + 127) / 128 * 128; }
 
 long cbinfer_conv_workspace_bytes(void) {
     return 4096 + (long)CB_CONV_GRID_PER_CU * cb_num_cus() * 64 * 64 * 4;
@@ -1237,3 +1345,12 @@ long cbinfer_frame_mask_bytes(int H, int W) { return 2 * cbinfer_mask_words(H, W
 int cbinfer_frame_mask_max_words(void) { return CB_SELFC_MAXW; }
 
 }  // extern "C"
+
+#ifdef CB_STAMP
+extern "C" int cbinfer_debug_stamps(void* host, long bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cb_stamp_buf), (size_t)bytes);
+}
+extern "C" int cbinfer_debug_clocks(void* host, long bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cb_stamp_clk), (size_t)bytes);
+}
+#endif

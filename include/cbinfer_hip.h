@@ -105,7 +105,7 @@ int cbinfer_gen_x_matrix(void* columns, const void* input, const int32_t* change
  * Y = X[N,Ckk] . W[K,Ckk]^T + bias; Y is [N,K] (transposeOut=0) or [K,N] (transposeOut=1).
  * fp32: exact-f32 MFMA (v_mfma_f32_32x32x2_f32); fp16: f16 MFMA with f32 accumulation.
  * weightsPrepared is the buffer produced by cbinfer_prep_weights from the [K,C,kH,kW] filter bank:
- * the matrix padded to the MFMA tile grid (fp32: transposed to k-major) followed by a k->(c,ky,kx)
+ * the matrix padded to the MFMA tile grid, W[Kpad][CkkPad] with k contiguous, followed by a k->(c,ky,kx)
  * tap table (byte offset, dy, dx per k, which depends on the H x W of the feature map the layer runs
  * on); cbinfer_prepared_weights_bytes gives its size.  For a plain [K,Ckk] matrix pass C=Ckk,
  * kH=kW=H=W=1. */

@@ -15,6 +15,7 @@ launch stream for the dominant kernel; `cpu_baseline` times the oracle port (tes
 same path on the host cores over a bounded sample.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -43,6 +44,11 @@ def parse():
     ap.add_argument("--experiment", type=int, default=6)
     ap.add_argument("--threshold", type=float, default=0.05)
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--sequences", type=int, default=1,
+                    help="independent video sequences in flight per GPU, one HIP stream + graph each "
+                         "(a step then feeds one frame to every sequence)")
+    ap.add_argument("--multi", type=int, default=4,
+                    help="also report the throughput with this many concurrent sequences (0/1: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel table to stderr")
@@ -57,17 +63,24 @@ def log(*a):
 
 
 class FrameRunner(object):
-    """Runs model(frame) either eagerly or as a replayed hipGraph with a static input buffer."""
+    """Runs model(frame) either eagerly or as a replayed hipGraph with a static input buffer, on its own
+    HIP stream when one is given (several sequences in flight on one GPU)."""
 
-    def __init__(self, model, example, mode):
+    def __init__(self, model, example, mode, stream=None):
         self.model, self.mode = model, mode
+        self.stream = stream
         self.static_in = example.clone()
+        if stream is not None:   # model weights, frames and this clone were produced on the default stream
+            stream.wait_stream(torch.cuda.current_stream())
         self.graph = None
         self.out = None
 
+    def _ctx(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def prime(self, frames):
         """Process `frames` eagerly (allocates state/workspaces); in graph mode capture afterwards."""
-        with torch.no_grad():
+        with torch.no_grad(), self._ctx():
             for f in frames:
                 if self.mode == "graph":
                     self.static_in.copy_(f)
@@ -75,34 +88,42 @@ class FrameRunner(object):
                 else:
                     self.out = self.model(f)
             if self.mode == "graph":
+                # capture on this runner's own side stream: the split-K workspace is keyed by stream, so
+                # graphs replayed concurrently never share one
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
                     self.out = self.model(self.static_in)      # same frame again: no change
                 torch.cuda.current_stream().wait_stream(s)
                 self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
+                with torch.cuda.graph(self.graph, stream=s):
                     self.out = self.model(self.static_in)
+                self._capture_stream = s
 
     def step(self, frame):
-        if self.graph is not None:
-            self.static_in.copy_(frame)
-            self.graph.replay()
-        else:
-            # eager: hand the module the frame tensor itself.  Modules that alias their input as state
-            # (copyInput=False without feedback loop, fine-grained; conv2d.py:175,237-238) need a NEW
-            # tensor per frame -- which also means such configurations cannot be graph-captured.
-            with torch.no_grad():
-                self.out = self.model(frame)
+        with self._ctx():
+            if self.graph is not None:
+                self.static_in.copy_(frame)
+                self.graph.replay()
+            else:
+                # eager: hand the module the frame tensor itself.  Modules that alias their input as
+                # state (copyInput=False without feedback loop, fine-grained; conv2d.py:175,237-238) need
+                # a NEW tensor per frame -- such configurations cannot be graph-captured.
+                with torch.no_grad():
+                    self.out = self.model(frame)
         return self.out
 
 
-def timed_loop(runner, frames, steps, barrier):
+def timed_loop(runners, frames, steps, barrier):
+    """K steps; a step feeds one frame to every runner (one runner = one sequence)."""
+    if not isinstance(runners, (list, tuple)):
+        runners, frames = [runners], [frames]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        runner.step(frames[i % len(frames)])
+        for r, fr in zip(runners, frames):
+            r.step(fr[i % len(fr)])
     torch.cuda.synchronize()
     barrier()
     return time.perf_counter() - t0
@@ -256,28 +277,39 @@ def main():
     import pycbinfer
     from cbinfer_amd import workloads
 
-    base, test = workloads.sceneLabelingModels(experimentIdx=args.experiment, threshold=args.threshold)
-    for m in test.modules():
-        if type(m) is pycbinfer.CBPoolMax2d:
-            m.cloneOutput = bool(args.pool_clone)
-    video_kw = dict(H=H, W=W, ratio=args.ratio, block=args.block, seed=shard.sequence_seed(1234),
-                    pattern=args.pattern)
-    vid = workloads.SyntheticVideo(**video_kw)
-    # one long non-repeating sequence: 2 priming frames, W warm-up frames, K timed frames, and a few
-    # spare ones for the per-kernel measurement -- all resident in HBM (1.8 MB each)
-    allframes = vid.frames(2 + args.warmup + args.steps + 4)
-    prime = allframes[:2]
-    warm = allframes[2:2 + args.warmup]
-    frames = allframes[2 + args.warmup:2 + args.warmup + args.steps]
-    spare = allframes[2 + args.warmup + args.steps:]
+    def run_sequences(S, steps, warmup, seq0, bar):
+        """Build S independent sequences (model + state + synthetic video + runner), warm them up and
+        time `steps` steps (one frame to every sequence per step).  Returns (elapsed, sequences)."""
+        nframes = 2 + warmup + steps + 4
+        seqs = []
+        for q in range(S):
+            base, test = workloads.sceneLabelingModels(experimentIdx=args.experiment, threshold=args.threshold)
+            for m in test.modules():
+                if type(m) is pycbinfer.CBPoolMax2d:
+                    m.cloneOutput = bool(args.pool_clone)
+            video_kw = dict(H=H, W=W, ratio=args.ratio, block=args.block,
+                            seed=shard.sequence_seed(1234) + 7919 * (seq0 + q), pattern=args.pattern)
+            vid = workloads.SyntheticVideo(**video_kw)
+            # one long non-repeating sequence: 2 priming frames, W warm-up frames, K timed frames, and a
+            # few spare ones for the per-kernel measurement -- all resident in HBM (1.8 MB each)
+            allframes = vid.frames(nframes)
+            runner = FrameRunner(test, allframes[0], args.mode, torch.cuda.Stream() if S > 1 else None)
+            runner.prime(allframes[:2])
+            seqs.append(dict(base=base, test=test, vid=vid, runner=runner,
+                             warm=allframes[2:2 + warmup], frames=allframes[2 + warmup:2 + warmup + steps],
+                             spare=allframes[2 + warmup + steps:]))
+        torch.cuda.synchronize()
+        for i in range(warmup):
+            for q in seqs:
+                q['runner'].step(q['warm'][i])
+        return timed_loop([q['runner'] for q in seqs], [q['frames'] for q in seqs], steps, bar), seqs
 
-    runner = FrameRunner(test, frames[0], args.mode)
-    runner.prime(prime)
-    for f in warm:
-        runner.step(f)
-    elapsed = timed_loop(runner, frames, args.steps, barrier)
+    S = max(1, args.sequences)
+    elapsed, seqs = run_sequences(S, args.steps, args.warmup, 0, barrier)
+    base, test, vid = seqs[0]['base'], seqs[0]['test'], seqs[0]['vid']
+    frames, spare = seqs[0]['frames'], seqs[0]['spare']
 
-    total_frames, elapsed = shard.aggregate(args.steps, elapsed, device="cuda")
+    total_frames, elapsed = shard.aggregate(args.steps * S, elapsed, device="cuda")
     fps = total_frames / elapsed
 
     if rank != 0:
@@ -291,25 +323,47 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "sceneLabeling CBConv2d coarse-grained fp32, synthetic 480x320 seq @%g%% "
-                               "change (%s), experiment %d, one sequence per GPU"
+                               "change (%s), experiment %d, %s per GPU"
                                % (100 * vid.ratio, ("%dx%d re-drawn blocks" % (args.block, args.block))
                                   if args.pattern == "blocks" else "one moving re-drawn rectangle",
-                                  args.experiment),
+                                  args.experiment,
+                                  "one sequence" if S == 1 else "%d concurrent sequences (one stream each)" % S),
+                   "sequences_per_gpu": S,
                    "launch": args.mode, "threshold": args.threshold, "pool_clone": bool(args.pool_clone)},
         "effective_gflops": fps * dense_ops / 1e9,
     }
 
     # dense network on the same GPU, timed the same way (eval01.py:68)
     if not args.no_dense and world == 1:
-        drunner = FrameRunner(base, frames[0], args.mode)
-        drunner.prime(prime)
-        for f in warm[:5]:
+        # (with S sequences per GPU the dense network gets them as one batch of S frames)
+        dframes = [torch.cat([q['frames'][i] for q in seqs]) for i in range(min(len(frames), 64))]
+        drunner = FrameRunner(base, dframes[0], args.mode)
+        drunner.prime(dframes[:2])
+        for f in dframes[:5]:
             drunner.step(f)
         dsteps = max(10, args.steps // 4)
-        delapsed = timed_loop(drunner, frames, dsteps, lambda: None)
-        result["dense_fps"] = dsteps / delapsed
+        delapsed = timed_loop(drunner, dframes, dsteps, lambda: None)
+        result["dense_fps"] = S * dsteps / delapsed
         result["speedup_vs_dense"] = fps / result["dense_fps"]
         result["dense_tflops"] = result["dense_fps"] * dense_ops / 1e12
+
+    # throughput mode: several sequences in flight on the one GPU, one stream + graph each;
+    # reported beside the headline, which stays the reference's one-sequence-at-a-time protocol
+    if S == 1 and world == 1 and args.multi > 1 and args.mode == "graph":
+        msteps = max(10, args.steps // 2)
+        melapsed, mseqs = run_sequences(args.multi, msteps, min(args.warmup, 10), 1, lambda: None)
+        result["multi_sequence"] = {"sequences_per_gpu": args.multi, "steps": msteps,
+                                    "value": args.multi * msteps / melapsed, "unit": "frames/s"}
+        if not args.no_dense:
+            dfr = [torch.cat([q['frames'][i] for q in mseqs]) for i in range(min(msteps, 32))]
+            drunner = FrameRunner(base, dfr[0], args.mode)
+            drunner.prime(dfr[:2])
+            for f in dfr[:3]:
+                drunner.step(f)
+            dsteps = max(5, msteps // 4)
+            result["multi_sequence"]["dense_fps_batched"] = args.multi * dsteps / timed_loop(
+                drunner, dfr, dsteps, lambda: None)
+        del mseqs
 
     # per-kernel measurement (HIP events on the launch stream) -> roofline of the dominant kernel
     if world == 1:

@@ -157,11 +157,14 @@ _workspaces = {}
 
 
 def convWorkspace(device):
-    """Zero-initialised split-K workspace of the persistent contraction kernel, one per device.
-    The kernels leave it zero; it is shared by all launches on the device, which is safe as long as
-    they are ordered (one stream, or one graph) -- modules running on several streams at once own
-    private ones (CBConv2d.privateWorkspace)."""
-    key = (device.type, device.index)
+    """Zero-initialised split-K workspace of the persistent contraction kernel, one per (device, stream).
+    The kernels leave it zero.  Launches that share one must be ordered; keying it by torch's current
+    stream gives that for free: sequences processed concurrently on different streams (or captured into
+    graphs on different streams) get private workspaces, everything on one stream shares one."""
+    if device.type == 'cuda':
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    else:
+        key = (device.type, device.index, 0)
     ws = _workspaces.get(key)
     if ws is None:
         ws = torch.zeros(C.cbinfer_conv_workspace_bytes(), dtype=torch.uint8, device=device)
@@ -170,8 +173,8 @@ def convWorkspace(device):
 
 
 def prepWeights(weights, H=1, W=1):
-    """Pad (and for fp32 transpose to k-major) the [K,C,kH,kW] filter bank for the MFMA kernels and
-    append the tap table for an H x W feature map."""
+    """Pad the [K,C,kH,kW] filter bank to the MFMA tile grid (W[Kpad][CkkPad], k contiguous) and append
+    the tap table for an H x W feature map."""
     require_device(weights)
     w = weights.detach().contiguous()
     K = w.size(0)

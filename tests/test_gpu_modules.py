@@ -207,6 +207,48 @@ def test_hip_graph_capture(pkg):
             assert torch.equal(static_out, ref), t
 
 
+def test_concurrent_sequences_on_streams(pkg):
+    """several sequences in flight on one GPU, one HIP stream and one captured graph each.
+    The split-K workspace is keyed by stream, so concurrent replays must not disturb each other: every
+    sequence has to reproduce what the same frames give when processed alone, eagerly."""
+    from cbinfer_amd import workloads
+    S, T = 3, 6
+    H, W = 160, 240          # big enough for split-K (few tiles, deep k) in the 64->256 layer
+    vids = [workloads.SyntheticVideo(H=H, W=W, ratio=0.1, block=16, seed=11 + q).frames(T) for q in range(S)]
+    ref_out = []
+    with torch.no_grad():
+        for q in range(S):
+            _, eager = workloads.sceneLabelingModels(experimentIdx=6, threshold=0.05, seed=1)
+            ref_out.append([eager(f).clone() for f in vids[q]])
+        torch.cuda.synchronize()
+        runners = []
+        for q in range(S):
+            _, m = workloads.sceneLabelingModels(experimentIdx=6, threshold=0.05, seed=1)
+            st = torch.cuda.Stream()
+            static_in = vids[q][0].clone()
+            st.wait_stream(torch.cuda.current_stream())          # weights, frames: made on the default stream
+            with torch.cuda.stream(st):
+                m(static_in)                                     # frame 0 eagerly (allocations)
+                cap = torch.cuda.Stream()
+                cap.wait_stream(st)
+                with torch.cuda.stream(cap):
+                    m(static_in)                                 # warm-up on the capture stream
+                st.wait_stream(cap)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cap):
+                    out = m(static_in)
+            runners.append((st, static_in, g, out, (cap, m)))   # keep the model (its state tensors) alive
+        torch.cuda.synchronize()
+        for t in range(1, T):
+            for q, (st, static_in, g, out, _) in enumerate(runners):     # all sequences in flight
+                with torch.cuda.stream(st):
+                    static_in.copy_(vids[q][t])
+                    g.replay()
+            torch.cuda.synchronize()
+            for q, (st, static_in, g, out, _) in enumerate(runners):
+                assert (out - ref_out[q][t]).abs().max().item() <= 1e-4, (q, t)
+
+
 def test_half_network(pkg):
     """cg_half path end to end: fp16 network vs the fp32 dense network on the same (fp16-rounded)
     weights, first frame and a changed frame; tolerance 3e-2 absolute on O(1) activations (fp16

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
     }
     const int MT = p.KP / BM;
     const int T = ((N + BN - 1) / BN) * MT;                  // output tiles
-    const int P = p.CkkP / (4 * BK);                         // groups of four stages along k
+    const int P = (p.CkkP + 4 * BK - 1) / (4 * BK);          // groups of four stages along k (last: partial)
     // Split along k only while whole CUs would otherwise idle (T below CB_SK_TARGET x the CU count) and
     // the k-depth is long enough to pay for the slab round trip: the reducer costs ~4 us of fences +
     // ~1 us per slab, a stage pair ~1.7 us, so the best slice count is ~sqrt(1.7 P).
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
     for (int item = blockIdx.x; item < items; item += gridDim.x) {
         const int tile = item / SK, slice = item - tile * SK;
         const int n0 = (tile / MT) * BN, m0 = (tile % MT) * BM;
-        const int kBeg = (P * slice / SK) * 4 * BK, kEnd = (P * (slice + 1) / SK) * 4 * BK;
+        const int kBeg = (P * slice / SK) * 4 * BK, kEnd = min((P * (slice + 1) / SK) * 4 * BK, p.CkkP);
         const int kLast = kEnd - BK;
 
         // per-thread B-load coordinates; a slot past the list is "outside the image"
@@ -511,11 +511,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
             // header inherits "set 0 is the youngest" and drains the queue every iteration)
             load_stage(FASTC, kBeg, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            load_stage(FASTC, kBeg + BK, a1, b1);
+            load_stage(FASTC, min(kBeg + BK, kLast), a1, b1);
             __builtin_amdgcn_sched_barrier(0);
-            load_stage(FASTC, kBeg + 2 * BK, a2, b2);
+            load_stage(FASTC, min(kBeg + 2 * BK, kLast), a2, b2);
             __builtin_amdgcn_sched_barrier(0);
-            load_stage(FASTC, kBeg + 3 * BK, a3, b3);
+            load_stage(FASTC, min(kBeg + 3 * BK, kLast), a3, b3);
             __builtin_amdgcn_sched_barrier(0);
             // LDS stage 0 <- set 0, which is then re-armed with stage 4
             store_stage(0, a0, b0);
@@ -536,10 +536,15 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
                 compute(BUF);                                     \
             }                                                     \
             __syncthreads();
+            // (only the slice that ends the k-range can stop inside a group of four: CkkP is a multiple
+            // of BK, not of 4 BK -- the exits leave the straight-line body, and its counted waits, alone)
             for (int k0 = kBeg; k0 < kEnd; k0 += 4 * BK) {
                 CB_STAGE(0, a1, b1, k0 + 5 * BK)
+                if (k0 + BK >= kEnd) break;
                 CB_STAGE(1, a2, b2, k0 + 6 * BK)
+                if (k0 + 2 * BK >= kEnd) break;
                 CB_STAGE(0, a3, b3, k0 + 7 * BK)
+                if (k0 + 3 * BK >= kEnd) break;
                 CB_STAGE(1, a0, b0, k0 + 8 * BK)
             }
 #undef CB_STAGE
@@ -1113,10 +1118,9 @@ int launch_f16(const ConvParams& p, hipStream_t s) {
     return cb_launch_status();
 }
 
-// k-depth padding of the prepared weights: a whole number of stage pairs (fp32: 2 x 32, fp16: 2 x 64)
+// k-depth padding of the prepared weights
 int cb_ckkpad(int Ckk, int dtype) {
-    const int q = 128;   // fp32: 4 x 32, fp16: 2 x 64
-    (void)dtype;
+    const int q = dtype == CB_F16 ? 128 : 32;   // fp32: whole 32-deep stages; fp16: stage pairs of 2 x 64
     return (Ckk + q - 1) / q * q;
 }
 
@@ -1164,7 +1168,7 @@ extern "C" {
 
 // K <= 32 uses the 32-row workgroup tile, anything larger the 64-row one: pad to whole tiles
 int cbinfer_weights_kpad(int K) { return K <= CB_MFMA_M ? CB_MFMA_M : (K + 63) / 64 * 64; }
-int cbinfer_weights_ckkpad(int Ckk) { return (Ckk + 127) / 128 * 128; }
+int cbinfer_weights_ckkpad(int Ckk) { return (Ckk + 31) / 32 * 32; }
 
 long cbinfer_conv_workspace_bytes(void) {
     return 4096 + (long)CB_CONV_GRID_PER_CU * cb_num_cus() * 64 * 64 * 4;

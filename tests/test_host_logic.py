@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.cbinfer_abi_version() == 1
     lib.cbinfer_mask_words.restype = ctypes.c_long
     assert lib.cbinfer_mask_words_per_row(480) == 8 and lib.cbinfer_mask_words(320, 480) == 2560
-    assert lib.cbinfer_weights_kpad(8) == 32 and lib.cbinfer_weights_ckkpad(147) == 256
+    assert lib.cbinfer_weights_kpad(8) == 32 and lib.cbinfer_weights_ckkpad(147) == 160
 
 
 def test_compat_shims_export_reference_symbols():

@@ -9,11 +9,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cbinfer_amd import conv2d_cg as cg, _lib
 from tools.bench_conv import LAYERS, blocks_list
 raw = ctypes.CDLL(_lib.LIB_PATH)
-C, K, k, H, W = LAYERS[2]
+C, K, k, H, W = LAYERS[int(sys.argv[1]) if len(sys.argv) > 1 else 2]
 gen = torch.Generator().manual_seed(0)
 x = torch.randn(1, C, H, W, device="cuda"); w = torch.randn(K, C, k, k, device="cuda") / (C*k*k)**0.5
 b = torch.randn(K, device="cuda"); out = torch.zeros(1, K, H, W, device="cuda"); wp = cg.prepWeights(w, H, W)
-for ratio in (0.1, 0.36, 1.0):
+for ratio in ([float(a) for a in sys.argv[2:]] or [0.1, 0.36, 1.0]):
     idx = blocks_list(H, W, ratio, 8, gen)
     for _ in range(5):
         cg.convChanged(x, idx, w, b, out, withReLU=True, weightsPrepared=wp)

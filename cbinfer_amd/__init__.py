@@ -100,6 +100,34 @@ def propChangeIndexesOf1x1(rootModule):
     return rootModule
 
 
+def insertCBPooling(rootModule, cloneOutput=True):
+    """what sceneLabeling/modelLoader.py:62-78 does by hand for experiments 5/6, for any
+    converted network: every 2x2/stride-2 nn.MaxPool2d that directly follows a CBConv2d inside an
+    nn.Sequential becomes a CBPoolMax2d fed by that layer's change indexes (propChangeIndexes on the
+    conv), so only the windows holding a changed pixel are pooled again.  A CBConv2d consuming the pool
+    then needs its own input copy (copyInput) unless it runs in feedback mode.  Returns rootModule."""
+    def _pair(v):
+        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    for seq in [m for m in rootModule.modules() if type(m) == torch.nn.Sequential]:
+        names = list(seq._modules.keys())
+        for a, b in zip(names[:-1], names[1:]):
+            conv, pool = seq._modules[a], seq._modules[b]
+            if (type(conv) == CBConv2d and type(pool) == torch.nn.MaxPool2d and
+                    _pair(pool.kernel_size) == (2, 2) and _pair(pool.stride) == (2, 2) and
+                    _pair(pool.padding) == (0, 0) and _pair(pool.dilation) == (1, 1)):
+                _log('change-based pooling after %s' % a)
+                conv.propChangeIndexes = True
+                cb = CBPoolMax2d(pool)
+                cb.cloneOutput = cloneOutput
+                seq._modules[b] = cb
+                nxt = names.index(b) + 1
+                if nxt < len(names) and type(seq._modules[names[nxt]]) == CBConv2d:
+                    consumer = seq._modules[names[nxt]]
+                    if not consumer.feedbackLoop:
+                        consumer.copyInput = True
+    return rootModule
+
+
 def clearMemory(net):
     for m in net.modules():
         if type(m) == CBConv2d or type(m) == CBPoolMax2d:
@@ -171,5 +199,5 @@ def tuneThresholdParameters(vidSeqReader, evalSequences, numFramesPerSeq, target
 
 
 __all__ = ['CBConv2d', 'CBPoolMax2d', 'ChangeIndexes', 'convert', 'convertRecur', 'subsitute',
-           'mergeReLURecur', 'propChangeIndexesOf1x1', 'clearMemory', 'getStateTensors',
+           'mergeReLURecur', 'propChangeIndexesOf1x1', 'insertCBPooling', 'clearMemory', 'getStateTensors',
            'setSyncIndexes', 'tuneThresholdParameters']

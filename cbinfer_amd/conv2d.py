@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from . import _lib
 from ._lib import C, check, dtype_code, ptr, require_device, stream_ptr
 from .conv2d_cg import (ChangeIndexes, changeDetection, changeIndexesExtr, convWorkspace, genXMatrix,
-                        matrixMult, maxPool2d, prepWeights, updateOutput)
+                        matrixMult, maxPool2d, poolChangeIndexes, prepWeights, updateOutput)
 from .conv2d_fg import cbconvFG, cbconvFG_deterministic
 
 
@@ -50,6 +50,10 @@ class CBPoolMax2d(nn.Module):
         # keep a reference to it -- CBConv2d with copyInput=False -- takes its copy then); this removes
         # one full-tensor copy per frame when the consumer copies or feeds back anyway.
         self.cloneOutput = True
+        # reference behaviour (conv2d.py:80-83): with propChangeIndexes the INPUT-resolution list is
+        # handed on as it came in.  downsampleIndexes=True hands on the list of changed OUTPUT pixels
+        # instead, which is what a consumer working at the pooled resolution needs.
+        self.downsampleIndexes = False
         self.register_buffer('outputState', torch.zeros(0))
         self.clearMemory()
 
@@ -92,6 +96,9 @@ class CBPoolMax2d(nn.Module):
             output = self.outputState
             output._cbinfer_inplace_state = True
         if self.propChangeIndexes:
+            if getattr(self, 'downsampleIndexes', False):
+                return 'changeIndexes', output, poolChangeIndexes(
+                    changeIndexes, (input.size(-2), input.size(-1)), (output.size(-2), output.size(-1)))
             return 'changeIndexes', output, inp[2]
         return output
 

@@ -282,6 +282,24 @@ def maxPool2d(input, outputState, changeIndexes, kernelSize, stride, useHalf=Fal
     return outputState
 
 
+def poolChangeIndexes(changeIndexes, inSize, outSize):
+    """the change-index list of a 2x2/stride-2 pool's OUTPUT from that of its input --
+    ascending, duplicate-free flat indexes yo*oW+xo of every window that holds a changed input pixel --
+    as a ChangeIndexes (device-side count, no host sync).  inSize = (iH, iW), outSize = (oH, oW)."""
+    idx, count, cap = _split_indexes(changeIndexes)
+    require_device(idx)
+    (iH, iW), (oH, oW) = inSize, outSize
+    dev = idx.device
+    words = C.cbinfer_mask_words(oH, oW)
+    bits = torch.zeros(words, dtype=torch.int64, device=dev)
+    out = torch.empty(oH * oW, dtype=torch.int32, device=dev)
+    ocount = torch.zeros(1, dtype=torch.int32, device=dev)
+    if cap > 0:
+        check(C.cbinfer_pool_change_indexes(ptr(idx), cap, ptr(count), iW, oH, oW, ptr(bits), stream_ptr(idx)))
+        check(C.cbinfer_compact_bits(ptr(bits), oW, oH, ptr(out), ptr(ocount), None, None, stream_ptr(idx)))
+    return ChangeIndexes(out, ocount)
+
+
 __all__ = ['ChangeIndexes', 'convWorkspace', 'changeDetection', 'changePropagation', 'changeIndexesExtr',
            'changeIndexesExtrAsync', 'genXMatrix', 'prepWeights', 'matrixMult', 'matrixMult_python',
-           'updateOutput', 'convChanged', 'maxPool2d', 'CBinferError']
+           'updateOutput', 'convChanged', 'maxPool2d', 'poolChangeIndexes', 'CBinferError']

@@ -42,6 +42,27 @@ __global__ __launch_bounds__(256) void cb_maxpool_kernel(const T* __restrict__ i
     }
 }
 
+// f4: change indexes carried THROUGH a 2x2/stride-2 pool.  Every changed input pixel marks
+// its output window in a row-padded bit mask of the pooled map (the reference hands the input-resolution
+// list on unchanged, conv2d.py:80-83, which no consumer can use); cbinfer_compact_bits then turns the
+// mask into the ascending, duplicate-free output-resolution list.
+__global__ __launch_bounds__(256) void cb_pool_indexes_kernel(const int32_t* __restrict__ list, int nHost,
+                                                             const int32_t* __restrict__ countDev,
+                                                             int iW, int oH, int oW, int wpr,
+                                                             unsigned long long* __restrict__ bits) {
+    const int N = countDev ? min(*countDev, nHost) : nHost;
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const int pos = list[n];
+        const int y = pos / iW, x = pos - y * iW;
+        const int yo = y >> 1, xo = x >> 1;
+        if (yo >= oH || xo >= oW) continue;
+        // the four pixels of a window are neighbours in the list order only along x: let the even-x
+        // (or first) one of a pair do the atomic when its partner is the next list entry
+        if ((x & 1) && n > 0 && list[n - 1] == pos - 1) continue;
+        atomicOr(bits + (long)yo * wpr + (xo >> 6), 1ull << (xo & 63));
+    }
+}
+
 __global__ __launch_bounds__(256) void cb_detect_fg_kernel(const float* __restrict__ in,
                                                           const float* __restrict__ prev,
                                                           float* __restrict__ diffs,
@@ -124,6 +145,18 @@ int cbinfer_max_pool2d(const void* input, void* output, const int32_t* changeInd
                            countDev, C, iH, iW, oH, oW);
     else
         return CB_ERR_BADARG;
+    return cb_launch_status();
+}
+
+int cbinfer_pool_change_indexes(const int32_t* changeIndexes, int numChanges, const int32_t* countDev,
+                                int iW, int oH, int oW, uint64_t* bitsOut, cbStream_t stream) {
+    CB_REQUIRE(changeIndexes && bitsOut && numChanges >= 0 && iW > 0 && oH > 0 && oW > 0);
+    if (numChanges == 0) return CB_OK;
+    long blocks = ((long)numChanges + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(cb_pool_indexes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       changeIndexes, numChanges, countDev, iW, oH, oW, (oW + 63) / 64,
+                       (unsigned long long*)bitsOut);
     return cb_launch_status();
 }
 

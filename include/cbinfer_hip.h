@@ -182,6 +182,15 @@ int cbinfer_max_pool2d(const void* input, void* output, const int32_t* changeInd
                        const int32_t* countDev, int C, int iH, int iW, int oH, int oW, int dtype,
                        cbStream_t stream);
 
+/* ---- 8f-4: change indexes through a pool ------------------------------------------------------
+ * The reference's CBPoolMax2d passes the INPUT-resolution index list on when propChangeIndexes is set
+ * (conv2d.py:80-83), which is not usable at the pooled resolution.  This marks, for every changed input
+ * pixel y*iW+x, bit (y/2, x/2) of a row-padded bit mask of the oH x oW pooled map (layout of
+ * cbinfer_mask_words; bitsOut must be zero on entry); cbinfer_compact_bits turns it into the ascending
+ * duplicate-free list of changed OUTPUT pixels and its device-side count. */
+int cbinfer_pool_change_indexes(const int32_t* changeIndexes, int numChanges, const int32_t* countDev,
+                                int iW, int oH, int oW, uint64_t* bitsOut, cbStream_t stream);
+
 /* ---- a10-a12: fine-grained path ---------------------------------------------------------------
  * replaces changeDetectionFG, conv2d_fg.py:34-46 -> cbconv2d_fg_backend.cu:25-35 (kernel :7-23):
  * d = in - prev; changeMap = |d| > th; diffs = d where changed.  zeroUnchanged=1 additionally writes

@@ -153,6 +153,17 @@ def maxPool2d(inp, outputState, changeIndexes, guardOutput=True):
     return outputState
 
 
+def poolChangeIndexes(changeIndexes, inSize, outSize):
+    """Indexes of the 2x2/stride-2 pool OUTPUT pixels whose window holds a changed input pixel (ascending,
+    unique) -- the set cbconv2d_cg_backend.cu:214-226 recomputes, in the order changeIndexesExtr would
+    give it.  (The reference itself hands the input list on unchanged, conv2d.py:80-83.)"""
+    idx = np.asarray(changeIndexes, dtype=np.int64)
+    (iH, iW), (oH, oW) = inSize, outSize
+    yo, xo = (idx // iW) // 2, (idx % iW) // 2
+    keep = (yo < oH) & (xo < oW)
+    return np.unique(yo[keep] * oW + xo[keep]).astype(np.int32)
+
+
 def changeDetectionFG(inp, prevInput, threshold, cmp=CMP_GT, diffs_init=None):
     """cbconv2d_fg_backend.cu:7-35.  diffs are only written where changed; elsewhere they keep
     diffs_init (default 0 here; uninitialised in the reference)."""

@@ -249,6 +249,32 @@ def test_concurrent_sequences_on_streams(pkg):
                 assert (out - ref_out[q][t]).abs().max().item() <= 1e-4, (q, t)
 
 
+def test_insert_cb_pooling_tracks_dense_and_downsamples_indexes(pkg, oracle):
+    """8f-4: automatic change-based pooling.  At threshold 0 the rewritten network must track the dense
+    one frame by frame; with downsampleIndexes the pool hands on the list of changed OUTPUT pixels."""
+    from cbinfer_amd import workloads
+    base = workloads.sceneLabelingBaseline(seed=3).cuda()
+    net = pkg.insertCBPooling(pkg.convert(base, threshold=0.0)).cuda()
+    vid = workloads.SyntheticVideo(H=64, W=96, ratio=0.1, block=16, seed=5)
+    with torch.no_grad():
+        for f in vid.frames(5):
+            assert (net(f) - base(f)).abs().max().item() <= FP32_TOL
+    conv = pkg.CBConv2d(nn.Conv2d(3, 4, 3, padding=1).cuda(), 0.05)
+    conv.propChangeIndexes = True
+    pool = pkg.CBPoolMax2d(nn.MaxPool2d(2, 2))
+    pool.propChangeIndexes = True
+    pool.downsampleIndexes = True
+    frames = workloads.SyntheticVideo(H=32, W=48, ratio=0.1, block=8, seed=9).frames(3)
+    with torch.no_grad():
+        for f in frames:
+            tag, out, idx_in = conv(f)
+            tag2, pooled, idx_out = pool((tag, out, idx_in))
+            assert tag2 == 'changeIndexes'
+            want = oracle.poolChangeIndexes(idx_in.tensor().cpu().numpy(), (32, 48), (16, 24))
+            assert idx_out.tensor().cpu().numpy().tolist() == want.tolist()
+            assert torch.equal(pooled, torch.nn.functional.max_pool2d(out, 2, 2))
+
+
 def test_half_network(pkg):
     """cg_half path end to end: fp16 network vs the fp32 dense network on the same (fp16-rounded)
     weights, first frame and a changed frame; tolerance 3e-2 absolute on O(1) activations (fp16

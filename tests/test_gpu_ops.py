@@ -346,3 +346,24 @@ def test_c_abi_rejects_bad_arguments(cb):
     with pytest.raises(CBinferError):
         check(lib.cbinfer_conv_changed(None, None, 1, None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, None,
                                        0, None, 0, None))
+
+
+@pytest.mark.parametrize("size", [(8, 8, False), (7, 9, False), (7, 9, True), (160, 240, False), (37, 130, True)])
+def test_pool_change_indexes_vs_oracle(oracle, size):
+    """8f-4: index list of the pooled map from the input list, bit-exact incl. order, device-side count."""
+    from cbinfer_amd import conv2d_cg as cg
+    H, W, ceil = size
+    oH, oW = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if ceil else (H // 2, W // 2)
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    for frac in (0.0, 0.03, 0.4, 1.0):
+        m = torch.rand(H, W, generator=g) < frac
+        idx = torch.nonzero(m.view(-1)).view(-1).int()
+        want = oracle.poolChangeIndexes(idx.numpy(), (H, W), (oH, oW))
+        # exact-length tensor and capacity buffer + device count
+        got = cg.poolChangeIndexes(idx.cuda(), (H, W), (oH, oW))
+        assert got.tensor().cpu().numpy().tolist() == want.tolist()
+        buf = torch.zeros(H * W, dtype=torch.int32)
+        buf[:idx.numel()] = idx
+        ci = cg.ChangeIndexes(buf.cuda(), torch.tensor([idx.numel()], dtype=torch.int32).cuda())
+        got = cg.poolChangeIndexes(ci, (H, W), (oH, oW))
+        assert got.tensor().cpu().numpy().tolist() == want.tolist()

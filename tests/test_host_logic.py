@@ -6,6 +6,7 @@ import io
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 import torch.nn as nn
@@ -160,3 +161,28 @@ def test_synthetic_video_change_ratio():
     f1 = vid.next()
     changed = (f0 != f1).any(dim=1)
     assert changed.float().mean().item() == pytest.approx(vid.ratio, abs=1e-3)
+
+
+def test_insert_cb_pooling_structure():
+    """insertCBPooling reproduces by rule what modelLoader.py:62-78 builds by hand for experiment 5/6."""
+    import pycbinfer
+    from cbinfer_amd import workloads
+    base = workloads.sceneLabelingBaseline()
+    net = pycbinfer.insertCBPooling(pycbinfer.convert(base, threshold=0.05))
+    kids = list(net.children())
+    assert [type(k).__name__ for k in kids[:5]] == ['CBConv2d', 'CBPoolMax2d', 'CBConv2d', 'CBPoolMax2d', 'CBConv2d']
+    assert kids[0].propChangeIndexes and kids[2].propChangeIndexes and not kids[4].propChangeIndexes
+    assert kids[2].copyInput and kids[4].copyInput
+    # a pool that does not follow a CBConv2d, or is not 2x2/2, stays
+    other = pycbinfer.insertCBPooling(pycbinfer.convert(nn.Sequential(
+        nn.MaxPool2d(2, 2), nn.Conv2d(3, 4, 3, padding=1), nn.MaxPool2d(3, 2, 1)), threshold=0.1))
+    assert [type(k).__name__ for k in other.children()] == ['MaxPool2d', 'CBConv2d', 'MaxPool2d']
+
+
+def test_oracle_pool_change_indexes():
+    from oracle import cb_oracle as orc
+    idx = np.array([0, 1, 7, 8, 9, 16, 63], dtype=np.int32)          # 8x8 input
+    assert orc.poolChangeIndexes(idx, (8, 8), (4, 4)).tolist() == [0, 3, 4, 15]
+    idx7 = np.array([6, 13, 48], dtype=np.int32)                     # 7x7 input, floor pool 3x3
+    assert orc.poolChangeIndexes(idx7, (7, 7), (3, 3)).tolist() == []
+    assert orc.poolChangeIndexes(idx7, (7, 7), (4, 4)).tolist() == [3, 15]        # ceil-mode pool

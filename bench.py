@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--sequences", type=int, default=1,
                     help="independent video sequences in flight per GPU, one HIP stream + graph each "
                          "(a step then feeds one frame to every sequence)")
+    ap.add_argument("--no-fuse-pool", action="store_true",
+                    help="keep the change-based pool launches (default: pooling is folded into the next "
+                         "layer's change detection, pycbinfer.fusePoolingIntoDetection; same results)")
     ap.add_argument("--multi", type=int, default=4,
                     help="also report the throughput with this many concurrent sequences (0/1: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,6 +151,7 @@ def kernel_breakdown(test, frames, reps=50):
     Returns a list of dicts with the algorithmic bytes / flops of SURVEY 8d."""
     import pycbinfer
     from cbinfer_amd import conv2d_cg as cg
+    from cbinfer_amd.conv2d import LazyPool
     from cbinfer_amd._lib import C as lib, check, stream_ptr, ptr
     rows = []
     # feed one more frame layer by layer, keeping each CB layer's input
@@ -157,7 +161,8 @@ def kernel_breakdown(test, frames, reps=50):
             xin = x
             x = m(x)
             if type(m) is pycbinfer.CBConv2d and not m.finegrained:
-                inp = xin[1] if isinstance(xin, tuple) else xin
+                lazy = xin if isinstance(xin, LazyPool) else None     # pool folded into this detection
+                inp = lazy.tensor() if lazy is not None else (xin[1] if isinstance(xin, tuple) else xin)
                 K, C, kH, kW = m.weight.shape
                 Hh, Ww = inp.shape[-2:]
                 s = 4 if inp.dtype == torch.float32 else 2
@@ -167,9 +172,15 @@ def kernel_breakdown(test, frames, reps=50):
                 cnt = torch.zeros(1, dtype=torch.int32, device=inp.device)
                 idx = torch.empty_like(m._work['idx'])
                 dt = 0 if s == 4 else 1
-                t_det = event_time_ms(lambda: (bits.zero_(), check(lib.cbinfer_change_detection_bits(
-                    ptr(inp), ptr(m.prevInput), ptr(bits), Ww, Hh, C, (kH - 1) // 2, (kW - 1) // 2,
-                    float(m.threshold), 0, dt, stream_ptr()))), reps)
+                if lazy is not None:
+                    src, st = lazy.source.contiguous(), m.prevInput.clone()
+                    t_det = event_time_ms(lambda: (bits.zero_(), check(lib.cbinfer_change_detection_frame_pooled(
+                        ptr(src), src.shape[-2], src.shape[-1], ptr(st), ptr(bits), Ww, Hh, C, (kH - 1) // 2,
+                        (kW - 1) // 2, float(m.threshold), dt, stream_ptr()))), reps)
+                else:
+                    t_det = event_time_ms(lambda: (bits.zero_(), check(lib.cbinfer_change_detection_bits(
+                        ptr(inp), ptr(m.prevInput), ptr(bits), Ww, Hh, C, (kH - 1) // 2, (kW - 1) // 2,
+                        float(m.threshold), 0, dt, stream_ptr()))), reps)
                 t_zero = event_time_ms(lambda: bits.zero_(), reps)
                 t_cmp = event_time_ms(lambda: check(lib.cbinfer_compact_bits(
                     ptr(m._work['bits']), Ww, Hh, ptr(idx), ptr(cnt), None, None, stream_ptr())), reps)
@@ -182,7 +193,9 @@ def kernel_breakdown(test, frames, reps=50):
                 HW = Hh * Ww
                 rows.append(dict(layer="conv %d->%d k%d @%dx%d" % (C, K, kH, Hh, Ww), N=N,
                                  ratio=N / float(HW),
-                                 detect_ms=max(t_det - t_zero, 0.0), detect_bytes=2 * C * HW * s + HW // 8,
+                                 detect_ms=max(t_det - t_zero, 0.0),
+                                 detect_bytes=(5 if lazy is not None else 2) * C * HW * s + HW // 8,
+                                 detect_pooled=lazy is not None,
                                  compact_ms=t_cmp, compact_bytes=HW // 8 + 4 * N,
                                  conv_ms=t_conv, conv_flops=2.0 * N * C * kH * kW * K,
                                  conv_bytes=(N * C * kH * kW + K * C * kH * kW + N * K) * s))
@@ -191,6 +204,10 @@ def kernel_breakdown(test, frames, reps=50):
                 N = ci.numel()
                 C = inp.shape[1]
                 s = 4 if inp.dtype == torch.float32 else 2
+                if getattr(m, 'lazy', False):   # no launch: folded into the next layer's detection
+                    rows.append(dict(layer="pool C%d @%dx%d (folded into the next detection)"
+                                     % (C, inp.shape[-2], inp.shape[-1]), N=N, pool_ms=0.0, pool_bytes=0))
+                    continue
                 t_pool = event_time_ms(lambda: cg.maxPool2d(inp, m.outputState, ci, (2, 2), (2, 2)), reps)
                 rows.append(dict(layer="pool C%d @%dx%d" % (C, inp.shape[-2], inp.shape[-1]), N=N,
                                  pool_ms=t_pool, pool_bytes=N * C * 5 * s + 4 * N))
@@ -287,6 +304,7 @@ def main():
             for m in test.modules():
                 if type(m) is pycbinfer.CBPoolMax2d:
                     m.cloneOutput = bool(args.pool_clone)
+            pycbinfer.fusePoolingIntoDetection(test, enabled=not args.no_fuse_pool)
             video_kw = dict(H=H, W=W, ratio=args.ratio, block=args.block,
                             seed=shard.sequence_seed(1234) + 7919 * (seq0 + q), pattern=args.pattern)
             vid = workloads.SyntheticVideo(**video_kw)
@@ -329,7 +347,8 @@ def main():
                                   args.experiment,
                                   "one sequence" if S == 1 else "%d concurrent sequences (one stream each)" % S),
                    "sequences_per_gpu": S,
-                   "launch": args.mode, "threshold": args.threshold, "pool_clone": bool(args.pool_clone)},
+                   "launch": args.mode, "threshold": args.threshold, "pool_clone": bool(args.pool_clone),
+                   "pool_fused_into_detection": not args.no_fuse_pool},
         "effective_gflops": fps * dense_ops / 1e9,
     }
 

@@ -128,6 +128,21 @@ def insertCBPooling(rootModule, cloneOutput=True):
     return rootModule
 
 
+def fusePoolingIntoDetection(rootModule, enabled=True):
+    """Execution-level fusion (no change of results): a CBPoolMax2d whose consumer inside the same
+    nn.Sequential is a feedback-mode CBConv2d stops pooling and lets that layer compute the pooled values
+    inside its change detection (CBPoolMax2d.lazy, cbinfer_cbconv2d_forward_pooled) -- one launch less
+    per pool and frame.  The pooled map is then not materialised, so the pool must not hand its indexes
+    on (propChangeIndexes) and nothing else may read its outputState.  Returns rootModule."""
+    for seq in [m for m in rootModule.modules() if type(m) == torch.nn.Sequential]:
+        kids = list(seq.children())
+        for pool, consumer in zip(kids[:-1], kids[1:]):
+            if type(pool) == CBPoolMax2d:
+                pool.lazy = bool(enabled and type(consumer) == CBConv2d and consumer.feedbackLoop and
+                                 not consumer.finegrained and not pool.propChangeIndexes)
+    return rootModule
+
+
 def clearMemory(net):
     for m in net.modules():
         if type(m) == CBConv2d or type(m) == CBPoolMax2d:
@@ -199,5 +214,6 @@ def tuneThresholdParameters(vidSeqReader, evalSequences, numFramesPerSeq, target
 
 
 __all__ = ['CBConv2d', 'CBPoolMax2d', 'ChangeIndexes', 'convert', 'convertRecur', 'subsitute',
-           'mergeReLURecur', 'propChangeIndexesOf1x1', 'insertCBPooling', 'clearMemory', 'getStateTensors',
+           'mergeReLURecur', 'propChangeIndexesOf1x1', 'insertCBPooling', 'fusePoolingIntoDetection',
+           'clearMemory', 'getStateTensors',
            'setSyncIndexes', 'tuneThresholdParameters']

@@ -41,6 +41,9 @@ _SIGNATURES = {
     "cbinfer_frame_mask_bytes": (_l, [_i, _i]),
     "cbinfer_frame_mask_max_words": (_i, []),
     "cbinfer_change_detection_frame": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "cbinfer_change_detection_frame_pooled": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "cbinfer_cbconv2d_forward_pooled": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
+                                             _i, _i, _i, _f, _i, _vp, _i, _vp]),
     "cbinfer_conv_changed_from_mask": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
                                             _i, _vp, _i, _vp]),
     "cbinfer_max_pool2d": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),

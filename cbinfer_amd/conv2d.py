@@ -33,6 +33,20 @@ def _same_shape(t, shape):
     return t is not None and tuple(t.size()) == tuple(shape)
 
 
+class LazyPool(object):
+    """What a CBPoolMax2d with lazy=True hands to the next module instead of a pooled tensor: the pool's
+    INPUT and the pooled size.  A feedback-mode CBConv2d folds the pooling into its change detection
+    (cbinfer_cbconv2d_forward_pooled) and never needs the pooled map; anything else calls tensor()."""
+
+    def __init__(self, source, outSize, ceil_mode):
+        self.source = source
+        self.outSize = tuple(outSize)
+        self.ceil_mode = ceil_mode
+
+    def tensor(self):
+        return F.max_pool2d(self.source, 2, 2, ceil_mode=self.ceil_mode)
+
+
 class CBPoolMax2d(nn.Module):
     """Change-based 2x2/stride-2 max pooling (reference: conv2d.py:24-84)."""
 
@@ -54,6 +68,10 @@ class CBPoolMax2d(nn.Module):
         # handed on as it came in.  downsampleIndexes=True hands on the list of changed OUTPUT pixels
         # instead, which is what a consumer working at the pooled resolution needs.
         self.downsampleIndexes = False
+        # lazy=True (set by fusePoolingIntoDetection when the consumer is a feedback-mode CBConv2d): do
+        # not pool at all, hand the consumer a LazyPool; it computes the pooled values inside its change
+        # detection.  One launch less per pool and frame, identical results.
+        self.lazy = False
         self.register_buffer('outputState', torch.zeros(0))
         self.clearMemory()
 
@@ -73,6 +91,10 @@ class CBPoolMax2d(nn.Module):
         input = inp[1].detach().contiguous()
         changeIndexes = inp[2]
         require_device(input)
+        if getattr(self, 'lazy', False) and not self.propChangeIndexes:
+            nc, h, w = input.size(-3), input.size(-2), input.size(-1)
+            oh, ow = ((h - 1) // 2 + 1, (w - 1) // 2 + 1) if self.ceil_mode else (h // 2, w // 2)
+            return LazyPool(input, (1, nc, oh, ow), self.ceil_mode)
         exact = isinstance(changeIndexes, torch.Tensor)
         if exact:
             changeIndexes = changeIndexes.detach().contiguous()
@@ -238,6 +260,13 @@ class CBConv2d(nn.Module):
     def forward_normal(self, inp):
         # input parsing and checks (conv2d.py:180-190)
         changeIndexes = None
+        pooled = None
+        if isinstance(inp, LazyPool):
+            if (self.feedbackLoop and not self.syncIndexes and not self.saveChangeMap and
+                    not self.gatherComputationStats and inp.source.dtype == self.weight.dtype):
+                pooled = inp
+                return self._forward_pooled(pooled)
+            inp = inp.tensor()           # any other configuration: pool densely, then as usual
         src = inp[1] if type(inp) == tuple else inp
         # a producer that hands out its in-place-updated state (CBPoolMax2d.cloneOutput=False) tags it
         self._inputIsLiveState = bool(getattr(src, '_cbinfer_inplace_state', False))
@@ -276,6 +305,39 @@ class CBConv2d(nn.Module):
 
         if self.propChangeIndexes:
             return 'changeIndexes', self.prevOutput, changeIndexes
+        return self.prevOutput
+
+    def _forward_pooled(self, lazy):
+        """Feedback-mode layer behind a lazy CBPoolMax2d: detection on pooled values computed on the fly
+        + self-compacting contraction (cbinfer_cbconv2d_forward_pooled).  Falls back to dense pooling
+        when the mask is too large for the self-compacting kernel."""
+        src = lazy.source.detach().contiguous()
+        size = lazy.outSize
+        H, W = size[-2], size[-1]
+        assert size[-3] == self.in_channels and src.dim() == 4 and src.size(0) == 1
+        require_device(src)
+        if C.cbinfer_mask_words(H, W) > C.cbinfer_frame_mask_max_words():
+            return self.forward_normal(lazy.tensor())
+        if (tuple(self.prevInput.size()) != tuple(size) or self.prevInput.dtype != src.dtype or
+                self.prevInput.device != src.device):
+            self.prevInput = torch.full(size, float('inf'), dtype=src.dtype, device=src.device)
+        outpSize = list(size)
+        outpSize[-3] = self.out_channels
+        if (not _same_shape(self.prevOutput, outpSize) or self.prevOutput.dtype != src.dtype or
+                self.prevOutput.device != src.device):
+            self.prevOutput = torch.full(outpSize, float('inf'), dtype=src.dtype, device=src.device)
+        self._inputIsLiveState = False
+        work = self._workspace(self.prevInput)
+        if not work['selfc']:
+            return self.forward_normal(lazy.tensor())
+        K, Cin, kH, kW = self.weight.size()
+        check(C.cbinfer_cbconv2d_forward_pooled(
+            ptr(src), src.size(-2), src.size(-1), ptr(self.prevInput), ptr(self.prevOutput),
+            ptr(work['bits']), ptr(work['idx']), ptr(work['count']), ptr(self._prepared_weights(H, W)),
+            ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold),
+            int(bool(self.withReLU)), ptr(convWorkspace(src.device)), dtype_code(src), stream_ptr(src)))
+        if self.propChangeIndexes:
+            return 'changeIndexes', self.prevOutput, ChangeIndexes(work['idx'], work['count'])
         return self.prevOutput
 
     def _forward_fused(self, input, changeIndexes):

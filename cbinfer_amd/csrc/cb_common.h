@@ -48,5 +48,10 @@ __device__ __forceinline__ bool cb_changed(cb_half s, cb_half x, cb_half th) {
     cb_half d = s - x;  // v_sub_f16: one rounding, like __hsub
     return (d > th) | (d < -th);
 }
+// max pooling primitives (shared by the pool kernel and the pooled change detection)
+__device__ __forceinline__ float cb_neg_inf(float*) { return -INFINITY; }
+__device__ __forceinline__ cb_half cb_neg_inf(cb_half*) { return (cb_half)(-INFINITY); }
+__device__ __forceinline__ float cb_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ cb_half cb_max(cb_half a, cb_half b) { return a < b ? b : a; }
 __device__ __forceinline__ float cb_threshold(float th, float*) { return th; }
 __device__ __forceinline__ cb_half cb_threshold(float th, cb_half*) { return (cb_half)th; }  // RNE

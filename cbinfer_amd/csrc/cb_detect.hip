@@ -18,13 +18,18 @@ __device__ __forceinline__ unsigned long long cb_valid_mask(int W, int tile) {
 // shifts.  BITS=true : atomicOr of the dilated words into the row-padded bit mask;
 // BITS=false: byte stores of 1 into the (pre-zeroed) [H,W] map -- same-value races are benign, as in
 // the reference (cbconv2d_cg_backend.cu:69).
-template <typename T, bool BITS>
+// POOL: `in` is the tensor BEFORE a 2x2/stride-2 max pool ([C, pH, pW]); the value compared with the
+// state at (c, y, x) is the pooled one, computed on the fly (windows clipped at the border as the pool
+// kernel clips them).  The pooled map itself is never written: a feedback-mode layer only needs it in
+// its state, which this kernel refreshes at the changed pixels.
+template <typename T, bool BITS, bool POOL = false>
 __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ in, T* state,
                                                         int8_t* __restrict__ map,
                                                         unsigned long long* __restrict__ bits, int W,
                                                         int H, int C, int kHH, int kWH, float thf,
                                                         int update, int wpr,
-                                                        const int* __restrict__ parity, long altWords) {
+                                                        const int* __restrict__ parity, long altWords,
+                                                        int pH = 0, int pW = 0) {
     // frame pipeline: two masks alternate by a device-side parity (flipped by the consumer kernel)
     if (BITS && parity && *parity) bits += altWords;
     const int lane = threadIdx.x & 63;
@@ -38,19 +43,36 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
     const long p = (long)y * W + x;
     const T th = cb_threshold(thf, (T*)nullptr);
 
+    // input value of channel c at this lane's pixel
+    const long pHW = (long)pH * pW;
+    const int py0 = 2 * y, px0 = 2 * x;
+    const bool inner = POOL && py0 + 1 < pH && px0 + 1 < pW;   // whole window inside the pre-pool map
+    auto ldin = [&](int c) -> T {
+        if (!POOL) return in[(long)c * HW + p];
+        const T* q = in + (long)c * pHW + (long)py0 * pW + px0;
+        if (inner) return cb_max(cb_max(q[0], q[1]), cb_max(q[pW], q[pW + 1]));
+        T v = q[0];                                            // (py0 < pH and px0 < pW by construction)
+        if (px0 + 1 < pW) v = cb_max(v, q[1]);
+        if (py0 + 1 < pH) {
+            v = cb_max(v, q[pW]);
+            if (px0 + 1 < pW) v = cb_max(v, q[pW + 1]);
+        }
+        return v;
+    };
+
     bool chg = false;
     if (valid) {
         int c = g;
 #pragma unroll 1
         for (; c + 3 * G < C; c += 4 * G) {  // 8 independent loads in flight per lane
-            const T s0 = state[(long)c * HW + p], x0 = in[(long)c * HW + p];
-            const T s1 = state[(long)(c + G) * HW + p], x1 = in[(long)(c + G) * HW + p];
-            const T s2 = state[(long)(c + 2 * G) * HW + p], x2 = in[(long)(c + 2 * G) * HW + p];
-            const T s3 = state[(long)(c + 3 * G) * HW + p], x3 = in[(long)(c + 3 * G) * HW + p];
+            const T s0 = state[(long)c * HW + p], x0 = ldin(c);
+            const T s1 = state[(long)(c + G) * HW + p], x1 = ldin(c + G);
+            const T s2 = state[(long)(c + 2 * G) * HW + p], x2 = ldin(c + 2 * G);
+            const T s3 = state[(long)(c + 3 * G) * HW + p], x3 = ldin(c + 3 * G);
             chg |= cb_changed(s0, x0, th) | cb_changed(s1, x1, th) | cb_changed(s2, x2, th) |
                    cb_changed(s3, x3, th);
         }
-        for (; c < C; c += G) chg |= cb_changed(state[(long)c * HW + p], in[(long)c * HW + p], th);
+        for (; c < C; c += G) chg |= cb_changed(state[(long)c * HW + p], ldin(c), th);
     }
 
     __shared__ unsigned long long sm[16];
@@ -63,7 +85,7 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
 
     // feedback: refresh the state at the (pre-dilation) changed pixels only (.cu:74-80)
     if (update && ((m >> lane) & 1ull)) {
-        for (int c = g; c < C; c += G) state[(long)c * HW + p] = in[(long)c * HW + p];
+        for (int c = g; c < C; c += G) state[(long)c * HW + p] = ldin(c);
     }
 
     // horizontal dilation of the 64-pixel word, with the parts spilling into the neighbour words
@@ -213,15 +235,16 @@ int detect_groups(int C) {
     return G;
 }
 
-template <typename T, bool BITS>
+template <typename T, bool BITS, bool POOL = false>
 int launch_detect(const void* input, void* state, int8_t* map, uint64_t* bits, int W, int H, int C,
                   int kHH, int kWH, float th, int update, hipStream_t s, const int* parity = nullptr,
-                  long altWords = 0) {
+                  long altWords = 0, int pH = 0, int pW = 0) {
     const int wpr = cbinfer_mask_words_per_row(W);
     const int G = detect_groups(C);
     dim3 grid(wpr, H), block(64 * G);
-    hipLaunchKernelGGL((cb_detect_kernel<T, BITS>), grid, block, 0, s, (const T*)input, (T*)state, map,
-                       (unsigned long long*)bits, W, H, C, kHH, kWH, th, update, wpr, parity, altWords);
+    hipLaunchKernelGGL((cb_detect_kernel<T, BITS, POOL>), grid, block, 0, s, (const T*)input, (T*)state,
+                       map, (unsigned long long*)bits, W, H, C, kHH, kWH, th, update, wpr, parity, altWords,
+                       pH, pW);
     return cb_launch_status();
 }
 
@@ -280,6 +303,26 @@ int cbinfer_change_detection_frame(const void* input, void* state, uint64_t* fra
     if (dtype == CB_F16)
         return launch_detect<cb_half, true>(input, state, nullptr, frameMasks, W, H, C, kHHalf, kWHalf,
                                             threshold, updateInputState, s, parity, words);
+    return CB_ERR_BADARG;
+}
+
+// The same with the 2x2/stride-2 max pool in front of the layer folded in: `prePool` is [C, pH, pW],
+// H x W the pooled size (floor: pH/2, ceil: (pH+1)/2).  The state is always refreshed (feedback mode).
+int cbinfer_change_detection_frame_pooled(const void* prePool, int pH, int pW, void* state,
+                                          uint64_t* frameMasks, int W, int H, int C, int kHHalf,
+                                          int kWHalf, float threshold, int dtype, cbStream_t stream) {
+    CB_REQUIRE(prePool && state && frameMasks && W > 0 && H > 0 && C > 0 && kHHalf >= 0 && kWHalf >= 0);
+    CB_REQUIRE((H == pH / 2 || H == (pH + 1) / 2) && (W == pW / 2 || W == (pW + 1) / 2));
+    if (kWHalf > 63 || H > 65535) return CB_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const long words = cbinfer_mask_words(H, W);
+    const int* parity = (const int*)(frameMasks + 2 * words);
+    if (dtype == CB_F32)
+        return launch_detect<float, true, true>(prePool, state, nullptr, frameMasks, W, H, C, kHHalf,
+                                                kWHalf, threshold, 1, s, parity, words, pH, pW);
+    if (dtype == CB_F16)
+        return launch_detect<cb_half, true, true>(prePool, state, nullptr, frameMasks, W, H, C, kHHalf,
+                                                  kWHalf, threshold, 1, s, parity, words, pH, pW);
     return CB_ERR_BADARG;
 }
 

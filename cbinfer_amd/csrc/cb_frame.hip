@@ -53,3 +53,22 @@ extern "C" int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void
                                 kH, kW, relu, 0, bits, bits ? cbinfer_mask_words(H, W) : 0, workspace,
                                 dtype, stream);
 }
+
+// The same for a feedback-mode layer that sits behind a 2x2/stride-2 max pool, with the pool folded into
+// the detection (cbinfer_change_detection_frame_pooled): `prePool` [C, pH, pW] is the pool's INPUT, the
+// pooled map is never materialised -- the layer gathers from its state, which holds the pooled values
+// of every pixel that ever changed.  Saves the pool launch; results are identical to pool + forward.
+extern "C" int cbinfer_cbconv2d_forward_pooled(const void* prePool, int pH, int pW, void* prevInput,
+                                               void* prevOutput, uint64_t* bits, int32_t* idx,
+                                               int32_t* countDev, const void* weightsPrepared,
+                                               const void* bias, int C, int H, int W, int K, int kH, int kW,
+                                               float threshold, int relu, void* workspace, int dtype,
+                                               cbStream_t stream) {
+    CB_REQUIRE(prePool && prevInput && prevOutput && bits && idx && countDev && weightsPrepared);
+    CB_REQUIRE(dtype == CB_F32 || dtype == CB_F16);
+    const int st = cbinfer_change_detection_frame_pooled(prePool, pH, pW, prevInput, bits, W, H, C,
+                                                         (kH - 1) / 2, (kW - 1) / 2, threshold, dtype, stream);
+    if (st != CB_OK) return st;
+    return cbinfer_conv_changed_from_mask(prevInput, bits, idx, countDev, weightsPrepared, bias, prevOutput,
+                                          C, H, W, K, kH, kW, relu, workspace, dtype, stream);
+}

@@ -7,10 +7,6 @@
 
 namespace {
 
-__device__ __forceinline__ float cb_neg_inf(float*) { return -INFINITY; }
-__device__ __forceinline__ cb_half cb_neg_inf(cb_half*) { return (cb_half)(-INFINITY); }
-__device__ __forceinline__ float cb_max(float a, float b) { return fmaxf(a, b); }
-__device__ __forceinline__ cb_half cb_max(cb_half a, cb_half b) { return a < b ? b : a; }
 
 // One thread per (changed input pixel, channel); the pixel index is the fastest-varying coordinate so
 // neighbouring lanes read neighbouring window columns of one channel plane and write neighbouring

@@ -169,6 +169,20 @@ int cbinfer_frame_mask_max_words(void);
 int cbinfer_change_detection_frame(const void* input, void* state, uint64_t* frameMasks, int W, int H,
                                    int C, int kHHalf, int kWHalf, float threshold,
                                    int updateInputState, int dtype, cbStream_t stream);
+/* A feedback-mode layer behind a 2x2/stride-2 max pool (CBPoolMax2d, conv2d.py:24-84) with the pool
+ * folded into its change detection: prePool [C,pH,pW] is the pool's INPUT; H x W is the pooled size
+ * (pH/2 or ceil).  The pooled value is computed on the fly, compared with the state and written to the
+ * state at the changed pixels; the pooled map itself is never materialised (the layer gathers from its
+ * state).  Identical results to cbinfer_max_pool2d + cbinfer_cbconv2d_forward(feedbackLoop=1), one
+ * launch less per frame. */
+int cbinfer_change_detection_frame_pooled(const void* prePool, int pH, int pW, void* state,
+                                          uint64_t* frameMasks, int W, int H, int C, int kHHalf,
+                                          int kWHalf, float threshold, int dtype, cbStream_t stream);
+int cbinfer_cbconv2d_forward_pooled(const void* prePool, int pH, int pW, void* prevInput,
+                                    void* prevOutput, uint64_t* bits, int32_t* idx, int32_t* countDev,
+                                    const void* weightsPrepared, const void* bias, int C, int H, int W,
+                                    int K, int kH, int kW, float threshold, int relu, void* workspace,
+                                    int dtype, cbStream_t stream);
 int cbinfer_conv_changed_from_mask(const void* input, uint64_t* frameMasks, int32_t* idxOut,
                                    int32_t* countOut, const void* weightsPrepared, const void* bias,
                                    void* output, int C, int H, int W, int K, int kH, int kW, int relu,

@@ -275,6 +275,35 @@ def test_insert_cb_pooling_tracks_dense_and_downsamples_indexes(pkg, oracle):
             assert torch.equal(pooled, torch.nn.functional.max_pool2d(out, 2, 2))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("size", [(64, 96, False), (45, 67, False), (45, 67, True)])
+def test_pooling_fused_into_detection_is_bit_identical(pkg, dtype, size):
+    """fusePoolingIntoDetection: the feedback-mode layer behind a pool computes the pooled values inside
+    its change detection (no pool launch, no pooled map).  Outputs and layer states must equal the
+    unfused execution bit for bit, for even/odd sizes and floor/ceil pooling."""
+    from cbinfer_amd import workloads
+    H, W, ceil = size
+    def build(fused):
+        base = workloads.sceneLabelingBaseline(seed=4, ceil_mode=ceil).to(device='cuda', dtype=dtype)
+        net = workloads.configureExperiment(base, pkg.convert(base, threshold=0.05), 6).cuda()
+        pkg.fusePoolingIntoDetection(net, enabled=fused)
+        return net
+    a, b = build(False), build(True)
+    assert [m.lazy for m in b.modules() if type(m) is pkg.CBPoolMax2d] == [True, True]
+    vid = workloads.SyntheticVideo(H=H, W=W, ratio=0.1, block=1 if (H % 16 or W % 16) else 16, seed=21,
+                                   dtype=dtype)
+    with torch.no_grad():
+        for f in vid.frames(5):
+            ya, yb = a(f), b(f)
+            if dtype == torch.float32:   # (the dense fp16 1x1 tail of experiment 6 is torch/MIOpen code
+                assert torch.equal(ya, yb)   # whose split-K reduction is not run-to-run deterministic)
+            ca = [m for m in a.modules() if type(m) is pkg.CBConv2d]
+            cb = [m for m in b.modules() if type(m) is pkg.CBConv2d]
+            for ma, mb in zip(ca, cb):
+                assert torch.equal(ma.prevOutput, mb.prevOutput)
+                assert torch.equal(ma.prevInput, mb.prevInput)
+
+
 def test_half_network(pkg):
     """cg_half path end to end: fp16 network vs the fp32 dense network on the same (fp16-rounded)
     weights, first frame and a changed frame; tolerance 3e-2 absolute on O(1) activations (fp16

@@ -43,7 +43,10 @@ def parse():
                     help="blocks: BASELINE.md config 2 (scattered re-drawn blocks); region: one moving rectangle")
     ap.add_argument("--experiment", type=int, default=6)
     ap.add_argument("--threshold", type=float, default=0.05)
-    ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--mode", choices=["auto", "graph", "eager"], default="auto",
+                    help="graph: one captured hipGraph per frame; eager: plain stream launches (the only form "
+                         "for configurations that alias their input as state); auto: calibrate both on a "
+                         "short run and time the faster one")
     ap.add_argument("--sequences", type=int, default=1,
                     help="independent video sequences in flight per GPU, one HIP stream + graph each "
                          "(a step then feeds one frame to every sequence)")
@@ -294,7 +297,7 @@ def main():
     import pycbinfer
     from cbinfer_amd import workloads
 
-    def run_sequences(S, steps, warmup, seq0, bar):
+    def run_sequences(S, steps, warmup, seq0, bar, mode):
         """Build S independent sequences (model + state + synthetic video + runner), warm them up and
         time `steps` steps (one frame to every sequence per step).  Returns (elapsed, sequences)."""
         nframes = 2 + warmup + steps + 4
@@ -311,7 +314,7 @@ def main():
             # one long non-repeating sequence: 2 priming frames, W warm-up frames, K timed frames, and a
             # few spare ones for the per-kernel measurement -- all resident in HBM (1.8 MB each)
             allframes = vid.frames(nframes)
-            runner = FrameRunner(test, allframes[0], args.mode, torch.cuda.Stream() if S > 1 else None)
+            runner = FrameRunner(test, allframes[0], mode, torch.cuda.Stream() if S > 1 else None)
             runner.prime(allframes[:2])
             seqs.append(dict(base=base, test=test, vid=vid, runner=runner,
                              warm=allframes[2:2 + warmup], frames=allframes[2 + warmup:2 + warmup + steps],
@@ -323,7 +326,29 @@ def main():
         return timed_loop([q['runner'] for q in seqs], [q['frames'] for q in seqs], steps, bar), seqs
 
     S = max(1, args.sequences)
-    elapsed, seqs = run_sequences(S, args.steps, args.warmup, 0, barrier)
+    # a module that keeps a reference to its input as state (copyInput=False without feedback loop, or the
+    # fine-grained path; conv2d.py:175,237-238) needs a new input tensor per frame: not capturable
+    _, probe = workloads.sceneLabelingModels(experimentIdx=args.experiment, threshold=args.threshold)
+    capturable = all(((m.feedbackLoop or m.copyInput) and not m.finegrained)
+                     for m in probe.modules() if type(m) is pycbinfer.CBConv2d)
+    del probe
+    mode, calibration = args.mode, None
+    if mode == "graph" and not capturable:
+        log("bench: this configuration aliases its input as state and cannot be graph-captured -> eager")
+        mode = "eager"
+    if mode == "auto":
+        if not capturable:
+            mode = "eager"
+        else:
+            calibration = {}
+            for cand in ("graph", "eager"):
+                csteps = 40
+                cel, cseqs = run_sequences(S, csteps, 10, 100, lambda: None, cand)
+                calibration[cand] = S * csteps / cel
+                del cseqs
+            mode = max(calibration, key=calibration.get)
+    args.mode = mode
+    elapsed, seqs = run_sequences(S, args.steps, args.warmup, 0, barrier, mode)
     base, test, vid = seqs[0]['base'], seqs[0]['test'], seqs[0]['vid']
     frames, spare = seqs[0]['frames'], seqs[0]['spare']
 
@@ -347,7 +372,8 @@ def main():
                                   args.experiment,
                                   "one sequence" if S == 1 else "%d concurrent sequences (one stream each)" % S),
                    "sequences_per_gpu": S,
-                   "launch": args.mode, "threshold": args.threshold, "pool_clone": bool(args.pool_clone),
+                   "launch": args.mode, "launch_calibration_fps": calibration, "threshold": args.threshold,
+                   "pool_clone": bool(args.pool_clone),
                    "pool_fused_into_detection": not args.no_fuse_pool},
         "effective_gflops": fps * dense_ops / 1e9,
     }
@@ -356,26 +382,30 @@ def main():
     if not args.no_dense and world == 1:
         # (with S sequences per GPU the dense network gets them as one batch of S frames)
         dframes = [torch.cat([q['frames'][i] for q in seqs]) for i in range(min(len(frames), 64))]
-        drunner = FrameRunner(base, dframes[0], args.mode)
-        drunner.prime(dframes[:2])
-        for f in dframes[:5]:
-            drunner.step(f)
         dsteps = max(10, args.steps // 4)
-        delapsed = timed_loop(drunner, dframes, dsteps, lambda: None)
-        result["dense_fps"] = S * dsteps / delapsed
+        dense = {}
+        for dmode in ("graph", "eager"):        # the dense network gets the better of the two as well
+            drunner = FrameRunner(base, dframes[0], dmode)
+            drunner.prime(dframes[:2])
+            for f in dframes[:5]:
+                drunner.step(f)
+            dense[dmode] = S * dsteps / timed_loop(drunner, dframes, dsteps, lambda: None)
+            del drunner
+        result["dense_fps"] = max(dense.values())
+        result["dense_launch"] = max(dense, key=dense.get)
         result["speedup_vs_dense"] = fps / result["dense_fps"]
         result["dense_tflops"] = result["dense_fps"] * dense_ops / 1e12
 
     # throughput mode: several sequences in flight on the one GPU, one stream + graph each;
     # reported beside the headline, which stays the reference's one-sequence-at-a-time protocol
-    if S == 1 and world == 1 and args.multi > 1 and args.mode == "graph":
+    if S == 1 and world == 1 and args.multi > 1 and capturable:
         msteps = max(10, args.steps // 2)
-        melapsed, mseqs = run_sequences(args.multi, msteps, min(args.warmup, 10), 1, lambda: None)
+        melapsed, mseqs = run_sequences(args.multi, msteps, min(args.warmup, 10), 1, lambda: None, "graph")
         result["multi_sequence"] = {"sequences_per_gpu": args.multi, "steps": msteps,
                                     "value": args.multi * msteps / melapsed, "unit": "frames/s"}
         if not args.no_dense:
             dfr = [torch.cat([q['frames'][i] for q in mseqs]) for i in range(min(msteps, 32))]
-            drunner = FrameRunner(base, dfr[0], args.mode)
+            drunner = FrameRunner(base, dfr[0], "graph")
             drunner.prime(dfr[:2])
             for f in dfr[:3]:
                 drunner.step(f)
@@ -394,6 +424,8 @@ def main():
             for kname in ("detect", "compact", "conv", "pool"):
                 if kname + "_ms" in r and (best is None or r[kname + "_ms"] > best[2]):
                     best = (r, kname, r[kname + "_ms"])
+        if best is None:     # (fine-grained experiment: no coarse-grained kernel to break down)
+            best = (None, None, 0.0)
         r, kname, ms = best
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (see the file's _note)
@@ -402,7 +434,9 @@ def main():
             traffic = pmc.get(key, {}).get("bytes_per_launch")
         except Exception:
             traffic = None
-        if kname == "conv":
+        if kname is None:
+            pass
+        elif kname == "conv":
             ach = r["conv_flops"] / (ms * 1e-3) / 1e12
             result["roofline"] = {"kernel": "cb_mfma_f32_kernel (fused gather->MFMA->scatter), " + r["layer"],
                                   "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,

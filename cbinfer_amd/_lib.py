@@ -100,6 +100,15 @@ def stream_ptr(t=None):
     return torch.cuda.current_stream(t.device if t is not None else None).cuda_stream
 
 
+def raw_stream(device_index):
+    """Raw handle of torch's current stream on a device (the cheap form used on the per-frame fast path)."""
+    import torch
+    try:
+        return torch._C._cuda_getCurrentRawStream(device_index)
+    except AttributeError:      # pragma: no cover  (older torch)
+        return torch.cuda.current_stream(device_index).cuda_stream
+
+
 def ptr(t):
     return t.data_ptr() if t is not None else None
 

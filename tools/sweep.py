@@ -45,15 +45,20 @@ def main():
     n = 2 + args.warmup + args.steps
 
     print("## scene labeling 480x320 fp32, 16x16 re-drawn blocks (config 3 sweep)\n")
-    print("| change | dense f/s | CG exp6 f/s (graph) | speed-up | post-dilation ratio per CB layer | "
+    print("| change | dense f/s | CG exp6 f/s | speed-up | post-dilation ratio per CB layer | "
           "FG exp7 atomics f/s (eager) | FG deterministic f/s (eager) |")
     print("|---|---|---|---|---|---|---|")
     for ratio in (() if args.skip_sweep else (0.01, 0.02, 0.05, 0.10, 0.20, 0.30, 0.50)):
         vid = workloads.SyntheticVideo(H=320, W=480, ratio=ratio, block=16, seed=7)
         frames = vid.frames(n)
         base, cg = workloads.sceneLabelingModels(experimentIdx=6, threshold=0.05)
-        dense = measure(base, frames, args.steps, args.warmup, "graph")
-        fcg = measure(cg, frames, args.steps, args.warmup, "graph")
+        for m in cg.modules():            # the bench's execution options (same results)
+            if type(m) is pycbinfer.CBPoolMax2d:
+                m.cloneOutput = False
+        pycbinfer.fusePoolingIntoDetection(cg)
+        # both launch forms for both networks, the better one counts (bench.py --mode auto)
+        dense = max(measure(base, frames, args.steps, args.warmup, m) for m in ("graph", "eager"))
+        fcg = max(measure(cg, frames, args.steps, args.warmup, m) for m in ("graph", "eager"))
         ratios = ", ".join("%.0f%%" % (100 * r) for r in layer_ratios(cg))
         ffg = ffd = float("nan")
         if not args.skip_fg:

@@ -304,6 +304,71 @@ def test_pooling_fused_into_detection_is_bit_identical(pkg, dtype, size):
                 assert torch.equal(ma.prevInput, mb.prevInput)
 
 
+def test_call_plan_is_dropped_when_its_assumptions_change(pkg, oracle):
+    """The per-frame fast path (CBConv2d._run_plan) replays a remembered library call.  Everything it
+    depends on is changed here between frames -- threshold, flags, weights (in place and replaced), input
+    size, state reset, stream -- and every frame must still equal what a module WITHOUT the fast path
+    (CBINFER_NO_FASTPATH) computes."""
+    from cbinfer_amd import workloads
+    torch.manual_seed(0)
+
+    def build():
+        conv = nn.Conv2d(3, 8, 3, padding=1).cuda()
+        m = pkg.CBConv2d(conv, 0.05)
+        m.feedbackLoop = True
+        return m
+
+    fast = build()
+    os.environ['CBINFER_NO_FASTPATH'] = '1'
+    try:
+        slow = build()
+        slow.weight.data.copy_(fast.weight.data)
+        slow.bias.data.copy_(fast.bias.data)
+        vid_a = workloads.SyntheticVideo(H=32, W=64, ratio=0.1, block=8, seed=1).frames(16)
+        vid_b = workloads.SyntheticVideo(H=48, W=64, ratio=0.1, block=8, seed=2).frames(4)
+        side = torch.cuda.Stream()
+
+        def step(f, both=True):
+            os.environ['CBINFER_NO_FASTPATH'] = '0'
+            a = fast(f)
+            os.environ['CBINFER_NO_FASTPATH'] = '1'
+            b = slow(f)
+            a = a[1] if isinstance(a, tuple) else a
+            b = b[1] if isinstance(b, tuple) else b
+            assert torch.equal(a, b)
+
+        with torch.no_grad():
+            step(vid_a[0]); step(vid_a[1]); step(vid_a[2])
+            assert fast._plan is not None and slow._plan is None
+            for m in (fast, slow):
+                m.threshold = 0.2                               # threshold
+            step(vid_a[3]); step(vid_a[4])
+            for m in (fast, slow):
+                m.withReLU = True                               # flag
+            step(vid_a[5])
+            for m in (fast, slow):
+                m.weight.data.mul_(1.5)                         # weights in place (version bump)
+            step(vid_a[6]); step(vid_a[7])
+            for m in (fast, slow):
+                m.propChangeIndexes = True                      # tuple output
+            step(vid_a[8])
+            for m in (fast, slow):
+                m.propChangeIndexes = False
+            step(vid_b[0]); step(vid_b[1])                      # other input size (state re-allocated)
+            step(vid_a[9]); step(vid_a[10])                     # ... and back
+            for m in (fast, slow):
+                m.clearMemory()                                 # state reset -> 100 % change frame
+            step(vid_a[11]); step(vid_a[12])
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):                       # another stream (workspace is per stream)
+                step(vid_a[13]); step(vid_a[14])
+            torch.cuda.synchronize()
+            step(vid_a[15])
+            step(vid_a[15].transpose(2, 3).contiguous().transpose(2, 3))   # non-contiguous input
+    finally:
+        os.environ['CBINFER_NO_FASTPATH'] = '0'
+
+
 def test_half_network(pkg):
     """cg_half path end to end: fp16 network vs the fp32 dense network on the same (fp16-rounded)
     weights, first frame and a changed frame; tolerance 3e-2 absolute on O(1) activations (fp16

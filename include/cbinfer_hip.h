@@ -159,7 +159,7 @@ int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void* prevOutpu
                              int copyInput, int relu, int haveIndexes, int capN, void* workspace,
                              int selfCompact, int dtype, cbStream_t stream);
 
-/* selfCompact=1 (fp32, no mapOut, no upstream indexes, cbinfer_mask_words(H,W) <=
+/* selfCompact=1 (fp32 or fp16, no mapOut, no upstream indexes, cbinfer_mask_words(H,W) <=
  * cbinfer_frame_mask_max_words()): `bits` is a zero-initialised buffer of cbinfer_frame_mask_bytes(H,W)
  * bytes holding two alternating masks and a device-side parity; the compaction launch disappears, the
  * fused kernel derives the change list from the mask by itself and still writes idx/countDev.

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
 #ifndef CB_SK_TARGET
 #define CB_SK_TARGET 2
 #endif
-    if (p.slabs && T > 0 && T < CB_SK_TARGET * cus && P >= 4)
+    if (p.slabs && T > 0 && T < CB_SK_TARGET * cus && P >= 8)   // (P < 8, i.e. < 1024 k: the slab round trip costs more than the idle CUs)
         SK = max(1, min(min(CB_SKMAX, (CB_SK_TARGET * cus) / T), min(P, (int)sqrtf(3.4f * (float)P))));
     const int items = T * SK;
     if (!SELFC && (int)blockIdx.x >= items) return;

@@ -291,16 +291,23 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
     const int MT = p.KP / BM;
     const int T = ((N + BN - 1) / BN) * MT;                  // output tiles
     const int P = (p.CkkP + 4 * BK - 1) / (4 * BK);          // groups of four stages along k (last: partial)
-    // Split along k only while whole CUs would otherwise idle (T below CB_SK_TARGET x the CU count) and
-    // the k-depth is long enough to pay for the slab round trip: the reducer costs ~4 us of fences +
-    // ~1 us per slab, a stage pair ~1.7 us, so the best slice count is ~sqrt(1.7 P).
+    // Split-K slice count (at most ~sqrt(3.4 P) <= 8: the reducer costs ~4 us of fences + ~1 us per slab)
     int SK = 1;
     const int cus = (int)gridDim.x / CB_CONV_GRID_PER_CU;
 #ifndef CB_SK_TARGET
 #define CB_SK_TARGET 2
 #endif
-    if (p.slabs && T > 0 && T < CB_SK_TARGET * cus && P >= 8)   // (P < 8, i.e. < 1024 k: the slab round trip costs more than the idle CUs)
-        SK = max(1, min(min(CB_SKMAX, (CB_SK_TARGET * cus) / T), min(P, (int)sqrtf(3.4f * (float)P))));
+    // Measured in the frame (not on warm re-launches, which mislead here): a deep contraction (>= 1024 k)
+    // with at least half a grid of tiles fills two workgroups per CU; everything else is only split as far
+    // as every slice still gets a CU of its own -- below that the slab round trip (~8 us) costs more than
+    // the idle CUs, above it slices of co-resident workgroups just slow each other down.
+    if (p.slabs && T > 0 && P >= 4) {
+        const int cap = min(CB_SKMAX, min(P, (int)sqrtf(3.4f * (float)P)));
+        if (P >= 8 && T * 2 >= cus)
+            SK = max(1, min(cap, (CB_SK_TARGET * cus) / T));
+        else
+            SK = max(1, min(cap, cus / T));
+    }
     const int items = T * SK;
     if (!SELFC && (int)blockIdx.x >= items) return;
 

@@ -297,6 +297,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
 #ifndef CB_SK_TARGET
 #define CB_SK_TARGET 2
 #endif
+    static_assert(CB_SK_TARGET <= CB_CONV_GRID_PER_CU, "one slab per work item: items <= workgroups");
     // Measured in the frame (not on warm re-launches, which mislead here): a deep contraction (>= 1024 k)
     // with at least half a grid of tiles fills two workgroups per CU; everything else is only split as far
     // as every slice still gets a CU of its own -- below that the slab round trip (~8 us) costs more than
@@ -777,6 +778,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
 #ifndef CB_SK_TARGET
 #define CB_SK_TARGET 2
 #endif
+    static_assert(CB_SK_TARGET <= CB_CONV_GRID_PER_CU, "one slab per work item: items <= workgroups");
     if (p.slabs && T > 0 && T < CB_SK_TARGET * cus && P >= 8)
         SK = max(1, min(min(CB_SKMAX, (CB_SK_TARGET * cus) / T), (int)sqrtf(1.7f * (float)P)));
     const int items = T * SK;

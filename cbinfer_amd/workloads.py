@@ -181,8 +181,12 @@ class OpenPoseModel(nn.Module):
     `model{t}_2` (19 confidence maps); stages t >= 2 see cat(branch1, branch2, features) = 185
     channels (PoseModel.py:122-137)."""
 
-    def __init__(self, T=2, seed=0):
+    def __init__(self, T=2, seed=0, concurrentBranches=False):
         super(OpenPoseModel, self).__init__()
+        # the two branches of a stage are independent: with concurrentBranches they are enqueued on two
+        # HIP streams (fork/join per stage), so that their per-launch fixed costs overlap
+        self.concurrentBranches = concurrentBranches
+        self._side = None
         state = torch.random.get_rng_state()
         torch.manual_seed(seed)
         self.T = T
@@ -196,9 +200,20 @@ class OpenPoseModel(nn.Module):
     def forward(self, x):
         feat = self.model0(x)
         cur = feat
+        fork = getattr(self, 'concurrentBranches', False) and cur.is_cuda
+        if fork and self._side is None:
+            self._side = torch.cuda.Stream()
         for t in range(1, self.T + 1):
-            outL = getattr(self, 'model%d_1' % t)(cur)
-            outS = getattr(self, 'model%d_2' % t)(cur)
+            if fork:
+                main = torch.cuda.current_stream()
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    outS = getattr(self, 'model%d_2' % t)(cur)
+                outL = getattr(self, 'model%d_1' % t)(cur)
+                main.wait_stream(self._side)
+            else:
+                outL = getattr(self, 'model%d_1' % t)(cur)
+                outS = getattr(self, 'model%d_2' % t)(cur)
             if t != self.T:
                 cur = torch.cat([outL, outS, feat], 1)
         return outL, outS

@@ -408,6 +408,15 @@ def test_openpose_half(pkg):
             err = max((L.float() - Lr).abs().max().item(), (S.float() - Sr).abs().max().item())
             assert L.shape == (1, 38, 8, 12) and S.shape == (1, 19, 8, 12)
             assert err <= (0.02 if t == 0 else 0.1) * scale, (t, err, scale)
+    # the two branches of a stage enqueued on two streams: same results, bit for bit
+    fork = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, seed=2, concurrentBranches=True).cuda().half(),
+                                     threshold=0.01)
+    seq = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, seed=2).cuda().half(), threshold=0.01)
+    with torch.no_grad():
+        for fr in frames:
+            (La, Sa), (Lb, Sb) = fork(fr), seq(fr)
+            torch.cuda.synchronize()
+            assert torch.equal(La, Lb) and torch.equal(Sa, Sb)
 
 
 def test_pool_without_clone_is_equivalent(pkg):

@@ -93,6 +93,13 @@ def main():
         cbm = {m: measure(test, frames, min(args.steps, 20), 3, m) for m in ("graph", "eager")}
         cb = max(cbm.values())
         print("CB launch forms:", cbm)
+        # the two branches of every stage on two streams (eager; applied to the dense network as well)
+        based = workloads.OpenPoseModel(T=2, concurrentBranches=True).cuda().half()
+        testd = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, concurrentBranches=True).cuda().half(),
+                                          threshold=0.02)
+        print("concurrent branches (eager): dense %.1f f/s, CB %.1f f/s" % (
+            measure(based, frames, min(args.steps, 20), 3, "eager"),
+            measure(testd, frames, min(args.steps, 20), 3, "eager")))
         rs = layer_ratios(test)
         print("| dense f/s | CB f/s | speed-up | mean post-dilation ratio over 36 layers |")
         print("|---|---|---|---|")

@@ -16,8 +16,13 @@ same path on the host cores over a bounded sample.
 """
 import argparse
 import contextlib
+import glob
+import hashlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -55,7 +60,16 @@ def parse():
                          "layer's change detection, pycbinfer.fusePoolingIntoDetection; same results)")
     ap.add_argument("--multi", type=int, default=4,
                     help="also report the throughput with this many concurrent sequences (0/1: skip)")
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="the timed region repeats the K steps until it lasts at least this long (a 20-step "
+                         "region is 3 ms: too short for a stable headline); `steps` in the JSON line is the "
+                         "number of steps actually timed, `steps_requested` is K")
+    ap.add_argument("--no-fuse-tail", action="store_true",
+                    help="keep the dense 1x1 tail as torch modules (default: pycbinfer.fuseTail1x1, one "
+                         "change-based launch for conv1x1->ReLU->conv1x1; results within 1e-4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="(internal) run only the CPU baseline leg and print its JSON object")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel table to stderr")
     ap.add_argument("--pool-clone", action="store_true",
@@ -120,16 +134,26 @@ class FrameRunner(object):
         return self.out
 
 
-def timed_loop(runners, frames, steps, barrier):
-    """K steps; a step feeds one frame to every runner (one runner = one sequence)."""
+def pingpong(i, L):
+    """Index into a list of L frames walked back and forth (0..L-1..1,0..): consecutive frames always
+    differ by exactly one frame's change set, however long the walk (evalTools.py:62 extends a frame list
+    the same way for the power measurement)."""
+    if L < 2:
+        return 0
+    j = i % (2 * L - 2)
+    return j if j < L else 2 * L - 2 - j
+
+
+def timed_loop(runners, frames, steps, barrier, start=0):
+    """`steps` steps; a step feeds one frame to every runner (one runner = one sequence)."""
     if not isinstance(runners, (list, tuple)):
         runners, frames = [runners], [frames]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(steps):
+    for i in range(start, start + steps):
         for r, fr in zip(runners, frames):
-            r.step(fr[i % len(fr)])
+            r.step(fr[pingpong(i, len(fr))])
     torch.cuda.synchronize()
     barrier()
     return time.perf_counter() - t0
@@ -188,7 +212,7 @@ def kernel_breakdown(test, frames, reps=50):
                 t_cmp = event_time_ms(lambda: check(lib.cbinfer_compact_bits(
                     ptr(m._work['bits']), Ww, Hh, ptr(idx), ptr(cnt), None, None, stream_ptr())), reps)
                 wp = m._prepared_weights(Hh, Ww)
-                ws = cg.convWorkspace(inp.device)
+                ws = m._work['conv']
                 t_conv = event_time_ms(lambda: check(lib.cbinfer_conv_changed(
                     ptr(m.prevInput), ptr(ci.buffer), Hh * Ww, ptr(ci.count), ptr(wp), ptr(m.bias.detach()),
                     ptr(m.prevOutput), C, Hh, Ww, K, kH, kW, int(m.withReLU), 0, None, 0, ptr(ws), dt,
@@ -202,6 +226,15 @@ def kernel_breakdown(test, frames, reps=50):
                                  compact_ms=t_cmp, compact_bytes=HW // 8 + 4 * N,
                                  conv_ms=t_conv, conv_flops=2.0 * N * C * kH * kW * K,
                                  conv_bytes=(N * C * kH * kW + K * C * kH * kW + N * K) * s))
+            elif type(m) is pycbinfer.CBTail1x1:
+                inp, ci = xin[1], xin[2]
+                N = ci.numel()
+                t_tail = event_time_ms(lambda: m(xin), reps)
+                rows.append(dict(layer="tail 1x1 %d->%d->%d @%dx%d" % (m.in_channels, m.hidden_channels,
+                                                                       m.out_channels, inp.shape[-2], inp.shape[-1]),
+                                 N=N, tail_ms=t_tail,
+                                 tail_flops=2.0 * N * (m.in_channels * m.hidden_channels +
+                                                       m.hidden_channels * m.out_channels)))
             elif type(m) is pycbinfer.CBPoolMax2d:
                 inp, ci = xin[1], xin[2]
                 N = ci.numel()
@@ -217,86 +250,208 @@ def kernel_breakdown(test, frames, reps=50):
     return rows
 
 
-def cpu_baseline(test, video_kw, budget_frames=60, budget_seconds=10.0):
-    """The oracle's port of the reference CPU path (C loops for detect/gather/scatter/pool, torch CPU
-    matmul for the contraction as conv2d_cg.py:346 does), timed on the host cores.  Sample: frame 0
-    (100 % change) untimed, then steady-state frames until `budget_seconds` of CPU work (at most
-    `budget_frames`)."""
+def inframe_conv_times(test, frames, reps=40):
+    """Duration of every CBConv2d's fused contraction kernel INSIDE the frame: the frame is enqueued eagerly
+    module by module as the network would, except that each change-based layer is issued as its two library
+    calls (detection, then the self-compacting contraction) with HIP events recorded around the second on
+    the launch stream.  The kernel then runs on what the preceding layers just left in the caches, next to
+    the same neighbours as in the timed loop -- stand-alone re-launches run warm and came out up to 35 %
+    shorter in round 1.  Returns {layer label: mean microseconds} or None if a layer is not in the
+    sync-free self-compacting form."""
+    import pycbinfer
+    from cbinfer_amd.conv2d import LazyPool
+    from cbinfer_amd._lib import C as lib, check, ptr, stream_ptr, dtype_code
+    mods = list(test.children())
+    acc = {}
+    with torch.no_grad():
+        for it in range(reps + 3):
+            x = frames[pingpong(it, len(frames))]
+            for m in mods:
+                if type(m) is not pycbinfer.CBConv2d or m.finegrained:
+                    x = m(x)
+                    continue
+                work = m._work
+                if (work is None or not work['selfc'] or not m.feedbackLoop or m.syncIndexes or
+                        isinstance(x, tuple)):
+                    return None
+                K, C, kH, kW = m.weight.shape
+                lazy = x if isinstance(x, LazyPool) else None
+                src = (lazy.source if lazy is not None else x).contiguous()
+                Hh, Ww = (lazy.outSize[-2:] if lazy is not None else src.shape[-2:])
+                dt, st = dtype_code(src), stream_ptr(src)
+                if lazy is not None:
+                    check(lib.cbinfer_change_detection_frame_pooled(
+                        ptr(src), src.shape[-2], src.shape[-1], ptr(m.prevInput), ptr(work['bits']), Ww, Hh, C,
+                        (kH - 1) // 2, (kW - 1) // 2, float(m.threshold), dt, st))
+                else:
+                    check(lib.cbinfer_change_detection_frame(
+                        ptr(src), ptr(m.prevInput), ptr(work['bits']), Ww, Hh, C, (kH - 1) // 2, (kW - 1) // 2,
+                        float(m.threshold), 1, dt, st))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                check(lib.cbinfer_conv_changed_from_mask(
+                    ptr(m.prevInput), ptr(work['bits']), ptr(work['idx']), ptr(work['count']),
+                    ptr(m._prepared_weights(Hh, Ww)), ptr(m.bias.detach()), ptr(m.prevOutput), C, Hh, Ww, K, kH,
+                    kW, int(m.withReLU), ptr(work['conv']), dt, st))
+                e1.record()
+                if it >= 3:
+                    acc.setdefault("conv %d->%d k%d @%dx%d" % (C, K, kH, Hh, Ww), []).append((e0, e1))
+                from cbinfer_amd.conv2d_cg import ChangeIndexes
+                x = (('changeIndexes', m.prevOutput, ChangeIndexes(work['idx'], work['count'], (Hh, Ww)))
+                     if m.propChangeIndexes else m.prevOutput)
+        torch.cuda.synchronize()
+    return {k: 1e3 * sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in acc.items()}
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: profiles/rNN_pmc_traffic.json records it at collection time, so a
+    bench line only carries `traffic` figures that were measured on the kernels it ran."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, "cbinfer_amd", "csrc", "*.h*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(kname, layer):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes
+    (tools/collect_profiles.sh), or (None, why)."""
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, "no profiles/r*_pmc_traffic.json"
+    pmc = json.load(open(files[-1]))
+    name = os.path.basename(files[-1])
+    if pmc.get("kernel_source_sha256") != kernel_source_hash():
+        return None, "%s was collected on other kernel sources (%s, now %s)" % (
+            name, pmc.get("kernel_source_sha256"), kernel_source_hash())
+    key = ("cb_mfma_f32_kernel " if kname == "conv" else "cb_%s_kernel " % kname) + layer
+    if key not in pmc:
+        return None, "%s has no entry %r" % (name, key)
+    return pmc[key].get("bytes_per_launch"), "%s (commit %s)" % (name, pmc.get("commit", "?"))
+
+
+def cpu_baseline_leg(args):
+    """The oracle's port of the reference CPU path (C/OpenMP loops for detect/compact/gather/scatter/pool,
+    torch CPU matmul for the contraction as conv2d_cg.py:346 does), timed on the host cores.  Sample: frame 0
+    (100 % change) untimed, then steady-state frames of the SAME workload for ~10 s of CPU work (at most 400
+    frames).  Runs in a process of its own without the GPU (see cpu_baseline)."""
     import numpy as np
     import pycbinfer
     from cbinfer_amd import workloads
     from oracle import cb_oracle as orc          # checker / baseline only
-
-    class TorchGemmConv(orc.OracleCBConv2d):
-        pass
+    budget_frames, budget_seconds = 400, 12.0
 
     def matmul(X, weight, bias, accMode=0):
         K = weight.shape[0]
         Y = torch.from_numpy(X).matmul(torch.from_numpy(np.ascontiguousarray(weight.reshape(K, -1))).t())
         return (Y + torch.from_numpy(bias)).numpy()
 
-    orc_matmul, orc.matrixMult = orc.matrixMult, matmul
-    try:
-        layers = []
-        for m in test.children():
-            if type(m) is pycbinfer.CBConv2d:
-                layers.append(orc.OracleCBConv2d(m.weight.detach().cpu().numpy(),
-                                                 m.bias.detach().cpu().numpy(), m.threshold,
-                                                 withReLU=m.withReLU, feedbackLoop=m.feedbackLoop,
-                                                 propChangeIndexes=m.propChangeIndexes,
-                                                 copyInput=m.copyInput))
-            elif type(m) is pycbinfer.CBPoolMax2d:
-                layers.append(orc.OracleCBPoolMax2d(m.ceil_mode, m.propChangeIndexes))
-            elif type(m) is torch.nn.ReLU:
-                layers.append(orc.OracleReLU())
-            elif type(m) is torch.nn.Conv2d:
-                mc = torch.nn.Conv2d(m.in_channels, m.out_channels, m.kernel_size, padding=m.padding)
-                mc.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
-                layers.append(type("DenseTorch", (), {
-                    "forward": lambda self, x, mc=mc: mc(torch.from_numpy(x)).detach().numpy(),
-                    "clearMemory": lambda self: None})())
-            else:
-                raise AssertionError(type(m))
-        net = orc.OracleSequential(layers)
-        vid = workloads.SyntheticVideo(device="cpu", **video_kw)
-        # the dense baseline CNN on the same host cores (torch CPU conv2d), min of 3 (evalTools.py:33)
-        dense_cpu = workloads.sceneLabelingBaseline()
-        xin = vid.frame.clone()
-        with torch.no_grad():
-            dense_cpu(xin)
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                dense_cpu(xin)
-                ts.append(time.perf_counter() - t0)
-        dense_cpu_fps = 1.0 / min(ts)
-        frames = [f.numpy() for f in vid.frames(budget_frames + 1)]
-        done = 0
-        with torch.no_grad():
-            net.forward(frames[0])
+    orc.matrixMult = matmul
+    base, test = workloads.sceneLabelingModels(experimentIdx=args.experiment, threshold=args.threshold,
+                                               device="cpu")
+    layers = []
+    for m in test.children():
+        if type(m) is pycbinfer.CBConv2d:
+            layers.append(orc.OracleCBConv2d(m.weight.detach().numpy(), m.bias.detach().numpy(), m.threshold,
+                                             withReLU=m.withReLU, feedbackLoop=m.feedbackLoop,
+                                             propChangeIndexes=m.propChangeIndexes, copyInput=m.copyInput,
+                                             finegrained=m.finegrained))
+        elif type(m) is pycbinfer.CBPoolMax2d:
+            layers.append(orc.OracleCBPoolMax2d(m.ceil_mode, m.propChangeIndexes))
+        elif type(m) is torch.nn.ReLU:
+            layers.append(orc.OracleReLU())
+        elif type(m) is torch.nn.MaxPool2d:
+            layers.append(orc.OracleMaxPool2d(m.ceil_mode))
+        elif type(m) is torch.nn.Conv2d:
+            layers.append(type("DenseTorch", (), {
+                "forward": lambda self, x, mc=m: mc(torch.from_numpy(x)).detach().numpy(),
+                "clearMemory": lambda self: None})())
+        else:
+            raise AssertionError(type(m))
+    net = orc.OracleSequential(layers)
+    vid = workloads.SyntheticVideo(device="cpu", H=H, W=W, ratio=args.ratio, block=args.block, seed=1234,
+                                   pattern=args.pattern)
+    # the dense baseline CNN on the same host cores (torch CPU conv2d), min of 3 (evalTools.py:33)
+    xin = vid.frame.clone()
+    with torch.no_grad():
+        base(xin)
+        ts = []
+        for _ in range(3):
             t0 = time.perf_counter()
-            for f in frames[1:]:
-                net.forward(f)
-                done += 1
-                if time.perf_counter() - t0 > budget_seconds:     # bounded: ~10 s of CPU work
-                    break
-            dt = time.perf_counter() - t0
-    finally:
-        orc.matrixMult = orc_matmul
-    return dict(value=done / dt, unit="frames/s", cores=torch.get_num_threads(), kind="port",
-                dense_cpu_fps=dense_cpu_fps,
+            base(xin)
+            ts.append(time.perf_counter() - t0)
+    frames = [f.numpy() for f in vid.frames(budget_frames + 1)]
+    done = 0
+    with torch.no_grad():
+        net.forward(frames[0])
+        t0 = time.perf_counter()
+        for f in frames[1:]:
+            net.forward(f)
+            done += 1
+            if time.perf_counter() - t0 > budget_seconds:
+                break
+        dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="frames/s", cores=max(torch.get_num_threads(), orc.num_threads()),
+                kind="port", dense_cpu_fps=1.0 / min(ts),
                 sample="%d steady-state frames (%.1f s) of the same 480x320 sequence after an untimed "
-                       "100%%-change first frame; oracle C ops + torch CPU matmul" % (done, dt))
+                       "100%%-change first frame; oracle C/OpenMP ops + torch CPU matmul, own process, "
+                       "OMP_WAIT_POLICY=passive" % (done, dt))
+
+
+def cpu_baseline(args):
+    """Run cpu_baseline_leg in a child process that never sees the GPU: the two OpenMP runtimes involved
+    (the oracle's libgomp and torch's own) otherwise spin against each other on the host cores -- round 1
+    measured 4 frames/s that way, 50x below the dense CPU network -- and passive waiting has to be set in the
+    environment before either is loaded."""
+    env = dict(os.environ)
+    env.update(OMP_WAIT_POLICY="passive", GOMP_SPINCOUNT="0", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="",
+               ROCR_VISIBLE_DEVICES="")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LD_PRELOAD"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--ratio", str(args.ratio),
+           "--block", str(args.block), "--pattern", args.pattern, "--experiment", str(args.experiment),
+           "--threshold", str(args.threshold)]
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+        line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:      # the headline must not depend on the baseline leg
+        return {"value": None, "unit": "frames/s", "cores": None, "kind": "port",
+                "sample": "cpu baseline leg failed: %r" % (e,)}
+
+
+def free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process and
+    before this process has made any GPU call, and finish with the child's exit code."""
+    n = torch.cuda.device_count()          # (counting devices does not initialise the GPU on this image)
+    if args.gpus > n:
+        sys.exit("bench.py: --gpus %d requested but only %d GPU(s) are visible" % (args.gpus, n))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_leg(args)), flush=True)
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     from cbinfer_amd.shard import SequenceShard
     shard = SequenceShard()
     world, rank = shard.world, shard.rank
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run "
+                 "--nproc-per-node %d, or without a launcher)" % (args.gpus, world, args.gpus))
     shard.device()
-    dist = shard.dist
     barrier = shard.barrier
 
     import pycbinfer
@@ -307,40 +462,60 @@ def main():
     # do not overlap (measured: 7.4k instead of 8.9k frames/s with 4 sequences).
     stream_pool = [torch.cuda.Stream() for _ in range(max(args.sequences, args.multi, 1))]
 
-    def run_sequences(S, steps, warmup, seq0, bar, mode):
-        """Build S independent sequences (model + state + synthetic video + runner), warm them up and
-        time `steps` steps (one frame to every sequence per step).  Returns (elapsed, sequences)."""
-        nframes = 2 + warmup + steps + 4
+    def build_sequences(S, nframes, seq0, mode):
+        """S independent sequences (model + state + synthetic video + runner), primed on two frames."""
         seqs = []
         for q in range(S):
             base, test = workloads.sceneLabelingModels(experimentIdx=args.experiment, threshold=args.threshold)
             for m in test.modules():
                 if type(m) is pycbinfer.CBPoolMax2d:
                     m.cloneOutput = bool(args.pool_clone)
+            pycbinfer.fuseTail1x1(test, enabled=not args.no_fuse_tail)
             pycbinfer.fusePoolingIntoDetection(test, enabled=not args.no_fuse_pool)
-            video_kw = dict(H=H, W=W, ratio=args.ratio, block=args.block,
-                            seed=shard.sequence_seed(1234) + 7919 * (seq0 + q), pattern=args.pattern)
-            vid = workloads.SyntheticVideo(**video_kw)
-            # one long non-repeating sequence: 2 priming frames, W warm-up frames, K timed frames, and a
-            # few spare ones for the per-kernel measurement -- all resident in HBM (1.8 MB each)
-            allframes = vid.frames(nframes)
+            vid = workloads.SyntheticVideo(H=H, W=W, ratio=args.ratio, block=args.block,
+                                           seed=shard.sequence_seed(1234) + 7919 * (seq0 + q),
+                                           pattern=args.pattern)
+            # 2 priming frames + a walk of nframes frames, all resident in HBM (1.8 MB each); the timed
+            # loop goes back and forth over the walk, so any number of steps sees the same change per step
+            allframes = vid.frames(2 + nframes)
             runner = FrameRunner(test, allframes[0], mode, stream_pool[q] if S > 1 else None)
             runner.prime(allframes[:2])
-            seqs.append(dict(base=base, test=test, vid=vid, runner=runner,
-                             warm=allframes[2:2 + warmup], frames=allframes[2 + warmup:2 + warmup + steps],
-                             spare=allframes[2 + warmup + steps:]))
+            seqs.append(dict(base=base, test=test, vid=vid, runner=runner, frames=allframes[2:]))
         torch.cuda.synchronize()
-        for i in range(warmup):
-            for q in seqs:
-                q['runner'].step(q['warm'][i])
-        return timed_loop([q['runner'] for q in seqs], [q['frames'] for q in seqs], steps, bar), seqs
+        return seqs
+
+    def run_sequences(S, steps, warmup, seq0, bar, mode, min_seconds=0.0, agree=None):
+        """Warm up, then time `steps` steps (x an integer repeat count that makes the region last
+        min_seconds; all ranks agree on it through `agree`).  Returns (elapsed, steps timed, sequences)."""
+        nframes = max(8, min(max(steps, warmup), 256))
+        seqs = build_sequences(S, nframes, seq0, mode)
+        runners, frs = [q['runner'] for q in seqs], [q['frames'] for q in seqs]
+        t_warm = timed_loop(runners, frs, max(warmup, 1), lambda: None)
+        reps = 1
+        if min_seconds > 0:
+            per_step = t_warm / max(warmup, 1)
+            reps = max(1, int(math.ceil(min_seconds / max(per_step * steps, 1e-9))))
+            if agree is not None:
+                reps = agree(reps)
+        total = steps * reps
+        return timed_loop(runners, frs, total, bar, start=max(warmup, 1)), total, seqs
 
     S = max(1, args.sequences)
     # a module that keeps a reference to its input as state (copyInput=False without feedback loop, or the
-    # fine-grained path; conv2d.py:175,237-238) needs a new input tensor per frame: not capturable
+    # fine-grained default form; conv2d.py:175,237-238) needs a new input tensor per frame: not capturable
     _, probe = workloads.sceneLabelingModels(experimentIdx=args.experiment, threshold=args.threshold)
     capturable = all(((m.feedbackLoop or m.copyInput) and not m.finegrained)
                      for m in probe.modules() if type(m) is pycbinfer.CBConv2d)
+    # effective GFLOP/s numerator: the dense op count as the reference's own statistics define it
+    # (compStats.totalInputValues per converted layer, conv2d.py:216) + the layers left dense
+    for m in probe.modules():
+        if type(m) is pycbinfer.CBConv2d:
+            m.gatherComputationStats = True
+    with torch.no_grad():
+        probe(torch.zeros(1, 3, H, W, device="cuda"))
+    cb_ops = sum(int(m.compStats["totalInputValues"]) for m in probe.modules() if type(m) is pycbinfer.CBConv2d)
+    dense_ops = workloads.denseOps(workloads.SCENE_LABELING_SPEC, H, W)
+    assert cb_ops <= dense_ops
     del probe
     # throughput mode (SURVEY 8f-1): several sequences in flight on the one GPU, one stream + graph each;
     # reported beside the headline, which stays the reference's one-sequence-at-a-time protocol.  Measured
@@ -348,17 +523,16 @@ def main():
     # ~17 % lower (7.4k vs 8.9k frames/s; cause not found).
     multi_result = None
     if S == 1 and world == 1 and args.multi > 1 and capturable:
-        msteps = args.steps
-        melapsed, mseqs = run_sequences(args.multi, msteps, args.warmup, 1, lambda: None, "graph")
+        melapsed, msteps, mseqs = run_sequences(args.multi, args.steps, args.warmup, 1, lambda: None, "graph",
+                                                min_seconds=args.min_seconds)
         multi_result = {"sequences_per_gpu": args.multi, "steps": msteps,
                         "value": args.multi * msteps / melapsed, "unit": "frames/s"}
         if not args.no_dense:
-            dfr = [torch.cat([q['frames'][i] for q in mseqs]) for i in range(min(msteps, 32))]
+            dfr = [torch.cat([q['frames'][i] for q in mseqs]) for i in range(min(len(mseqs[0]['frames']), 32))]
             drunner = FrameRunner(mseqs[0]['base'], dfr[0], "graph")
             drunner.prime(dfr[:2])
-            for f in dfr[:3]:
-                drunner.step(f)
-            dsteps = max(5, msteps // 4)
+            timed_loop(drunner, dfr, 3, lambda: None)
+            dsteps = max(5, msteps // 8)
             multi_result["dense_fps_batched"] = args.multi * dsteps / timed_loop(
                 drunner, dfr, dsteps, lambda: None)
             del drunner, dfr
@@ -375,28 +549,41 @@ def main():
         else:
             calibration = {}
             for cand in ("graph", "eager"):
-                csteps = 40
-                cel, cseqs = run_sequences(S, csteps, 10, 100, lambda: None, cand)
+                cel, csteps, cseqs = run_sequences(S, 100, 10, 100, lambda: None, cand, min_seconds=0.1)
                 calibration[cand] = S * csteps / cel
                 del cseqs
             mode = max(calibration, key=calibration.get)
+            if world > 1:       # every rank must run the same launch form
+                pick = torch.tensor([1.0 if mode == "graph" else 0.0], device="cuda")
+                shard.dist.broadcast(pick, 0)
+                mode = "graph" if pick.item() > 0.5 else "eager"
     args.mode = mode
-    elapsed, seqs = run_sequences(S, args.steps, args.warmup, 0, barrier, mode)
-    base, test, vid = seqs[0]['base'], seqs[0]['test'], seqs[0]['vid']
-    frames, spare = seqs[0]['frames'], seqs[0]['spare']
 
-    total_frames, elapsed = shard.aggregate(args.steps * S, elapsed, device="cuda")
+    def agree(reps):
+        if shard.dist is None:
+            return reps
+        t = torch.tensor([float(reps)], device="cuda")
+        shard.dist.all_reduce(t, op=shard.dist.ReduceOp.MAX)
+        return int(t.item())
+
+    elapsed, steps_timed, seqs = run_sequences(S, args.steps, args.warmup, 0, barrier, mode,
+                                               min_seconds=args.min_seconds, agree=agree)
+    base, test, vid = seqs[0]['base'], seqs[0]['test'], seqs[0]['vid']
+    frames = seqs[0]['frames']
+
+    total_frames, elapsed = shard.aggregate(steps_timed * S, elapsed, device="cuda")
     fps = total_frames / elapsed
 
     if rank != 0:
         shard.finish()
         return
 
-    dense_ops = workloads.denseOps(workloads.SCENE_LABELING_SPEC, H, W)
     result = {
         "metric": "frames/sec + effective GFLOP/s vs dense, scene-labeling CNN 480x320 @10% change",
-        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": steps_timed,
+        "steps_requested": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / steps_timed, "timed_region_s": elapsed,
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "sceneLabeling CBConv2d coarse-grained fp32, synthetic 480x320 seq @%g%% "
                                "change (%s), experiment %d, %s per GPU"
@@ -407,8 +594,12 @@ def main():
                    "sequences_per_gpu": S,
                    "launch": args.mode, "launch_calibration_fps": calibration, "threshold": args.threshold,
                    "pool_clone": bool(args.pool_clone),
-                   "pool_fused_into_detection": not args.no_fuse_pool},
+                   "pool_fused_into_detection": not args.no_fuse_pool,
+                   "tail_1x1_fused": not args.no_fuse_tail},
+        # dense op count per frame: compStats.totalInputValues of the converted layers (conv2d.py:216)
+        # + the 1x1 tail the experiment leaves unconverted
         "effective_gflops": fps * dense_ops / 1e9,
+        "dense_ops_per_frame": dense_ops, "dense_ops_converted_layers_compstats": cb_ops,
     }
 
     if multi_result is not None:
@@ -418,13 +609,12 @@ def main():
     if not args.no_dense and world == 1:
         # (with S sequences per GPU the dense network gets them as one batch of S frames)
         dframes = [torch.cat([q['frames'][i] for q in seqs]) for i in range(min(len(frames), 64))]
-        dsteps = max(10, args.steps // 4)
         dense = {}
         for dmode in ("graph", "eager"):        # the dense network gets the better of the two as well
             drunner = FrameRunner(base, dframes[0], dmode)
             drunner.prime(dframes[:2])
-            for f in dframes[:5]:
-                drunner.step(f)
+            t5 = timed_loop(drunner, dframes, 5, lambda: None)
+            dsteps = max(10, int(math.ceil(args.min_seconds / (t5 / 5))))
             dense[dmode] = S * dsteps / timed_loop(drunner, dframes, dsteps, lambda: None)
             del drunner
         result["dense_fps"] = max(dense.values())
@@ -434,7 +624,13 @@ def main():
 
     # per-kernel measurement (HIP events on the launch stream) -> roofline of the dominant kernel
     if world == 1:
-        test_rows = kernel_breakdown(test, spare)
+        inframe = inframe_conv_times(test, frames)          # contraction kernels as they run in the frame
+        test_rows = kernel_breakdown(test, frames)          # every kernel stand-alone (warm re-launches)
+        for r in test_rows:
+            if inframe and r.get("layer") in inframe:
+                r["conv_ms_standalone"] = r["conv_ms"]
+                r["conv_ms"] = inframe[r["layer"]] * 1e-3
+                r["conv_timing"] = "in-frame (HIP events around the kernel inside the eager frame)"
         result["layers"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()}
                             for r in test_rows]
         best = None
@@ -445,33 +641,29 @@ def main():
         if best is None:     # (fine-grained experiment: no coarse-grained kernel to break down)
             best = (None, None, 0.0)
         r, kname, ms = best
-        traffic = None
-        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (see the file's _note)
-            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
-            key = ("cb_mfma_f32_kernel " if kname == "conv" else "cb_%s_kernel " % kname) + r["layer"]
-            traffic = pmc.get(key, {}).get("bytes_per_launch")
-        except Exception:
-            traffic = None
-        if kname is None:
-            pass
-        elif kname == "conv":
-            ach = r["conv_flops"] / (ms * 1e-3) / 1e12
-            result["roofline"] = {"kernel": "cb_mfma_f32_kernel (fused gather->MFMA->scatter), " + r["layer"],
-                                  "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                                  "avg_duration_us": ms * 1e3, "units_per_launch": r["N"]}
-        else:
-            ach = r[kname + "_bytes"] / (ms * 1e-3) / 1e9
-            result["roofline"] = {"kernel": kname + ", " + r["layer"], "bound": "hbm", "achieved": ach,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                  "traffic": traffic, "avg_duration_us": ms * 1e3, "units_per_launch": r["N"]}
+        if kname is not None:
+            traffic, traffic_src = measured_traffic(kname, r["layer"])
+            timing = r.get("conv_timing", "stand-alone re-launches") if kname == "conv" else "stand-alone re-launches"
+            if kname == "conv":
+                ach = r["conv_flops"] / (ms * 1e-3) / 1e12
+                result["roofline"] = {"kernel": "cb_mfma_f32_kernel (fused gather->MFMA->scatter), " + r["layer"],
+                                      "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                                      "traffic_source": traffic_src, "avg_duration_us": ms * 1e3,
+                                      "duration_timing": timing, "units_per_launch": r["N"]}
+            else:
+                ach = r[kname + "_bytes"] / (ms * 1e-3) / 1e9
+                result["roofline"] = {"kernel": kname + ", " + r["layer"], "bound": "hbm", "achieved": ach,
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                      "traffic": traffic, "traffic_source": traffic_src,
+                                      "avg_duration_us": ms * 1e3, "duration_timing": timing,
+                                      "units_per_launch": r["N"]}
         if args.breakdown:
             for r in test_rows:
                 log(json.dumps(r))
 
     if not args.no_cpu_baseline and world == 1:
-        result["cpu_baseline"] = cpu_baseline(test, dict(H=H, W=W, ratio=args.ratio, block=args.block,
-                                                         seed=1234, pattern=args.pattern))
+        result["cpu_baseline"] = cpu_baseline(args)
 
     print(json.dumps(result), flush=True)
     shard.finish()

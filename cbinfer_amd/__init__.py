@@ -12,6 +12,7 @@ import torch.nn as nn
 from . import _lib                      # loads libcbinfer_hip.so; raises ImportError if not built
 from .conv2d import CBConv2d
 from .conv2d import CBPoolMax2d
+from .conv2d import CBTail1x1
 from .conv2d_cg import ChangeIndexes
 
 __version__ = "0.1.0"
@@ -24,60 +25,77 @@ def _log(msg):
         print(msg)
 
 
+def _rebuild(container, rule):
+    """A new nn.Sequential holding the children of `container` under their old names, each passed
+    through rule(child, before, after) -> the module to put in its place, or None to leave it out.
+    `before` / `after` are the child's neighbours in the ORIGINAL container (None at the ends)."""
+    kids = list(container.named_children())
+    out = nn.Sequential()
+    for pos, (name, child) in enumerate(kids):
+        before = kids[pos - 1][1] if pos > 0 else None
+        after = kids[pos + 1][1] if pos + 1 < len(kids) else None
+        keep = rule(child, before, after)
+        if keep is not None:
+            out.add_module(name, keep)
+    return out
+
+
 def subsitute(node, threshold=1e-1, finegrained=False):
-    """Replace exactly torch.nn.Conv2d by CBConv2d (reference: __init__.py:10-17; the spelling of the
-    name is the reference's)."""
-    if type(node) is torch.nn.modules.conv.Conv2d:
-        _log('replacing conv2d')
-        m = CBConv2d(node, threshold)
-        m.finegrained = finegrained
-        return m, True
-    return node, False
+    """(module, replaced?): exactly torch.nn.Conv2d -- not a subclass -- becomes a CBConv2d sharing its
+    parameters (reference: __init__.py:10-17; the spelling of the name is the reference's)."""
+    if type(node) is not nn.Conv2d:
+        return node, False
+    _log('replacing conv2d')
+    cb = CBConv2d(node, threshold)
+    cb.finegrained = finegrained
+    return cb, True
 
 
 def convertRecur(m, ignoreList=[], threshold=1e-1, finegrained=False):
-    """reference: __init__.py:20-45.  Child names are preserved; nn.Dropout and ignoreList types are
-    dropped; nn.Sequential children are converted recursively.  As in the reference `finegrained` is
-    not forwarded into nested containers (:28)."""
-    changed = False
-    mout = nn.Sequential()
-    for nodeName, node in m.named_children():
-        if type(node) in [nn.Sequential]:
-            sub, c = convertRecur(node, ignoreList, threshold)
-            mout.add_module(nodeName, sub)
-            changed |= c
-        elif type(node) in list(ignoreList) + [nn.Dropout]:
-            _log('removing node %s' % (type(node),))
-            changed = True
-            continue
+    """(converted nn.Sequential, anything changed?) for the children of `m` (reference: __init__.py:20-45):
+    names preserved; nn.Dropout and the types of ignoreList dropped; nested nn.Sequential containers
+    converted recursively -- as in the reference (:28) WITHOUT handing `finegrained` down; every other
+    child goes through subsitute().  If anything changed the ReLUs are merged right away: the reference
+    calls convert() on its result at this point (:43-44), a pass that finds nothing left to substitute
+    and so amounts to mergeReLURecur()."""
+    dropped = tuple(ignoreList) + (nn.Dropout,)
+    outcomes = []
+
+    def rule(child, before, after):
+        if type(child) is nn.Sequential:
+            child, hit = convertRecur(child, ignoreList, threshold)
+        elif type(child) in dropped:
+            _log('removing node %s' % (type(child),))
+            child, hit = None, True
         else:
-            nodeOut, newNode = subsitute(node, threshold=threshold, finegrained=finegrained)
-            mout.add_module(nodeName, nodeOut)
-            changed |= newNode
+            child, hit = subsitute(child, threshold=threshold, finegrained=finegrained)
+        outcomes.append(hit)
+        return child
+
+    mout = _rebuild(m, rule)
+    changed = any(outcomes)
     if changed:
-        # the reference runs convert() once more until nothing changes (:43-44); that second pass
-        # finds no Conv2d left and only re-merges ReLUs
-        mout = convert(mout, ignoreList)
+        mout = mergeReLURecur(mout)
     return mout, changed
 
 
 def mergeReLURecur(m):
-    """A CBConv2d directly followed by nn.ReLU absorbs it (withReLU=True) (reference: :47-66)."""
-    mout = nn.Sequential()
-    children = list(m.children())
-    for i, (nodeName, node) in enumerate(m.named_children()):
-        if type(node) in [nn.Sequential]:
-            mout.add_module(nodeName, mergeReLURecur(node))
-            continue
-        elif type(node) in [CBConv2d]:
-            if len(children) > i + 1 and type(children[i + 1]) is torch.nn.modules.activation.ReLU:
-                node.withReLU = True
-        elif (type(node) is torch.nn.modules.activation.ReLU and i >= 1 and
-              type(children[i - 1]) is CBConv2d):
+    """An nn.ReLU right behind a CBConv2d is absorbed into it (withReLU=True) and leaves the container,
+    nested nn.Sequential containers included (reference: __init__.py:47-66)."""
+    def rule(child, before, after):
+        if type(child) is nn.Sequential:
+            return mergeReLURecur(child)
+        if type(child) is CBConv2d and type(after) is nn.ReLU:
+            child.withReLU = True
+        if type(child) is nn.ReLU and type(before) is CBConv2d:
             _log('merging ReLU layer')
-            continue
-        mout.add_module(nodeName, node)
-    return mout
+            return None
+        return child
+    return _rebuild(m, rule)
+
+
+def _sequentials(rootModule):
+    return [m for m in rootModule.modules() if type(m) == nn.Sequential]
 
 
 def propChangeIndexesOf1x1(rootModule):
@@ -88,15 +106,13 @@ def propChangeIndexesOf1x1(rootModule):
     is never equal, so there this function is a no-op and the applications set the flags by hand
     (sceneLabeling/modelLoader.py:43-44).  Here the comparison is done on values, i.e. the function
     does what its name and the hand-written code say."""
-    seqContainers = [m for m in rootModule.modules() if type(m) == torch.nn.Sequential]
-    for seqCont in seqContainers:
-        mPrev = None
-        for m in seqCont:
-            if (type(m) == CBConv2d and type(mPrev) == CBConv2d and
-                    tuple(m.kernel_size) == (1, 1)):
+    for seq in _sequentials(rootModule):
+        kids = list(seq.children())
+        for producer, consumer in zip(kids[:-1], kids[1:]):
+            if (type(producer) == CBConv2d and type(consumer) == CBConv2d and
+                    tuple(consumer.kernel_size) == (1, 1)):
                 _log('enabling propagation of change indexes for 1x1')
-                mPrev.propChangeIndexes = True
-            mPrev = m
+                producer.propChangeIndexes = True
     return rootModule
 
 
@@ -108,7 +124,7 @@ def insertCBPooling(rootModule, cloneOutput=True):
     then needs its own input copy (copyInput) unless it runs in feedback mode.  Returns rootModule."""
     def _pair(v):
         return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
-    for seq in [m for m in rootModule.modules() if type(m) == torch.nn.Sequential]:
+    for seq in _sequentials(rootModule):
         names = list(seq._modules.keys())
         for a, b in zip(names[:-1], names[1:]):
             conv, pool = seq._modules[a], seq._modules[b]
@@ -134,7 +150,7 @@ def fusePoolingIntoDetection(rootModule, enabled=True):
     inside its change detection (CBPoolMax2d.lazy, cbinfer_cbconv2d_forward_pooled) -- one launch less
     per pool and frame.  The pooled map is then not materialised, so the pool must not hand its indexes
     on (propChangeIndexes) and nothing else may read its outputState.  Returns rootModule."""
-    for seq in [m for m in rootModule.modules() if type(m) == torch.nn.Sequential]:
+    for seq in _sequentials(rootModule):
         kids = list(seq.children())
         for pool, consumer in zip(kids[:-1], kids[1:]):
             if type(pool) == CBPoolMax2d:
@@ -143,25 +159,29 @@ def fusePoolingIntoDetection(rootModule, enabled=True):
     return rootModule
 
 
+_STATEFUL = (CBConv2d, CBPoolMax2d, CBTail1x1)
+
+
+def _stateful(net):
+    return [m for m in net.modules() if type(m) in _STATEFUL]
+
+
 def clearMemory(net):
-    for m in net.modules():
-        if type(m) == CBConv2d or type(m) == CBPoolMax2d:
-            m.clearMemory()
+    """Drop the frame-to-frame state of every change-based module (reference: __init__.py:79-82)."""
+    for m in _stateful(net):
+        m.clearMemory()
 
 
 def getStateTensors(net):
-    state = []
-    for m in net.modules():
-        if type(m) == CBConv2d or type(m) == CBPoolMax2d:
-            state += m.getStateTensors()
-    return state
+    """Flat list of the state tensors of every change-based module (reference: __init__.py:84-89)."""
+    return [t for m in _stateful(net) for t in m.getStateTensors()]
 
 
 def convert(m, ignoreList=[], threshold=1e-1):
     """nn.Sequential in -> nn.Sequential out with every Conv2d replaced by a CBConv2d sharing its
     weights, ReLUs merged, Dropout removed (reference: __init__.py:91-94)."""
-    m1, changed = convertRecur(m, ignoreList=ignoreList, threshold=threshold)
-    return mergeReLURecur(m1)
+    converted, _ = convertRecur(m, ignoreList=ignoreList, threshold=threshold)
+    return mergeReLURecur(converted)
 
 
 def setSyncIndexes(net, enabled):
@@ -173,47 +193,84 @@ def setSyncIndexes(net, enabled):
     return net
 
 
+def fuseTail1x1(rootModule, enabled=True):
+    """Execution-level fusion (results within the fp32 bar of the unfused network): inside every
+    nn.Sequential the run  CBConv2d -> nn.Conv2d 1x1 -> nn.ReLU -> nn.Conv2d 1x1  (the dense tail that
+    sceneLabeling/modelLoader.py:45-47 keeps for experiments 2-7) becomes  CBConv2d -> CBTail1x1 : the
+    two 1x1 layers are evaluated in ONE launch, only at the pixels of the CBConv2d's change list (its
+    propChangeIndexes is switched on) -- a 1x1 layer's output changes only where its input did.  The new
+    module takes the first 1x1 layer's name and shares the parameters of both.  enabled=False is a no-op.
+    Returns rootModule."""
+    if not enabled:
+        return rootModule
+
+    def is1x1(m):
+        return type(m) is nn.Conv2d and CBTail1x1.accepts(m)
+
+    for seq in _sequentials(rootModule):
+        names = list(seq._modules.keys())
+        kids = [seq._modules[n] for n in names]
+        for i in range(len(kids) - 3):
+            head, a, act, b = kids[i:i + 4]
+            if (type(head) is CBConv2d and not head.finegrained and is1x1(a) and type(act) is nn.ReLU and
+                    is1x1(b) and a.out_channels <= CBTail1x1.maxHidden() and
+                    a.weight.dtype == torch.float32):
+                _log('fusing the 1x1 tail behind %s' % names[i])
+                head.propChangeIndexes = True
+                seq._modules[names[i + 1]] = CBTail1x1(a, b, relu=True)
+                del seq._modules[names[i + 2]]
+                del seq._modules[names[i + 3]]
+                break
+    return rootModule
+
+
+_THRESHOLD_CEILING = 1e30   # a tolerance that is never exceeded must not loop forever (the reference would)
+
+
 def tuneThresholdParameters(vidSeqReader, evalSequences, numFramesPerSeq, targetGenerator,
                             preprocessor, modelBaseline, modelTest, evaluator, cbModuleList,
                             lossToleranceList, initThreshold=1e-2, thresholdIncrFactor=1.2):
     """Greedy front-to-back per-layer threshold search with the reference's callback protocol
-    (reference: __init__.py:98-149): for each CB module in turn raise its threshold by
-    thresholdIncrFactor while the loss increase over the previous level stays within the module's
-    tolerance, then step back once."""
-    if type(lossToleranceList) is not list:
-        lossToleranceList = [lossToleranceList] * len(cbModuleList)
-    assert len(cbModuleList) == len(lossToleranceList)
+    (reference: __init__.py:98-149).  Modules are visited in list order; a module's threshold climbs
+    from initThreshold by thresholdIncrFactor per step for as long as the summed evaluator loss over
+    evalSequences stays within the module's tolerance of the loss measured before the module was
+    touched, and the last level that did is kept (the reference's "one step back").  As there,
+    initThreshold itself is never evaluated.  The loss the next module is judged against is re-measured
+    with the kept level."""
+    tolerances = lossToleranceList if type(lossToleranceList) is list \
+        else [lossToleranceList] * len(cbModuleList)
+    assert len(cbModuleList) == len(tolerances)
     device = next(modelTest.parameters()).device
 
-    def evaluateModel():
+    def sequenceLoss(seqName):
+        frames, target = vidSeqReader.getDataFrames(seqName=seqName, numFrames=numFramesPerSeq)
+        if target is None:
+            target = targetGenerator(frames[-1])
+        with torch.no_grad():
+            for frame in frames:
+                prediction = modelTest(preprocessor(frame).to(device))
+        return evaluator(prediction, target)
+
+    def measure():
         clearMemory(modelTest)
-        totalLoss = 0
-        for seqName in evalSequences:
-            frames, target = vidSeqReader.getDataFrames(seqName=seqName, numFrames=numFramesPerSeq)
-            if target is None:
-                target = targetGenerator(frames[-1])
-            with torch.no_grad():
-                for frame in frames:
-                    outTest = modelTest(preprocessor(frame).to(device))
-            totalLoss += evaluator(outTest, target)
-        return totalLoss
+        return sum(sequenceLoss(name) for name in evalSequences)
 
-    prevLoss = evaluateModel()
-    for i, m in enumerate(cbModuleList):
-        _log('adjusting threshold for module %d of %d' % (i + 1, len(cbModuleList)))
-        m.threshold = initThreshold
-        while True:
-            m.threshold *= thresholdIncrFactor
-            loss = evaluateModel()
-            _log('. (%f < %f + %f)' % (loss, prevLoss, lossToleranceList[i]))
-            # (guard absent in the reference: a tolerance that is never exceeded would loop forever)
-            if loss - prevLoss > lossToleranceList[i] or not (m.threshold < 1e30):
-                m.threshold /= thresholdIncrFactor
+    anchor = measure()
+    for pos, (module, tolerance) in enumerate(zip(cbModuleList, tolerances)):
+        _log('adjusting threshold for module %d of %d' % (pos + 1, len(cbModuleList)))
+        kept = initThreshold
+        while kept * thresholdIncrFactor < _THRESHOLD_CEILING:
+            module.threshold = kept * thresholdIncrFactor
+            loss = measure()
+            _log('. (%f < %f + %f)' % (loss, anchor, tolerance))
+            if loss - anchor > tolerance:
                 break
-        prevLoss = evaluateModel()
+            kept = module.threshold
+        module.threshold = kept
+        anchor = measure()
 
 
-__all__ = ['CBConv2d', 'CBPoolMax2d', 'ChangeIndexes', 'convert', 'convertRecur', 'subsitute',
-           'mergeReLURecur', 'propChangeIndexesOf1x1', 'insertCBPooling', 'fusePoolingIntoDetection',
+__all__ = ['CBConv2d', 'CBPoolMax2d', 'CBTail1x1', 'ChangeIndexes', 'convert', 'convertRecur', 'subsitute',
+           'mergeReLURecur', 'propChangeIndexesOf1x1', 'insertCBPooling', 'fusePoolingIntoDetection', 'fuseTail1x1',
            'clearMemory', 'getStateTensors',
            'setSyncIndexes', 'tuneThresholdParameters']

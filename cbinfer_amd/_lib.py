@@ -22,7 +22,7 @@ _SIGNATURES = {
     "cbinfer_mask_words_per_row": (_i, [_i]),
     "cbinfer_mask_words": (_l, [_i, _i]),
     "cbinfer_weights_kpad": (_i, [_i]),
-    "cbinfer_weights_ckkpad": (_i, [_i]),
+    "cbinfer_weights_ckkpad": (_i, [_i, _i]),
     "cbinfer_change_detection": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "cbinfer_change_detection_bits": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "cbinfer_change_propagation": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -50,6 +50,16 @@ _SIGNATURES = {
     "cbinfer_pool_change_indexes": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "cbinfer_change_detection_fg": (_i, [_vp, _vp, _vp, _vp, _l, _f, _i, _vp]),
     "cbinfer_update_output_fg": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _vp]),
+    "cbinfer_update_output_fg_list": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "cbinfer_change_detection_fg_frame": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "cbinfer_conv_accumulate_from_mask": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
+                                               _vp, _vp]),
+    "cbinfer_cbconv2d_forward_fg": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
+                                         _i, _f, _i, _vp, _vp]),
+    "cbinfer_tail1x1_max_hidden": (_i, []),
+    "cbinfer_tail1x1_prepared_bytes": (_l, [_i, _i]),
+    "cbinfer_tail1x1_prep": (_i, [_vp, _vp, _i, _i, _vp]),
+    "cbinfer_tail1x1": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cbinfer_conv2d_fg_cpu": (None, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i]),
 }
 
@@ -67,7 +77,7 @@ def _load():
         fn = getattr(lib, name)     # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.cbinfer_abi_version() != 1:
+    if lib.cbinfer_abi_version() != 2:
         raise ImportError("cbinfer_amd: libcbinfer_hip.so ABI version mismatch")
     return lib
 

@@ -24,8 +24,8 @@ import torch.nn.functional as F
 
 from . import _lib
 from ._lib import C, check, dtype_code, ptr, raw_stream, require_device, stream_ptr
-from .conv2d_cg import (ChangeIndexes, changeDetection, changeIndexesExtr, convWorkspace, genXMatrix,
-                        matrixMult, maxPool2d, poolChangeIndexes, prepWeights, updateOutput)
+from .conv2d_cg import (ChangeIndexes, changeDetection, changeIndexesExtr, genXMatrix, matrixMult, maxPool2d,
+                        newConvWorkspace, poolChangeIndexes, prepWeights, updateOutput)
 from .conv2d_fg import cbconvFG, cbconvFG_deterministic
 
 
@@ -195,7 +195,7 @@ class CBConv2d(nn.Module):
         for name, val in (('saveChangeMap', False), ('propChangeIndexes', False),
                           ('gatherComputationStats', False), ('finegrained', False),
                           ('copyInput', True), ('feedbackLoop', False), ('syncIndexes', False),
-                          ('deterministicFG', False), ('_work', None), ('_wprep', None),
+                          ('deterministicFG', False), ('atomicFG', False), ('fgInPlace', False), ('_work', None), ('_wprep', None),
                           ('_inputIsLiveState', False), ('_plan', None)):
             if name not in self.__dict__:
                 self.__dict__[name] = val
@@ -224,39 +224,87 @@ class CBConv2d(nn.Module):
         key = (H, W, input.device, selfc)
         if self._work is None or self._work['key'] != key:
             dev = input.device
+            # split-K workspace of the contraction kernel: owned by the module (kept across a change of
+            # the frame size), so graphs and call plans of different modules or sequences never share
+            # one, whatever stream they are captured or replayed on
+            conv = self._work['conv'] if (self._work is not None and self._work['key'][2] == dev) \
+                else newConvWorkspace(dev)
             nbytes = C.cbinfer_frame_mask_bytes(H, W) if selfc else 8 * C.cbinfer_mask_words(H, W)
             self._work = dict(
                 key=key, selfc=selfc,
                 bits=torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=dev),
                 idx=torch.empty(H * W, dtype=torch.int32, device=dev),
                 count=torch.zeros(1, dtype=torch.int32, device=dev),
-                map=None)
+                conv=conv, map=None)
         if self.saveChangeMap and self._work['map'] is None:
             self._work['map'] = torch.zeros(H, W, dtype=torch.int8, device=input.device)
         return self._work
 
     # ---------------------------------------------------------------- fine-grained
+    # Execution forms of a fine-grained frame (results agree within the fp32 bar; selected by attributes):
+    #   default      cbinfer_cbconv2d_forward_fg: per-value detection + accumulating fused contraction,
+    #                two launches, no atomics, no host sync, deterministic
+    #   atomicFG     the reference-structured op sequence changeDetectionFG -> compaction ->
+    #                updateOutputFG (f32 atomics), also without a host sync
+    #   fgInPlace    default form updating the module's own tensors in place: prevOutput (and the
+    #                relu'd copy handed out when withReLU) alias the state across frames, as in
+    #                coarse-grained mode, and prevInput is the module's own copy -- no clone, no full-tensor
+    #                ReLU pass, capturable.  The reference hands out fresh tensors (conv2d.py:169,173) and
+    #                keeps the caller's input tensor as state (:175); that is the default here too.
+    def _fg_workspace(self, x):
+        work = self._workspace(x)
+        if work.get('delta') is None or work['delta'].shape != x.shape:
+            work['delta'] = torch.empty_like(x)
+            work['relu'] = None
+        return work
+
     def forward_fg(self, inp):
-        input = inp.detach()
-        if self.prevInput.size() != input.size():
-            # first frame / size change: dense convolution (conv2d.py:163-167)
-            self.prevOutput = F.conv2d(input, self.weight.detach(),
-                                       padding=tuple(s // 2 for s in self.weight.size()[2:]),
-                                       bias=self.bias.detach())
+        x = inp.detach()
+        K, Cin, kH, kW = self.weight.size()
+        if self.prevInput.size() != x.size():
+            # first frame / new size: dense convolution incl. bias (conv2d.py:163-167)
+            self.prevOutput = F.conv2d(x, self.weight.detach(), bias=self.bias.detach(),
+                                       padding=(kH // 2, kW // 2))
+            self.prevInput = x.clone() if (self.fgInPlace and x.is_cuda) else x
+            if self._work is not None:
+                self._work['relu'] = None
+            return F.relu(self.prevOutput) if self.withReLU else self.prevOutput
+        x = x.contiguous()
+        H, W = x.size(-2), x.size(-1)
+        fused = (x.is_cuda and not self.atomicFG and x.dtype == torch.float32 and
+                 C.cbinfer_mask_words(H, W) <= C.cbinfer_frame_mask_max_words())
+        if fused and self.fgInPlace:
+            work = self._fg_workspace(x)
+            relu = None
+            if self.withReLU:
+                if work['relu'] is None:
+                    work['relu'] = F.relu(self.prevOutput)
+                relu = work['relu']
+            if not self.prevInput.is_contiguous():
+                self.prevInput = self.prevInput.contiguous()
+            args = (ptr(x), ptr(self.prevInput), ptr(work['delta']), ptr(self.prevOutput), ptr(relu),
+                    ptr(work['bits']), ptr(work['idx']), ptr(work['count']),
+                    ptr(self._prepared_weights(H, W)), Cin, H, W, K, kH, kW, float(self.threshold), 1,
+                    ptr(work['conv']), stream_ptr(x))
+            check(C.cbinfer_cbconv2d_forward_fg(*args))
+            result = relu if self.withReLU else self.prevOutput
+            self._make_plan(False, x, C.cbinfer_cbconv2d_forward_fg, args, 0, result=result)
+            return result
+        po = self.prevOutput.clone()                                 # conv2d.py:169
+        if fused:
+            work = self._fg_workspace(x)
+            check(C.cbinfer_cbconv2d_forward_fg(
+                ptr(x), ptr(self.prevInput.contiguous()), ptr(work['delta']), ptr(po), None,
+                ptr(work['bits']), ptr(work['idx']), ptr(work['count']), ptr(self._prepared_weights(H, W)),
+                Cin, H, W, K, kH, kW, float(self.threshold), 0, ptr(work['conv']), stream_ptr(x)))
+        elif x.is_cuda and self.deterministicFG and not self.atomicFG:
+            po = cbconvFG_deterministic(x, self.prevInput, po, self.weight.detach(), self.threshold,
+                                        weightsPrepared=self._prepared_weights(H, W))
         else:
-            po = self.prevOutput.clone()
-            if self.deterministicFG and input.is_cuda:
-                self.prevOutput = cbconvFG_deterministic(
-                    input.contiguous(), self.prevInput, po, self.weight.detach(), self.threshold,
-                    weightsPrepared=self._prepared_weights(input.size(-2), input.size(-1)))
-            else:
-                self.prevOutput = cbconvFG(input.contiguous(), self.prevInput, po,
-                                           self.weight.detach(), self.threshold)
-        outp = self.prevOutput
-        if self.withReLU:
-            outp = F.relu(outp)
-        self.prevInput = input
-        return outp
+            po = cbconvFG(x, self.prevInput, po, self.weight.detach(), self.threshold)
+        self.prevOutput = po
+        self.prevInput = x                                           # conv2d.py:175
+        return F.relu(po) if self.withReLU else po
 
     # ---------------------------------------------------------------- coarse-grained
     def forward_normal(self, inp):
@@ -336,11 +384,11 @@ class CBConv2d(nn.Module):
         args = (ptr(src), src.size(-2), src.size(-1), ptr(self.prevInput), ptr(self.prevOutput),
                 ptr(work['bits']), ptr(work['idx']), ptr(work['count']), ptr(self._prepared_weights(H, W)),
                 ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold),
-                int(bool(self.withReLU)), ptr(convWorkspace(src.device)), dtype_code(src), stream_ptr(src))
+                int(bool(self.withReLU)), ptr(work['conv']), dtype_code(src), stream_ptr(src))
         check(C.cbinfer_cbconv2d_forward_pooled(*args))
         self._make_plan(True, src, C.cbinfer_cbconv2d_forward_pooled, args, 0)
         if self.propChangeIndexes:
-            return 'changeIndexes', self.prevOutput, ChangeIndexes(work['idx'], work['count'])
+            return 'changeIndexes', self.prevOutput, ChangeIndexes(work['idx'], work['count'], (H, W))
         return self.prevOutput
 
     def _forward_fused(self, input, changeIndexes):
@@ -357,14 +405,22 @@ class CBConv2d(nn.Module):
         if have:
             if isinstance(changeIndexes, ChangeIndexes):
                 idx, count, cap = changeIndexes.buffer, changeIndexes.count, changeIndexes.buffer.numel()
+                if changeIndexes.size is not None and changeIndexes.size != (H, W):
+                    raise _lib.CBinferError(
+                        "CBConv2d: the propagated change indexes address a %dx%d map, this layer runs at "
+                        "%dx%d (a CBPoolMax2d in between must hand on down-sampled indexes: "
+                        "downsampleIndexes=True)" % (changeIndexes.size + (H, W)))
             else:
                 idx, cap = changeIndexes, changeIndexes.numel()
                 count = None
+            if idx.dtype != torch.int32 or not idx.is_contiguous():
+                raise _lib.CBinferError("CBConv2d: propagated change indexes must be a contiguous int32 "
+                                        "tensor (conv2d_cg.py:207: nonzero(...).int())")
             cap = min(cap, H * W)
             result = changeIndexes
         else:
             idx, count, cap = work['idx'], work['count'], H * W
-            result = ChangeIndexes(idx, count)
+            result = ChangeIndexes(idx, count, (H, W))
         if have and count is None:
             # exact host-side list: write its length where the kernels look for it
             count = torch.full((1,), cap, dtype=torch.int32, device=input.device)
@@ -377,7 +433,7 @@ class CBConv2d(nn.Module):
                     ptr(idx), ptr(count), ptr(mapOut), ptr(self._prepared_weights(H, W)),
                     ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold),
                     int(bool(self.feedbackLoop)), int(bool(self.copyInput)), int(bool(self.withReLU)),
-                    int(have), cap, ptr(convWorkspace(input.device)),
+                    int(have), cap, ptr(work['conv']),
                     int(work['selfc'] and not have), dtype_code(input), stream_ptr(input))
             check(C.cbinfer_cbconv2d_forward(*args))
             if not have and not self._inputIsLiveState:
@@ -435,14 +491,15 @@ class CBConv2d(nn.Module):
     # keeps the host ahead of the GPU without graph capture (~10 instead of ~35 us per layer and frame).
     def _flags(self):
         return (self.threshold, self.feedbackLoop, self.copyInput, self.withReLU, self.propChangeIndexes,
-                self.syncIndexes, self.saveChangeMap, self.gatherComputationStats, self.finegrained)
+                self.syncIndexes, self.saveChangeMap, self.gatherComputationStats, self.finegrained,
+                self.atomicFG, self.fgInPlace)
 
-    def _make_plan(self, pooled, src, fn, args, srcSlot):
+    def _make_plan(self, pooled, src, fn, args, srcSlot, result=None):
         """Remember a finished sync-free call: fn(*args) with args[srcSlot] = source pointer, args[-1] =
         stream.  Only for configurations whose call does not depend on per-frame host state."""
         if self.syncIndexes or self.saveChangeMap or self.gatherComputationStats:
             return
-        if not (self.feedbackLoop or self.copyInput):
+        if not (self.feedbackLoop or self.copyInput or result is not None):
             return
         w, b = self._parameters.get('weight'), self._parameters.get('bias')
         if w is None or b is None or os.environ.get('CBINFER_NO_FASTPATH', '0') == '1':
@@ -452,8 +509,8 @@ class CBConv2d(nn.Module):
             pooled=pooled, shape=tuple(src.shape), dtype=src.dtype, device=src.device, flags=self._flags(),
             w=(w.data_ptr(), w._version), b=(b.data_ptr(), b._version),
             state=(self._buffers['prevInput'].data_ptr(), self._buffers['prevOutput'].data_ptr()),
-            stream=args[-1], work=work, fn=fn, args=list(args), srcSlot=srcSlot,
-            indexes=ChangeIndexes(work['idx'], work['count']))
+            stream=args[-1], work=work, fn=fn, args=list(args), srcSlot=srcSlot, result=result,
+            indexes=ChangeIndexes(work['idx'], work['count'], work['key'][:2]))
 
     def _run_plan(self, inp):
         plan = self._plan
@@ -478,6 +535,8 @@ class CBConv2d(nn.Module):
         if status != 0:
             check(status)
         self._inputIsLiveState = False
+        if plan['result'] is not None:          # fine-grained in-place frame: prevOutput or its relu'd copy
+            return plan['result']
         if self.propChangeIndexes:
             return 'changeIndexes', bufs['prevOutput'], plan['indexes']
         return bufs['prevOutput']
@@ -495,21 +554,107 @@ class CBConv2d(nn.Module):
         return self.forward_normal(inp)
 
     def __repr__(self):
+        """One line in the reference's format (conv2d.py:271-290): fixed head, then the conv attributes
+        that differ from their defaults, then the change-based flags."""
         self._setDefaultValues()
-        s = '%s (th=%s, %s->%s, k=%s, s=%s, copyInput=%s' % (
-            self.__class__.__name__, self.threshold, self.in_channels, self.out_channels,
-            self.kernel_size, self.stride, self.copyInput)
-        if self.padding != (0,) * len(self.padding):
-            s += ', pad=%s' % (self.padding,)
-        if self.dilation != (1,) * len(self.dilation):
-            s += ', dilation=%s' % (self.dilation,)
-        if self.output_padding != (0,) * len(self.output_padding):
-            s += ', outpad=%s' % (self.output_padding,)
-        if self.groups != 1:
-            s += ', grp=%s' % (self.groups,)
+        optional = [('pad', self.padding, (0,) * len(self.padding)),
+                    ('dilation', self.dilation, (1,) * len(self.dilation)),
+                    ('outpad', self.output_padding, (0,) * len(self.output_padding)),
+                    ('grp', self.groups, 1)]
+        parts = ['th=%s' % (self.threshold,), '%s->%s' % (self.in_channels, self.out_channels),
+                 'k=%s' % (self.kernel_size,), 's=%s' % (self.stride,), 'copyInput=%s' % (self.copyInput,)]
+        parts += ['%s=%s' % (label, value) for label, value, default in optional if value != default]
         if self.bias is None:
-            s += ', bias=False'
+            parts.append('bias=False')
         if self.withReLU:
-            s += ', withReLU=%s' % (self.withReLU,)
-        s += ', propChgIdxs=%s)' % (self.propChangeIndexes,)
-        return s
+            parts.append('withReLU=%s' % (self.withReLU,))
+        parts.append('propChgIdxs=%s' % (self.propChangeIndexes,))
+        return '%s (%s)' % (self.__class__.__name__, ', '.join(parts))
+
+
+class CBTail1x1(nn.Module):
+    """conv1x1 -> [ReLU] -> conv1x1 evaluated in one launch at the pixels of the change list handed on by
+    the CBConv2d in front of it (tuple protocol, conv2d.py:180-186); every other output pixel keeps its
+    value.  Stands for two CBConv2d fed by propagated change indexes (sceneLabeling/modelLoader.py:41-44)
+    or for the dense 1x1 tail the other experiments keep (:45-47); built by pycbinfer.fuseTail1x1().
+    The parameters are shared with the source modules."""
+
+    @staticmethod
+    def maxHidden():
+        return int(C.cbinfer_tail1x1_max_hidden())
+
+    @staticmethod
+    def accepts(m):
+        def pair(v):
+            return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+        return (pair(m.kernel_size) == (1, 1) and pair(m.stride) == (1, 1) and pair(m.padding) == (0, 0) and
+                pair(m.dilation) == (1, 1) and m.groups == 1 and m.bias is not None)
+
+    def __init__(self, conv1, conv2, relu=True):
+        super(CBTail1x1, self).__init__()
+        assert CBTail1x1.accepts(conv1) and CBTail1x1.accepts(conv2)
+        assert conv1.out_channels == conv2.in_channels and conv1.out_channels <= CBTail1x1.maxHidden()
+        self.weight1, self.bias1 = conv1.weight, conv1.bias
+        self.weight2, self.bias2 = conv2.weight, conv2.bias
+        self.in_channels, self.hidden_channels, self.out_channels = (
+            conv1.in_channels, conv1.out_channels, conv2.out_channels)
+        self.relu = bool(relu)
+        self.withReLU = False
+        self.propChangeIndexes = False
+        self.register_buffer('prevOutput', torch.zeros(0))
+        self._w1prep = None
+
+    def clearMemory(self):
+        self.prevOutput = self.weight1.detach().new_zeros(0)
+
+    def getStateTensors(self):
+        return [self.prevOutput]
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d['_w1prep'] = None
+        return d
+
+    def _prepared(self):
+        w = self.weight1
+        key = (w.data_ptr(), w._version, w.device)
+        if self._w1prep is None or self._w1prep[0] != key:
+            nbytes = C.cbinfer_tail1x1_prepared_bytes(self.hidden_channels, self.in_channels)
+            wp = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+            check(C.cbinfer_tail1x1_prep(ptr(w.detach().contiguous()), ptr(wp), self.hidden_channels,
+                                         self.in_channels, stream_ptr(w)))
+            self._w1prep = (key, wp)
+        return self._w1prep[1]
+
+    def forward(self, inp):
+        assert type(inp) == tuple and inp[0] == 'changeIndexes', \
+            "CBTail1x1 needs the ('changeIndexes', tensor, indexes) tuple of a CBConv2d with propChangeIndexes"
+        x, indexes = inp[1].detach().contiguous(), inp[2]
+        require_device(x)
+        assert x.dim() == 4 and x.size(0) == 1 and x.size(1) == self.in_channels
+        if x.dtype != torch.float32:
+            raise _lib.CBinferError("CBTail1x1 is fp32 only")
+        H, W = x.size(-2), x.size(-1)
+        size = (1, self.out_channels, H, W)
+        if not _same_shape(self.prevOutput, size) or self.prevOutput.device != x.device:
+            self.prevOutput = torch.full(size, float('inf'), dtype=x.dtype, device=x.device)
+        if isinstance(indexes, ChangeIndexes):
+            idx, count, cap = indexes.buffer, indexes.count, min(indexes.buffer.numel(), H * W)
+        else:
+            idx = indexes.detach().contiguous()
+            assert idx.dim() == 1 and idx.dtype == torch.int32
+            count, cap = None, idx.numel()
+        if cap > 0:
+            check(C.cbinfer_tail1x1(ptr(x), ptr(idx), cap, ptr(count), ptr(self._prepared()),
+                                    ptr(self.bias1.detach()), ptr(self.weight2.detach().contiguous()),
+                                    ptr(self.bias2.detach()), ptr(self.prevOutput), self.in_channels,
+                                    self.hidden_channels, self.out_channels, H, W, int(self.relu),
+                                    int(bool(self.withReLU)), stream_ptr(x)))
+        if self.propChangeIndexes:
+            return 'changeIndexes', self.prevOutput, indexes
+        return self.prevOutput
+
+    def __repr__(self):
+        return '%s (%s->%s->%s, relu=%s, propChgIdxs=%s)' % (
+            self.__class__.__name__, self.in_channels, self.hidden_channels, self.out_channels, self.relu,
+            self.propChangeIndexes)

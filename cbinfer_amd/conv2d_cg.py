@@ -25,9 +25,10 @@ class ChangeIndexes(object):
     `.tensor()` synchronises and returns the exact IntTensor the reference would have produced.
     """
 
-    def __init__(self, buffer, count):
+    def __init__(self, buffer, count, size=None):
         self.buffer = buffer
         self.count = count
+        self.size = tuple(size) if size is not None else None   # (H, W) of the map the indexes address
 
     # duck-typing for the places the reference touches the third tuple element
     @property
@@ -51,7 +52,7 @@ class ChangeIndexes(object):
         return self.numel()
 
     def clone(self):
-        return ChangeIndexes(self.buffer.clone(), self.count.clone())
+        return ChangeIndexes(self.buffer.clone(), self.count.clone(), self.size)
 
 
 def _split_indexes(changeIndexes):
@@ -156,18 +157,29 @@ def genXMatrix(input, changeIndexes, filtSize, useHalf=False):
 _workspaces = {}
 
 
+def newConvWorkspace(device):
+    """A private, zero-initialised split-K workspace (tickets + slabs) for the persistent contraction
+    kernel.  The kernels leave it zero.  Two launches that may run concurrently must not share one, so
+    every CBConv2d owns its workspace (launches of ONE module are ordered by its state anyway); the
+    pointer is then safe to bake into captured graphs and call plans whatever stream they replay on."""
+    return torch.zeros(C.cbinfer_conv_workspace_bytes(), dtype=torch.uint8, device=device)
+
+
 def convWorkspace(device):
-    """Zero-initialised split-K workspace of the persistent contraction kernel, one per (device, stream).
-    The kernels leave it zero.  Launches that share one must be ordered; keying it by torch's current
-    stream gives that for free: sequences processed concurrently on different streams (or captured into
-    graphs on different streams) get private workspaces, everything on one stream shares one."""
+    """Workspace for the OP-LEVEL entry points (convChanged without a module), one per (device, stream):
+    launches on one stream are ordered.  Refuses to be created inside a stream capture -- the allocation
+    and the fill would become graph nodes, and graphs captured on torch's shared default capture stream
+    would end up sharing one workspace while replaying concurrently: pass `workspace=` instead."""
     if device.type == 'cuda':
         key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     else:
         key = (device.type, device.index, 0)
     ws = _workspaces.get(key)
     if ws is None:
-        ws = torch.zeros(C.cbinfer_conv_workspace_bytes(), dtype=torch.uint8, device=device)
+        if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            raise CBinferError("convWorkspace: no workspace exists for the capturing stream; create one "
+                               "with newConvWorkspace() before the capture and pass it as workspace=")
+        ws = newConvWorkspace(device)
         _workspaces[key] = ws
     return ws
 
@@ -240,7 +252,7 @@ def updateOutput(YMatrix, changeIndexes, prevOutput, withReLU=False, useHalf=Fal
 # a5..a8 fused
 # ------------------------------------------------------------------------------------------------
 def convChanged(input, changeIndexes, weights, bias, prevOutput, withReLU=False, accumulate=False,
-                weightsPrepared=None):
+                weightsPrepared=None, workspace=None):
     """gather -> MFMA -> bias/ReLU -> scatter for the changed pixels in ONE launch; prevOutput is
     updated in place.  Equivalent to genXMatrix + matrixMult + transpose + updateOutput."""
     require_device(input, prevOutput, weights)
@@ -257,7 +269,8 @@ def convChanged(input, changeIndexes, weights, bias, prevOutput, withReLU=False,
     b = bias.detach().contiguous() if bias is not None else None
     check(C.cbinfer_conv_changed(ptr(inp), ptr(idx), cap, ptr(count), ptr(wp), ptr(b), ptr(prevOutput),
                                  Cin, H, W, K, kH, kW, int(bool(withReLU)), int(bool(accumulate)), None,
-                                 0, ptr(convWorkspace(inp.device)), dtype_code(inp), stream_ptr(inp)))
+                                 0, ptr(workspace if workspace is not None else convWorkspace(inp.device)),
+                                 dtype_code(inp), stream_ptr(inp)))
     return prevOutput
 
 
@@ -297,9 +310,9 @@ def poolChangeIndexes(changeIndexes, inSize, outSize):
     if cap > 0:
         check(C.cbinfer_pool_change_indexes(ptr(idx), cap, ptr(count), iW, oH, oW, ptr(bits), stream_ptr(idx)))
         check(C.cbinfer_compact_bits(ptr(bits), oW, oH, ptr(out), ptr(ocount), None, None, stream_ptr(idx)))
-    return ChangeIndexes(out, ocount)
+    return ChangeIndexes(out, ocount, (oH, oW))
 
 
-__all__ = ['ChangeIndexes', 'convWorkspace', 'changeDetection', 'changePropagation', 'changeIndexesExtr',
+__all__ = ['ChangeIndexes', 'convWorkspace', 'newConvWorkspace', 'changeDetection', 'changePropagation', 'changeIndexesExtr',
            'changeIndexesExtrAsync', 'genXMatrix', 'prepWeights', 'matrixMult', 'matrixMult_python',
            'updateOutput', 'convChanged', 'maxPool2d', 'poolChangeIndexes', 'CBinferError']

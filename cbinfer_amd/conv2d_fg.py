@@ -6,7 +6,7 @@ reference's names and argument meaning, launching the HIP kernels of libcbinfer_
 import torch
 
 from ._lib import C, check, ptr, require_device, stream_ptr
-from .conv2d_cg import ChangeIndexes, convChanged
+from .conv2d_cg import ChangeIndexes, changeIndexesExtrAsync, convChanged
 
 
 def changeDetectionFG(input, prevInput, threshold, zeroUnchanged=False):
@@ -24,34 +24,48 @@ def changeDetectionFG(input, prevInput, threshold, zeroUnchanged=False):
     return diffs, changeMap
 
 
+def changeCoordsExtrFG(changeMap):
+    """a11: the coordinates of the changed VALUES -- ascending flat indexes into [C,H,W] -- as a
+    ChangeIndexes (int32 list + device-side count) by the library's ballot/popcount-prefix compaction,
+    where the reference blocks on torch.nonzero(changeTensor.view(-1)) (conv2d_fg.py:82).
+    `.tensor().long().view(-1, 1)` is the reference's int64 [N,1] tensor (one sync)."""
+    return changeIndexesExtrAsync(changeMap)
+
+
 def updateOutputFG(diffs, weight, output, changeCoords):
-    """reference: conv2d_fg.py:48-72.  changeCoords: int64 flat coordinates into [C,H,W]
-    (torch.nonzero of the flattened change map, shape [N] or [N,1]).  output is updated in place
-    with f32 atomic adds (summation order unspecified, as in the reference)."""
-    require_device(diffs, weight, output, changeCoords)
+    """reference: conv2d_fg.py:48-72.  changeCoords: flat coordinates into [C,H,W] of the changed values,
+    either the reference's int64 tensor ([N] or [N,1], torch.nonzero of the flattened change map) or a
+    ChangeIndexes from changeCoordsExtrFG (length read on the device: no host sync).  output is updated
+    in place with f32 atomic adds (summation order unspecified, as in the reference)."""
+    require_device(diffs, weight, output)
     assert output.is_contiguous()
-    assert weight.dim() == 4 and changeCoords.dtype == torch.int64
+    assert weight.dim() == 4
     numOut, numIn, kH, kW = weight.size()
     inH, inW = output.size(-2), output.size(-1)
-    numChanges = changeCoords.size(0)
+    d, w = diffs.contiguous(), weight.detach().contiguous()
+    if isinstance(changeCoords, ChangeIndexes):
+        check(C.cbinfer_update_output_fg_list(ptr(d), ptr(w), ptr(output), ptr(changeCoords.buffer),
+                                              changeCoords.buffer.numel(), ptr(changeCoords.count), numOut,
+                                              numIn, inH, inW, kH, kW, stream_ptr(output)))
+        return output
+    require_device(changeCoords)
+    assert changeCoords.dtype == torch.int64
     coords = changeCoords.contiguous()
-    check(C.cbinfer_update_output_fg(ptr(diffs.contiguous()), ptr(weight.detach().contiguous()),
-                                     ptr(output), ptr(coords), numOut, numIn, inH, inW, kH, kW,
-                                     numChanges, stream_ptr(output)))
+    check(C.cbinfer_update_output_fg(ptr(d), ptr(w), ptr(output), ptr(coords), numOut, numIn, inH, inW,
+                                     kH, kW, coords.size(0), stream_ptr(output)))
     return output
 
 
 def cbconvFG(input, prevInput, output, weight, threshold):
     """reference: conv2d_fg.py:75-96.  output (= previous output, updated in place and returned)
-    receives conv(weight, delta) for every input value whose change exceeds the threshold."""
+    receives conv(weight, delta) for every input value whose change exceeds the threshold.  The device
+    path is the reference's op sequence -- per-value detection, coordinate extraction, atomic scatter --
+    with the coordinate count kept on the device (no torch.nonzero round trip)."""
     if input.is_cuda:
         deltaInput, changeTensor = changeDetectionFG(input, prevInput, threshold)
-        changeIdx = torch.nonzero(changeTensor.view(-1))   # device->host sync, as in the reference
-        if changeIdx.numel() != 0:
-            output = updateOutputFG(deltaInput, weight, output, changeIdx)
-        return output
-    # host tensors: the reference's compiled CPU routine (cbconv2d_fg_backend.cu:81-112), here the
-    # race-free host function exported by the same library
+        return updateOutputFG(deltaInput, weight, output, changeCoordsExtrFG(changeTensor))
+    # host tensors: the library's counterpart of the reference's compiled CPU routine
+    # (cbconv2d_fg_backend.cu:81-112)
     assert input.dtype == torch.float32 and output.is_contiguous()
     inp, prev, w = input.contiguous(), prevInput.contiguous(), weight.detach().contiguous()
     C.cbinfer_conv2d_fg_cpu(inp.data_ptr(), prev.data_ptr(), output.data_ptr(), w.data_ptr(),
@@ -79,4 +93,4 @@ def cbconvFG_deterministic(input, prevInput, output, weight, threshold, weightsP
     return output
 
 
-__all__ = ['changeDetectionFG', 'updateOutputFG', 'cbconvFG', 'cbconvFG_deterministic']
+__all__ = ['changeDetectionFG', 'changeCoordsExtrFG', 'updateOutputFG', 'cbconvFG', 'cbconvFG_deterministic']

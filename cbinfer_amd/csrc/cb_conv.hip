@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void cb_scatter_kernel(const T* __restrict__ Y
         const int k = (int)(e / N), n = (int)(e % N);
         T v = Yt[(long)k * nHost + n];
         if (relu) v = cb_relu(v);
-        out[(long)k * HW + list[n]] = v;
+        const int pix = list[n];
+        if ((unsigned)pix < (unsigned)HW) out[(long)k * HW + pix] = v;
     }
 }
 
@@ -130,6 +131,7 @@ struct ConvParams {
     int maskWords, wpr;
     int32_t* listOut;                 // the list and its length are written out as a by-product
     int32_t* countOut;
+    void* reluOut;                    // EPI_SCATTER_ACC: optional second plane set receiving relu(out)
 };
 
 #define CB_SELFC_MAXW 4096
@@ -636,9 +638,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
 
         // epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
         const int n = n0 + wn * 32 + l31;
-        if (ks == 0 && n < N) {
-            int pix = 0;
-            if (EPI >= CB_EPI_SCATTER) pix = SELFC ? s_tilePix[wn * 32 + l31] : p.list[n];
+        int pix = 0;
+        if (EPI >= CB_EPI_SCATTER && ks == 0 && n < N) pix = SELFC ? s_tilePix[wn * 32 + l31] : p.list[n];
+        // (a list entry outside the map -- a propagated list of another resolution -- is dropped, never
+        // written through: the reference's scatter would corrupt a neighbouring plane, .cu:187)
+        if (ks == 0 && n < N && (unsigned)pix < (unsigned)HW) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -654,8 +658,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
                     out[(long)m * p.nHost + n] = v;
                 else if (EPI == CB_EPI_SCATTER)
                     out[(long)m * HW + pix] = v;
-                else
-                    out[(long)m * HW + pix] += v;
+                else {
+                    const float nv = out[(long)m * HW + pix] + v;
+                    out[(long)m * HW + pix] = nv;
+                    if (p.reluOut) ((float*)p.reluOut)[(long)m * HW + pix] = cb_relu(nv);
+                }
             }
         }
         CB_STAMP_AT(6);
@@ -1049,9 +1056,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
 
         // epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
         const int n = n0 + wn * 32 + l31;
-        if (ks == 0 && n < N) {
-            int pix = 0;
-            if (EPI >= CB_EPI_SCATTER) pix = SELFC ? s_tilePix[wn * 32 + l31] : p.list[n];
+        int pix = 0;
+        if (EPI >= CB_EPI_SCATTER && ks == 0 && n < N) pix = SELFC ? s_tilePix[wn * 32 + l31] : p.list[n];
+        // (a list entry outside the map -- a propagated list of another resolution -- is dropped, never
+        // written through: the reference's scatter would corrupt a neighbouring plane, .cu:187)
+        if (ks == 0 && n < N && (unsigned)pix < (unsigned)HW) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -1146,9 +1155,10 @@ int launch_mfma(const ConvParams& p, int dtype, hipStream_t s) {
         if (cfg == 0) cfg = narrow ? 142 : 222;
         if (narrow && cfg / 100 != 1) cfg = 142;
         if (p.frameMasks) {   // self-compacting frame pipeline: only the default configurations
-            if (MODE != CB_MODE_GATHER || EPI != CB_EPI_SCATTER) return CB_ERR_BADARG;
-            if (narrow) return launch_f32<1, 4, 2, CB_MODE_GATHER, CB_EPI_SCATTER, true>(p, s);
-            return launch_f32<2, 2, 2, CB_MODE_GATHER, CB_EPI_SCATTER, true>(p, s);
+            if (MODE != CB_MODE_GATHER || EPI < CB_EPI_SCATTER) return CB_ERR_BADARG;
+            constexpr int E = EPI < CB_EPI_SCATTER ? CB_EPI_SCATTER : EPI;
+            if (narrow) return launch_f32<1, 4, 2, CB_MODE_GATHER, E, true>(p, s);
+            return launch_f32<2, 2, 2, CB_MODE_GATHER, E, true>(p, s);
         }
         switch (cfg) {
             case 141: return launch_f32<1, 4, 1, MODE, EPI>(p, s);
@@ -1177,7 +1187,7 @@ extern "C" {
 
 // K <= 32 uses the 32-row workgroup tile, anything larger the 64-row one: pad to whole tiles
 int cbinfer_weights_kpad(int K) { return K <= CB_MFMA_M ? CB_MFMA_M : (K + 63) / 64 * 64; }
-int cbinfer_weights_ckkpad(int Ckk) { return (Ckk + 31) / 32 * 32; }
+int cbinfer_weights_ckkpad(int Ckk, int dtype) { return cb_ckkpad(Ckk, dtype); }
 
 long cbinfer_conv_workspace_bytes(void) {
     return 4096 + (long)CB_CONV_GRID_PER_CU * cb_num_cus() * 64 * 64 * 4;
@@ -1316,10 +1326,10 @@ int cbinfer_conv_changed(const void* input, const int32_t* changeList, int numCh
 
 // Self-compacting form of cbinfer_conv_changed (used by cbinfer_cbconv2d_forward): the change list is
 // derived inside the kernel from the frame's bit mask; idxOut/countOut receive it as a by-product.
-int cbinfer_conv_changed_from_mask(const void* input, uint64_t* frameMasks, int32_t* idxOut,
-                                   int32_t* countOut, const void* weightsPrepared, const void* bias,
-                                   void* output, int C, int H, int W, int K, int kH, int kW, int relu,
-                                   void* workspace, int dtype, cbStream_t stream) {
+static int cb_conv_from_mask(const void* input, uint64_t* frameMasks, int32_t* idxOut,
+                             int32_t* countOut, const void* weightsPrepared, const void* bias,
+                             void* output, int C, int H, int W, int K, int kH, int kW, int relu,
+                             void* workspace, int dtype, cbStream_t stream, int accumulate, void* reluOut) {
     CB_REQUIRE(input && frameMasks && idxOut && countOut && weightsPrepared && output && C > 0 && H > 0 &&
                W > 0 && K > 0 && kH > 0 && kW > 0);
     if (dtype != CB_F32 && dtype != CB_F16) return CB_ERR_BADARG;
@@ -1351,7 +1361,31 @@ int cbinfer_conv_changed_from_mask(const void* input, uint64_t* frameMasks, int3
         p.tickets = (int*)workspace;
         p.slabs = (float*)((char*)workspace + 4096);
     }
+    if (accumulate) {
+        if (dtype != CB_F32) return CB_ERR_UNSUPPORTED;
+        p.reluOut = reluOut;
+        return launch_mfma<CB_MODE_GATHER, CB_EPI_SCATTER_ACC>(p, dtype, (hipStream_t)stream);
+    }
     return launch_mfma<CB_MODE_GATHER, CB_EPI_SCATTER>(p, dtype, (hipStream_t)stream);
+}
+
+int cbinfer_conv_changed_from_mask(const void* input, uint64_t* frameMasks, int32_t* idxOut,
+                                   int32_t* countOut, const void* weightsPrepared, const void* bias,
+                                   void* output, int C, int H, int W, int K, int kH, int kW, int relu,
+                                   void* workspace, int dtype, cbStream_t stream) {
+    return cb_conv_from_mask(input, frameMasks, idxOut, countOut, weightsPrepared, bias, output, C, H, W, K,
+                             kH, kW, relu, workspace, dtype, stream, 0, nullptr);
+}
+
+// Fine-grained form: `delta` holds the thresholded per-value differences (0 where unchanged); the kernel
+// ADDS conv(weights, delta) to `output` at the pixels of the frame mask and, if reluOut is given, keeps
+// relu(output) up to date there.
+int cbinfer_conv_accumulate_from_mask(const float* delta, uint64_t* frameMasks, int32_t* idxOut,
+                                      int32_t* countOut, const void* weightsPrepared, float* output,
+                                      float* reluOut, int C, int H, int W, int K, int kH, int kW,
+                                      void* workspace, cbStream_t stream) {
+    return cb_conv_from_mask(delta, frameMasks, idxOut, countOut, weightsPrepared, nullptr, output, C, H, W,
+                             K, kH, kW, 0, workspace, CB_F32, stream, 1, reluOut);
 }
 
 long cbinfer_frame_mask_bytes(int H, int W) { return 2 * cbinfer_mask_words(H, W) * 8 + 16; }

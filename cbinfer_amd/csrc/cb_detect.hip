@@ -125,6 +125,83 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
     }
 }
 
+// Fine-grained frame detection (cbconv2d_fg_backend.cu:7-23 + the any-channel dilated pixel mask the
+// contraction needs).  Same decomposition as cb_detect_kernel: one workgroup = one 64-pixel row segment x
+// all channels.  Per value d = in - prev; delta = |d| > th ? d : 0 is written for EVERY value (the gather
+// of the contraction reads unchanged neighbours too); with refresh != 0 prev <- in wherever they differ at
+// all, which is what the reference's `self.prevInput = input` amounts to (conv2d.py:175: sub-threshold
+// differences are absorbed, not accumulated).  The pixels any of whose values changed are dilated by the
+// filter support and ORed into the frame mask the parity selects.
+__global__ __launch_bounds__(1024) void cb_detect_fg_frame_kernel(
+    const float* __restrict__ in, float* prev, float* __restrict__ delta,
+    unsigned long long* __restrict__ bits, int W, int H, int C, int kHH, int kWH, float th, int refresh,
+    int wpr, const int* __restrict__ parity, long altWords) {
+    if (parity && *parity) bits += altWords;
+    const int lane = threadIdx.x & 63;
+    const int g = threadIdx.x >> 6;
+    const int G = blockDim.x >> 6;
+    const int tx = blockIdx.x;
+    const int y = blockIdx.y;
+    const int x = tx * 64 + lane;
+    const long HW = (long)H * W;
+    const long p = (long)y * W + x;
+    bool chg = false;
+    if (x < W) {
+        int c = g;
+#pragma unroll 1
+        for (; c + 3 * G < C; c += 4 * G) {  // 8 independent loads in flight per lane
+            float s[4], v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s[u] = prev[(long)(c + u * G) * HW + p];
+                v[u] = in[(long)(c + u * G) * HW + p];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float d = v[u] - s[u];
+                const bool pred = fabsf(d) > th;
+                chg |= pred;
+                delta[(long)(c + u * G) * HW + p] = pred ? d : 0.f;
+                if (refresh && d != 0.f) prev[(long)(c + u * G) * HW + p] = v[u];
+            }
+        }
+        for (; c < C; c += G) {
+            const float s0 = prev[(long)c * HW + p], v0 = in[(long)c * HW + p];
+            const float d = v0 - s0;
+            const bool pred = fabsf(d) > th;
+            chg |= pred;
+            delta[(long)c * HW + p] = pred ? d : 0.f;
+            if (refresh && d != 0.f) prev[(long)c * HW + p] = v0;
+        }
+    }
+    __shared__ unsigned long long sm[16];
+    const unsigned long long b = __ballot(chg);
+    if (lane == 0) sm[g] = b;
+    __syncthreads();
+    if (g != 0) return;
+    unsigned long long m = 0;
+    for (int i = 0; i < G; ++i) m |= sm[i];
+    if (m == 0) return;
+    unsigned long long D = m, SR = 0, SL = 0;
+    for (int d = 1; d <= kWH; ++d) {
+        D |= (m << d) | (m >> d);
+        SR |= m >> (64 - d);
+        SL |= m << (64 - d);
+    }
+    D &= cb_valid_mask(W, tx);
+    SR = (tx + 1 < wpr) ? (SR & cb_valid_mask(W, tx + 1)) : 0ull;
+    if (tx == 0) SL = 0;
+    const int items = 3 * (2 * kHH + 1);
+    for (int i = lane; i < items; i += 64) {
+        const int yy = y + i / 3 - kHH;
+        const int which = i % 3;
+        if (yy < 0 || yy >= H) continue;
+        const unsigned long long v = which == 0 ? D : (which == 1 ? SR : SL);
+        const int t2 = which == 0 ? tx : (which == 1 ? tx + 1 : tx - 1);
+        if (v) atomicOr(&bits[(long)yy * wpr + t2], v);
+    }
+}
+
 // Stand-alone gather-form dilation of a byte map (cbconv2d_cg_backend.cu:101-124).
 __global__ __launch_bounds__(256) void cb_propagate_kernel(const int8_t* __restrict__ in,
                                                           int8_t* __restrict__ out, int W, int H,
@@ -324,6 +401,23 @@ int cbinfer_change_detection_frame_pooled(const void* prePool, int pH, int pW, v
         return launch_detect<cb_half, true, true>(prePool, state, nullptr, frameMasks, W, H, C, kHHalf,
                                                   kWHalf, threshold, 1, s, parity, words, pH, pW);
     return CB_ERR_BADARG;
+}
+
+// Fine-grained frame detection (see cb_detect_fg_frame_kernel); frameMasks as in
+// cbinfer_change_detection_frame.
+int cbinfer_change_detection_fg_frame(const float* input, float* prevInput, float* delta,
+                                      uint64_t* frameMasks, int W, int H, int C, int kHHalf, int kWHalf,
+                                      float threshold, int refreshState, cbStream_t stream) {
+    CB_REQUIRE(input && prevInput && delta && frameMasks && W > 0 && H > 0 && C > 0 && kHHalf >= 0 &&
+               kWHalf >= 0);
+    if (kWHalf > 63 || H > 65535) return CB_ERR_UNSUPPORTED;
+    const long words = cbinfer_mask_words(H, W);
+    const int wpr = cbinfer_mask_words_per_row(W);
+    dim3 grid(wpr, H), block(64 * detect_groups(C));
+    hipLaunchKernelGGL(cb_detect_fg_frame_kernel, grid, block, 0, (hipStream_t)stream, input, prevInput,
+                       delta, (unsigned long long*)frameMasks, W, H, C, kHHalf, kWHalf, threshold,
+                       refreshState, wpr, (const int*)(frameMasks + 2 * words), words);
+    return cb_launch_status();
 }
 
 int cbinfer_change_propagation(const int8_t* mapIn, int8_t* mapOut, int W, int H, int kHHalf,

@@ -72,3 +72,28 @@ extern "C" int cbinfer_cbconv2d_forward_pooled(const void* prePool, int pH, int 
     return cbinfer_conv_changed_from_mask(prevInput, bits, idx, countDev, weightsPrepared, bias, prevOutput,
                                           C, H, W, K, kH, kW, relu, workspace, dtype, stream);
 }
+
+// CBConv2d.forward_fg (conv2d.py:160-176 -> conv2d_fg.py:75-85) for frames after the first, as two
+// launches without a host round trip, atomics or per-value coordinate list (the reference blocks on
+// torch.nonzero, conv2d_fg.py:82, and scatters K*kH*kW atomicAdds per changed value, .cu:37-66):
+//   1. per-value detection: delta = in - prev where |in - prev| > th, else 0 (dense [C,H,W] workspace);
+//      the pixels with a changed value, dilated by the filter support, go to the frame mask;
+//      refreshState=1 also performs the reference's `prevInput = input` (conv2d.py:175) in place,
+//      otherwise the caller re-points its state at `input` as the reference does;
+//   2. the self-compacting contraction ADDS conv(weights, delta) at exactly the masked output pixels --
+//      every other output receives only zero contributions in the reference too -- and keeps
+//      reluOut = relu(prevOutput) current there when given (conv2d.py:172-174 without a full-tensor pass).
+// Deterministic (fixed summation order); idx/countDev receive the list of touched output pixels.
+extern "C" int cbinfer_cbconv2d_forward_fg(const float* input, float* prevInput, float* delta,
+                                           float* prevOutput, float* reluOut, uint64_t* frameMasks,
+                                           int32_t* idx, int32_t* countDev, const void* weightsPrepared,
+                                           int C, int H, int W, int K, int kH, int kW, float threshold,
+                                           int refreshState, void* workspace, cbStream_t stream) {
+    CB_REQUIRE(input && prevInput && delta && prevOutput && frameMasks && idx && countDev && weightsPrepared);
+    const int st = cbinfer_change_detection_fg_frame(input, prevInput, delta, frameMasks, W, H, C,
+                                                     (kH - 1) / 2, (kW - 1) / 2, threshold, refreshState,
+                                                     stream);
+    if (st != CB_OK) return st;
+    return cbinfer_conv_accumulate_from_mask(delta, frameMasks, idx, countDev, weightsPrepared, prevOutput,
+                                             reluOut, C, H, W, K, kH, kW, workspace, stream);
+}

@@ -76,34 +76,35 @@ __global__ __launch_bounds__(256) void cb_detect_fg_kernel(const float* __restri
     }
 }
 
-// grid.x over changed values (consecutive lanes = consecutive list entries = mostly consecutive x, so
-// one atomic wave-instruction touches a contiguous run of one output row), grid.y over output
-// channels.  f32 atomic adds execute at the memory side on gfx950; summation order is unspecified,
-// as with the reference's atomicAdd (cbconv2d_fg_backend.cu:61).
+// Per-value delta scatter (a12, API-parity form of cbconv2d_fg_backend.cu:37-66).  grid.x strides over
+// the changed values (consecutive lanes = consecutive list entries = mostly consecutive x, so one atomic
+// wave-instruction touches a contiguous run of one output row -- the shape the memory-side f32 atomic
+// units take at full rate), grid.y over output channels.  The list is int64 (torch.nonzero,
+// conv2d_fg.py:82) or int32 with a device-side length (cbinfer_change_indexes_extr: no host round trip).
+// Summation order is unspecified, as with the reference's atomicAdd (.cu:61).  The modules do not use this
+// kernel: their fine-grained frame runs cbinfer_cbconv2d_forward_fg (no atomics, see cb_frame.hip).
+template <typename IDX>
 __global__ __launch_bounds__(256) void cb_update_fg_kernel(const float* __restrict__ diffs,
                                                           const float* __restrict__ weight,
-                                                          float* output,
-                                                          const int64_t* __restrict__ coords, int K,
-                                                          int C, int H, int W, int kH, int kW,
-                                                          long numChanges) {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= numChanges) return;
+                                                          float* output, const IDX* __restrict__ coords,
+                                                          const int32_t* __restrict__ countDev, int C,
+                                                          int H, int W, int kH, int kW, long numChanges) {
+    const long N = countDev ? min((long)*countDev, numChanges) : numChanges;
     const int co = blockIdx.y;
-    const int pos = (int)coords[t];
-    const int ci = pos / (H * W);
-    const int y = (pos / W) % H;
-    const int x = pos % W;
-    const float d = diffs[pos];
-    const float* w = weight + ((long)co * C + ci) * kH * kW;
-    float* o = output + (long)co * H * W;
-    for (int iky = 0; iky < kH; ++iky) {
-        const int ytot = y - iky + kH / 2;
-        if (ytot < 0 || ytot >= H) continue;
-        for (int ikx = 0; ikx < kW; ++ikx) {
-            const int xtot = x - ikx + kW / 2;
-            if (xtot < 0 || xtot >= W) continue;
-            atomicAdd(o + (long)ytot * W + xtot, w[iky * kW + ikx] * d);
-        }
+    const int HW = H * W, ph = kH / 2, pw = kW / 2;
+    float* o = output + (long)co * HW;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < N; t += (long)gridDim.x * blockDim.x) {
+        const int pos = (int)coords[t];
+        const int ci = pos / HW, pix = pos - ci * HW;
+        const int y = pix / W, x = pix - y * W;
+        const float d = diffs[pos];
+        const float* w = weight + ((long)co * C + ci) * kH * kW;
+        // tap (ky,kx) of the value at (y,x) lands on output (y - ky + ph, x - kx + pw)
+        const int ky0 = max(0, y + ph - (H - 1)), ky1 = min(kH - 1, y + ph);
+        const int kx0 = max(0, x + pw - (W - 1)), kx1 = min(kW - 1, x + pw);
+        for (int ky = ky0; ky <= ky1; ++ky)
+            for (int kx = kx0; kx <= kx1; ++kx)
+                atomicAdd(o + (long)(y - ky + ph) * W + (x - kx + pw), w[ky * kW + kx] * d);
     }
 }
 
@@ -167,44 +168,67 @@ int cbinfer_change_detection_fg(const float* input, const float* prevInput, floa
     return cb_launch_status();
 }
 
-int cbinfer_update_output_fg(const float* diffs, const float* weight, float* output,
-                             const int64_t* changeCoords, int K, int C, int H, int W, int kH, int kW,
-                             long numChanges, cbStream_t stream) {
-    CB_REQUIRE(diffs && weight && output && changeCoords && K > 0 && C > 0 && H > 0 && W > 0 &&
-               kH > 0 && kW > 0 && numChanges >= 0);
+static int cb_update_fg_launch(const float* diffs, const float* weight, float* output,
+                               const void* coords, int coords64, const int32_t* countDev, int K, int C,
+                               int H, int W, int kH, int kW, long numChanges, cbStream_t stream) {
+    CB_REQUIRE(diffs && weight && output && coords && K > 0 && C > 0 && H > 0 && W > 0 && kH > 0 &&
+               kW > 0 && numChanges >= 0);
     if ((long)C * H * W >= (1l << 31) || K > 65535) return CB_ERR_UNSUPPORTED;
     if (numChanges == 0) return CB_OK;
-    dim3 grid(cb_div_up(numChanges, 256), K), block(256);
-    hipLaunchKernelGGL(cb_update_fg_kernel, grid, block, 0, (hipStream_t)stream, diffs, weight, output,
-                       changeCoords, K, C, H, W, kH, kW, numChanges);
+    long bx = (numChanges + 255) / 256;
+    if (bx > 4096) bx = 4096;   // grid-stride: the capacity may be the whole tensor when the count is on the device
+    dim3 grid((unsigned)bx, K), block(256);
+    if (coords64)
+        hipLaunchKernelGGL((cb_update_fg_kernel<int64_t>), grid, block, 0, (hipStream_t)stream, diffs, weight,
+                           output, (const int64_t*)coords, countDev, C, H, W, kH, kW, numChanges);
+    else
+        hipLaunchKernelGGL((cb_update_fg_kernel<int32_t>), grid, block, 0, (hipStream_t)stream, diffs, weight,
+                           output, (const int32_t*)coords, countDev, C, H, W, kH, kW, numChanges);
     return cb_launch_status();
 }
 
-// Host fine-grained delta convolution (cbconv2d_fg_backend.cu:81-112).  Parallel over OUTPUT
-// channels, which own disjoint output planes -- the reference's `omp for` over input channels races.
+int cbinfer_update_output_fg(const float* diffs, const float* weight, float* output,
+                             const int64_t* changeCoords, int K, int C, int H, int W, int kH, int kW,
+                             long numChanges, cbStream_t stream) {
+    return cb_update_fg_launch(diffs, weight, output, changeCoords, 1, nullptr, K, C, H, W, kH, kW,
+                               numChanges, stream);
+}
+
+int cbinfer_update_output_fg_list(const float* diffs, const float* weight, float* output,
+                                  const int32_t* changeCoords, long capacity, const int32_t* countDev,
+                                  int K, int C, int H, int W, int kH, int kW, cbStream_t stream) {
+    return cb_update_fg_launch(diffs, weight, output, changeCoords, 0, countDev, K, C, H, W, kH, kW,
+                               capacity, stream);
+}
+
+// Host fine-grained delta convolution, the library's counterpart of conv2d_fg_cpu
+// (cbconv2d_fg_backend.cu:81-112): every input value whose difference is not below the threshold
+// (`!(|d| < th)`, i.e. >=, as there) adds d * w[:, c, ky, kx] to the outputs its taps reach.  One OpenMP
+// task per OUTPUT plane (planes are disjoint, so no two threads ever touch the same float -- the reference
+// parallelises over input channels, which all accumulate into the same planes), and the in-image tap range
+// of a value is computed once instead of testing every tap.
 void cbinfer_conv2d_fg_cpu(const float* input, const float* prevInput, float* output,
                            const float* weight, float threshold, int no, int ni, int h, int w,
                            int kh, int kw) {
-    const int khhalf = kh / 2, kwhalf = kw / 2;
+    const int ph = kh / 2, pw = kw / 2;
+    const long hw = (long)h * w;
 #pragma omp parallel for schedule(static)
-    for (int co = 0; co < no; ++co)
-        for (int ci = 0; ci < ni; ++ci)
-            for (int y = 0; y < h; ++y)
-                for (int x = 0; x < w; ++x) {
-                    const long iidx = ((long)ci * h + y) * w + x;
-                    const float diff = input[iidx] - prevInput[iidx];
-                    if (fabsf(diff) < threshold) continue;
-                    for (int iky = 0; iky < kh; ++iky) {
-                        const int oy = y - iky + khhalf;
-                        if (oy < 0 || oy >= h) continue;
-                        for (int ikx = 0; ikx < kw; ++ikx) {
-                            const int ox = x - ikx + kwhalf;
-                            if (ox < 0 || ox >= w) continue;
-                            output[((long)co * h + oy) * w + ox] +=
-                                diff * weight[(((long)co * ni + ci) * kh + iky) * kw + ikx];
-                        }
-                    }
-                }
+    for (int plane = 0; plane < no; ++plane) {
+        float* const dst = output + plane * hw;
+        for (long v = 0; v < (long)ni * hw; ++v) {
+            const float d = input[v] - prevInput[v];
+            if (fabsf(d) < threshold) continue;
+            const int c = (int)(v / hw);
+            const int pix = (int)(v - c * hw), y = pix / w, x = pix - y * w;
+            const float* taps = weight + ((long)plane * ni + c) * kh * kw;
+            const int ky0 = y + ph - (h - 1) > 0 ? y + ph - (h - 1) : 0, ky1 = y + ph < kh - 1 ? y + ph : kh - 1;
+            const int kx0 = x + pw - (w - 1) > 0 ? x + pw - (w - 1) : 0, kx1 = x + pw < kw - 1 ? x + pw : kw - 1;
+            for (int ky = ky0; ky <= ky1; ++ky) {
+                float* row = dst + (long)(y - ky + ph) * w + (x + pw);
+                for (int kx = kx0; kx <= kx1; ++kx) row[-kx] += d * taps[ky * kw + kx];
+            }
+        }
+    }
 }
 
 }  // extern "C"

@@ -1,0 +1,141 @@
+// Change-based evaluation of a chain of two 1x1 convolutions (conv -> [ReLU] -> conv) at the changed pixels
+// of the layer in front of it, in ONE launch: the dense "1x1 tail" of the scene-labeling network
+// (sceneLabeling/modelLoader.py:45-47 keeps baseline modules 8..10 dense; experiment 1, :41-44, runs them as
+// two CBConv2d fed by propagated change indexes).  A 1x1 layer's output can only change where its input
+// did, and the producing CBConv2d rewrites its output exactly at the pixels of its change list, so
+// recomputing the chain at those pixels and keeping every other output gives the dense result.
+//
+// Shape: 16 changed pixels per workgroup, so that even a few thousand pixels spread over all CUs (the
+// whole job is ~100 MFLOP: latency, not throughput, is what counts).  Wave w owns hidden channels
+// 16w..16w+15: H[16 x 16 px] = W1[16 x C0] . X[C0 x 16 px] on v_mfma_f32_16x16x4_f32 (exact f32 fma
+// chain), A fragments straight from the re-laid-out weights (one 16-byte load per four MFMAs and lane),
+// the gathered X tile staged once through LDS.  relu(H + b1) goes to LDS, and the C2 x 16 outputs of the
+// second (tiny) layer are plain f32 dot products over it.
+#include "cb_common.h"
+
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define CB_TAIL_PX 16
+#define CB_TAIL_MAXW 8          // waves per workgroup = ceil(C1/16) <= 8  -> C1 <= 128
+
+// W1 [C1, C0] -> fragment order [mt][s4][lane][4]: element (mt, s4, lane, j) = W1[16 mt + lane%16][16 s4 + 4 j + lane/16]
+__global__ __launch_bounds__(256) void cb_tail_prep_kernel(const float* __restrict__ w1, float* __restrict__ w1p,
+                                                          int C1, int C0, int C0P) {
+    const long total = (long)((C1 + 15) / 16) * (C0P / 16) * 64 * 4;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int j = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    const long r = e >> 8;
+    const int s4 = (int)(r % (C0P / 16)), mt = (int)(r / (C0P / 16));
+    const int m = 16 * mt + (lane & 15), k = 16 * s4 + 4 * j + (lane >> 4);
+    w1p[e] = (m < C1 && k < C0) ? w1[(long)m * C0 + k] : 0.f;
+}
+
+__global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cb_tail1x1_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ list, int nHost,
+    const int32_t* __restrict__ countDev, const float* __restrict__ w1p, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, float* out, int C0, int C0P, int C1, int C2,
+    int HW, int relu1, int relu2) {
+    extern __shared__ float sm[];   // Xs[C0P][16] | Hs[C1P][17]
+    const int N = countDev ? min(*countDev, nHost) : nHost;
+    const int t = threadIdx.x, NT = blockDim.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    float* Xs = sm;
+    float* Hs = sm + (long)C0P * CB_TAIL_PX;
+    __shared__ int s_pix[CB_TAIL_PX];
+
+    for (int tile = blockIdx.x; tile * CB_TAIL_PX < N; tile += gridDim.x) {
+        const int n0 = tile * CB_TAIL_PX;
+        __syncthreads();   // previous tile's Hs / s_pix reads are done
+        if (t < CB_TAIL_PX) {
+            int pix = n0 + t < N ? list[n0 + t] : -1;
+            if ((unsigned)pix >= (unsigned)HW) pix = -1;   // foreign-resolution entry: dropped
+            s_pix[t] = pix;
+        }
+        __syncthreads();
+        // gather X[c][px]: thread -> (px = t % 16, c = t / 16 + i * NT/16); 16 neighbouring lanes read the
+        // 16 pixels of one channel plane (contiguous where the changed pixels are)
+        const int px = t & 15;
+        const int mypix = s_pix[px];
+        for (int c = t >> 4; c < C0P; c += NT >> 4)
+            Xs[c * CB_TAIL_PX + px] = (mypix >= 0 && c < C0) ? x[(long)c * HW + mypix] : 0.f;
+        __syncthreads();
+
+        // H tile of this wave: rows 16 wave .. +15, cols = 16 px.  A: lane holds W1[16w + l%16][4s + l/16],
+        // B: lane holds X[4s + l/16][l%16]
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        const floatx4* ap = (const floatx4*)w1p + ((long)wave * (C0P / 16)) * 64 + lane;
+        const float* bp = Xs + (lane >> 4) * CB_TAIL_PX + (lane & 15);
+        for (int s4 = 0; s4 < C0P / 16; ++s4) {
+            const floatx4 a = ap[(long)s4 * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bp[(16 * s4 + 4 * j) * CB_TAIL_PX], acc, 0, 0, 0);
+        }
+        // C/D map of the 16x16 tile: col = lane%16, row = 4*(lane/16) + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 16 * wave + 4 * (lane >> 4) + r;
+            float v = acc[r] + (m < C1 ? b1[m] : 0.f);
+            if (relu1) v = v <= 0.f ? 0.f : v;
+            Hs[m * (CB_TAIL_PX + 1) + (lane & 15)] = v;
+        }
+        __syncthreads();
+        // second layer: out[c2][px] = b2[c2] + sum_j W2[c2][j] * H[j][px]
+        for (int o = t; o < C2 * CB_TAIL_PX; o += NT) {
+            const int c2 = o >> 4, p2 = o & 15;
+            const int pix = s_pix[p2];
+            if (pix < 0) continue;
+            float v = b2[c2];
+            const float* wr = w2 + (long)c2 * C1;
+            for (int j = 0; j < C1; ++j) v = fmaf(wr[j], Hs[j * (CB_TAIL_PX + 1) + p2], v);
+            if (relu2) v = v <= 0.f ? 0.f : v;
+            out[(long)c2 * HW + pix] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cbinfer_tail1x1_max_hidden(void) { return 16 * CB_TAIL_MAXW; }
+
+long cbinfer_tail1x1_prepared_bytes(int C1, int C0) {
+    const long C0P = (C0 + 15) / 16 * 16;
+    return (long)((C1 + 15) / 16) * 16 * C0P * 4;
+}
+
+int cbinfer_tail1x1_prep(const float* w1, float* w1Prepared, int C1, int C0, cbStream_t stream) {
+    CB_REQUIRE(w1 && w1Prepared && C1 > 0 && C0 > 0);
+    if (C1 > 16 * CB_TAIL_MAXW) return CB_ERR_UNSUPPORTED;
+    const int C0P = (C0 + 15) / 16 * 16;
+    const long total = cbinfer_tail1x1_prepared_bytes(C1, C0) / 4;
+    hipLaunchKernelGGL(cb_tail_prep_kernel, dim3(cb_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w1, w1Prepared, C1, C0, C0P);
+    return cb_launch_status();
+}
+
+int cbinfer_tail1x1(const float* input, const int32_t* changeList, int numChanges, const int32_t* countDev,
+                    const float* w1Prepared, const float* b1, const float* w2, const float* b2,
+                    float* output, int C0, int C1, int C2, int H, int W, int relu1, int relu2,
+                    cbStream_t stream) {
+    CB_REQUIRE(input && changeList && w1Prepared && b1 && w2 && b2 && output && C0 > 0 && C1 > 0 &&
+               C2 > 0 && H > 0 && W > 0 && numChanges >= 0);
+    if (C1 > 16 * CB_TAIL_MAXW) return CB_ERR_UNSUPPORTED;
+    if (numChanges == 0) return CB_OK;
+    const int C0P = (C0 + 15) / 16 * 16;
+    const int waves = (C1 + 15) / 16;
+    const size_t lds = ((size_t)C0P * CB_TAIL_PX + (size_t)waves * 16 * (CB_TAIL_PX + 1)) * 4;
+    if (lds > 60 * 1024) return CB_ERR_UNSUPPORTED;   // stays below the 64 KB that needs no opt-in
+    long tiles = ((long)numChanges + CB_TAIL_PX - 1) / CB_TAIL_PX;
+    if (tiles > 2048) tiles = 2048;   // grid-stride beyond: the capacity is H*W when the count is on the device
+    hipLaunchKernelGGL(cb_tail1x1_kernel, dim3((unsigned)tiles), dim3(64 * waves), lds, (hipStream_t)stream,
+                       input, changeList, numChanges, countDev, w1Prepared, b1, w2, b2, output, C0, C0P, C1,
+                       C2, H * W, relu1, relu2);
+    return cb_launch_status();
+}
+
+}  // extern "C"

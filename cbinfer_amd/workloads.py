@@ -176,6 +176,18 @@ def _seq(spec, relu_after_last):
     return nn.Sequential(*layers)
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+    """One side stream per device for the forked branches (kept out of the module: streams do not pickle
+    and belong to a device, not to a model)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device)
+    return _side_streams[key]
+
+
 class OpenPoseModel(nn.Module):
     """Feature extractor `model0` + per stage t two branches `model{t}_1` (38 PAF maps) and
     `model{t}_2` (19 confidence maps); stages t >= 2 see cat(branch1, branch2, features) = 185
@@ -186,7 +198,6 @@ class OpenPoseModel(nn.Module):
         # the two branches of a stage are independent: with concurrentBranches they are enqueued on two
         # HIP streams (fork/join per stage), so that their per-launch fixed costs overlap
         self.concurrentBranches = concurrentBranches
-        self._side = None
         state = torch.random.get_rng_state()
         torch.manual_seed(seed)
         self.T = T
@@ -201,16 +212,15 @@ class OpenPoseModel(nn.Module):
         feat = self.model0(x)
         cur = feat
         fork = getattr(self, 'concurrentBranches', False) and cur.is_cuda
-        if fork and self._side is None:
-            self._side = torch.cuda.Stream()
+        side = _side_stream(cur.device) if fork else None
         for t in range(1, self.T + 1):
             if fork:
-                main = torch.cuda.current_stream()
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
+                main = torch.cuda.current_stream(cur.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
                     outS = getattr(self, 'model%d_2' % t)(cur)
                 outL = getattr(self, 'model%d_1' % t)(cur)
-                main.wait_stream(self._side)
+                main.wait_stream(side)
             else:
                 outL = getattr(self, 'model%d_1' % t)(cur)
                 outS = getattr(self, 'model%d_2' % t)(cur)

@@ -42,7 +42,7 @@ typedef void* cbStream_t; /* hipStream_t */
 #define CB_ERR_BADARG (-1)      /* null pointer, non-positive size, unsupported dtype */
 #define CB_ERR_UNSUPPORTED (-2) /* shape outside what the kernels implement (e.g. kWHalf > 63) */
 
-#define CBINFER_ABI_VERSION 1
+#define CBINFER_ABI_VERSION 2
 
 int cbinfer_abi_version(void);
 const char* cbinfer_status_string(int status);
@@ -52,9 +52,11 @@ const char* cbinfer_status_string(int status);
  * rows padded to whole words.  Returns words per row / total words for an H x W map. */
 int cbinfer_mask_words_per_row(int W);
 long cbinfer_mask_words(int H, int W);
-/* Padded sizes of the prepared weight matrix (see cbinfer_prep_weights). */
+/* Padded sizes of the prepared weight matrix (see cbinfer_prep_weights); the k-depth padding depends on
+ * the dtype (fp32: whole 32-deep stages, fp16: stage pairs of 2 x 64).  Size buffers with
+ * cbinfer_prepared_weights_bytes. */
 int cbinfer_weights_kpad(int K);
-int cbinfer_weights_ckkpad(int Ckk);
+int cbinfer_weights_ckkpad(int Ckk, int dtype);
 
 /* ---- a1: change detection + dilation (+ feedback state update) ------------------------------
  * replaces changeDetection, conv2d_cg.py:100-122 -> cbconv2d_cg_backend.cu:83-100 (kernels :6-81),
@@ -218,6 +220,49 @@ int cbinfer_change_detection_fg(const float* input, const float* prevInput, floa
 int cbinfer_update_output_fg(const float* diffs, const float* weight, float* output,
                              const int64_t* changeCoords, int K, int C, int H, int W, int kH, int kW,
                              long numChanges, cbStream_t stream);
+/* a11 + a12 without the host round trip: the same scatter driven by an int32 coordinate list with a
+ * device-side length, as cbinfer_change_indexes_extr produces it from the per-value change map (replaces
+ * torch.nonzero, conv2d_fg.py:82, and its int64 list).  capacity: number of entries the grid may assume. */
+int cbinfer_update_output_fg_list(const float* diffs, const float* weight, float* output,
+                                  const int32_t* changeCoords, long capacity, const int32_t* countDev,
+                                  int K, int C, int H, int W, int kH, int kW, cbStream_t stream);
+
+/* ---- a14 (fine-grained) in one call: CBConv2d.forward_fg (conv2d.py:160-176) for the frames after the
+ * first, enqueued without a host sync, atomics or coordinate list.
+ *   cbinfer_change_detection_fg_frame: delta[c,p] = |in - prev| > th ? in - prev : 0 for EVERY value
+ *     (dense fp32 [C,H,W] workspace); pixels with a changed value, dilated by the filter support, are ORed
+ *     into the frame mask (layout of cbinfer_change_detection_frame); refreshState=1 also stores
+ *     prev <- in wherever they differ (the reference's `prevInput = input`, conv2d.py:175, in place);
+ *   cbinfer_conv_accumulate_from_mask: output += conv(weights, delta) at the masked pixels (same fused
+ *     gather/MFMA kernel as cbinfer_conv_changed_from_mask, accumulating epilogue, no bias), and
+ *     reluOut = relu(output) there if reluOut is non-NULL (conv2d.py:172-174);
+ *   cbinfer_cbconv2d_forward_fg: both.  Deterministic.  fp32 only, like the reference's FG path. */
+int cbinfer_change_detection_fg_frame(const float* input, float* prevInput, float* delta,
+                                      uint64_t* frameMasks, int W, int H, int C, int kHHalf, int kWHalf,
+                                      float threshold, int refreshState, cbStream_t stream);
+int cbinfer_conv_accumulate_from_mask(const float* delta, uint64_t* frameMasks, int32_t* idxOut,
+                                      int32_t* countOut, const void* weightsPrepared, float* output,
+                                      float* reluOut, int C, int H, int W, int K, int kH, int kW,
+                                      void* workspace, cbStream_t stream);
+int cbinfer_cbconv2d_forward_fg(const float* input, float* prevInput, float* delta, float* prevOutput,
+                                float* reluOut, uint64_t* frameMasks, int32_t* idx, int32_t* countDev,
+                                const void* weightsPrepared, int C, int H, int W, int K, int kH, int kW,
+                                float threshold, int refreshState, void* workspace, cbStream_t stream);
+
+/* ---- change-based 1x1 tail: conv1x1 -> [ReLU] -> conv1x1 at the changed pixels of the producing layer,
+ * one launch.  Replaces two CBConv2d fed by propagated change indexes (sceneLabeling/modelLoader.py:41-44,
+ * experiment 1) or the dense baseline modules 8..10 the other experiments keep (:45-47): a 1x1 layer's
+ * output changes only where its input did.  output [C2,H,W] keeps every other pixel.  fp32.
+ *   w1Prepared: w1 [C1,C0] re-laid out by cbinfer_tail1x1_prep (cbinfer_tail1x1_prepared_bytes bytes);
+ *   C1 <= cbinfer_tail1x1_max_hidden(); w2 is the plain [C2,C1] matrix. */
+int cbinfer_tail1x1_max_hidden(void);
+long cbinfer_tail1x1_prepared_bytes(int C1, int C0);
+int cbinfer_tail1x1_prep(const float* w1, float* w1Prepared, int C1, int C0, cbStream_t stream);
+int cbinfer_tail1x1(const float* input, const int32_t* changeList, int numChanges, const int32_t* countDev,
+                    const float* w1Prepared, const float* b1, const float* w2, const float* b2,
+                    float* output, int C0, int C1, int C2, int H, int W, int relu1, int relu2,
+                    cbStream_t stream);
+
 /* replaces conv2d_fg_cpu, cbconv2d_fg_backend.cu:81-112: HOST pointers, host code, race-free. */
 void cbinfer_conv2d_fg_cpu(const float* input, const float* prevInput, float* output,
                            const float* weight, float threshold, int no, int ni, int h, int w,

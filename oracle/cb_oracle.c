@@ -92,10 +92,27 @@ void orc_changePropagation(const int8_t* in, int8_t* out, int width, int height,
 /* changeIndexesExtr: conv2d_cg.py:200-209, torch.nonzero(map.view(-1)).int() -- ascending flat
  * indices y*W+x of the non-zero map entries.  Returns N. */
 int orc_changeIndexesExtr(const int8_t* changeMap, long numel, int32_t* idx) {
-    int n = 0;
-    for (long p = 0; p < numel; ++p)
-        if (changeMap[p]) idx[n++] = (int32_t)p;
-    return n;
+    /* chunked two-pass form (count per chunk, exclusive prefix, ordered write): the result is the
+     * sequential scan's, the chunks only let the host cores share the work when this port is timed as
+     * the CPU baseline */
+    enum { CHUNKS = 256 };
+    long cnt[CHUNKS + 1];
+    const long per = (numel + CHUNKS - 1) / CHUNKS;
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < CHUNKS; ++c) {
+        long lo = c * per, hi = lo + per < numel ? lo + per : numel, n = 0;
+        for (long p = lo; p < hi; ++p) n += changeMap[p] != 0;
+        cnt[c + 1] = n;
+    }
+    cnt[0] = 0;
+    for (int c = 0; c < CHUNKS; ++c) cnt[c + 1] += cnt[c];
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < CHUNKS; ++c) {
+        long lo = c * per, hi = lo + per < numel ? lo + per : numel, n = cnt[c];
+        for (long p = lo; p < hi; ++p)
+            if (changeMap[p]) idx[n++] = (int32_t)p;
+    }
+    return (int)cnt[CHUNKS];
 }
 
 /* genXMatrix: cbconv2d_cg_backend.cu:138-161; python twin conv2d_cg.py:263-281.
@@ -164,12 +181,15 @@ void orc_updateOutput(const float* Yt, float* output, const int32_t* changeList,
 void orc_maxPool2d(const float* input, float* output, const int32_t* changeIndexes, int numChanges,
                    int numCh, int iheight, int iwidth, int oheight, int owidth, int stridey,
                    int stridex, int guardOutput) {
-    for (int t = 0; t < numChanges; ++t) {
-        int pxIdx = changeIndexes[t];
-        int y = pxIdx / iwidth, x = pxIdx % iwidth;
-        int yo = y / stridey, xo = x / stridex;
-        if (guardOutput && (yo >= oheight || xo >= owidth)) continue;
-        for (int ch = 0; ch < numCh; ++ch) {
+    /* channel planes are disjoint, so the host cores share them; within a plane the list is walked in
+     * order, exactly as a single thread of the reference's grid would */
+#pragma omp parallel for schedule(static)
+    for (int ch = 0; ch < numCh; ++ch)
+        for (int t = 0; t < numChanges; ++t) {
+            int pxIdx = changeIndexes[t];
+            int y = pxIdx / iwidth, x = pxIdx % iwidth;
+            int yo = y / stridey, xo = x / stridex;
+            if (guardOutput && (yo >= oheight || xo >= owidth)) continue;
             float v = -INFINITY;
             for (int j = 0; j < stridey; ++j)
                 for (int i = 0; i < stridex; ++i) {
@@ -179,7 +199,6 @@ void orc_maxPool2d(const float* input, float* output, const int32_t* changeIndex
                 }
             output[((long)ch * oheight + yo) * owidth + xo] = v;
         }
-    }
 }
 
 /* changeDetectionFG: cbconv2d_fg_backend.cu:7-23.  Per value: d = in - prev; pred = |d| > th;

@@ -1,8 +1,9 @@
 """cb_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
 numpy front-end of the plain-C CPU restatement (oracle/cb_oracle.c) of CBinfer's change-based
-convolution path, plus numpy restatements of the fp16 change predicate and of the module-level state
-machines (CBConv2d.forward_normal / forward_fg, CBPoolMax2d.forward).
+convolution path, plus numpy restatements of the cg_half backend's ops, of the operation-count
+statistics (compStats) and of the module-level state machines (CBConv2d.forward_normal / forward_fg,
+CBPoolMax2d.forward) in fp32 and fp16 (OracleCBConv2dHalf / OracleCBPoolMax2dHalf).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  The
 product package never does.  Parity status: PINNED (see the header of cb_oracle.c).
@@ -377,3 +378,156 @@ class OracleSequential:
     def clearMemory(self):
         for l in self.layers:
             l.clearMemory()
+
+
+# ----------------------------------------------------------------------------------------------
+# a17: operation-count statistics (conv2d.py:201-218), restated in numpy
+# ----------------------------------------------------------------------------------------------
+def compStats(inp, prevInput, weightShape, threshold):
+    """The five operation counts CBConv2d gathers when gatherComputationStats is set.  `proped` is a
+    VALID (unpadded) grouped convolution of the per-value change tensor with a ones filter
+    (conv2d.py:205-209: F.conv2d without a padding argument), i.e. a sliding-window OR over
+    (H-kH+1) x (W-kW+1) positions."""
+    x, p = np.asarray(inp, dtype=np.float32), np.asarray(prevInput, dtype=np.float32)
+    K, C, kH, kW = weightShape
+    with np.errstate(invalid='ignore'):
+        changeTensor = np.abs(x - p) > np.float32(threshold)          # [1,C,H,W], strict (torch .gt)
+    H, W = changeTensor.shape[-2:]
+    win = np.lib.stride_tricks.sliding_window_view(changeTensor[0], (kH, kW), axis=(1, 2))
+    proped = win.any(axis=(-1, -2))                                    # [C, H-kH+1, W-kW+1]
+    opsPerValue = K * kH * kW * 2
+    return dict(
+        numInputChangesPerFeatureMap=int(changeTensor.sum()) * opsPerValue,
+        numInputChanges=int(changeTensor[0].any(axis=0).sum()) * C * opsPerValue,
+        numInputPropedChangesPerFeatureMap=int(proped.sum()) * opsPerValue,
+        numInputPropedChanges=int(proped.any(axis=0).sum()) * C * opsPerValue,
+        totalInputValues=W * H * C * opsPerValue)
+
+
+# ----------------------------------------------------------------------------------------------
+# cg_half path: module state machine on float16 arrays (cbconv2d_cg_half_backend.cu + conv2d.py)
+# ----------------------------------------------------------------------------------------------
+def genXMatrix_half(inp, changeIndexes, filtSize):
+    """cbconv2d_cg_half_backend.cu:146-169 (pure data movement, zero outside the image)."""
+    assert inp.dtype == np.float16
+    _, C, H, W = inp.shape
+    kH, kW = filtSize
+    ph, pw = (kH - 1) // 2, (kW - 1) // 2
+    pad = np.zeros((C, H + kH - 1, W + kW - 1), dtype=np.float16)
+    pad[:, ph:ph + H, pw:pw + W] = inp[0]
+    win = np.lib.stride_tricks.sliding_window_view(pad, (kH, kW), axis=(1, 2))   # [C,H,W,kH,kW]
+    idx = np.asarray(changeIndexes, dtype=np.int64)
+    X = win[:, idx // W, idx % W]                                     # [C,N,kH,kW]
+    return np.ascontiguousarray(X.transpose(1, 0, 2, 3)).reshape(idx.size, C * kH * kW)
+
+
+def matrixMult_half(X, weight, bias):
+    """conv2d_cg.py:342-349 on half tensors: fp16 operands; the products and the sum are formed
+    exactly (float64) and rounded to fp16 ONCE, bias included.  (torch's hgemm + add_ would round the
+    product sum and the biased sum separately; the accumulation precision of the reference's cuBLAS
+    hgemm is unpinned, SURVEY 7 'fp16 parity' -- this is the tightest statement both satisfy within
+    the 2-ulp bar of DESIGN.md 6.)"""
+    assert X.dtype == np.float16 and weight.dtype == np.float16 and bias.dtype == np.float16
+    K = weight.shape[0]
+    Y = X.astype(np.float64) @ weight.reshape(K, -1).astype(np.float64).T + bias.astype(np.float64)
+    return Y.astype(np.float16)
+
+
+def updateOutput_half(Yt, changeIndexes, prevOutput, withReLU=False):
+    """cbconv2d_cg_half_backend.cu:183-197: v = relu && __hle(v, 0) ? 0 : v."""
+    assert Yt.dtype == np.float16 and prevOutput.dtype == np.float16
+    idx = np.asarray(changeIndexes, dtype=np.int64)
+    K, H, W = prevOutput.shape[-3:]
+    v = np.where(Yt <= np.float16(0), np.float16(0), Yt) if withReLU else Yt
+    prevOutput.reshape(K, H * W)[:, idx] = v
+    return prevOutput
+
+
+def maxPool2d_half(inp, outputState, changeIndexes):
+    """cbconv2d_cg_half_backend.cu:207-237 with the yo<oh / xo<ow guard (see maxPool2d)."""
+    assert inp.dtype == np.float16 and outputState.dtype == np.float16
+    C, H, W = inp.shape[-3:]
+    oh, ow = outputState.shape[-2:]
+    idx = np.asarray(changeIndexes, dtype=np.int64)
+    yo, xo = (idx // W) // 2, (idx % W) // 2
+    keep = (yo < oh) & (xo < ow)
+    yo, xo = yo[keep], xo[keep]
+    v = np.full((C, yo.size), -np.inf, dtype=np.float16)
+    for j in range(2):
+        for i in range(2):
+            yi, xi = yo * 2 + j, xo * 2 + i
+            ok = (yi < H) & (xi < W)
+            val = np.where(ok[None, :], inp[0][:, np.minimum(yi, H - 1), np.minimum(xi, W - 1)],
+                           np.float16(-np.inf))
+            v = np.where(val > v, val, v)                             # __hgt: a NaN is never taken
+    outputState[0][:, yo, xo] = v
+    return outputState
+
+
+class OracleCBConv2dHalf(OracleCBConv2d):
+    """CBConv2d.forward_normal (conv2d.py:178-259) on float16 arrays through the half backend's ops."""
+
+    def __init__(self, weight, bias, threshold, **kw):
+        assert not kw.get('finegrained', False), "the fine-grained path is fp32 only (conv2d_fg.py)"
+        super().__init__(np.zeros(weight.shape, np.float32), np.zeros(bias.shape, np.float32),
+                         threshold, **kw)
+        self.weight = np.ascontiguousarray(weight, dtype=np.float16)
+        self.bias = np.ascontiguousarray(bias, dtype=np.float16)
+        self.clearMemory()
+
+    def clearMemory(self):
+        self.prevInput = np.zeros((0,), np.float16)
+        self.prevOutput = np.zeros((0,), np.float16)
+        self.changeMap = None
+        self.changeIndexes = None
+
+    def forward(self, inp):
+        changeIndexes = None
+        if isinstance(inp, tuple):
+            assert inp[0] == 'changeIndexes'
+            x, changeIndexes = inp[1], np.asarray(inp[2], dtype=np.int32)
+        else:
+            x = inp
+        assert x.dtype == np.float16
+        x = np.ascontiguousarray(x)
+        K = self.weight.shape[0]
+        if self.prevInput.shape != x.shape:
+            self.prevInput = np.full(x.shape, np.inf, np.float16)
+        oshape = (1, K) + x.shape[2:]
+        if self.prevOutput.shape != oshape:
+            self.prevOutput = np.full(oshape, np.inf, np.float16)
+        if changeIndexes is None:
+            self.changeMap = changeDetection_half(x, self.prevInput, self.kernel_size, self.threshold,
+                                                  updateInputState=self.feedbackLoop)
+            changeIndexes = changeIndexesExtr(self.changeMap)
+        if not self.feedbackLoop:
+            self.prevInput = x.copy() if self.copyInput else x
+        self.changeIndexes = changeIndexes
+        if changeIndexes.size:
+            X = genXMatrix_half(self.prevInput, changeIndexes, self.kernel_size)
+            Y = matrixMult_half(X, self.weight, self.bias)
+            updateOutput_half(np.ascontiguousarray(Y.T), changeIndexes, self.prevOutput,
+                              withReLU=self.withReLU)
+        if self.propChangeIndexes:
+            return ('changeIndexes', self.prevOutput, changeIndexes)
+        return self.prevOutput
+
+
+class OracleCBPoolMax2dHalf(OracleCBPoolMax2d):
+    def clearMemory(self):
+        self.outputState = np.zeros((0,), np.float16)
+
+    def forward(self, inp):
+        assert isinstance(inp, tuple) and inp[0] == 'changeIndexes'
+        x, idx = np.ascontiguousarray(inp[1]), np.asarray(inp[2], dtype=np.int32)
+        assert x.dtype == np.float16
+        if idx.size:
+            _, C, H, W = x.shape
+            oh, ow = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if self.ceil_mode else (H // 2, W // 2)
+            if self.outputState.shape != (1, C, oh, ow):
+                self.outputState = np.full((1, C, oh, ow), np.inf, np.float16)
+            maxPool2d_half(x, self.outputState, idx)
+        out = self.outputState.copy()
+        if self.propChangeIndexes:
+            return ('changeIndexes', out, idx)
+        return out

@@ -586,3 +586,350 @@ def test_fuzz_shapes_track_dense(pkg, dtype):
                     got = ChangeIndexes(cbm._work['idx'], cbm._work['count']).tensor()
                     expect = cg.changeIndexesExtr(cg.changePropagation(changed.to(torch.int8), (kH, kW)))
                     assert torch.equal(got, expect), (C, K, kH, kW, H, W, t)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 2: fp16 oracle twin, full-size configs 3/4, execution-level fusions, shipped-but-unexercised
+# ------------------------------------------------------------------------------------------------
+def build_oracle_twin_half(oracle, test_model, pkg):
+    layers = []
+    for m in test_model.children():
+        if type(m) is pkg.CBConv2d:
+            layers.append(oracle.OracleCBConv2dHalf(
+                m.weight.detach().cpu().numpy(), m.bias.detach().cpu().numpy(), m.threshold,
+                withReLU=m.withReLU, feedbackLoop=m.feedbackLoop, propChangeIndexes=m.propChangeIndexes,
+                copyInput=m.copyInput))
+        elif type(m) is pkg.CBPoolMax2d:
+            layers.append(oracle.OracleCBPoolMax2dHalf(ceil_mode=m.ceil_mode,
+                                                       propChangeIndexes=m.propChangeIndexes))
+        else:
+            layers.append(None)        # dense torch module: not part of the cg_half path
+    return layers
+
+
+@pytest.mark.parametrize("experiment", [1, 2, 4, 6])
+@pytest.mark.parametrize("sync", [False, True])
+def test_half_experiment_presets_vs_oracle(pkg, oracle, experiment, sync):
+    """The cg_half MODULE path against its oracle twin (OracleCBConv2dHalf: fp16 operands, exact products
+    and sum, one rounding -- cbconv2d_cg_half_backend.cu + conv2d_cg.py:342-349), teacher-forced layer by
+    layer like the fp32 preset test: masks and index lists bit-exact, states within 2 fp16 ulp of the
+    largest output of the layer (DESIGN.md section 6's fp16 bar)."""
+    from cbinfer_amd import workloads
+    spec = dict(convs=[(3, 8, 7), (8, 12, 7), (12, 20, 3), (20, 12, 1), (12, 5, 1)], pools_after=(0, 1))
+    base = workloads.sceneLabelingBaseline(spec, seed=3).cuda().half()
+    test = workloads.configureExperiment(base, pkg.convert(base, threshold=0.03), experiment).cuda()
+    pkg.setSyncIndexes(test, sync)
+    for m in test.modules():
+        if type(m) is pkg.CBConv2d:
+            m.saveChangeMap = True
+    twin = build_oracle_twin_half(oracle, test, pkg)
+    vid = workloads.SyntheticVideo(H=48, W=64, ratio=0.125, block=8, seed=5, dtype=torch.float16)
+    checked = 0
+    with torch.no_grad():
+        for t, frame in enumerate(vid.frames(4)):
+            x = frame
+            for m, o in zip(test.children(), twin):
+                x_in = _to_np(x)
+                x = m(x.clone() if isinstance(x, torch.Tensor) else x)
+                if o is None:
+                    continue
+                y_o = o.forward(x_in)
+                got = _to_np(x)
+                if isinstance(got, tuple):
+                    assert np.array_equal(got[2], y_o[2]), (experiment, t, type(m).__name__)
+                    got, y_o = got[1], y_o[1]
+                if type(m) is pkg.CBConv2d and not isinstance(x_in, tuple):
+                    assert np.array_equal(m.changeMap.cpu().numpy(), o.changeMap), (experiment, t)
+                assert got.dtype == np.float16
+                if type(m) is pkg.CBPoolMax2d:
+                    assert np.array_equal(got, y_o)
+                else:
+                    tol = 2 * 2.0 ** -10 * max(1.0, float(np.abs(y_o.astype(np.float32)).max()))
+                    np.testing.assert_allclose(got.astype(np.float32), y_o.astype(np.float32), rtol=0, atol=tol)
+                checked += 1
+    assert checked >= 4 * 3
+
+
+def test_openpose_fullsize_half_threshold_zero(pkg):
+    """BASELINE config 4 at its real size: OpenPose T=2 (poseDetection/openPose/PoseModel.py:34-68,122-137),
+    368x654, fp16, all 36 convs converted per sub-model (poseDetection/modelConverter.py:20-24).  The
+    368 x 11-word change mask (4048 words) sits just under the self-compacting kernel's limit, Ckk reaches
+    9065 (185*49) and the 327-wide map is floor-pooled to 163.  Size-independent property: with threshold 0
+    every change is detected, so after several frames the network must equal a fresh evaluation of the
+    last frame (same kernels, all-changed) within fp16 accumulation-order noise and track the dense fp16
+    torch network within the bar of test_openpose_half's first frame; a repeated frame leaves all 36
+    change lists empty and the outputs bit-identical."""
+    from cbinfer_amd import workloads
+    from cbinfer_amd.conv2d_cg import ChangeIndexes
+    H, W = 368, 654
+    test = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, seed=2).cuda().half(), threshold=0.0)
+    fresh = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, seed=2).cuda().half(), threshold=0.0)
+    dense = workloads.OpenPoseModel(T=2, seed=2).cuda().half()
+    cbs = [m for m in test.modules() if type(m) is pkg.CBConv2d]
+    assert len(cbs) == 36
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    frame = (torch.rand(1, 3, H, W, generator=gen) * (255.0 / 256.0) - 0.5)
+    frames = [frame]
+    for t in range(3):              # re-draw 16 blocks of 46 x 109 pixels (~20 % of the frame) per frame
+        f = frames[-1].clone()
+        for _ in range(16):
+            y0 = int(torch.randint(0, H - 46, (1,), generator=gen))
+            x0 = int(torch.randint(0, W - 109, (1,), generator=gen))
+            f[:, :, y0:y0 + 46, x0:x0 + 109] = torch.rand(1, 3, 46, 109, generator=gen) * (255.0 / 256.0) - 0.5
+        frames.append(f)
+    frames = [f.cuda().half() for f in frames]
+    with torch.no_grad():
+        for f in frames:
+            L, S = test(f)
+        assert L.shape == (1, 38, 46, 81) and S.shape == (1, 19, 46, 81)
+        Lf, Sf = fresh(frames[-1])
+        Ld, Sd = dense(frames[-1])
+        scale = max(Ld.float().abs().max().item(), Sd.float().abs().max().item(), 1e-3)
+        err_fresh = max((L.float() - Lf.float()).abs().max().item(), (S.float() - Sf.float()).abs().max().item())
+        err_dense = max((L.float() - Ld.float()).abs().max().item(), (S.float() - Sd.float()).abs().max().item())
+        print("openpose 368x654 fp16: scale %.4g, vs fresh CB %.3g, vs dense torch %.3g" % (scale, err_fresh, err_dense))
+        assert err_fresh <= 0.01 * scale, (err_fresh, scale)
+        assert err_dense <= 0.02 * scale, (err_dense, scale)
+        # something must actually have been change-based: frame 3 touched far fewer pixels than frame 0 did
+        n1 = ChangeIndexes(cbs[0]._work['idx'], cbs[0]._work['count']).numel()
+        assert 0 < n1 < 0.6 * H * W
+        L2, S2 = test(frames[-1].clone())
+        assert torch.equal(L, L2) and torch.equal(S, S2)
+        for m in cbs:
+            assert ChangeIndexes(m._work['idx'], m._work['count']).numel() == 0
+
+
+@pytest.mark.parametrize("form", ["default", "inplace", "atomic"])
+def test_fg_fullsize_threshold_zero_tracks_dense(pkg, form):
+    """BASELINE config 3 at its real size (experiment 7: fine-grained CBConv2d, 480x320): with threshold 0
+    every changed VALUE is propagated, so after several frames the network equals the dense network on the
+    last frame (<= 1e-4 absolute... the deltas add up over frames, so the bar is 5e-4 on O(1) outputs), in
+    every execution form of the fine-grained frame."""
+    from cbinfer_amd import workloads
+    base, test = workloads.sceneLabelingModels(experimentIdx=7, threshold=0.0, seed=3)
+    for m in test.modules():
+        if type(m) is pkg.CBConv2d:
+            assert m.finegrained
+            m.fgInPlace = form == "inplace"
+            m.atomicFG = form == "atomic"
+    vid = workloads.SyntheticVideo(H=320, W=480, ratio=0.05 if form == "atomic" else 0.10, block=32, seed=21)
+    with torch.no_grad():
+        for f in vid.frames(4):
+            y = test(f.clone())
+        ref = base(vid.frame)
+        err = (y - ref).abs().max().item()
+        assert err <= 5e-4, err
+        y2 = test(vid.frame.clone()).clone()
+        assert torch.equal(y, y2)
+
+
+def test_fg_execution_forms_vs_oracle(pkg, oracle):
+    """Experiment 7 against the oracle state machine, teacher-forced per layer, in the three execution
+    forms (default fused, in-place, reference-structured atomics): outputs <= 1e-4, and the in-place form
+    really hands out its own state tensors while the default form hands out fresh ones."""
+    from cbinfer_amd import workloads
+    spec = dict(convs=[(3, 8, 7), (8, 12, 7), (12, 20, 7), (20, 12, 1), (12, 5, 1)], pools_after=(0, 1))
+    for form in ("default", "inplace", "atomic"):
+        base = workloads.sceneLabelingBaseline(spec, seed=3).cuda()
+        test = workloads.configureExperiment(base, pkg.convert(base, threshold=0.03), 7).cuda()
+        cbs = [m for m in test.modules() if type(m) is pkg.CBConv2d]
+        for m in cbs:
+            m.fgInPlace = form == "inplace"
+            m.atomicFG = form == "atomic"
+        twin = build_oracle_twin(oracle, test, pkg)
+        vid = workloads.SyntheticVideo(H=48, W=64, ratio=0.125, block=8, seed=5)
+        outs = []
+        with torch.no_grad():
+            for t, frame in enumerate(vid.frames(4)):
+                x = frame.clone()
+                for m, o in zip(test.children(), twin):
+                    x_in = x.cpu().numpy()
+                    x = m(x)
+                    y_o = o.forward(x_in)
+                    np.testing.assert_allclose(x.cpu().numpy(), y_o, rtol=0, atol=FP32_TOL)
+                    if m is cbs[0]:
+                        outs.append(x)
+        same = outs[-1].data_ptr() == outs[-2].data_ptr()
+        assert same == (form == "inplace")
+        if form != "inplace":
+            assert cbs[0].prevInput.data_ptr() != cbs[0].prevOutput.data_ptr()
+
+
+def test_tail1x1_fusion_matches_unfused(pkg, oracle):
+    """pycbinfer.fuseTail1x1: experiment 6 with the dense 1x1 tail replaced by one change-based launch.
+    Same outputs as the unfused network (<= 1e-4) over a sequence, first frame included; structure:
+    the fused module takes the first 1x1 layer's name and shares the parameters."""
+    from cbinfer_amd import workloads
+    base, plain = workloads.sceneLabelingModels(experimentIdx=6, threshold=0.02, seed=4)
+    _, fused = workloads.sceneLabelingModels(experimentIdx=6, threshold=0.02, seed=4)
+    names_before = [n for n, _ in fused.named_children()]
+    pkg.fuseTail1x1(fused)
+    names = [n for n, _ in fused.named_children()]
+    assert names == names_before[:-2]
+    tail = list(fused.children())[-1]
+    assert type(tail) is pkg.CBTail1x1 and tail.weight1 is list(plain.children())[-3].weight is not None
+    assert list(fused.children())[-2].propChangeIndexes
+    pkg.fusePoolingIntoDetection(fused)
+    vid = workloads.SyntheticVideo(H=64, W=96, ratio=0.125, block=16, seed=9)
+    with torch.no_grad():
+        for f in vid.frames(5):
+            a, b = plain(f), fused(f)
+            assert (a - b).abs().max().item() <= FP32_TOL
+        ref = base(vid.frame)
+    assert (b - ref).abs().max().item() < 0.5
+    assert len(pkg.getStateTensors(fused)) == 2 * 3 + 2 + 1     # 3 convs, 2 pools, the tail
+    pkg.clearMemory(fused)
+    assert tail.prevOutput.numel() == 0
+    # graph capture of the fused network (7 launches per frame)
+    static_in = vid.frame.clone()
+    with torch.no_grad():
+        fused(static_in)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fused(static_in)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            out = fused(static_in)
+        nxt = vid.next()
+        static_in.copy_(nxt)
+        g.replay()
+        torch.cuda.synchronize()
+        plain(vid.frames(1)[0])
+        assert (out - plain(nxt)).abs().max().item() <= FP32_TOL
+
+
+def test_two_graphs_on_the_default_capture_stream_replay_concurrently(pkg):
+    """two models captured the natural way (torch.cuda.graph without stream=, i.e. torch's one
+    shared capture stream) used to share one split-K workspace keyed by that stream; replayed concurrently
+    on different streams they raced.  Each CBConv2d owns its workspace now: concurrent replays must
+    reproduce the stand-alone results bit for bit, and capturing allocates nothing."""
+    from cbinfer_amd import workloads
+    nets, vids, graphs, ins, outs = [], [], [], [], []
+    for q in range(2):
+        _, test = workloads.sceneLabelingModels(experimentIdx=4, threshold=0.02, seed=q)
+        vid = workloads.SyntheticVideo(H=80, W=120, ratio=0.10, block=8, seed=40 + q)
+        nets.append(test)
+        vids.append(vid.frames(6))
+    with torch.no_grad():
+        # stand-alone results, eager
+        expect = []
+        for test, fr in zip(nets, vids):
+            for f in fr:
+                y = test(f)
+            expect.append(y.clone())
+            pkg.clearMemory(test)
+        for test, fr in zip(nets, vids):
+            static = fr[0].clone()
+            test(static)
+            test(static)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):                  # default (shared) capture stream
+                out = test(static)
+            graphs.append(g)
+            ins.append(static)
+            outs.append(out)
+        ws = [m._work['conv'].data_ptr() for test in nets for m in test.modules() if type(m) is pkg.CBConv2d]
+        assert len(set(ws)) == len(ws)
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        torch.cuda.synchronize()
+        for t in range(1, 6):
+            for q in range(2):
+                with torch.cuda.stream(streams[q]):
+                    ins[q].copy_(vids[q][t])
+                    graphs[q].replay()
+        torch.cuda.synchronize()
+    for q in range(2):
+        assert torch.equal(outs[q], expect[q])
+
+
+def test_propagated_indexes_are_validated(pkg):
+    """a change list of another resolution (what CBPoolMax2d hands on by default, like the
+    reference, conv2d.py:80-83) or of another dtype must not reach the kernels."""
+    from cbinfer_amd._lib import CBinferError
+    from cbinfer_amd.conv2d_cg import ChangeIndexes
+    conv = pkg.CBConv2d(torch.nn.Conv2d(4, 6, 3, padding=1).cuda(), 0.1)
+    x = torch.rand(1, 4, 10, 12, device="cuda")
+    with torch.no_grad():
+        conv(x)
+        with pytest.raises(CBinferError):
+            conv(('changeIndexes', x, torch.arange(5, device="cuda")))                 # int64 list
+        foreign = ChangeIndexes(torch.zeros(480, dtype=torch.int32, device="cuda"),
+                                torch.zeros(1, dtype=torch.int32, device="cuda"), (20, 24))
+        with pytest.raises(CBinferError):
+            conv(('changeIndexes', x, foreign))
+        # an exact int32 list holding an out-of-map entry: the entry is dropped, nothing else is touched
+        before = conv.prevOutput.clone()
+        x2 = x.clone()
+        x2[:, :, 3, 4] += 1.0
+        conv.copyInput = True
+        lst = torch.tensor([3 * 12 + 4, 10 * 12 + 7], dtype=torch.int32, device="cuda")
+        y = conv(('changeIndexes', x2, lst)).clone()
+        ref = torch.nn.functional.conv2d(x2, conv.weight, conv.bias, padding=1)
+        assert (y[:, :, 3, 4] - ref[:, :, 3, 4]).abs().max().item() <= FP32_TOL
+        mask = torch.ones_like(y, dtype=torch.bool)
+        mask[:, :, 3, 4] = False
+        assert torch.equal(y[mask], before[mask])
+
+
+def test_compstats_vs_oracle(pkg, oracle):
+    """a17: gatherComputationStats (conv2d.py:201-218) against the oracle's numpy restatement, on the first
+    frame (state +inf: every value counts as changed) and on a changed frame; totalInputValues is the
+    dense op count the 'effective GOp/s' metric divides by."""
+    from cbinfer_amd import workloads
+    conv = torch.nn.Conv2d(5, 7, (3, 5), padding=(1, 2)).cuda()
+    cbm = pkg.CBConv2d(conv, 0.2)
+    cbm.gatherComputationStats = True
+    rng = np.random.default_rng(2)
+    x0 = rng.standard_normal((1, 5, 20, 31)).astype(np.float32)
+    x1 = x0.copy()
+    x1[0, 1, 4:9, 10:14] += 1.0
+    x1[0, 3, 15, 30] -= 0.5
+    x1[0, 0, 0, 0] += 0.1          # below the threshold
+    with torch.no_grad():
+        cbm(torch.from_numpy(x0).cuda())
+        first = {k: int(v) for k, v in cbm.compStats.items()}
+        assert first == oracle.compStats(x0, np.full_like(x0, np.inf), (7, 5, 3, 5), 0.2)
+        assert first["totalInputValues"] == 2 * 5 * 7 * 3 * 5 * 20 * 31
+        assert first["numInputChanges"] == first["totalInputValues"]
+        cbm(torch.from_numpy(x1).cuda())
+        second = {k: int(v) for k, v in cbm.compStats.items()}
+    assert second == oracle.compStats(x1, x0, (7, 5, 3, 5), 0.2)
+    assert second["numInputChangesPerFeatureMap"] == (20 + 1) * 7 * 3 * 5 * 2
+    # the bench's effective-GFLOP/s numerator is the sum of totalInputValues over the converted layers
+    _, test = workloads.sceneLabelingModels(experimentIdx=1, threshold=0.05)
+    for m in test.modules():
+        if type(m) is pkg.CBConv2d:
+            m.gatherComputationStats = True
+    with torch.no_grad():
+        test(torch.rand(1, 3, 32, 48, device="cuda"))
+    total = sum(int(m.compStats["totalInputValues"]) for m in test.modules() if type(m) is pkg.CBConv2d)
+    assert total == workloads.denseOps(workloads.SCENE_LABELING_SPEC, 32, 48)
+
+
+def test_power_logger_and_power_measurement(pkg):
+    """f3: evalTools.PowerLogger (amdgpu hwmon board power) and inferFramesetPowerMeasurement
+    (poseDetection/evalTools.py:54-83: back-and-forth extended frame list under a sampling thread)."""
+    from cbinfer_amd import evalTools, workloads
+    _, test = workloads.sceneLabelingModels(experimentIdx=4, threshold=0.02, seed=1)
+    vid = workloads.SyntheticVideo(H=64, W=96, ratio=0.125, block=16, seed=2)
+    frames = [f.cpu() for f in vid.frames(4)]
+    pl = evalTools.inferFramesetPowerMeasurement(test, frames, numFrames=400)
+    assert len(pl.samples) >= 2
+    times = [t for t, _ in pl.samples]
+    assert all(b >= a for a, b in zip(times[:-1], times[1:]))
+    energy = pl.getTotalEnergy()
+    assert energy >= 0.0 and np.isfinite(energy)
+    if pl.path is not None and os.access(pl.path, os.R_OK):
+        watts = pl.getAveragePower()
+        assert np.isfinite(watts) and 5.0 < watts < 2000.0, watts
+        assert energy > 0.0
+        partial = evalTools.PowerLogger()
+        partial.samples = pl.samples[:max(2, len(pl.samples) // 2)]
+        assert partial.getTotalEnergy() <= energy + 1e-9          # energy is monotone in time
+    else:
+        print("no readable amdgpu hwmon power sensor on this box: sampling thread exercised, values NaN")
+    pl.recordEvent("done")
+    assert pl.events and pl.events[-1][1] == "done"

@@ -367,3 +367,267 @@ def test_pool_change_indexes_vs_oracle(oracle, size):
         ci = cg.ChangeIndexes(buf.cuda(), torch.tensor([idx.numel()], dtype=torch.int32).cuda())
         got = cg.poolChangeIndexes(ci, (H, W), (oH, oW))
         assert got.tensor().cpu().numpy().tolist() == want.tolist()
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference-signature compat shims, executed on the GPU
+# ------------------------------------------------------------------------------------------------
+def _compat_case(dtype, seed=31):
+    rng = np.random.default_rng(seed)
+    C, H, W = 6, 37, 83
+    inp = rng.standard_normal((1, C, H, W)).astype(np.float32)
+    prev = inp.copy()
+    ys, xs = rng.integers(0, H, 40), rng.integers(0, W, 40)
+    prev[0, rng.integers(0, C, 40), ys, xs] += rng.choice([-1.0, 1.0], 40).astype(np.float32)
+    prev[0, 0, 0, 0] += 1.0
+    prev[0, C - 1, H - 1, W - 1] -= 1.0
+    return inp.astype(dtype), prev.astype(dtype)
+
+
+@pytest.mark.parametrize("symbol", ["changeDetection", "changePropagation", "genXMatrix", "updateOutput",
+                                    "maxPool2d"])
+def test_compat_cg_shim_matches_reference_kernels(oracle, symbol):
+    """cbinfer_amd/compat/cbconv2d_cg_backend_<machine>.so called with the reference's own argument lists
+    (conv2d_cg.py:6-38: six geometry ints, bool* map) must give what the reference's kernels give
+    (oracle/_ref, compiled from the reference's .cu) -- and what the oracle says when _ref is absent."""
+    import refgpu
+    so = refgpu.compat("cg")
+    ref = refgpu.available()
+    inp, prev = _compat_case(np.float32)
+    filt, th = (5, 3), 0.3
+    if symbol == "changeDetection":
+        for update in (False, True):
+            st = dev(prev)
+            cm = refgpu.changeDetection(dev(inp), st, filt, th, update, so=so)
+            st_o = prev.copy()
+            cm_o = oracle.changeDetection(inp, st_o, filt, th, updateInputState=update)
+            assert np.array_equal(cm.cpu().numpy(), cm_o) and np.array_equal(st.cpu().numpy(), st_o)
+            if ref:
+                st_r = dev(prev)
+                assert torch.equal(cm, refgpu.changeDetection(dev(inp), st_r, filt, th, update))
+                assert torch.equal(st, st_r)
+        return
+    cm_o = oracle.changeDetection(inp, prev.copy(), (1, 1), th)
+    if symbol == "changePropagation":
+        out = refgpu.changePropagation(dev(cm_o), filt, so=so)
+        assert np.array_equal(out.cpu().numpy(), oracle.changePropagation(cm_o, filt))
+        if ref:
+            assert torch.equal(out, refgpu.changePropagation(dev(cm_o), filt))
+        return
+    idx_o = oracle.changeIndexesExtr(oracle.changePropagation(cm_o, filt))
+    if symbol == "genXMatrix":
+        X = refgpu.genXMatrix(dev(inp), dev(idx_o), filt, so=so)
+        assert np.array_equal(X.cpu().numpy(), oracle.genXMatrix(inp, idx_o, filt))
+        if ref:
+            assert torch.equal(X, refgpu.genXMatrix(dev(inp), dev(idx_o), filt))
+    elif symbol == "updateOutput":
+        rng = np.random.default_rng(5)
+        K, (H, W) = 7, inp.shape[-2:]
+        Yt = rng.standard_normal((K, idx_o.size)).astype(np.float32)
+        base = rng.standard_normal((1, K, H, W)).astype(np.float32)
+        for relu in (False, True):
+            out = refgpu.updateOutput(dev(Yt), dev(idx_o), dev(base), relu, so=so)
+            assert np.array_equal(out.cpu().numpy(), oracle.updateOutput(Yt, idx_o, base.copy(), relu))
+            if ref:
+                assert torch.equal(out, refgpu.updateOutput(dev(Yt), dev(idx_o), dev(base), relu))
+    else:
+        C, H, W = inp.shape[-3:]
+        even = inp[:, :, :H - 1, :W - 1].copy()          # 36 x 82: the reference kernel has no output guard
+        idx_e = oracle.changeIndexesExtr((np.random.default_rng(6).random((H - 1, W - 1)) < 0.2).astype(np.int8))
+        base = np.full((1, C, (H - 1) // 2, (W - 1) // 2), np.inf, np.float32)
+        out = refgpu.maxPool2d(dev(even), dev(base), dev(idx_e), so=so)
+        assert np.array_equal(out.cpu().numpy(), oracle.maxPool2d(even, base.copy(), idx_e))
+        if ref:
+            assert torch.equal(out, refgpu.maxPool2d(dev(even), dev(base), dev(idx_e)))
+
+
+@pytest.mark.parametrize("symbol", ["changeDetection", "changePropagation", "genXMatrix", "updateOutput",
+                                    "maxPool2d"])
+def test_compat_cg_half_shim_matches_oracle(oracle, symbol):
+    """The half library of the reference reuses the float* header (conv2d_cg.py:46-50): same symbols on
+    fp16 buffers.  cbconv2d_cg_half_backend.cu cannot be built here, so the checker is the oracle's
+    restatement of it."""
+    import refgpu
+    so = refgpu.compat("cg_half")
+    inp, prev = _compat_case(np.float16)
+    filt, th = (3, 5), 0.3
+    if symbol == "changeDetection":
+        for update in (False, True):
+            st = dev(prev)
+            cm = refgpu.changeDetection(dev(inp), st, filt, th, update, so=so)
+            st_o = prev.copy()
+            cm_o = oracle.changeDetection_half(inp, st_o, filt, th, updateInputState=update)
+            assert np.array_equal(cm.cpu().numpy(), cm_o) and np.array_equal(st.cpu().numpy(), st_o)
+        return
+    cm_o = oracle.changeDetection_half(inp, prev.copy(), (1, 1), th)
+    if symbol == "changePropagation":
+        out = refgpu.changePropagation(dev(cm_o), filt, so=so)
+        assert np.array_equal(out.cpu().numpy(), oracle.changePropagation(cm_o, filt))
+        return
+    idx_o = oracle.changeIndexesExtr(oracle.changePropagation(cm_o, filt))
+    if symbol == "genXMatrix":
+        X = refgpu.genXMatrix(dev(inp), dev(idx_o), filt, so=so)
+        assert np.array_equal(X.cpu().numpy(), oracle.genXMatrix_half(inp, idx_o, filt))
+    elif symbol == "updateOutput":
+        rng = np.random.default_rng(5)
+        K, (H, W) = 7, inp.shape[-2:]
+        Yt = rng.standard_normal((K, idx_o.size)).astype(np.float16)
+        base = rng.standard_normal((1, K, H, W)).astype(np.float16)
+        for relu in (False, True):
+            out = refgpu.updateOutput(dev(Yt), dev(idx_o), dev(base), relu, so=so)
+            assert np.array_equal(out.cpu().numpy(), oracle.updateOutput_half(Yt, idx_o, base.copy(), relu))
+    else:
+        C, H, W = inp.shape[-3:]
+        idx_e = oracle.changeIndexesExtr((np.random.default_rng(6).random((H, W)) < 0.2).astype(np.int8))
+        base = np.full((1, C, H // 2, W // 2), np.inf, np.float16)
+        out = refgpu.maxPool2d(dev(inp), dev(base), dev(idx_e), so=so)      # odd sizes: guarded here
+        assert np.array_equal(out.cpu().numpy(), oracle.maxPool2d_half(inp, base.copy(), idx_e))
+
+
+@pytest.mark.parametrize("symbol", ["changeDetectionFG", "updateOutputFG", "conv2d_fg_cpu"])
+def test_compat_fg_shim_matches_reference_kernels(oracle, golden_dir, symbol):
+    """cbconv2d_fg_backend shim with the reference's argument lists (conv2d_fg.py:14-29: const long*
+    coordinates, geometry ints ignored)."""
+    import refgpu
+    so = refgpu.compat("fg")
+    ref = refgpu.available()
+    rng = np.random.default_rng(12)
+    inp = rng.standard_normal((1, 5, 23, 41)).astype(np.float32)
+    prev = inp + ((rng.random(inp.shape) < 0.05) * rng.standard_normal(inp.shape)).astype(np.float32)
+    w = (rng.standard_normal((9, 5, 3, 5)) * 0.1).astype(np.float32)
+    th = 0.15
+    d_o, cm_o = oracle.changeDetectionFG(inp, prev, th)
+    if symbol == "changeDetectionFG":
+        d, cm = refgpu.changeDetectionFG(dev(inp), dev(prev), th, so=so)
+        assert np.array_equal(cm.cpu().numpy(), cm_o)
+        assert np.array_equal(d.cpu().numpy()[cm_o != 0], d_o[cm_o != 0])
+        if ref:
+            d_r, cm_r = refgpu.changeDetectionFG(dev(inp), dev(prev), th)
+            assert torch.equal(cm, cm_r) and torch.equal(d[cm_r != 0], d_r[cm_r != 0])
+    elif symbol == "updateOutputFG":
+        coords = np.nonzero(cm_o.reshape(-1))[0].astype(np.int64).reshape(-1, 1)
+        po = oracle.conv2d_dense(prev, w, None)
+        out = refgpu.updateOutputFG(dev(d_o), dev(w), dev(po), dev(coords), so=so)
+        np.testing.assert_allclose(out.cpu().numpy(), oracle.updateOutputFG(d_o, w, po.copy(), coords),
+                                   rtol=0, atol=FP32_TOL)
+        if ref:
+            out_r = refgpu.updateOutputFG(dev(d_o), dev(w), dev(po), dev(coords))
+            np.testing.assert_allclose(out.cpu().numpy(), out_r.cpu().numpy(), rtol=0, atol=FP32_TOL)
+    else:
+        d = dict(np.load(os.path.join(golden_dir, "fg_case1.npz")))
+        out = torch.from_numpy(d["prevOutput"].copy())
+        refgpu.conv2d_fg_cpu(torch.from_numpy(d["input"]), torch.from_numpy(d["prevInput"]), out,
+                             torch.from_numpy(d["weight"]), float(d["threshold"]), so=so)
+        np.testing.assert_allclose(out.numpy(), d["output"], rtol=0, atol=1e-5)
+
+
+def test_fg_coordinate_extraction_and_list_scatter(cb, oracle):
+    """a11: per-value coordinate extraction on the device (ascending int32 list + device count) equals
+    numpy.nonzero of the oracle's change tensor, and the scatter driven by it (no host sync) equals the
+    int64-list form and the oracle."""
+    _, _, fg = cb
+    rng = np.random.default_rng(19)
+    inp = rng.standard_normal((1, 16, 40, 60)).astype(np.float32)
+    prev = inp + ((rng.random(inp.shape) < 0.04) * rng.standard_normal(inp.shape)).astype(np.float32)
+    w = (rng.standard_normal((24, 16, 7, 7)) * 0.05).astype(np.float32)
+    th = 0.2
+    diffs, cm = fg.changeDetectionFG(dev(inp), dev(prev), th)
+    d_o, cm_o = oracle.changeDetectionFG(inp, prev, th)
+    coords = fg.changeCoordsExtrFG(cm)
+    expect = np.nonzero(cm_o.reshape(-1))[0]
+    assert coords.buffer.dtype == torch.int32
+    assert np.array_equal(coords.tensor().cpu().numpy(), expect.astype(np.int32))
+    po = oracle.conv2d_dense(prev, w, None)
+    out_list = fg.updateOutputFG(diffs, dev(w), dev(po), coords)
+    out_o = oracle.updateOutputFG(d_o, w, po.copy(), expect.astype(np.int64))
+    np.testing.assert_allclose(out_list.cpu().numpy(), out_o, rtol=0, atol=FP32_TOL)
+    # empty change set: nothing is touched
+    d0, cm0 = fg.changeDetectionFG(dev(inp), dev(inp), th)
+    c0 = fg.changeCoordsExtrFG(cm0)
+    assert c0.numel() == 0
+    out0 = fg.updateOutputFG(d0, dev(w), dev(po), c0)
+    assert np.array_equal(out0.cpu().numpy(), po)
+
+
+def test_fg_frame_kernels_vs_oracle(cb, oracle):
+    """cbinfer_cbconv2d_forward_fg (per-value detection + accumulating self-compacting contraction) against
+    the oracle's forward_fg arithmetic: delta tensor and touched-pixel list bit-exact, output <= 1e-4,
+    the relu'd copy consistent, prevInput refreshed exactly where input and state differ."""
+    from cbinfer_amd._lib import C as lib, check, ptr
+    from cbinfer_amd import conv2d_cg as cg
+    rng = np.random.default_rng(23)
+    for (C, K, H, W, k, frac) in [(16, 24, 40, 60, 7, 0.03), (3, 16, 64, 96, 7, 0.2), (64, 70, 20, 30, 3, 0.01)]:
+        inp = rng.standard_normal((1, C, H, W)).astype(np.float32)
+        prev = inp.copy()
+        sel = rng.random(inp.shape) < frac
+        prev[sel] += rng.standard_normal(int(sel.sum())).astype(np.float32)
+        tiny = rng.random(inp.shape) < 0.05          # sub-threshold drift: absorbed into the state, not computed
+        prev[tiny & ~sel] += 1e-3
+        w = (rng.standard_normal((K, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)
+        th = 0.1
+        po = oracle.conv2d_dense(prev, w, None)
+        d_o, cm_o = oracle.changeDetectionFG(inp, prev, th)
+        coords = np.nonzero(cm_o.reshape(-1))[0].astype(np.int64)
+        out_o = oracle.updateOutputFG(d_o, w, po.copy(), coords)
+        touched_o = oracle.changeIndexesExtr(oracle.changePropagation(cm_o[0].max(axis=0), (k, k)))
+        x, st, out = dev(inp), dev(prev), dev(po)
+        relu = torch.relu(out)
+        delta = torch.full_like(x, 7.0)
+        bits = torch.zeros(lib.cbinfer_frame_mask_bytes(H, W) // 8 + 1, dtype=torch.int64, device="cuda")
+        idx = torch.empty(H * W, dtype=torch.int32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        wp = cg.prepWeights(dev(w), H, W)
+        ws = cg.newConvWorkspace(x.device)
+        for rep in range(2):        # second call: input == state -> nothing changes, masks were re-zeroed
+            check(lib.cbinfer_cbconv2d_forward_fg(ptr(x), ptr(st), ptr(delta), ptr(out), ptr(relu), ptr(bits),
+                                                  ptr(idx), ptr(cnt), ptr(wp), C, H, W, K, k, k, th, 1, ptr(ws),
+                                                  None))
+            torch.cuda.synchronize()
+            if rep == 0:
+                assert np.array_equal(delta.cpu().numpy(), np.where(cm_o != 0, d_o, 0).astype(np.float32))
+                assert np.array_equal(idx[:int(cnt.item())].cpu().numpy(), touched_o)
+            else:
+                assert int(cnt.item()) == 0 and float(delta.abs().max()) == 0.0
+            np.testing.assert_allclose(out.cpu().numpy(), out_o, rtol=0, atol=FP32_TOL)
+            assert torch.equal(relu, torch.relu(out))
+            assert torch.equal(st, x)
+
+
+def test_tail1x1_vs_numpy(cb, oracle):
+    """cbinfer_tail1x1: conv1x1 -> ReLU -> conv1x1 at listed pixels only (double-accumulated numpy reference,
+    1e-4), other pixels untouched, device-side count honoured, foreign-resolution entries dropped."""
+    from cbinfer_amd._lib import C as lib, check, ptr
+    rng = np.random.default_rng(29)
+    for (C0, C1, C2, H, W, n) in [(256, 64, 8, 80, 120, 3458), (20, 12, 5, 12, 16, 50), (128, 128, 38, 46, 81, 700),
+                                  (7, 3, 1, 5, 9, 45)]:
+        x = rng.standard_normal((1, C0, H, W)).astype(np.float32)
+        w1 = (rng.standard_normal((C1, C0)) / np.sqrt(C0)).astype(np.float32)
+        b1 = rng.standard_normal(C1).astype(np.float32)
+        w2 = (rng.standard_normal((C2, C1)) / np.sqrt(C1)).astype(np.float32)
+        b2 = rng.standard_normal(C2).astype(np.float32)
+        idx = np.sort(rng.choice(H * W, n, replace=False)).astype(np.int32)
+        xs = x.reshape(C0, -1)[:, idx].astype(np.float64)
+        h = np.maximum(w1.astype(np.float64) @ xs + b1[:, None], 0)
+        y = (w2.astype(np.float64) @ h + b2[:, None]).astype(np.float32)
+        wp = torch.empty(lib.cbinfer_tail1x1_prepared_bytes(C1, C0) // 4, device="cuda")
+        check(lib.cbinfer_tail1x1_prep(ptr(dev(w1)), ptr(wp), C1, C0, None))
+        out = torch.full((1, C2, H, W), 123.0, device="cuda")
+        cap = H * W
+        buf = torch.full((cap,), H * W + 5, dtype=torch.int32, device="cuda")   # garbage beyond the count
+        buf[:n] = dev(idx)
+        cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
+        dw2, db1, db2, dx = dev(w2), dev(b1), dev(b2), dev(x)
+        check(lib.cbinfer_tail1x1(ptr(dx), ptr(buf), cap, ptr(cnt), ptr(wp), ptr(db1), ptr(dw2), ptr(db2),
+                                  ptr(out), C0, C1, C2, H, W, 1, 0, None))
+        got = out.cpu().numpy().reshape(C2, -1)
+        np.testing.assert_allclose(got[:, idx], y, rtol=0, atol=FP32_TOL)
+        rest = np.setdiff1d(np.arange(H * W), idx)
+        assert np.all(got[:, rest] == 123.0)
+        # host count, list containing an out-of-map entry: dropped, nothing written through it
+        out2 = torch.full((1, C2, H, W), 123.0, device="cuda")
+        lst = torch.cat([dev(idx[:10]), torch.tensor([H * W + 3], dtype=torch.int32, device="cuda")])
+        check(lib.cbinfer_tail1x1(ptr(dx), ptr(lst), 11, None, ptr(wp), ptr(db1), ptr(dw2), ptr(db2),
+                                  ptr(out2), C0, C1, C2, H, W, 1, 0, None))
+        got2 = out2.cpu().numpy().reshape(C2, -1)
+        np.testing.assert_allclose(got2[:, idx[:10]], y[:, :10], rtol=0, atol=FP32_TOL)
+        assert int((got2 != 123.0).sum()) == C2 * 10

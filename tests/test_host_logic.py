@@ -23,10 +23,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     from cbinfer_amd import _lib
     assert declared == set(_lib.EXPORTED_SYMBOLS)
-    assert lib.cbinfer_abi_version() == 1
+    assert lib.cbinfer_abi_version() == 2
     lib.cbinfer_mask_words.restype = ctypes.c_long
     assert lib.cbinfer_mask_words_per_row(480) == 8 and lib.cbinfer_mask_words(320, 480) == 2560
-    assert lib.cbinfer_weights_kpad(8) == 32 and lib.cbinfer_weights_ckkpad(147) == 160
+    assert lib.cbinfer_weights_kpad(8) == 32 and lib.cbinfer_weights_ckkpad(147, 0) == 160
+    # fp16 prepared weights are padded to stage PAIRS (2 x 64): the helper must agree with the byte count
+    assert lib.cbinfer_weights_ckkpad(147, 1) == 256
+    lib.cbinfer_prepared_weights_bytes.restype = ctypes.c_long
+    assert lib.cbinfer_prepared_weights_bytes(8, 3, 7, 7, 1) == 32 * 256 * 2 + 256 * 8
 
 
 def test_compat_shims_export_reference_symbols():

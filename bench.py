@@ -172,7 +172,7 @@ def event_time_ms(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-def kernel_breakdown(test, frames, reps=50):
+def kernel_breakdown(test, frame, reps=50):
     """Per-layer, per-kernel time of the change-based layers on the state left by the timed sequence,
     by re-launching each kernel stand-alone through the C ABI (idempotent: same inputs, same outputs).
     Returns a list of dicts with the algorithmic bytes / flops of SURVEY 8d."""
@@ -182,7 +182,7 @@ def kernel_breakdown(test, frames, reps=50):
     from cbinfer_amd._lib import C as lib, check, stream_ptr, ptr
     rows = []
     # feed one more frame layer by layer, keeping each CB layer's input
-    x = frames[0]
+    x = frame
     with torch.no_grad():
         for m in test.children():
             xin = x
@@ -250,22 +250,23 @@ def kernel_breakdown(test, frames, reps=50):
     return rows
 
 
-def inframe_conv_times(test, frames, reps=40):
+def inframe_conv_times(test, frames, start, reps=40):
     """Duration of every CBConv2d's fused contraction kernel INSIDE the frame: the frame is enqueued eagerly
     module by module as the network would, except that each change-based layer is issued as its two library
     calls (detection, then the self-compacting contraction) with HIP events recorded around the second on
     the launch stream.  The kernel then runs on what the preceding layers just left in the caches, next to
     the same neighbours as in the timed loop -- stand-alone re-launches run warm and came out up to 35 %
-    shorter in round 1.  Returns {layer label: mean microseconds} or None if a layer is not in the
-    sync-free self-compacting form."""
+    shorter in round 1.  The walk over `frames` continues at step `start`, where the timed loop stopped.
+    Returns {layer label: (mean microseconds, mean changed pixels per launch)} or None if a layer is not in
+    the sync-free self-compacting form."""
     import pycbinfer
     from cbinfer_amd.conv2d import LazyPool
     from cbinfer_amd._lib import C as lib, check, ptr, stream_ptr, dtype_code
     mods = list(test.children())
-    acc = {}
+    acc, cnt = {}, {}
     with torch.no_grad():
         for it in range(reps + 3):
-            x = frames[pingpong(it, len(frames))]
+            x = frames[pingpong(start + it, len(frames))]
             for m in mods:
                 if type(m) is not pycbinfer.CBConv2d or m.finegrained:
                     x = m(x)
@@ -295,12 +296,17 @@ def inframe_conv_times(test, frames, reps=40):
                     kW, int(m.withReLU), ptr(work['conv']), dt, st))
                 e1.record()
                 if it >= 3:
-                    acc.setdefault("conv %d->%d k%d @%dx%d" % (C, K, kH, Hh, Ww), []).append((e0, e1))
+                    label = "conv %d->%d k%d @%dx%d" % (C, K, kH, Hh, Ww)
+                    acc.setdefault(label, []).append((e0, e1))
+                    if label not in cnt:
+                        cnt[label] = torch.zeros(1, dtype=torch.int64, device=src.device)
+                    cnt[label] += work['count']
                 from cbinfer_amd.conv2d_cg import ChangeIndexes
                 x = (('changeIndexes', m.prevOutput, ChangeIndexes(work['idx'], work['count'], (Hh, Ww)))
                      if m.propChangeIndexes else m.prevOutput)
         torch.cuda.synchronize()
-    return {k: 1e3 * sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in acc.items()}
+    return {k: (1e3 * sum(a.elapsed_time(b) for a, b in v) / len(v), cnt[k].item() / float(len(v)))
+            for k, v in acc.items()}
 
 
 def kernel_source_hash():
@@ -498,6 +504,8 @@ def main():
             if agree is not None:
                 reps = agree(reps)
         total = steps * reps
+        for q in seqs:
+            q['pos'] = max(warmup, 1) + total        # where the walk over the frames stands afterwards
         return timed_loop(runners, frs, total, bar, start=max(warmup, 1)), total, seqs
 
     S = max(1, args.sequences)
@@ -624,13 +632,18 @@ def main():
 
     # per-kernel measurement (HIP events on the launch stream) -> roofline of the dominant kernel
     if world == 1:
-        inframe = inframe_conv_times(test, frames)          # contraction kernels as they run in the frame
-        test_rows = kernel_breakdown(test, frames)          # every kernel stand-alone (warm re-launches)
+        pos = seqs[0]['pos']
+        inframe = inframe_conv_times(test, frames, pos)     # contraction kernels as they run in the frame
+        pos += 43
+        # every kernel stand-alone (warm re-launches) on the next frame of the walk
+        test_rows = kernel_breakdown(test, frames[pingpong(pos, len(frames))])
         for r in test_rows:
             if inframe and r.get("layer") in inframe:
-                r["conv_ms_standalone"] = r["conv_ms"]
-                r["conv_ms"] = inframe[r["layer"]] * 1e-3
-                r["conv_timing"] = "in-frame (HIP events around the kernel inside the eager frame)"
+                us, n = inframe[r["layer"]]
+                r["conv_ms_standalone"], r["N_standalone"] = r["conv_ms"], r["N"]
+                r["conv_ms"], r["N"] = us * 1e-3, n
+                r["conv_flops"] = r["conv_flops"] * n / max(r["N_standalone"], 1)
+                r["conv_timing"] = "in-frame (HIP events around the kernel inside the eager frame, mean N)"
         result["layers"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()}
                             for r in test_rows]
         best = None

@@ -198,7 +198,8 @@ def fuseTail1x1(rootModule, enabled=True):
     nn.Sequential the run  CBConv2d -> nn.Conv2d 1x1 -> nn.ReLU -> nn.Conv2d 1x1  (the dense tail that
     sceneLabeling/modelLoader.py:45-47 keeps for experiments 2-7) becomes  CBConv2d -> CBTail1x1 : the
     two 1x1 layers are evaluated in ONE launch, only at the pixels of the CBConv2d's change list (its
-    propChangeIndexes is switched on) -- a 1x1 layer's output changes only where its input did.  The new
+    propChangeIndexes is switched on; a fine-grained head hands on the output pixels its frame touched) -- a
+    1x1 layer's output changes only where its input did.  The new
     module takes the first 1x1 layer's name and shares the parameters of both.  enabled=False is a no-op.
     Returns rootModule."""
     if not enabled:
@@ -212,7 +213,7 @@ def fuseTail1x1(rootModule, enabled=True):
         kids = [seq._modules[n] for n in names]
         for i in range(len(kids) - 3):
             head, a, act, b = kids[i:i + 4]
-            if (type(head) is CBConv2d and not head.finegrained and is1x1(a) and type(act) is nn.ReLU and
+            if (type(head) is CBConv2d and is1x1(a) and type(act) is nn.ReLU and
                     is1x1(b) and a.out_channels <= CBTail1x1.maxHidden() and
                     a.weight.dtype == torch.float32):
                 _log('fusing the 1x1 tail behind %s' % names[i])

@@ -214,11 +214,12 @@ class CBConv2d(nn.Module):
             self._wprep = (key, prepWeights(w, H, W))
         return self._wprep[1]
 
-    def _workspace(self, input):
+    def _workspace(self, input, wantMap=None):
         H, W = input.size(-2), input.size(-1)
         # self-compacting frame pipeline (detection + fused kernel, no compaction launch): mask small
         # enough for the kernel's LDS prefix, and no int8 copy of the mask requested
-        selfc = (not self.saveChangeMap and
+        wantMap = self.saveChangeMap if wantMap is None else wantMap
+        selfc = (not wantMap and
                  C.cbinfer_mask_words(H, W) <= C.cbinfer_frame_mask_max_words() and
                  os.environ.get('CBINFER_NO_SELFCOMPACT', '0') != '1')
         key = (H, W, input.device, selfc)
@@ -236,7 +237,7 @@ class CBConv2d(nn.Module):
                 idx=torch.empty(H * W, dtype=torch.int32, device=dev),
                 count=torch.zeros(1, dtype=torch.int32, device=dev),
                 conv=conv, map=None)
-        if self.saveChangeMap and self._work['map'] is None:
+        if wantMap and self._work['map'] is None:
             self._work['map'] = torch.zeros(H, W, dtype=torch.int8, device=input.device)
         return self._work
 
@@ -252,7 +253,8 @@ class CBConv2d(nn.Module):
     #                ReLU pass, capturable.  The reference hands out fresh tensors (conv2d.py:169,173) and
     #                keeps the caller's input tensor as state (:175); that is the default here too.
     def _fg_workspace(self, x):
-        work = self._workspace(x)
+        work = self._workspace(x, wantMap=False)     # (saveChangeMap has no meaning in fine-grained mode)
+        assert work['selfc']
         if work.get('delta') is None or work['delta'].shape != x.shape:
             work['delta'] = torch.empty_like(x)
             work['relu'] = None
@@ -268,11 +270,17 @@ class CBConv2d(nn.Module):
             self.prevInput = x.clone() if (self.fgInPlace and x.is_cuda) else x
             if self._work is not None:
                 self._work['relu'] = None
-            return F.relu(self.prevOutput) if self.withReLU else self.prevOutput
+            first = F.relu(self.prevOutput) if self.withReLU else self.prevOutput
+            if self.propChangeIndexes and x.is_cuda:      # every output pixel is new on the first frame
+                H, W = x.size(-2), x.size(-1)
+                allpix = torch.arange(H * W, dtype=torch.int32, device=x.device)
+                return 'changeIndexes', first, allpix
+            return first
         x = x.contiguous()
         H, W = x.size(-2), x.size(-1)
         fused = (x.is_cuda and not self.atomicFG and x.dtype == torch.float32 and
-                 C.cbinfer_mask_words(H, W) <= C.cbinfer_frame_mask_max_words())
+                 C.cbinfer_mask_words(H, W) <= C.cbinfer_frame_mask_max_words() and
+                 os.environ.get('CBINFER_NO_SELFCOMPACT', '0') != '1')
         if fused and self.fgInPlace:
             work = self._fg_workspace(x)
             relu = None
@@ -288,6 +296,8 @@ class CBConv2d(nn.Module):
                     ptr(work['conv']), stream_ptr(x))
             check(C.cbinfer_cbconv2d_forward_fg(*args))
             result = relu if self.withReLU else self.prevOutput
+            if self.propChangeIndexes:      # (extension: the reference's forward_fg hands no indexes on)
+                result = ('changeIndexes', result, ChangeIndexes(work['idx'], work['count'], (H, W)))
             self._make_plan(False, x, C.cbinfer_cbconv2d_forward_fg, args, 0, result=result)
             return result
         po = self.prevOutput.clone()                                 # conv2d.py:169
@@ -304,7 +314,10 @@ class CBConv2d(nn.Module):
             po = cbconvFG(x, self.prevInput, po, self.weight.detach(), self.threshold)
         self.prevOutput = po
         self.prevInput = x                                           # conv2d.py:175
-        return F.relu(po) if self.withReLU else po
+        outp = F.relu(po) if self.withReLU else po
+        if self.propChangeIndexes and fused:
+            return 'changeIndexes', outp, ChangeIndexes(work['idx'], work['count'], (H, W))
+        return outp
 
     # ---------------------------------------------------------------- coarse-grained
     def forward_normal(self, inp):

@@ -58,13 +58,35 @@ def inferFrameset(m, frameset, cuda=True, preprocessor=None, postproc=None):
     return y
 
 
+def _power_sensor(device=0):
+    """sysfs file with the board power of HIP device `device` in microwatts: the amdgpu hwmon node
+    (`power1_average` on older parts, `power1_input` on MI300/MI355X) of the card whose PCI address is the
+    device's; the first card with such a node if the address cannot be matched; None if there is none."""
+    nodes = []
+    for name in ('power1_average', 'power1_input'):
+        nodes += glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*/' + name)
+    nodes = sorted(nodes)
+    if not nodes:
+        return None
+    try:
+        prop = torch.cuda.get_device_properties(device)
+        addr = '%04x:%02x:%02x.' % (prop.pci_domain_id, prop.pci_bus_id, prop.pci_device_id)
+        for n in nodes:
+            card = os.path.realpath(os.path.join(os.path.dirname(n), '..', '..'))
+            if os.path.basename(card).startswith(addr):
+                return n
+    except Exception:
+        pass
+    return nodes[0]
+
+
 class PowerLogger(object):
-    """Samples the GPU board power (amdgpu hwmon `power1_average`, microwatts) in a thread."""
+    """Samples the GPU board power in a thread (the reference's tx2power.PowerLogger reads the Tegra
+    INA3221 rails, sceneLabeling/tx2power.py; here the amdgpu hwmon sensor, see _power_sensor)."""
 
     def __init__(self, interval=0.05, device=0):
         self.interval = interval
-        paths = sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*/power1_average'))
-        self.path = paths[device] if device < len(paths) else None
+        self.path = _power_sensor(device)
         self.samples = []     # (time, watts)
         self.events = []
         self._stop = threading.Event()
@@ -94,6 +116,7 @@ class PowerLogger(object):
         self._stop.set()
         if self._thread is not None:
             self._thread.join()
+        self.samples.append((time.time(), self._read()))      # closing sample: the run ends here
 
     def getTotalEnergy(self):
         """Joules, trapezoidal over the samples."""
@@ -108,7 +131,7 @@ class PowerLogger(object):
         return sum(vals) / len(vals) if vals else float('nan')
 
 
-def inferFramesetPowerMeasurement(m, frameset, cuda=True, numFrames=0, preprocessor=None):
+def inferFramesetPowerMeasurement(m, frameset, cuda=True, numFrames=0, preprocessor=None, interval=0.05):
     """Run a (back-and-forth extended) sequence under a PowerLogger (reference: evalTools.py:54-83)."""
     if preprocessor is not None:
         frameset = list(map(preprocessor, frameset))
@@ -123,7 +146,7 @@ def inferFramesetPowerMeasurement(m, frameset, cuda=True, numFrames=0, preproces
         m(frameset[0])
         if cuda:
             torch.cuda.synchronize()
-        pl = PowerLogger()
+        pl = PowerLogger(interval=interval)
         pl.start()
         for frame in frameset[1:]:
             m(frame)

@@ -688,8 +688,10 @@ def test_openpose_fullsize_half_threshold_zero(pkg):
         err_fresh = max((L.float() - Lf.float()).abs().max().item(), (S.float() - Sf.float()).abs().max().item())
         err_dense = max((L.float() - Ld.float()).abs().max().item(), (S.float() - Sd.float()).abs().max().item())
         print("openpose 368x654 fp16: scale %.4g, vs fresh CB %.3g, vs dense torch %.3g" % (scale, err_fresh, err_dense))
-        assert err_fresh <= 0.01 * scale, (err_fresh, scale)
-        assert err_dense <= 0.02 * scale, (err_dense, scale)
+        # measured on MI355X: both 6.1e-5 at scale 0.109, i.e. one fp16 ulp of the largest output; the bar
+        # is the fp16 bar of test_fuzz_shapes_track_dense (4 ulp of the largest output)
+        assert err_fresh <= 4 * 2.0 ** -10 * scale, (err_fresh, scale)
+        assert err_dense <= 4 * 2.0 ** -10 * scale, (err_dense, scale)
         # something must actually have been change-based: frame 3 touched far fewer pixels than frame 0 did
         n1 = ChangeIndexes(cbs[0]._work['idx'], cbs[0]._work['count']).numel()
         assert 0 < n1 < 0.6 * H * W
@@ -703,8 +705,7 @@ def test_openpose_fullsize_half_threshold_zero(pkg):
 def test_fg_fullsize_threshold_zero_tracks_dense(pkg, form):
     """BASELINE config 3 at its real size (experiment 7: fine-grained CBConv2d, 480x320): with threshold 0
     every changed VALUE is propagated, so after several frames the network equals the dense network on the
-    last frame (<= 1e-4 absolute... the deltas add up over frames, so the bar is 5e-4 on O(1) outputs), in
-    every execution form of the fine-grained frame."""
+    last frame within the fp32 bar (1e-4), in every execution form of the fine-grained frame."""
     from cbinfer_amd import workloads
     base, test = workloads.sceneLabelingModels(experimentIdx=7, threshold=0.0, seed=3)
     for m in test.modules():
@@ -718,7 +719,7 @@ def test_fg_fullsize_threshold_zero_tracks_dense(pkg, form):
             y = test(f.clone())
         ref = base(vid.frame)
         err = (y - ref).abs().max().item()
-        assert err <= 5e-4, err
+        assert err <= 1e-4, err
         y2 = test(vid.frame.clone()).clone()
         assert torch.equal(y, y2)
 
@@ -763,11 +764,12 @@ def test_tail1x1_fusion_matches_unfused(pkg, oracle):
     base, plain = workloads.sceneLabelingModels(experimentIdx=6, threshold=0.02, seed=4)
     _, fused = workloads.sceneLabelingModels(experimentIdx=6, threshold=0.02, seed=4)
     names_before = [n for n, _ in fused.named_children()]
+    first1x1 = list(fused.children())[-3]
     pkg.fuseTail1x1(fused)
     names = [n for n, _ in fused.named_children()]
     assert names == names_before[:-2]
     tail = list(fused.children())[-1]
-    assert type(tail) is pkg.CBTail1x1 and tail.weight1 is list(plain.children())[-3].weight is not None
+    assert type(tail) is pkg.CBTail1x1 and tail.weight1 is first1x1.weight and tail.bias1 is first1x1.bias
     assert list(fused.children())[-2].propChangeIndexes
     pkg.fusePoolingIntoDetection(fused)
     vid = workloads.SyntheticVideo(H=64, W=96, ratio=0.125, block=16, seed=9)
@@ -779,10 +781,12 @@ def test_tail1x1_fusion_matches_unfused(pkg, oracle):
     assert (b - ref).abs().max().item() < 0.5
     assert len(pkg.getStateTensors(fused)) == 2 * 3 + 2 + 1     # 3 convs, 2 pools, the tail
     pkg.clearMemory(fused)
+    pkg.clearMemory(plain)         # (both restart from this frame: the feedback-loop state is history-dependent)
     assert tail.prevOutput.numel() == 0
     # graph capture of the fused network (7 launches per frame)
     static_in = vid.frame.clone()
     with torch.no_grad():
+        plain(static_in)
         fused(static_in)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -796,7 +800,6 @@ def test_tail1x1_fusion_matches_unfused(pkg, oracle):
         static_in.copy_(nxt)
         g.replay()
         torch.cuda.synchronize()
-        plain(vid.frames(1)[0])
         assert (out - plain(nxt)).abs().max().item() <= FP32_TOL
 
 
@@ -916,7 +919,7 @@ def test_power_logger_and_power_measurement(pkg):
     _, test = workloads.sceneLabelingModels(experimentIdx=4, threshold=0.02, seed=1)
     vid = workloads.SyntheticVideo(H=64, W=96, ratio=0.125, block=16, seed=2)
     frames = [f.cpu() for f in vid.frames(4)]
-    pl = evalTools.inferFramesetPowerMeasurement(test, frames, numFrames=400)
+    pl = evalTools.inferFramesetPowerMeasurement(test, frames, numFrames=3000, interval=0.01)
     assert len(pl.samples) >= 2
     times = [t for t, _ in pl.samples]
     assert all(b >= a for a, b in zip(times[:-1], times[1:]))

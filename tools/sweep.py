@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[2] and [3] on one MI355X: frames/s of the change-based scene-labeling net over
-change ratios (coarse-grained experiment 6, fine-grained experiment 7 with atomics and with the
-deterministic MFMA variant) and of the OpenPose T=2 net in fp16 (cg_half path), each next to the dense
+change ratios (coarse-grained experiment 6; fine-grained experiment 7 in its three execution forms: the
+default fused frame, the in-place fused frame and the reference-structured atomic scatter) and of the
+OpenPose T=2 net in fp16 (cg_half path), each next to the dense
 network timed the same way.  Prints markdown tables."""
 import argparse
 import os
@@ -46,8 +47,9 @@ def main():
 
     print("## scene labeling 480x320 fp32, 16x16 re-drawn blocks (config 3 sweep)\n")
     print("| change | dense f/s | CG exp6 f/s | speed-up | post-dilation ratio per CB layer | "
-          "FG exp7 atomics f/s (eager) | FG deterministic f/s (eager) |")
-    print("|---|---|---|---|---|---|---|")
+          "FG exp7 f/s (default: fresh tensors, eager) | FG exp7 in-place f/s (best of graph/eager) | "
+          "FG in-place speed-up | FG exp7 atomic scatter f/s (eager) |")
+    print("|---|---|---|---|---|---|---|---|---|")
     if not args.skip_sweep:      # throw-away measurement: clocks, allocator and MIOpen find are cold at first
         _b, _t = workloads.sceneLabelingModels(experimentIdx=6, threshold=0.05)
         _f = workloads.SyntheticVideo(H=320, W=480, ratio=0.05, block=16, seed=5).frames(n)
@@ -61,23 +63,30 @@ def main():
         for m in cg.modules():            # the bench's execution options (same results)
             if type(m) is pycbinfer.CBPoolMax2d:
                 m.cloneOutput = False
+        pycbinfer.fuseTail1x1(cg)
         pycbinfer.fusePoolingIntoDetection(cg)
         # both launch forms for both networks, the better one counts (bench.py --mode auto)
         dense = max(measure(base, frames, args.steps, args.warmup, m) for m in ("graph", "eager"))
         fcg = max(measure(cg, frames, args.steps, args.warmup, m) for m in ("graph", "eager"))
         ratios = ", ".join("%.0f%%" % (100 * r) for r in layer_ratios(cg))
-        ffg = ffd = float("nan")
+        ffg = ffd = ffa = float("nan")
         if not args.skip_fg:
             _, fg = workloads.sceneLabelingModels(experimentIdx=7, threshold=0.05)
-            nfg = min(len(frames), 2 + 2 + 12)
-            ffg = measure(fg, frames[:nfg], 12, 2, "eager")
+            ffg = measure(fg, frames, args.steps, args.warmup, "eager")
             _, fd = workloads.sceneLabelingModels(experimentIdx=7, threshold=0.05)
             for m in fd.modules():
                 if type(m) is pycbinfer.CBConv2d:
-                    m.deterministicFG = True
-            ffd = measure(fd, frames[:nfg], 12, 2, "eager")
-        print("| %.0f%% | %.0f | %.0f | %.2fx | %s | %.1f | %.1f |" %
-              (100 * vid.ratio, dense, fcg, fcg / dense, ratios, ffg, ffd), flush=True)
+                    m.fgInPlace = True
+            pycbinfer.fuseTail1x1(fd)
+            ffd = max(measure(fd, frames, args.steps, args.warmup, m) for m in ("graph", "eager"))
+            _, fa = workloads.sceneLabelingModels(experimentIdx=7, threshold=0.05)
+            for m in fa.modules():
+                if type(m) is pycbinfer.CBConv2d:
+                    m.atomicFG = True
+            nfg = min(len(frames), 2 + 2 + 12)
+            ffa = measure(fa, frames[:nfg], 12, 2, "eager")
+        print("| %.0f%% | %.0f | %.0f | %.2fx | %s | %.0f | %.0f | %.2fx | %.1f |" %
+              (100 * vid.ratio, dense, fcg, fcg / dense, ratios, ffg, ffd, ffd / dense, ffa), flush=True)
 
     if not args.skip_pose:
         print("\n## OpenPose T=2 368x654 fp16, coarse-grained (config 4), 10 % change in 46x... blocks\n")

@@ -193,8 +193,9 @@ def kernel_breakdown(test, frame, reps=50):
                 K, C, kH, kW = m.weight.shape
                 Hh, Ww = inp.shape[-2:]
                 s = 4 if inp.dtype == torch.float32 else 2
-                ci = cg.ChangeIndexes(m._work['idx'], m._work['count'])
+                ci = m.lastChangeIndexes()
                 N = ci.numel()
+                rowsws = m._work.get('rows') if m._rows_path(inp.dtype, Hh, Ww) else None
                 bits = torch.zeros_like(m._work['bits'])
                 cnt = torch.zeros(1, dtype=torch.int32, device=inp.device)
                 idx = torch.empty_like(m._work['idx'])
@@ -209,16 +210,27 @@ def kernel_breakdown(test, frame, reps=50):
                         ptr(inp), ptr(m.prevInput), ptr(bits), Ww, Hh, C, (kH - 1) // 2, (kW - 1) // 2,
                         float(m.threshold), 0, dt, stream_ptr()))), reps)
                 t_zero = event_time_ms(lambda: bits.zero_(), reps)
+                mask_now = rowsws['copy'] if rowsws is not None else m._work['bits']
                 t_cmp = event_time_ms(lambda: check(lib.cbinfer_compact_bits(
-                    ptr(m._work['bits']), Ww, Hh, ptr(idx), ptr(cnt), None, None, stream_ptr())), reps)
+                    ptr(mask_now), Ww, Hh, ptr(idx), ptr(cnt), None, None, stream_ptr())), reps)
                 wp = m._prepared_weights(Hh, Ww)
                 ws = m._work['conv']
-                t_conv = event_time_ms(lambda: check(lib.cbinfer_conv_changed(
-                    ptr(m.prevInput), ptr(ci.buffer), Hh * Ww, ptr(ci.count), ptr(wp), ptr(m.bias.detach()),
-                    ptr(m.prevOutput), C, Hh, Ww, K, kH, kW, int(m.withReLU), 0, None, 0, ptr(ws), dt,
-                    stream_ptr())), reps)
+                if rowsws is not None:      # row-segment kernel: it consumes its mask, so refill it per launch
+                    saved, rb = rowsws['copy'].clone(), torch.zeros_like(rowsws['bits'])
+                    sink = torch.empty_like(saved)
+                    rw = m._prepared_row_weights()
+                    t_fill = event_time_ms(lambda: rb.copy_(saved), reps)
+                    t_conv = max(0.0, event_time_ms(lambda: (rb.copy_(saved), check(lib.cbinfer_conv_changed_rows(
+                        ptr(m.prevInput), ptr(rb), ptr(rowsws['arrive']), ptr(sink), ptr(rw), ptr(m.bias.detach()),
+                        ptr(m.prevOutput), C, Hh, Ww, K, kH, kW, int(m.withReLU), stream_ptr()))), reps) - t_fill)
+                else:
+                    t_conv = event_time_ms(lambda: check(lib.cbinfer_conv_changed(
+                        ptr(m.prevInput), ptr(ci.buffer), Hh * Ww, ptr(ci.count), ptr(wp), ptr(m.bias.detach()),
+                        ptr(m.prevOutput), C, Hh, Ww, K, kH, kW, int(m.withReLU), 0, None, 0, ptr(ws), dt,
+                        stream_ptr())), reps)
                 HW = Hh * Ww
                 rows.append(dict(layer="conv %d->%d k%d @%dx%d" % (C, K, kH, Hh, Ww), N=N,
+                                 conv_kernel="cb_rowconv_f32_kernel" if rowsws is not None else "cb_mfma_f32_kernel",
                                  ratio=N / float(HW),
                                  detect_ms=max(t_det - t_zero, 0.0),
                                  detect_bytes=(5 if lazy is not None else 2) * C * HW * s + HW // 8,
@@ -280,30 +292,41 @@ def inframe_conv_times(test, frames, start, reps=40):
                 src = (lazy.source if lazy is not None else x).contiguous()
                 Hh, Ww = (lazy.outSize[-2:] if lazy is not None else src.shape[-2:])
                 dt, st = dtype_code(src), stream_ptr(src)
+                rows = work.get('rows') if m._rows_path(src.dtype, Hh, Ww) else None
+                bits = rows['bits'] if rows is not None else work['bits']
                 if lazy is not None:
-                    check(lib.cbinfer_change_detection_frame_pooled(
-                        ptr(src), src.shape[-2], src.shape[-1], ptr(m.prevInput), ptr(work['bits']), Ww, Hh, C,
-                        (kH - 1) // 2, (kW - 1) // 2, float(m.threshold), dt, st))
+                    det = lib.cbinfer_change_detection_bits_pooled if rows is not None else \
+                        lib.cbinfer_change_detection_frame_pooled
+                    check(det(ptr(src), src.shape[-2], src.shape[-1], ptr(m.prevInput), ptr(bits), Ww, Hh, C,
+                              (kH - 1) // 2, (kW - 1) // 2, float(m.threshold), dt, st))
                 else:
-                    check(lib.cbinfer_change_detection_frame(
-                        ptr(src), ptr(m.prevInput), ptr(work['bits']), Ww, Hh, C, (kH - 1) // 2, (kW - 1) // 2,
-                        float(m.threshold), 1, dt, st))
+                    det = lib.cbinfer_change_detection_bits if rows is not None else \
+                        lib.cbinfer_change_detection_frame
+                    check(det(ptr(src), ptr(m.prevInput), ptr(bits), Ww, Hh, C, (kH - 1) // 2, (kW - 1) // 2,
+                              float(m.threshold), 1, dt, st))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                check(lib.cbinfer_conv_changed_from_mask(
-                    ptr(m.prevInput), ptr(work['bits']), ptr(work['idx']), ptr(work['count']),
-                    ptr(m._prepared_weights(Hh, Ww)), ptr(m.bias.detach()), ptr(m.prevOutput), C, Hh, Ww, K, kH,
-                    kW, int(m.withReLU), ptr(work['conv']), dt, st))
+                if rows is not None:
+                    check(lib.cbinfer_conv_changed_rows(
+                        ptr(m.prevInput), ptr(rows['bits']), ptr(rows['arrive']), ptr(rows['copy']),
+                        ptr(m._prepared_row_weights()), ptr(m.bias.detach()), ptr(m.prevOutput), C, Hh, Ww, K,
+                        kH, kW, int(m.withReLU), st))
+                else:
+                    check(lib.cbinfer_conv_changed_from_mask(
+                        ptr(m.prevInput), ptr(work['bits']), ptr(work['idx']), ptr(work['count']),
+                        ptr(m._prepared_weights(Hh, Ww)), ptr(m.bias.detach()), ptr(m.prevOutput), C, Hh, Ww, K,
+                        kH, kW, int(m.withReLU), ptr(work['conv']), dt, st))
                 e1.record()
+                from cbinfer_amd.conv2d_cg import ChangeIndexes, MaskChangeIndexes
+                ci = (MaskChangeIndexes(rows['copy'], (Hh, Ww), work['idx'], work['count']) if rows is not None
+                      else ChangeIndexes(work['idx'], work['count'], (Hh, Ww)))
                 if it >= 3:
                     label = "conv %d->%d k%d @%dx%d" % (C, K, kH, Hh, Ww)
                     acc.setdefault(label, []).append((e0, e1))
                     if label not in cnt:
                         cnt[label] = torch.zeros(1, dtype=torch.int64, device=src.device)
-                    cnt[label] += work['count']
-                from cbinfer_amd.conv2d_cg import ChangeIndexes
-                x = (('changeIndexes', m.prevOutput, ChangeIndexes(work['idx'], work['count'], (Hh, Ww)))
-                     if m.propChangeIndexes else m.prevOutput)
+                    cnt[label] += ci.count       # (after the timed kernel; a mask-driven frame compacts here)
+                x = ('changeIndexes', m.prevOutput, ci) if m.propChangeIndexes else m.prevOutput
         torch.cuda.synchronize()
     return {k: (1e3 * sum(a.elapsed_time(b) for a, b in v) / len(v), cnt[k].item() / float(len(v)))
             for k, v in acc.items()}

@@ -60,6 +60,13 @@ _SIGNATURES = {
     "cbinfer_tail1x1_prepared_bytes": (_l, [_i, _i]),
     "cbinfer_tail1x1_prep": (_i, [_vp, _vp, _i, _i, _vp]),
     "cbinfer_tail1x1": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "cbinfer_rowconv_supported": (_i, [_i, _i, _i, _i]),
+    "cbinfer_rowconv_prepared_bytes": (_l, [_i, _i, _i, _i]),
+    "cbinfer_rowconv_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "cbinfer_conv_changed_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "cbinfer_change_detection_bits_pooled": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "cbinfer_cbconv2d_forward_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
+                                           _i, _i, _i, _f, _i, _i, _i, _vp]),
     "cbinfer_conv2d_fg_cpu": (None, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i]),
 }
 

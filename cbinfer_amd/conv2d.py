@@ -24,8 +24,8 @@ import torch.nn.functional as F
 
 from . import _lib
 from ._lib import C, check, dtype_code, ptr, raw_stream, require_device, stream_ptr
-from .conv2d_cg import (ChangeIndexes, changeDetection, changeIndexesExtr, genXMatrix, matrixMult, maxPool2d,
-                        newConvWorkspace, poolChangeIndexes, prepWeights, updateOutput)
+from .conv2d_cg import (ChangeIndexes, MaskChangeIndexes, changeDetection, changeIndexesExtr, genXMatrix,
+                        matrixMult, maxPool2d, newConvWorkspace, poolChangeIndexes, prepWeights, updateOutput)
 from .conv2d_fg import cbconvFG, cbconvFG_deterministic
 
 
@@ -181,6 +181,7 @@ class CBConv2d(nn.Module):
         # device work buffers (not part of the module state)
         self._work = None
         self._plan = None
+        self._lastIndexes = None
 
     def getStateTensors(self):
         state = []
@@ -196,7 +197,7 @@ class CBConv2d(nn.Module):
                           ('gatherComputationStats', False), ('finegrained', False),
                           ('copyInput', True), ('feedbackLoop', False), ('syncIndexes', False),
                           ('deterministicFG', False), ('atomicFG', False), ('fgInPlace', False), ('_work', None), ('_wprep', None),
-                          ('_inputIsLiveState', False), ('_plan', None)):
+                          ('_inputIsLiveState', False), ('_plan', None), ('_wrows', None), ('_lastIndexes', None)):
             if name not in self.__dict__:
                 self.__dict__[name] = val
 
@@ -205,7 +206,52 @@ class CBConv2d(nn.Module):
         d['_work'] = None     # transient device buffers are not serialised
         d['_wprep'] = None
         d['_plan'] = None
+        d['_wrows'] = None
+        d['_lastIndexes'] = None
         return d
+
+    def lastChangeIndexes(self):
+        """The change list of the most recent coarse-grained frame as a ChangeIndexes (None before the first
+        frame).  For mask-driven frames it is materialised on this call; valid until the next frame."""
+        return self._lastIndexes
+
+    def invalidateWeights(self):
+        """Forget the cached re-laid-out copies of the filter bank and the per-frame call plan.  They are
+        refreshed on their own when the Parameter object or its version counter changes; a write through
+        `weight.data` (the reference's own idiom) bumps neither, so call this after one."""
+        self._wprep = self._wrows = self._plan = None
+
+    def _rows_path(self, dtype, H, W):
+        """Row-segment contraction (cb_rowconv.hip) for this layer?  fp32, sync-free frame without an int8
+        mask copy, and at most 16 output channels: measured in the frame (MI355X, 480x320 @10 %) the kernel
+        takes 15 us against the list kernel's 21 on the 3->16 layer, but 36 against 36 on the 16->64 layer,
+        whose full 64-pixel words keep single CUs busy while others idle (CBINFER_ROWCONV_MAXK overrides)."""
+        K, Cin, kH, kW = self.weight.size()
+        if K > int(os.environ.get('CBINFER_ROWCONV_MAXK', '16')):
+            return False
+        return (dtype == torch.float32 and not self.syncIndexes and not self.saveChangeMap and
+                os.environ.get('CBINFER_NO_ROWCONV', '0') != '1' and
+                os.environ.get('CBINFER_NO_SELFCOMPACT', '0') != '1' and
+                bool(C.cbinfer_rowconv_supported(Cin, K, kH, kW)))
+
+    def _rows_workspace(self, work, H, W, dev):
+        if work['rows'] is None:
+            words = C.cbinfer_mask_words(H, W)
+            work['rows'] = dict(bits=torch.zeros(words, dtype=torch.int64, device=dev),
+                                arrive=torch.zeros(words, dtype=torch.int32, device=dev),
+                                copy=torch.zeros(words, dtype=torch.int64, device=dev))
+        return work['rows']
+
+    def _prepared_row_weights(self):
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if self._wrows is None or self._wrows[0] != key:
+            K, Cin, kH, kW = w.size()
+            wp = torch.empty(C.cbinfer_rowconv_prepared_bytes(Cin, K, kH, kW), dtype=torch.uint8, device=w.device)
+            check(C.cbinfer_rowconv_prep_weights(ptr(w.detach().contiguous()), ptr(wp), K, Cin, kH, kW,
+                                                 stream_ptr(w)))
+            self._wrows = (key, wp)
+        return self._wrows[1]
 
     def _prepared_weights(self, H=1, W=1):
         w = self.weight
@@ -236,7 +282,9 @@ class CBConv2d(nn.Module):
                 bits=torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=dev),
                 idx=torch.empty(H * W, dtype=torch.int32, device=dev),
                 count=torch.zeros(1, dtype=torch.int32, device=dev),
-                conv=conv, map=None)
+                conv=conv, map=None,
+                # row-segment contraction (cbinfer_conv_changed_rows): single mask, arrival counters, mask copy
+                rows=None)
         if wantMap and self._work['map'] is None:
             self._work['map'] = torch.zeros(H, W, dtype=torch.int8, device=input.device)
         return self._work
@@ -363,6 +411,10 @@ class CBConv2d(nn.Module):
 
         if self.syncIndexes:
             changeIndexes = self._forward_ops(input, changeIndexes)
+            self._lastIndexes = (changeIndexes if isinstance(changeIndexes, ChangeIndexes) else
+                                 ChangeIndexes(changeIndexes, torch.tensor([changeIndexes.numel()],
+                                                                          dtype=torch.int32, device=input.device),
+                                               (input.size(-2), input.size(-1))))
         else:
             changeIndexes = self._forward_fused(input, changeIndexes)
 
@@ -394,14 +446,27 @@ class CBConv2d(nn.Module):
         if not work['selfc']:
             return self.forward_normal(lazy.tensor())
         K, Cin, kH, kW = self.weight.size()
+        if self._rows_path(src.dtype, H, W):
+            rows = self._rows_workspace(work, H, W, src.device)
+            args = (None, ptr(src), src.size(-2), src.size(-1), ptr(self.prevInput), ptr(self.prevOutput),
+                    ptr(rows['bits']), ptr(rows['arrive']), ptr(rows['copy']), ptr(self._prepared_row_weights()),
+                    ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold), 1, 0,
+                    int(bool(self.withReLU)), stream_ptr(src))
+            check(C.cbinfer_cbconv2d_forward_rows(*args))
+            self._make_plan(True, src, C.cbinfer_cbconv2d_forward_rows, args, 1, rows=True)
+            self._lastIndexes = MaskChangeIndexes(rows['copy'], (H, W), work['idx'], work['count'])
+            if self.propChangeIndexes:
+                return 'changeIndexes', self.prevOutput, self._lastIndexes
+            return self.prevOutput
         args = (ptr(src), src.size(-2), src.size(-1), ptr(self.prevInput), ptr(self.prevOutput),
                 ptr(work['bits']), ptr(work['idx']), ptr(work['count']), ptr(self._prepared_weights(H, W)),
                 ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold),
                 int(bool(self.withReLU)), ptr(work['conv']), dtype_code(src), stream_ptr(src))
         check(C.cbinfer_cbconv2d_forward_pooled(*args))
         self._make_plan(True, src, C.cbinfer_cbconv2d_forward_pooled, args, 0)
+        self._lastIndexes = ChangeIndexes(work['idx'], work['count'], (H, W))
         if self.propChangeIndexes:
-            return 'changeIndexes', self.prevOutput, ChangeIndexes(work['idx'], work['count'], (H, W))
+            return 'changeIndexes', self.prevOutput, self._lastIndexes
         return self.prevOutput
 
     def _forward_fused(self, input, changeIndexes):
@@ -441,6 +506,18 @@ class CBConv2d(nn.Module):
         if not prev.is_contiguous():
             prev = self.prevInput = prev.contiguous()
         mapOut = work['map'] if (self.saveChangeMap and not have) else None
+        if not have and work['selfc'] and self._rows_path(input.dtype, H, W):
+            rows = self._rows_workspace(work, H, W, input.device)
+            args = (ptr(input), None, 0, 0, ptr(prev), ptr(self.prevOutput), ptr(rows['bits']),
+                    ptr(rows['arrive']), ptr(rows['copy']), ptr(self._prepared_row_weights()),
+                    ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold),
+                    int(bool(self.feedbackLoop)), int(bool(self.copyInput)), int(bool(self.withReLU)),
+                    stream_ptr(input))
+            check(C.cbinfer_cbconv2d_forward_rows(*args))
+            if not self._inputIsLiveState:
+                self._make_plan(False, input, C.cbinfer_cbconv2d_forward_rows, args, 0, rows=True)
+            result = MaskChangeIndexes(rows['copy'], (H, W), work['idx'], work['count'])
+            cap = 0      # (done)
         if cap > 0:
             args = (ptr(input), ptr(prev), ptr(self.prevOutput), None if have else ptr(work['bits']),
                     ptr(idx), ptr(count), ptr(mapOut), ptr(self._prepared_weights(H, W)),
@@ -456,6 +533,7 @@ class CBConv2d(nn.Module):
         if not self.feedbackLoop and not self.copyInput:
             # alias, conv2d.py:237-238 (a producer's in-place-updated state is copied first)
             self.prevInput = input.clone() if self._inputIsLiveState else input
+        self._lastIndexes = result
         return result
 
     def _forward_ops(self, input, changeIndexes):
@@ -507,7 +585,7 @@ class CBConv2d(nn.Module):
                 self.syncIndexes, self.saveChangeMap, self.gatherComputationStats, self.finegrained,
                 self.atomicFG, self.fgInPlace)
 
-    def _make_plan(self, pooled, src, fn, args, srcSlot, result=None):
+    def _make_plan(self, pooled, src, fn, args, srcSlot, result=None, rows=False):
         """Remember a finished sync-free call: fn(*args) with args[srcSlot] = source pointer, args[-1] =
         stream.  Only for configurations whose call does not depend on per-frame host state."""
         if self.syncIndexes or self.saveChangeMap or self.gatherComputationStats:
@@ -522,7 +600,7 @@ class CBConv2d(nn.Module):
             pooled=pooled, shape=tuple(src.shape), dtype=src.dtype, device=src.device, flags=self._flags(),
             w=(w.data_ptr(), w._version), b=(b.data_ptr(), b._version),
             state=(self._buffers['prevInput'].data_ptr(), self._buffers['prevOutput'].data_ptr()),
-            stream=args[-1], work=work, fn=fn, args=list(args), srcSlot=srcSlot, result=result,
+            stream=args[-1], work=work, fn=fn, args=list(args), srcSlot=srcSlot, result=result, rows=rows,
             indexes=ChangeIndexes(work['idx'], work['count'], work['key'][:2]))
 
     def _run_plan(self, inp):
@@ -550,8 +628,14 @@ class CBConv2d(nn.Module):
         self._inputIsLiveState = False
         if plan['result'] is not None:          # fine-grained in-place frame: prevOutput or its relu'd copy
             return plan['result']
+        if plan['rows']:                        # mask-driven frame: the list is made when somebody asks
+            work = plan['work']
+            self._lastIndexes = MaskChangeIndexes(work['rows']['copy'], work['key'][:2], work['idx'],
+                                                  work['count'])
+        else:
+            self._lastIndexes = plan['indexes']
         if self.propChangeIndexes:
-            return 'changeIndexes', bufs['prevOutput'], plan['indexes']
+            return 'changeIndexes', bufs['prevOutput'], self._lastIndexes
         return bufs['prevOutput']
 
     def forward(self, inp):

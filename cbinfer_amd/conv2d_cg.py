@@ -55,6 +55,39 @@ class ChangeIndexes(object):
         return ChangeIndexes(self.buffer.clone(), self.count.clone(), self.size)
 
 
+class MaskChangeIndexes(ChangeIndexes):
+    """The change list of a frame whose contraction ran mask-driven (cbinfer_conv_changed_rows): the frame
+    only left a copy of its change bit mask; the ascending index list and its device-side length are made
+    from it by cbinfer_compact_bits the first time somebody asks (one launch on the current stream, no host
+    sync) -- a frame none of whose consumers wants the list never pays for it.  Valid until the producing
+    layer's next frame."""
+
+    def __init__(self, maskCopy, size, idxBuffer, countBuffer):
+        self._mask, self.size = maskCopy, tuple(size)
+        self._idx, self._cnt = idxBuffer, countBuffer
+        self._made = False
+
+    def _make(self):
+        if not self._made:
+            H, W = self.size
+            check(C.cbinfer_compact_bits(ptr(self._mask), W, H, ptr(self._idx), ptr(self._cnt), None, None,
+                                         stream_ptr(self._idx)))
+            self._made = True
+
+    @property
+    def buffer(self):
+        self._make()
+        return self._idx
+
+    @property
+    def count(self):
+        self._make()
+        return self._cnt
+
+    def clone(self):
+        return ChangeIndexes(self.buffer.clone(), self.count.clone(), self.size)
+
+
 def _split_indexes(changeIndexes):
     """-> (int32 buffer, device count tensor or None, capacity)."""
     if isinstance(changeIndexes, ChangeIndexes):
@@ -313,6 +346,6 @@ def poolChangeIndexes(changeIndexes, inSize, outSize):
     return ChangeIndexes(out, ocount, (oH, oW))
 
 
-__all__ = ['ChangeIndexes', 'convWorkspace', 'newConvWorkspace', 'changeDetection', 'changePropagation', 'changeIndexesExtr',
+__all__ = ['ChangeIndexes', 'MaskChangeIndexes', 'convWorkspace', 'newConvWorkspace', 'changeDetection', 'changePropagation', 'changeIndexesExtr',
            'changeIndexesExtrAsync', 'genXMatrix', 'prepWeights', 'matrixMult', 'matrixMult_python',
            'updateOutput', 'convChanged', 'maxPool2d', 'poolChangeIndexes', 'CBinferError']

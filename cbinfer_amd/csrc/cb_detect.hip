@@ -364,6 +364,23 @@ int cbinfer_change_detection_bits(const void* input, void* state, uint64_t* bits
     return CB_ERR_BADARG;
 }
 
+// Single-mask form of the pooled detection (see cbinfer_change_detection_frame_pooled): ORs into bitsOut.
+int cbinfer_change_detection_bits_pooled(const void* prePool, int pH, int pW, void* state, uint64_t* bitsOut,
+                                         int W, int H, int C, int kHHalf, int kWHalf, float threshold,
+                                         int dtype, cbStream_t stream) {
+    CB_REQUIRE(prePool && state && bitsOut && W > 0 && H > 0 && C > 0 && kHHalf >= 0 && kWHalf >= 0);
+    CB_REQUIRE((H == pH / 2 || H == (pH + 1) / 2) && (W == pW / 2 || W == (pW + 1) / 2));
+    if (kWHalf > 63 || H > 65535) return CB_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CB_F32)
+        return launch_detect<float, true, true>(prePool, state, nullptr, bitsOut, W, H, C, kHHalf, kWHalf,
+                                                threshold, 1, s, nullptr, 0, pH, pW);
+    if (dtype == CB_F16)
+        return launch_detect<cb_half, true, true>(prePool, state, nullptr, bitsOut, W, H, C, kHHalf, kWHalf,
+                                                  threshold, 1, s, nullptr, 0, pH, pW);
+    return CB_ERR_BADARG;
+}
+
 // Frame-pipeline form: frameMasks = [2][words] masks followed by {parity, done}; the detection ORs into
 // the mask the parity selects (cbinfer_conv_changed_from_mask consumes it and flips the parity).
 int cbinfer_change_detection_frame(const void* input, void* state, uint64_t* frameMasks, int W, int H,

@@ -97,3 +97,36 @@ extern "C" int cbinfer_cbconv2d_forward_fg(const float* input, float* prevInput,
     return cbinfer_conv_accumulate_from_mask(delta, frameMasks, idx, countDev, weightsPrepared, prevOutput,
                                              reluOut, C, H, W, K, kH, kW, workspace, stream);
 }
+
+// The frame of a layer whose contraction runs on the row-segment kernel (cbinfer_conv_changed_rows, fp32,
+// cbinfer_rowconv_supported): detection -> [state copy] -> row-segment contraction, two launches, single
+// mask.  prePool != NULL: the layer sits behind a 2x2/stride-2 max pool folded into its detection
+// (cbinfer_cbconv2d_forward_pooled's contract; feedback mode).  maskCopy keeps the frame's mask: the
+// change list is made from it on demand (cbinfer_compact_bits), no launch of this frame depends on it.
+extern "C" int cbinfer_cbconv2d_forward_rows(const float* input, const float* prePool, int pH, int pW,
+                                             float* prevInput, float* prevOutput, uint64_t* bits,
+                                             int32_t* arrive, uint64_t* maskCopy, const void* rowWeights,
+                                             const float* bias, int C, int H, int W, int K, int kH, int kW,
+                                             float threshold, int feedbackLoop, int copyInput, int relu,
+                                             cbStream_t stream) {
+    CB_REQUIRE((input || prePool) && prevInput && prevOutput && bits && arrive && maskCopy && rowWeights);
+    int st;
+    if (prePool) {
+        st = cbinfer_change_detection_bits_pooled(prePool, pH, pW, prevInput, bits, W, H, C, (kH - 1) / 2,
+                                                  (kW - 1) / 2, threshold, CB_F32, stream);
+        if (st != CB_OK) return st;
+        return cbinfer_conv_changed_rows(prevInput, bits, arrive, maskCopy, rowWeights, bias, prevOutput, C, H,
+                                         W, K, kH, kW, relu, stream);
+    }
+    st = cbinfer_change_detection_bits(input, prevInput, bits, W, H, C, (kH - 1) / 2, (kW - 1) / 2, threshold,
+                                       feedbackLoop, CB_F32, stream);
+    if (st != CB_OK) return st;
+    if (!feedbackLoop && copyInput && prevInput != input) {
+        hipError_t e = hipMemcpyAsync(prevInput, input, (size_t)C * H * W * 4, hipMemcpyDeviceToDevice,
+                                      (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    const float* src = (feedbackLoop || copyInput) ? prevInput : input;
+    return cbinfer_conv_changed_rows(src, bits, arrive, maskCopy, rowWeights, bias, prevOutput, C, H, W, K, kH,
+                                     kW, relu, stream);
+}

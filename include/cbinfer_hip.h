@@ -190,6 +190,35 @@ int cbinfer_conv_changed_from_mask(const void* input, uint64_t* frameMasks, int3
                                    void* output, int C, int H, int W, int K, int kH, int kW, int relu,
                                    void* workspace, int dtype, cbStream_t stream);
 
+/* ---- a5..a8 fused, row-segment form (fp32, small filter banks) ----------------------------------
+ * Same contract as cbinfer_conv_changed (gather -> MFMA -> bias/ReLU -> scatter, replaces conv2d.py:240-251)
+ * for layers cbinfer_rowconv_supported() accepts -- the 3->16 and 16->64 7x7 layers of the scene-labeling
+ * net -- driven directly by the change BIT MASK: one workgroup per 64-pixel row segment (mask word) stages
+ * the kH x (64+kW-1) input rows of every channel once in LDS and derives all taps from there.
+ *   bits     : single row-padded mask (cbinfer_mask_words(H,W) words) as cbinfer_change_detection_bits
+ *              (or cbinfer_change_detection_bits_pooled) fills it; zero on first use, left zero;
+ *   arrive   : cbinfer_mask_words(H,W) int32, zero on first use, left zero;
+ *   maskCopy : receives the frame's mask (cbinfer_compact_bits makes the index list from it on demand);
+ *   prepared : cbinfer_rowconv_prep_weights' re-layout of the [K,C,kH,kW] filter bank
+ *              (cbinfer_rowconv_prepared_bytes bytes).
+ * cbinfer_cbconv2d_forward_rows is CBConv2d.forward_normal (conv2d.py:178-259) on it: detection (pooled on
+ * the fly when prePool != NULL, see cbinfer_cbconv2d_forward_pooled) -> [state copy] -> contraction. */
+int cbinfer_rowconv_supported(int C, int K, int kH, int kW);
+long cbinfer_rowconv_prepared_bytes(int C, int K, int kH, int kW);
+int cbinfer_rowconv_prep_weights(const float* weight, void* prepared, int K, int C, int kH, int kW,
+                                 cbStream_t stream);
+int cbinfer_conv_changed_rows(const float* state, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
+                              const void* prepared, const float* bias, float* output, int C, int H, int W,
+                              int K, int kH, int kW, int relu, cbStream_t stream);
+int cbinfer_change_detection_bits_pooled(const void* prePool, int pH, int pW, void* state, uint64_t* bitsOut,
+                                         int W, int H, int C, int kHHalf, int kWHalf, float threshold,
+                                         int dtype, cbStream_t stream);
+int cbinfer_cbconv2d_forward_rows(const float* input, const float* prePool, int pH, int pW, float* prevInput,
+                                  float* prevOutput, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
+                                  const void* rowWeights, const float* bias, int C, int H, int W, int K,
+                                  int kH, int kW, float threshold, int feedbackLoop, int copyInput, int relu,
+                                  cbStream_t stream);
+
 /* ---- a9: change-based 2x2/stride-2 max pooling -----------------------------------------------
  * replaces maxPool2d, conv2d_cg.py:58-82 -> cbconv2d_cg_backend.cu:229-240 (kernel :199-227).
  * changeIndexes are INPUT-resolution pixel indices.  Unlike the reference, windows with

@@ -464,7 +464,7 @@ def test_self_compacting_pipeline_matches_op_sequence(pkg):
             ya, yb = a(f.clone()), b(f.clone())
             for ma, mb in zip(ca, cb_):
                 assert ma._work['selfc'], "self-compacting path not taken"
-                ia = ChangeIndexes(ma._work['idx'], ma._work['count']).tensor()
+                ia = ma.lastChangeIndexes().tensor()
                 # the op-sequence twin re-derives its list from its own (bit-identical) state
                 assert torch.allclose(ma.prevOutput, mb.prevOutput, rtol=0, atol=1e-5), (t,)
                 assert torch.allclose(ma.prevInput, mb.prevInput, rtol=0, atol=1e-5), (t,)
@@ -483,7 +483,7 @@ def test_self_compacting_pipeline_matches_op_sequence(pkg):
         st = conv.prevInput.clone()
         conv(x1)
     expect = cg.changeIndexesExtr(cg.changeDetection(x1, st, (7, 7), 0.05))
-    got = ChangeIndexes(conv._work['idx'], conv._work['count']).tensor()
+    got = conv.lastChangeIndexes().tensor()
     assert torch.equal(got, expect)
 
 
@@ -505,7 +505,7 @@ def test_fullsize_threshold_zero_tracks_dense(pkg):
         assert torch.equal(y, y2)
         for m in test.modules():
             if type(m) is pkg.CBConv2d:
-                assert ChangeIndexes(m._work['idx'], m._work['count']).numel() == 0
+                assert m.lastChangeIndexes().numel() == 0
 
 
 def test_eval_harness_and_threshold_tuner(pkg, tmp_path):
@@ -583,7 +583,7 @@ def test_fuzz_shapes_track_dense(pkg, dtype):
                 bound = tol if tol else 4 * 2.0 ** -10 * max(1.0, ref.float().abs().max().item())
                 assert err <= bound, (C, K, kH, kW, H, W, t, err)
                 if t:
-                    got = ChangeIndexes(cbm._work['idx'], cbm._work['count']).tensor()
+                    got = cbm.lastChangeIndexes().tensor()
                     expect = cg.changeIndexesExtr(cg.changePropagation(changed.to(torch.int8), (kH, kW)))
                     assert torch.equal(got, expect), (C, K, kH, kW, H, W, t)
 
@@ -693,12 +693,12 @@ def test_openpose_fullsize_half_threshold_zero(pkg):
         assert err_fresh <= 4 * 2.0 ** -10 * scale, (err_fresh, scale)
         assert err_dense <= 4 * 2.0 ** -10 * scale, (err_dense, scale)
         # something must actually have been change-based: frame 3 touched far fewer pixels than frame 0 did
-        n1 = ChangeIndexes(cbs[0]._work['idx'], cbs[0]._work['count']).numel()
+        n1 = cbs[0].lastChangeIndexes().numel()
         assert 0 < n1 < 0.6 * H * W
         L2, S2 = test(frames[-1].clone())
         assert torch.equal(L, L2) and torch.equal(S, S2)
         for m in cbs:
-            assert ChangeIndexes(m._work['idx'], m._work['count']).numel() == 0
+            assert m.lastChangeIndexes().numel() == 0
 
 
 @pytest.mark.parametrize("form", ["default", "inplace", "atomic"])

@@ -631,3 +631,56 @@ def test_tail1x1_vs_numpy(cb, oracle):
         got2 = out2.cpu().numpy().reshape(C2, -1)
         np.testing.assert_allclose(got2[:, idx[:10]], y[:, :10], rtol=0, atol=FP32_TOL)
         assert int((got2 != 123.0).sum()) == C2 * 10
+
+
+@pytest.mark.parametrize("C,K,kH,kW,H,W,frac", [
+    (3, 16, 7, 7, 64, 96, 0.05), (16, 64, 7, 7, 40, 60, 0.03), (5, 20, 3, 5, 37, 83, 0.02),
+    (1, 1, 3, 3, 9, 130, 0.1), (4, 33, 5, 3, 21, 64, 0.02), (16, 64, 7, 7, 160, 240, 0.02),
+    (3, 16, 7, 7, 320, 480, 0.01), (7, 16, 1, 7, 18, 200, 0.05)])
+def test_rowconv_vs_oracle(cb, oracle, C, K, kH, kW, H, W, frac):
+    """Row-segment contraction (cbinfer_conv_changed_rows) behind the single-mask detection: outputs at the
+    changed pixels <= 1e-4 from the double-accumulated dense convolution of the state (incl. image borders,
+    partial last mask word, K not a multiple of 16, C not a multiple of 4), every other output untouched,
+    maskCopy == the frame's mask (its compaction = the oracle's index list), mask and arrival counters left
+    zero; a second launch on the emptied mask changes nothing."""
+    from cbinfer_amd._lib import C as lib, check, ptr
+    assert lib.cbinfer_rowconv_supported(C, K, kH, kW)
+    rng = np.random.default_rng(C * 131 + K)
+    x, st_np = rand_case(rng, C, H, W, frac, th=0.1, blocks=True)
+    w = (rng.standard_normal((K, C, kH, kW)) / np.sqrt(C * kH * kW)).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    st_o = st_np.copy()
+    cm_o = oracle.changeDetection(x, st_o, (kH, kW), 0.1, updateInputState=True)
+    idx_o = oracle.changeIndexesExtr(cm_o)
+    assert idx_o.size > 0
+    dense = oracle.conv2d_dense(st_o, w, b, relu=True)
+    words = lib.cbinfer_mask_words(H, W)
+    bits = torch.zeros(words, dtype=torch.int64, device="cuda")
+    arrive = torch.zeros(words, dtype=torch.int32, device="cuda")
+    copy = torch.full((words,), -1, dtype=torch.int64, device="cuda")
+    wq = torch.empty(lib.cbinfer_rowconv_prepared_bytes(C, K, kH, kW), dtype=torch.uint8, device="cuda")
+    dw, db = dev(w), dev(b)
+    check(lib.cbinfer_rowconv_prep_weights(ptr(dw), ptr(wq), K, C, kH, kW, None))
+    dx, st = dev(x), dev(st_np)
+    out = torch.full((1, K, H, W), 77.0, device="cuda")
+    check(lib.cbinfer_change_detection_bits(ptr(dx), ptr(st), ptr(bits), W, H, C, (kH - 1) // 2, (kW - 1) // 2,
+                                            0.1, 1, 0, None))
+    mask = bits.clone()
+    check(lib.cbinfer_conv_changed_rows(ptr(st), ptr(bits), ptr(arrive), ptr(copy), ptr(wq), ptr(db), ptr(out),
+                                        C, H, W, K, kH, kW, 1, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(st.cpu().numpy(), st_o)
+    assert torch.equal(copy, mask) and int(bits.abs().sum()) == 0 and int(arrive.abs().sum()) == 0
+    idx = torch.empty(H * W, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    check(lib.cbinfer_compact_bits(ptr(copy), W, H, ptr(idx), ptr(cnt), None, None, None))
+    assert np.array_equal(idx[:int(cnt.item())].cpu().numpy(), idx_o)
+    got = out.cpu().numpy().reshape(K, -1)
+    np.testing.assert_allclose(got[:, idx_o], dense.reshape(K, -1)[:, idx_o], rtol=0, atol=FP32_TOL)
+    rest = np.setdiff1d(np.arange(H * W), idx_o)
+    assert np.all(got[:, rest] == 77.0)
+    before = out.clone()
+    check(lib.cbinfer_conv_changed_rows(ptr(st), ptr(bits), ptr(arrive), ptr(copy), ptr(wq), ptr(db), ptr(out),
+                                        C, H, W, K, kH, kW, 1, None))
+    torch.cuda.synchronize()
+    assert torch.equal(out, before) and int(copy.abs().sum()) == 0

@@ -30,8 +30,9 @@ def measure(model, frames, steps, warm, mode):
 def layer_ratios(model):
     out = []
     for m in model.modules():
-        if type(m) is pycbinfer.CBConv2d and m._work is not None:
-            out.append(int(m._work['count'].item()) / float(m._work['idx'].numel()))
+        if type(m) is pycbinfer.CBConv2d and m.lastChangeIndexes() is not None:
+            ci = m.lastChangeIndexes()
+            out.append(ci.numel() / float(ci.size[0] * ci.size[1]))
     return out
 
 

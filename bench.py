@@ -213,7 +213,8 @@ def kernel_breakdown(test, frame, reps=50):
                 mask_now = rowsws['copy'] if rowsws is not None else m._work['bits']
                 t_cmp = event_time_ms(lambda: check(lib.cbinfer_compact_bits(
                     ptr(mask_now), Ww, Hh, ptr(idx), ptr(cnt), None, None, stream_ptr())), reps)
-                wp = m._prepared_weights(Hh, Ww)
+                ar = m._arith(inp)
+                wp = m._prepared_weights(Hh, Ww, ar)
                 ws = m._work['conv']
                 if rowsws is not None:      # row-segment kernel: it consumes its mask, so refill it per launch
                     saved, rb = rowsws['copy'].clone(), torch.zeros_like(rowsws['bits'])
@@ -226,11 +227,12 @@ def kernel_breakdown(test, frame, reps=50):
                 else:
                     t_conv = event_time_ms(lambda: check(lib.cbinfer_conv_changed(
                         ptr(m.prevInput), ptr(ci.buffer), Hh * Ww, ptr(ci.count), ptr(wp), ptr(m.bias.detach()),
-                        ptr(m.prevOutput), C, Hh, Ww, K, kH, kW, int(m.withReLU), 0, None, 0, ptr(ws), dt,
+                        ptr(m.prevOutput), C, Hh, Ww, K, kH, kW, int(m.withReLU), 0, None, 0, ptr(ws), ar,
                         stream_ptr())), reps)
                 HW = Hh * Ww
                 rows.append(dict(layer="conv %d->%d k%d @%dx%d" % (C, K, kH, Hh, Ww), N=N,
-                                 conv_kernel="cb_rowconv_f32_kernel" if rowsws is not None else "cb_mfma_f32_kernel",
+                                 conv_kernel="cb_rowconv_f32_kernel" if rowsws is not None else
+                                 ("cb_mfma_f32_kernel<X3: bf16x3 split>" if ar == 2 else "cb_mfma_f32_kernel"),
                                  ratio=N / float(HW),
                                  detect_ms=max(t_det - t_zero, 0.0),
                                  detect_bytes=(5 if lazy is not None else 2) * C * HW * s + HW // 8,
@@ -314,8 +316,8 @@ def inframe_conv_times(test, frames, start, reps=40):
                 else:
                     check(lib.cbinfer_conv_changed_from_mask(
                         ptr(m.prevInput), ptr(work['bits']), ptr(work['idx']), ptr(work['count']),
-                        ptr(m._prepared_weights(Hh, Ww)), ptr(m.bias.detach()), ptr(m.prevOutput), C, Hh, Ww, K,
-                        kH, kW, int(m.withReLU), ptr(work['conv']), dt, st))
+                        ptr(m._prepared_weights(Hh, Ww, m._arith(src))), ptr(m.bias.detach()), ptr(m.prevOutput), C,
+                        Hh, Ww, K, kH, kW, int(m.withReLU), ptr(work['conv']), m._arith(src), st))
                 e1.record()
                 from cbinfer_amd.conv2d_cg import ChangeIndexes, MaskChangeIndexes
                 ci = (MaskChangeIndexes(rows['copy'], (Hh, Ww), work['idx'], work['count']) if rows is not None

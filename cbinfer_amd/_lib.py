@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_PKG, "libcbinfer_hip.so")
 
 CB_F32 = 0
 CB_F16 = 1
+CB_F32S = 2     # f32 tensors, contraction as bf16x3 split products on the bf16 MFMA
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -53,9 +54,9 @@ _SIGNATURES = {
     "cbinfer_update_output_fg_list": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cbinfer_change_detection_fg_frame": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "cbinfer_conv_accumulate_from_mask": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
-                                               _vp, _vp]),
+                                               _vp, _i, _vp]),
     "cbinfer_cbconv2d_forward_fg": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
-                                         _i, _f, _i, _vp, _vp]),
+                                         _i, _f, _i, _vp, _i, _vp]),
     "cbinfer_tail1x1_max_hidden": (_i, []),
     "cbinfer_tail1x1_prepared_bytes": (_l, [_i, _i]),
     "cbinfer_tail1x1_prep": (_i, [_vp, _vp, _i, _i, _vp]),

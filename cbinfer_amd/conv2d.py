@@ -196,7 +196,7 @@ class CBConv2d(nn.Module):
         for name, val in (('saveChangeMap', False), ('propChangeIndexes', False),
                           ('gatherComputationStats', False), ('finegrained', False),
                           ('copyInput', True), ('feedbackLoop', False), ('syncIndexes', False),
-                          ('deterministicFG', False), ('atomicFG', False), ('fgInPlace', False), ('_work', None), ('_wprep', None),
+                          ('deterministicFG', False), ('atomicFG', False), ('fgInPlace', False), ('exactF32', False), ('_work', None), ('_wprep', None),
                           ('_inputIsLiveState', False), ('_plan', None), ('_wrows', None), ('_lastIndexes', None)):
             if name not in self.__dict__:
                 self.__dict__[name] = val
@@ -253,11 +253,20 @@ class CBConv2d(nn.Module):
             self._wrows = (key, wp)
         return self._wrows[1]
 
-    def _prepared_weights(self, H=1, W=1):
+    def _arith(self, t):
+        """Arithmetic of the fused contraction: fp16 as is; fp32 as bf16x3 split products on the bf16 MFMA
+        (CB_F32S: every operand as three bf16 terms, the six cross products above 2^-24, f32 accumulation
+        -- f32-level accuracy at 2.7x the f32 MFMA's rate) unless exactF32 asks for the exact f32 fma chain."""
+        code = dtype_code(t)
+        if code == _lib.CB_F32 and not self.exactF32 and os.environ.get('CBINFER_EXACT_F32', '0') != '1':
+            return _lib.CB_F32S
+        return code
+
+    def _prepared_weights(self, H=1, W=1, arith=None):
         w = self.weight
-        key = (w.data_ptr(), w._version, w.dtype, w.device, H, W)
+        key = (w.data_ptr(), w._version, w.dtype, w.device, H, W, arith)
         if self._wprep is None or self._wprep[0] != key:
-            self._wprep = (key, prepWeights(w, H, W))
+            self._wprep = (key, prepWeights(w, H, W, arith=arith))
         return self._wprep[1]
 
     def _workspace(self, input, wantMap=None):
@@ -338,10 +347,11 @@ class CBConv2d(nn.Module):
                 relu = work['relu']
             if not self.prevInput.is_contiguous():
                 self.prevInput = self.prevInput.contiguous()
+            arith = self._arith(x)
             args = (ptr(x), ptr(self.prevInput), ptr(work['delta']), ptr(self.prevOutput), ptr(relu),
                     ptr(work['bits']), ptr(work['idx']), ptr(work['count']),
-                    ptr(self._prepared_weights(H, W)), Cin, H, W, K, kH, kW, float(self.threshold), 1,
-                    ptr(work['conv']), stream_ptr(x))
+                    ptr(self._prepared_weights(H, W, arith)), Cin, H, W, K, kH, kW, float(self.threshold), 1,
+                    ptr(work['conv']), arith, stream_ptr(x))
             check(C.cbinfer_cbconv2d_forward_fg(*args))
             result = relu if self.withReLU else self.prevOutput
             if self.propChangeIndexes:      # (extension: the reference's forward_fg hands no indexes on)
@@ -351,10 +361,12 @@ class CBConv2d(nn.Module):
         po = self.prevOutput.clone()                                 # conv2d.py:169
         if fused:
             work = self._fg_workspace(x)
+            arith = self._arith(x)
             check(C.cbinfer_cbconv2d_forward_fg(
                 ptr(x), ptr(self.prevInput.contiguous()), ptr(work['delta']), ptr(po), None,
-                ptr(work['bits']), ptr(work['idx']), ptr(work['count']), ptr(self._prepared_weights(H, W)),
-                Cin, H, W, K, kH, kW, float(self.threshold), 0, ptr(work['conv']), stream_ptr(x)))
+                ptr(work['bits']), ptr(work['idx']), ptr(work['count']),
+                ptr(self._prepared_weights(H, W, arith)), Cin, H, W, K, kH, kW, float(self.threshold), 0,
+                ptr(work['conv']), arith, stream_ptr(x)))
         elif x.is_cuda and self.deterministicFG and not self.atomicFG:
             po = cbconvFG_deterministic(x, self.prevInput, po, self.weight.detach(), self.threshold,
                                         weightsPrepared=self._prepared_weights(H, W))
@@ -458,10 +470,11 @@ class CBConv2d(nn.Module):
             if self.propChangeIndexes:
                 return 'changeIndexes', self.prevOutput, self._lastIndexes
             return self.prevOutput
+        arith = self._arith(src)
         args = (ptr(src), src.size(-2), src.size(-1), ptr(self.prevInput), ptr(self.prevOutput),
-                ptr(work['bits']), ptr(work['idx']), ptr(work['count']), ptr(self._prepared_weights(H, W)),
-                ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold),
-                int(bool(self.withReLU)), ptr(work['conv']), dtype_code(src), stream_ptr(src))
+                ptr(work['bits']), ptr(work['idx']), ptr(work['count']),
+                ptr(self._prepared_weights(H, W, arith)), ptr(self.bias.detach()), Cin, H, W, K, kH, kW,
+                float(self.threshold), int(bool(self.withReLU)), ptr(work['conv']), arith, stream_ptr(src))
         check(C.cbinfer_cbconv2d_forward_pooled(*args))
         self._make_plan(True, src, C.cbinfer_cbconv2d_forward_pooled, args, 0)
         self._lastIndexes = ChangeIndexes(work['idx'], work['count'], (H, W))
@@ -519,12 +532,13 @@ class CBConv2d(nn.Module):
             result = MaskChangeIndexes(rows['copy'], (H, W), work['idx'], work['count'])
             cap = 0      # (done)
         if cap > 0:
+            arith = self._arith(input)
             args = (ptr(input), ptr(prev), ptr(self.prevOutput), None if have else ptr(work['bits']),
-                    ptr(idx), ptr(count), ptr(mapOut), ptr(self._prepared_weights(H, W)),
+                    ptr(idx), ptr(count), ptr(mapOut), ptr(self._prepared_weights(H, W, arith)),
                     ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold),
                     int(bool(self.feedbackLoop)), int(bool(self.copyInput)), int(bool(self.withReLU)),
                     int(have), cap, ptr(work['conv']),
-                    int(work['selfc'] and not have), dtype_code(input), stream_ptr(input))
+                    int(work['selfc'] and not have), arith, stream_ptr(input))
             check(C.cbinfer_cbconv2d_forward(*args))
             if not have and not self._inputIsLiveState:
                 self._make_plan(False, input, C.cbinfer_cbconv2d_forward, args, 0)
@@ -583,7 +597,7 @@ class CBConv2d(nn.Module):
     def _flags(self):
         return (self.threshold, self.feedbackLoop, self.copyInput, self.withReLU, self.propChangeIndexes,
                 self.syncIndexes, self.saveChangeMap, self.gatherComputationStats, self.finegrained,
-                self.atomicFG, self.fgInPlace)
+                self.atomicFG, self.fgInPlace, self.exactF32)
 
     def _make_plan(self, pooled, src, fn, args, srcSlot, result=None, rows=False):
         """Remember a finished sync-free call: fn(*args) with args[srcSlot] = source pointer, args[-1] =

@@ -217,9 +217,10 @@ def convWorkspace(device):
     return ws
 
 
-def prepWeights(weights, H=1, W=1):
+def prepWeights(weights, H=1, W=1, arith=None):
     """Pad the [K,C,kH,kW] filter bank to the MFMA tile grid (W[Kpad][CkkPad], k contiguous) and append
-    the tap table for an H x W feature map."""
+    the tap table for an H x W feature map.  arith: the library's arithmetic code when it differs from the
+    tensor's dtype (CB_F32S: f32 weights pre-split into three bf16 planes for the bf16x3 contraction)."""
     require_device(weights)
     w = weights.detach().contiguous()
     K = w.size(0)
@@ -227,9 +228,10 @@ def prepWeights(weights, H=1, W=1):
         Cin, kH, kW = w.size(1), w.size(2), w.size(3)
     else:
         Cin, kH, kW = w.numel() // K, 1, 1
-    nbytes = C.cbinfer_prepared_weights_bytes(K, Cin, kH, kW, dtype_code(w))
+    code = dtype_code(w) if arith is None else arith
+    nbytes = C.cbinfer_prepared_weights_bytes(K, Cin, kH, kW, code)
     wp = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    check(C.cbinfer_prep_weights(ptr(w), ptr(wp), K, Cin, kH, kW, H, W, dtype_code(w), stream_ptr(w)))
+    check(C.cbinfer_prep_weights(ptr(w), ptr(wp), K, Cin, kH, kW, H, W, code, stream_ptr(w)))
     return wp
 
 
@@ -285,7 +287,7 @@ def updateOutput(YMatrix, changeIndexes, prevOutput, withReLU=False, useHalf=Fal
 # a5..a8 fused
 # ------------------------------------------------------------------------------------------------
 def convChanged(input, changeIndexes, weights, bias, prevOutput, withReLU=False, accumulate=False,
-                weightsPrepared=None, workspace=None):
+                weightsPrepared=None, workspace=None, arith=None):
     """gather -> MFMA -> bias/ReLU -> scatter for the changed pixels in ONE launch; prevOutput is
     updated in place.  Equivalent to genXMatrix + matrixMult + transpose + updateOutput."""
     require_device(input, prevOutput, weights)
@@ -298,12 +300,13 @@ def convChanged(input, changeIndexes, weights, bias, prevOutput, withReLU=False,
     idx, count, cap = _split_indexes(changeIndexes)
     if cap == 0:
         return prevOutput
-    wp = weightsPrepared if weightsPrepared is not None else prepWeights(weights, H, W)
+    code = dtype_code(inp) if arith is None else arith
+    wp = weightsPrepared if weightsPrepared is not None else prepWeights(weights, H, W, arith=code)
     b = bias.detach().contiguous() if bias is not None else None
     check(C.cbinfer_conv_changed(ptr(inp), ptr(idx), cap, ptr(count), ptr(wp), ptr(b), ptr(prevOutput),
                                  Cin, H, W, K, kH, kW, int(bool(withReLU)), int(bool(accumulate)), None,
                                  0, ptr(workspace if workspace is not None else convWorkspace(inp.device)),
-                                 dtype_code(inp), stream_ptr(inp)))
+                                 code, stream_ptr(inp)))
     return prevOutput
 
 

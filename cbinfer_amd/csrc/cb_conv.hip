@@ -18,6 +18,20 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x = hi + mid + lo with three bf16 terms (24 significant bits): hi = bf16(x), mid = bf16(x - hi),
+// lo = bf16(x - hi - mid); both differences are exact in f32.  Returned as the raw 16-bit patterns.
+__device__ __forceinline__ void cb_split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    const __bf16 l = (__bf16)r2;
+    hi = __builtin_bit_cast(unsigned short, h);
+    mid = __builtin_bit_cast(unsigned short, m);
+    lo = __builtin_bit_cast(unsigned short, l);
+}
 typedef __attribute__((address_space(4))) int cb_const_int;   // constant address space: scalar loads
 
 __device__ __forceinline__ float cb_relu(float v) { return v <= 0.f ? 0.f : v; }
@@ -51,6 +65,23 @@ __global__ __launch_bounds__(256) void cb_prep_w_f32_kernel(const float* __restr
     if (e >= (long)KP * CkkP) return;
     const int k = (int)(e % CkkP), m = (int)(e / CkkP);
     wp[e] = (m < K && k < Ckk) ? w[(long)m * Ckk + k] : 0.f;
+}
+// fp32 weights for the bf16x3 contraction: W3[KP][CkkP/32][3 planes][32 k] bf16 (a row's 32 k of one stage
+// as hi | mid | lo, 192 B, exactly the LDS row image), followed by the same tap table as the f32 layout
+__global__ __launch_bounds__(256) void cb_prep_w_f32s_kernel(const float* __restrict__ w,
+                                                            unsigned short* __restrict__ wp, int K, int Ckk,
+                                                            int KP, int CkkP, int kH, int kW, int H, int W) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < CkkP) cb_pack_k((int*)(wp + (long)KP * CkkP * 3), (int)e, Ckk, CkkP, kH, kW, H, W, 4);
+    if (e >= (long)KP * CkkP) return;
+    const int k = (int)(e % CkkP), m = (int)(e / CkkP);
+    const float v = (m < K && k < Ckk) ? w[(long)m * Ckk + k] : 0.f;
+    unsigned hi, mid, lo;
+    cb_split3(v, hi, mid, lo);
+    unsigned short* row = wp + ((long)m * (CkkP / 32) + k / 32) * 96 + (k & 31);
+    row[0] = (unsigned short)hi;
+    row[32] = (unsigned short)mid;
+    row[64] = (unsigned short)lo;
 }
 __global__ __launch_bounds__(256) void cb_prep_w_f16_kernel(const cb_half* __restrict__ w,
                                                            cb_half* __restrict__ wp, int K, int Ckk,
@@ -132,6 +163,7 @@ struct ConvParams {
     int32_t* listOut;                 // the list and its length are written out as a by-product
     int32_t* countOut;
     void* reluOut;                    // EPI_SCATTER_ACC: optional second plane set receiving relu(out)
+    int dbg;                          // diagnostic ablations (CBINFER_CONV_DBG): 1 no gather loads, 2 no weight loads
 };
 
 #define CB_SELFC_MAXW 4096
@@ -205,7 +237,13 @@ __device__ unsigned long long cb_stamp_clk[1024 * 2];   // s_memtime (shader clo
 #define CB_STAMP_AT(i)
 #endif
 #define CB_SKMAX 8
-template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false>
+// X3: the same kernel with every f32 operand split into three bf16 terms (cb_split3) and the six cross
+// products that matter -- hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi; the dropped ones are below 2^-24
+// of the product -- issued on v_mfma_f32_32x32x16_bf16 with f32 accumulation: f32-level accuracy at 16/6
+// of the f32 MFMA's rate (the f32-input MFMA runs at 1/16 of the bf16 one on gfx950).  Weights come
+// pre-split (cb_prep_w_f32s_kernel); gathered values are split on their way into LDS.  LDS row = the
+// stage's 32 k as hi | mid | lo (192 B + 16 B pad: 16-byte fragment reads of any 16 rows are conflict-free).
+template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false, bool X3 = false>
 __global__ __launch_bounds__(64 * WM * WN * KS)
     __attribute__((amdgpu_waves_per_eu((WM * WN * KS >= 8 ? 4 : WM * WN * KS >= 4 ? 2 : 1)))) void cb_mfma_f32_kernel(
         ConvParams p) {
@@ -213,8 +251,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * WN;
     constexpr int BK = 32;
-    constexpr int LDK = BK + 4;         // LDS row = the stage's 32 k of one m / one pixel + 16 B pad
-    constexpr int A_F4 = BK * BM / 4;
+    constexpr int LDK = X3 ? 52 : BK + 4;   // LDS row in floats: 32 k of one m / one pixel + 16 B pad
+    constexpr int A_F4 = X3 ? 12 * BM : BK * BM / 4;   // 16-byte chunks of an A stage
     constexpr int A_PER_T = (A_F4 + NT - 1) / NT;
     constexpr int B_PER_T = BK * BN / NT;
     constexpr int NPP = NT / BK;        // matrix: pixel slots covered by one pass
@@ -224,6 +262,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
     constexpr int TILE = BM * BN;
     static_assert(BN % 64 == 0, "gather rows must be wave-uniform");
     static_assert(BK * BN % NT == 0 && S % 4 == 0, "bad decomposition");
+    static_assert(!X3 || (KS == 2 && MODE == CB_MODE_GATHER && (BK * BN / NT) % 4 == 0), "X3: 16 k per wave group");
     static_assert(KS == 1 || 2 * (A_STAGE + B_STAGE) >= WM * WN * 64 * 16, "reduce buffer");
 
 #ifdef CB_STAMP
@@ -328,7 +367,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
 
     const float* __restrict__ Ag = (const float*)p.A;
     const float* __restrict__ Bg = (const float*)p.B;
-    const cb_const_int* koff_c = (const cb_const_int*)(Ag + (long)p.KP * p.CkkP);
+    const cb_const_int* koff_c = X3 ? (const cb_const_int*)((const unsigned short*)p.A + (long)p.KP * p.CkkP * 3)
+                                    : (const cb_const_int*)(Ag + (long)p.KP * p.CkkP);
     const cb_const_int* kdyx_c = koff_c + p.CkkP;
     const int HW = p.H * p.W;
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -421,17 +461,28 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
             constexpr bool FAST = decltype(FASTC)::value;
 #pragma unroll
             for (int i = 0; i < A_PER_T; ++i) {
-                const int f = t + i * NT;
-                if (A_F4 % NT == 0 || f < A_F4) {
-                    const int row = f / (BK / 4), c4 = f % (BK / 4);
-                    const float4 v = *(const float4*)(Ag + (long)(m0 + row) * p.CkkP + k0 + c4 * 4);
+                const int f = X3 ? min(t + i * NT, A_F4 - 1) : t + i * NT;   // (X3: every thread loads, the
+                if (A_F4 % NT == 0 || f < A_F4) {                            //  surplus is not stored)
+                    float4 v;
+                    if (X3 && (p.dbg & 2)) {
+                        v = make_float4(1.f, 1.f, 1.f, 1.f);
+                    } else if (X3) {   // 12 chunks per row and stage in the pre-split layout
+                        const int row = f / 12, c = f % 12;
+                        v = *((const float4*)Ag + ((long)(m0 + row) * (p.CkkP / 32) + k0 / 32) * 12 + c);
+                    } else {
+                        const int row = f / (BK / 4), c4 = f % (BK / 4);
+                        v = *(const float4*)(Ag + (long)(m0 + row) * p.CkkP + k0 + c4 * 4);
+                    }
                     areg[4 * i] = v.x;
                     areg[4 * i + 1] = v.y;
                     areg[4 * i + 2] = v.z;
                     areg[4 * i + 3] = v.w;
                 }
             }
-            if (MODE == CB_MODE_GATHER && FAST) {
+            if (X3 && (p.dbg & 1)) {
+#pragma unroll
+                for (int i = 0; i < B_PER_T; ++i) breg[i] = 1.0f;
+            } else if (MODE == CB_MODE_GATHER && FAST) {
 #pragma unroll
                 for (int i = 0; i < B_PER_T; ++i)   // (a padded k-row has offset 2^30 -> reads 0)
                     breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
@@ -464,10 +515,21 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
             for (int i = 0; i < A_PER_T; ++i) {
                 const int f = t + i * NT;
                 if (A_F4 % NT == 0 || f < A_F4)
-                    *(float4*)(as + (f / (BK / 4)) * LDK + (f % (BK / 4)) * 4) =
+                    *(float4*)(as + (X3 ? (f / 12) * LDK + (f % 12) * 4 : (f / (BK / 4)) * LDK + (f % (BK / 4)) * 4)) =
                         make_float4(areg[4 * i], areg[4 * i + 1], areg[4 * i + 2], areg[4 * i + 3]);
             }
-            if (MODE == CB_MODE_GATHER && B_PER_T % 4 == 0) {   // the thread's taps are k-consecutive
+            if (X3) {   // split the thread's k-consecutive values, 8-byte writes into the three planes
+#pragma unroll
+                for (int q = 0; q < B_PER_T / 4; ++q) {
+                    unsigned h[4], m[4], l[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cb_split3(breg[q * 4 + e], h[e], m[e], l[e]);
+                    char* row = (char*)(bs + bj * LDK) + (br + q * 4) * 2;
+                    *(uint2*)(row) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                    *(uint2*)(row + 64) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+                    *(uint2*)(row + 128) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                }
+            } else if (MODE == CB_MODE_GATHER && B_PER_T % 4 == 0) {   // the thread's taps are k-consecutive
 #pragma unroll
                 for (int q = 0; q < B_PER_T / 4; ++q)
                     *(float4*)(bs + bj * LDK + br + q * 4) =
@@ -491,6 +553,21 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
         // half h takes the second); any pairing works as long as both operands use it, and this one
         // makes a lane's S values per operand contiguous: S/4 ds_read_b128 instead of S ds_read_b32.
         auto compute = [&](int buf) {
+            if (X3) {
+                // wave group ks owns k 16 ks .. 16 ks + 15 of the stage; a lane's fragment = 8 consecutive k
+                const char* ap = (const char*)(As + buf * A_STAGE + (wm * 32 + l31) * LDK) + ks * 32 + h * 16;
+                const char* bp = (const char*)(Bs + buf * B_STAGE + (wn * 32 + l31) * LDK) + ks * 32 + h * 16;
+                const bf16x8 ah = *(const bf16x8*)ap, am = *(const bf16x8*)(ap + 64), al = *(const bf16x8*)(ap + 128);
+                const bf16x8 bh = *(const bf16x8*)bp, bm = *(const bf16x8*)(bp + 64), bl = *(const bf16x8*)(bp + 128);
+                // smallest terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                return;
+            }
             const float* ap = As + buf * A_STAGE + (wm * 32 + l31) * LDK + h * (BK / 2) + ks * S;
             const float* bp = Bs + buf * B_STAGE + (wn * 32 + l31) * LDK + h * (BK / 2) + ks * S;
             float4 av[S / 4], bv[S / 4];
@@ -1112,7 +1189,7 @@ int cb_num_cus() {
     return cus;
 }
 
-template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false>
+template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false, bool X3 = false>
 int launch_f32(const ConvParams& p, hipStream_t s) {
     const long tilesCap = (long)cb_div_up(p.nHost, 32 * WN) * (p.KP / (32 * WM));
     if (tilesCap == 0) return CB_OK;
@@ -1121,7 +1198,7 @@ int launch_f32(const ConvParams& p, hipStream_t s) {
     long g = CB_CONV_GRID_PER_CU * (long)cb_num_cus();
     if (!p.slabs && tilesCap < g && !SELFC) g = tilesCap;
     dim3 grid((unsigned)g), block(64 * WM * WN * KS);
-    hipLaunchKernelGGL((cb_mfma_f32_kernel<WM, WN, KS, MODE, EPI, SELFC>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((cb_mfma_f32_kernel<WM, WN, KS, MODE, EPI, SELFC, X3>), grid, block, 0, s, p);
     return cb_launch_status();
 }
 
@@ -1138,7 +1215,7 @@ int launch_f16(const ConvParams& p, hipStream_t s) {
 
 // k-depth padding of the prepared weights
 int cb_ckkpad(int Ckk, int dtype) {
-    const int q = dtype == CB_F16 ? 128 : 32;   // fp32: whole 32-deep stages; fp16: stage pairs of 2 x 64
+    const int q = dtype == CB_F16 ? 128 : 32;   // fp32 (both layouts): whole 32-deep stages; fp16: stage pairs of 2 x 64
     return (Ckk + q - 1) / q * q;
 }
 
@@ -1146,10 +1223,32 @@ int conv_cfg_override() {
     const char* e = getenv("CBINFER_CONV_CFG");
     return e ? atoi(e) : 0;
 }
+int conv_dbg() {
+    static int d = -1;
+    if (d < 0) {
+        const char* e = getenv("CBINFER_CONV_DBG");
+        d = e ? atoi(e) : 0;
+    }
+    return d;
+}
 
 template <int MODE, int EPI>
-int launch_mfma(const ConvParams& p, int dtype, hipStream_t s) {
+int launch_mfma(const ConvParams& p0, int dtype, hipStream_t s) {
+    ConvParams p = p0;
+    p.dbg = conv_dbg();
     const bool narrow = p.KP <= 32;
+    if (dtype == CB_F32S) {   // f32 tensors, bf16x3 split products (gather modes only)
+        if constexpr (MODE == CB_MODE_GATHER && EPI >= CB_EPI_SCATTER) {
+            if (p.frameMasks) {
+                if (narrow) return launch_f32<1, 4, 2, CB_MODE_GATHER, EPI, true, true>(p, s);
+                return launch_f32<2, 2, 2, CB_MODE_GATHER, EPI, true, true>(p, s);
+            }
+            if (narrow) return launch_f32<1, 4, 2, CB_MODE_GATHER, EPI, false, true>(p, s);
+            return launch_f32<2, 2, 2, CB_MODE_GATHER, EPI, false, true>(p, s);
+        } else {
+            return CB_ERR_UNSUPPORTED;
+        }
+    }
     if (dtype == CB_F32) {
         int cfg = conv_cfg_override();
         if (cfg == 0) cfg = narrow ? 142 : 222;
@@ -1195,7 +1294,7 @@ long cbinfer_conv_workspace_bytes(void) {
 
 long cbinfer_prepared_weights_bytes(int K, int C, int kH, int kW, int dtype) {
     const long KP = cbinfer_weights_kpad(K), CkkP = cb_ckkpad(C * kH * kW, dtype);
-    return KP * CkkP * (dtype == CB_F16 ? 2 : 4) + CkkP * 8;
+    return KP * CkkP * (dtype == CB_F16 ? 2 : dtype == CB_F32S ? 6 : 4) + CkkP * 8;
 }
 
 int cbinfer_prep_weights(const void* weight, void* weightsPrepared, int K, int C, int kH, int kW,
@@ -1212,6 +1311,9 @@ int cbinfer_prep_weights(const void* weight, void* weightsPrepared, int K, int C
     else if (dtype == CB_F16)
         hipLaunchKernelGGL(cb_prep_w_f16_kernel, grid, block, 0, (hipStream_t)stream,
                            (const cb_half*)weight, (cb_half*)weightsPrepared, K, Ckk, KP, CkkP, kH, kW, H, W);
+    else if (dtype == CB_F32S)
+        hipLaunchKernelGGL(cb_prep_w_f32s_kernel, grid, block, 0, (hipStream_t)stream, (const float*)weight,
+                           (unsigned short*)weightsPrepared, K, Ckk, KP, CkkP, kH, kW, H, W);
     else
         return CB_ERR_BADARG;
     return cb_launch_status();
@@ -1292,7 +1394,7 @@ int cbinfer_conv_changed(const void* input, const int32_t* changeList, int numCh
                          int dtype, cbStream_t stream) {
     CB_REQUIRE(input && changeList && weightsPrepared && output && C > 0 && H > 0 && W > 0 && K > 0 &&
                kH > 0 && kW > 0 && numChanges >= 0);
-    CB_REQUIRE(dtype == CB_F32 || dtype == CB_F16);
+    CB_REQUIRE(dtype == CB_F32 || dtype == CB_F16 || dtype == CB_F32S);
     if ((long)C * kH * kW > 65535 || (long)C * H * W * 4 >= (1l << 30)) return CB_ERR_UNSUPPORTED;
     if (numChanges == 0) return CB_OK;
     ConvParams p = {};
@@ -1332,7 +1434,7 @@ static int cb_conv_from_mask(const void* input, uint64_t* frameMasks, int32_t* i
                              void* workspace, int dtype, cbStream_t stream, int accumulate, void* reluOut) {
     CB_REQUIRE(input && frameMasks && idxOut && countOut && weightsPrepared && output && C > 0 && H > 0 &&
                W > 0 && K > 0 && kH > 0 && kW > 0);
-    if (dtype != CB_F32 && dtype != CB_F16) return CB_ERR_BADARG;
+    if (dtype != CB_F32 && dtype != CB_F16 && dtype != CB_F32S) return CB_ERR_BADARG;
     const long words = cbinfer_mask_words(H, W);
     if (words > CB_SELFC_MAXW || (long)C * kH * kW > 65535 || (long)C * H * W * 4 >= (1l << 30))
         return CB_ERR_UNSUPPORTED;
@@ -1362,7 +1464,7 @@ static int cb_conv_from_mask(const void* input, uint64_t* frameMasks, int32_t* i
         p.slabs = (float*)((char*)workspace + 4096);
     }
     if (accumulate) {
-        if (dtype != CB_F32) return CB_ERR_UNSUPPORTED;
+        if (dtype != CB_F32 && dtype != CB_F32S) return CB_ERR_UNSUPPORTED;
         p.reluOut = reluOut;
         return launch_mfma<CB_MODE_GATHER, CB_EPI_SCATTER_ACC>(p, dtype, (hipStream_t)stream);
     }
@@ -1383,9 +1485,10 @@ int cbinfer_conv_changed_from_mask(const void* input, uint64_t* frameMasks, int3
 int cbinfer_conv_accumulate_from_mask(const float* delta, uint64_t* frameMasks, int32_t* idxOut,
                                       int32_t* countOut, const void* weightsPrepared, float* output,
                                       float* reluOut, int C, int H, int W, int K, int kH, int kW,
-                                      void* workspace, cbStream_t stream) {
+                                      void* workspace, int dtype, cbStream_t stream) {
+    if (dtype != CB_F32 && dtype != CB_F32S) return CB_ERR_BADARG;
     return cb_conv_from_mask(delta, frameMasks, idxOut, countOut, weightsPrepared, nullptr, output, C, H, W,
-                             K, kH, kW, 0, workspace, CB_F32, stream, 1, reluOut);
+                             K, kH, kW, 0, workspace, dtype, stream, 1, reluOut);
 }
 
 long cbinfer_frame_mask_bytes(int H, int W) { return 2 * cbinfer_mask_words(H, W) * 8 + 16; }

@@ -12,15 +12,16 @@ extern "C" int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void
                                         int capN, void* workspace, int selfCompact, int dtype,
                                         cbStream_t stream) {
     CB_REQUIRE(input && prevInput && prevOutput && idx && countDev && weightsPrepared);
-    CB_REQUIRE(dtype == CB_F32 || dtype == CB_F16);
+    CB_REQUIRE(dtype == CB_F32 || dtype == CB_F16 || dtype == CB_F32S);
     CB_REQUIRE(capN >= 0 && capN <= H * W);
+    const int edt = dtype == CB_F32S ? CB_F32 : dtype;   // element type (CB_F32S only selects the arithmetic)
     int st;
     if (selfCompact) {
         // detection -> [state copy] -> self-compacting fused kernel: 2 launches per layer and frame.
         // `bits` is a cbinfer_frame_mask_bytes(H,W) buffer (two alternating masks + parity).
         CB_REQUIRE(!haveIndexes && bits && !mapOut);
         st = cbinfer_change_detection_frame(input, prevInput, bits, W, H, C, (kH - 1) / 2, (kW - 1) / 2,
-                                            threshold, feedbackLoop, dtype, stream);
+                                            threshold, feedbackLoop, edt, stream);
         if (st != CB_OK) return st;
         if (!feedbackLoop && copyInput && prevInput != input) {
             const size_t bytes = (size_t)C * H * W * (dtype == CB_F16 ? 2 : 4);
@@ -35,7 +36,7 @@ extern "C" int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void
     if (!haveIndexes) {
         CB_REQUIRE(bits != nullptr);
         st = cbinfer_change_detection_bits(input, prevInput, bits, W, H, C, (kH - 1) / 2, (kW - 1) / 2,
-                                           threshold, feedbackLoop, dtype, stream);
+                                           threshold, feedbackLoop, edt, stream);
         if (st != CB_OK) return st;
         st = cbinfer_compact_bits(bits, W, H, idx, countDev, nullptr, mapOut, stream);
         if (st != CB_OK) return st;
@@ -65,9 +66,10 @@ extern "C" int cbinfer_cbconv2d_forward_pooled(const void* prePool, int pH, int 
                                                float threshold, int relu, void* workspace, int dtype,
                                                cbStream_t stream) {
     CB_REQUIRE(prePool && prevInput && prevOutput && bits && idx && countDev && weightsPrepared);
-    CB_REQUIRE(dtype == CB_F32 || dtype == CB_F16);
+    CB_REQUIRE(dtype == CB_F32 || dtype == CB_F16 || dtype == CB_F32S);
     const int st = cbinfer_change_detection_frame_pooled(prePool, pH, pW, prevInput, bits, W, H, C,
-                                                         (kH - 1) / 2, (kW - 1) / 2, threshold, dtype, stream);
+                                                         (kH - 1) / 2, (kW - 1) / 2, threshold,
+                                                         dtype == CB_F32S ? CB_F32 : dtype, stream);
     if (st != CB_OK) return st;
     return cbinfer_conv_changed_from_mask(prevInput, bits, idx, countDev, weightsPrepared, bias, prevOutput,
                                           C, H, W, K, kH, kW, relu, workspace, dtype, stream);
@@ -88,14 +90,14 @@ extern "C" int cbinfer_cbconv2d_forward_fg(const float* input, float* prevInput,
                                            float* prevOutput, float* reluOut, uint64_t* frameMasks,
                                            int32_t* idx, int32_t* countDev, const void* weightsPrepared,
                                            int C, int H, int W, int K, int kH, int kW, float threshold,
-                                           int refreshState, void* workspace, cbStream_t stream) {
+                                           int refreshState, void* workspace, int dtype, cbStream_t stream) {
     CB_REQUIRE(input && prevInput && delta && prevOutput && frameMasks && idx && countDev && weightsPrepared);
     const int st = cbinfer_change_detection_fg_frame(input, prevInput, delta, frameMasks, W, H, C,
                                                      (kH - 1) / 2, (kW - 1) / 2, threshold, refreshState,
                                                      stream);
     if (st != CB_OK) return st;
     return cbinfer_conv_accumulate_from_mask(delta, frameMasks, idx, countDev, weightsPrepared, prevOutput,
-                                             reluOut, C, H, W, K, kH, kW, workspace, stream);
+                                             reluOut, C, H, W, K, kH, kW, workspace, dtype, stream);
 }
 
 // The frame of a layer whose contraction runs on the row-segment kernel (cbinfer_conv_changed_rows, fp32,

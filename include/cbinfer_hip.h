@@ -37,6 +37,13 @@ typedef void* cbStream_t; /* hipStream_t */
 
 #define CB_F32 0
 #define CB_F16 1
+/* f32 tensors whose contraction runs as bf16x3 split products on the bf16 MFMA (f32 accumulation): every
+ * operand x = hi + mid + lo (three bf16 terms, 24 significant bits), the six cross products above 2^-24 of
+ * the product are summed -- f32-level accuracy at 16/6 of the f32 MFMA's rate.  Accepted wherever a `dtype`
+ * selects the arithmetic of a gather-mode contraction (cbinfer_prep_weights, cbinfer_prepared_weights_bytes,
+ * cbinfer_conv_changed[_from_mask], cbinfer_conv_accumulate_from_mask, cbinfer_cbconv2d_forward[_pooled,
+ * _fg]); the tensors stay f32 and CB_F32 keeps the exact f32 fma chain. */
+#define CB_F32S 2
 
 #define CB_OK 0
 #define CB_ERR_BADARG (-1)      /* null pointer, non-positive size, unsupported dtype */
@@ -272,11 +279,12 @@ int cbinfer_change_detection_fg_frame(const float* input, float* prevInput, floa
 int cbinfer_conv_accumulate_from_mask(const float* delta, uint64_t* frameMasks, int32_t* idxOut,
                                       int32_t* countOut, const void* weightsPrepared, float* output,
                                       float* reluOut, int C, int H, int W, int K, int kH, int kW,
-                                      void* workspace, cbStream_t stream);
+                                      void* workspace, int dtype, cbStream_t stream);
 int cbinfer_cbconv2d_forward_fg(const float* input, float* prevInput, float* delta, float* prevOutput,
                                 float* reluOut, uint64_t* frameMasks, int32_t* idx, int32_t* countDev,
                                 const void* weightsPrepared, int C, int H, int W, int K, int kH, int kW,
-                                float threshold, int refreshState, void* workspace, cbStream_t stream);
+                                float threshold, int refreshState, void* workspace, int dtype,
+                                cbStream_t stream);
 
 /* ---- change-based 1x1 tail: conv1x1 -> [ReLU] -> conv1x1 at the changed pixels of the producing layer,
  * one launch.  Replaces two CBConv2d fed by propagated change indexes (sceneLabeling/modelLoader.py:41-44,

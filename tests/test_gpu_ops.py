@@ -581,7 +581,7 @@ def test_fg_frame_kernels_vs_oracle(cb, oracle):
         for rep in range(2):        # second call: input == state -> nothing changes, masks were re-zeroed
             check(lib.cbinfer_cbconv2d_forward_fg(ptr(x), ptr(st), ptr(delta), ptr(out), ptr(relu), ptr(bits),
                                                   ptr(idx), ptr(cnt), ptr(wp), C, H, W, K, k, k, th, 1, ptr(ws),
-                                                  None))
+                                                  0, None))
             torch.cuda.synchronize()
             if rep == 0:
                 assert np.array_equal(delta.cpu().numpy(), np.where(cm_o != 0, d_o, 0).astype(np.float32))
@@ -684,3 +684,36 @@ def test_rowconv_vs_oracle(cb, oracle, C, K, kH, kW, H, W, frac):
                                         C, H, W, K, kH, kW, 1, None))
     torch.cuda.synchronize()
     assert torch.equal(out, before) and int(copy.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("C,K,H,W,filt,frac", [(64, 256, 80, 120, (7, 7), 0.3), (16, 64, 160, 240, (7, 7), 0.1),
+                                               (185, 128, 46, 81, (7, 7), 0.2), (5, 20, 33, 70, (3, 5), 0.5),
+                                               (3, 16, 64, 96, (7, 7), 0.2)])
+def test_split_contraction_accuracy(cb, oracle, C, K, H, W, filt, frac):
+    """CB_F32S: the fused contraction with every f32 operand split into three bf16 terms and six cross
+    products on the bf16 MFMA.  Against the double-accumulated oracle it must meet the fp32 bar (1e-4) with a
+    wide margin -- the dropped terms are below 2^-24 of each product -- also for operands spanning many
+    binades; and it must agree with the exact-f32 kernel to a few f32 ulp of the accumulated magnitude."""
+    from cbinfer_amd._lib import CB_F32S
+    _, cg, _ = cb
+    rng = np.random.default_rng(C + K)
+    inp = (rng.standard_normal((1, C, H, W)) * np.exp(rng.uniform(-6, 3, (1, C, 1, 1)))).astype(np.float32)
+    w = (rng.standard_normal((K, C) + filt) / np.sqrt(C * filt[0] * filt[1])).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    idx_o = np.sort(rng.choice(H * W, int(frac * H * W), replace=False)).astype(np.int32)
+    X_o = oracle.genXMatrix(inp, idx_o, filt)
+    Y_o = oracle.matrixMult(X_o, w, b).T                     # [K, N], accumulated in double
+    mag = np.abs(X_o).astype(np.float64) @ np.abs(w.reshape(K, -1)).astype(np.float64).T   # sum |a||b|
+    res = {}
+    for name, arith in (("split", CB_F32S), ("exact", None)):
+        po = torch.zeros(1, K, H, W, device="cuda")
+        cg.convChanged(dev(inp), dev(idx_o), dev(w), dev(b), po, withReLU=False, arith=arith)
+        res[name] = po.cpu().numpy().reshape(K, -1)[:, idx_o]
+    err_s = np.abs(res["split"] - Y_o)
+    err_e = np.abs(res["exact"] - Y_o)
+    print("C%d K%d: max |err| split %.3g, exact f32 %.3g; relative to sum|a||b| %.3g / %.3g"
+          % (C, K, err_s.max(), err_e.max(), (err_s / mag.T).max(), (err_e / mag.T).max()))
+    assert err_s.max() <= FP32_TOL
+    # per-element bound: a few 2^-24 of the accumulated magnitude (each product is off by < 3 * 2^-24, plus
+    # the f32 roundings of the running sum) -- i.e. no worse than the exact chain's own rounding error bound
+    assert np.all(err_s <= 64 * 2.0 ** -24 * mag.T + 1e-30)

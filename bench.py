@@ -195,7 +195,8 @@ def kernel_breakdown(test, frame, reps=50):
                 s = 4 if inp.dtype == torch.float32 else 2
                 ci = m.lastChangeIndexes()
                 N = ci.numel()
-                rowsws = m._work.get('rows') if m._rows_path(inp.dtype, Hh, Ww) else None
+                mpath = m._rows_path(inp.dtype, Hh, Ww)
+                rowsws = m._work.get('rows') if mpath else None
                 bits = torch.zeros_like(m._work['bits'])
                 cnt = torch.zeros(1, dtype=torch.int32, device=inp.device)
                 idx = torch.empty_like(m._work['idx'])
@@ -219,9 +220,10 @@ def kernel_breakdown(test, frame, reps=50):
                 if rowsws is not None:      # row-segment kernel: it consumes its mask, so refill it per launch
                     saved, rb = rowsws['copy'].clone(), torch.zeros_like(rowsws['bits'])
                     sink = torch.empty_like(saved)
-                    rw = m._prepared_row_weights()
+                    rw = m._masked_call(mpath)[1]
+                    kern = lib.cbinfer_conv_changed_rows if mpath == 'rows' else lib.cbinfer_conv_changed_blocks
                     t_fill = event_time_ms(lambda: rb.copy_(saved), reps)
-                    t_conv = max(0.0, event_time_ms(lambda: (rb.copy_(saved), check(lib.cbinfer_conv_changed_rows(
+                    t_conv = max(0.0, event_time_ms(lambda: (rb.copy_(saved), check(kern(
                         ptr(m.prevInput), ptr(rb), ptr(rowsws['arrive']), ptr(sink), ptr(rw), ptr(m.bias.detach()),
                         ptr(m.prevOutput), C, Hh, Ww, K, kH, kW, int(m.withReLU), stream_ptr()))), reps) - t_fill)
                 else:
@@ -231,7 +233,8 @@ def kernel_breakdown(test, frame, reps=50):
                         stream_ptr())), reps)
                 HW = Hh * Ww
                 rows.append(dict(layer="conv %d->%d k%d @%dx%d" % (C, K, kH, Hh, Ww), N=N,
-                                 conv_kernel="cb_rowconv_f32_kernel" if rowsws is not None else
+                                 conv_kernel=("cb_rowconv_f32_kernel" if mpath == 'rows' else "cb_blockconv_kernel")
+                                 if rowsws is not None else
                                  ("cb_mfma_f32_kernel<X3: bf16x3 split>" if ar == 2 else "cb_mfma_f32_kernel"),
                                  ratio=N / float(HW),
                                  detect_ms=max(t_det - t_zero, 0.0),
@@ -294,7 +297,8 @@ def inframe_conv_times(test, frames, start, reps=40):
                 src = (lazy.source if lazy is not None else x).contiguous()
                 Hh, Ww = (lazy.outSize[-2:] if lazy is not None else src.shape[-2:])
                 dt, st = dtype_code(src), stream_ptr(src)
-                rows = work.get('rows') if m._rows_path(src.dtype, Hh, Ww) else None
+                mpath = m._rows_path(src.dtype, Hh, Ww)
+                rows = work.get('rows') if mpath else None
                 bits = rows['bits'] if rows is not None else work['bits']
                 if lazy is not None:
                     det = lib.cbinfer_change_detection_bits_pooled if rows is not None else \
@@ -309,10 +313,10 @@ def inframe_conv_times(test, frames, start, reps=40):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 if rows is not None:
-                    check(lib.cbinfer_conv_changed_rows(
-                        ptr(m.prevInput), ptr(rows['bits']), ptr(rows['arrive']), ptr(rows['copy']),
-                        ptr(m._prepared_row_weights()), ptr(m.bias.detach()), ptr(m.prevOutput), C, Hh, Ww, K,
-                        kH, kW, int(m.withReLU), st))
+                    kern = lib.cbinfer_conv_changed_rows if mpath == 'rows' else lib.cbinfer_conv_changed_blocks
+                    check(kern(ptr(m.prevInput), ptr(rows['bits']), ptr(rows['arrive']), ptr(rows['copy']),
+                               ptr(m._masked_call(mpath)[1]), ptr(m.bias.detach()), ptr(m.prevOutput), C, Hh, Ww, K,
+                               kH, kW, int(m.withReLU), st))
                 else:
                     check(lib.cbinfer_conv_changed_from_mask(
                         ptr(m.prevInput), ptr(work['bits']), ptr(work['idx']), ptr(work['count']),

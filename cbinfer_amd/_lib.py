@@ -68,6 +68,12 @@ _SIGNATURES = {
     "cbinfer_change_detection_bits_pooled": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "cbinfer_cbconv2d_forward_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
                                            _i, _i, _i, _f, _i, _i, _i, _vp]),
+    "cbinfer_cbconv2d_forward_blocks": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
+                                             _i, _i, _i, _f, _i, _i, _i, _vp]),
+    "cbinfer_blockconv_supported": (_i, [_i, _i, _i, _i]),
+    "cbinfer_blockconv_prepared_bytes": (_l, [_i, _i, _i, _i]),
+    "cbinfer_blockconv_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "cbinfer_conv_changed_blocks": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cbinfer_conv2d_fg_cpu": (None, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i]),
 }
 

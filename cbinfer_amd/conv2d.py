@@ -222,17 +222,42 @@ class CBConv2d(nn.Module):
         self._wprep = self._wrows = self._plan = None
 
     def _rows_path(self, dtype, H, W):
-        """Row-segment contraction (cb_rowconv.hip) for this layer?  fp32, sync-free frame without an int8
-        mask copy, and at most 16 output channels: measured in the frame (MI355X, 480x320 @10 %) the kernel
-        takes 15 us against the list kernel's 21 on the 3->16 layer, but 36 against 36 on the 16->64 layer,
-        whose full 64-pixel words keep single CUs busy while others idle (CBINFER_ROWCONV_MAXK overrides)."""
+        """Which mask-driven contraction, if any, runs this layer's sync-free fp32 frame (no int8 mask copy):
+          'rows'    cb_rowconv.hip, at most 16 output channels (3->16 7x7: 15 us in the frame against the list
+                    kernel's 21 on MI355X at 480x320 @10 %);
+          'blocks'  cb_blockconv.hip (bf16x3 arithmetic, so not with exactF32), 17..64 output channels
+                    (16->64 7x7: 19 us stand-alone against 27); wider layers stay on the list kernel, whose
+                    64-pixel tiles reuse the streamed weights better while few pixels change;
+          None      the list kernel (cb_conv.hip).
+        CBINFER_NO_ROWCONV=1 / CBINFER_NO_BLOCKCONV=1 switch a kernel off, CBINFER_BLOCKCONV_MAXK moves the bound."""
         K, Cin, kH, kW = self.weight.size()
-        if K > int(os.environ.get('CBINFER_ROWCONV_MAXK', '16')):
-            return False
-        return (dtype == torch.float32 and not self.syncIndexes and not self.saveChangeMap and
-                os.environ.get('CBINFER_NO_ROWCONV', '0') != '1' and
-                os.environ.get('CBINFER_NO_SELFCOMPACT', '0') != '1' and
-                bool(C.cbinfer_rowconv_supported(Cin, K, kH, kW)))
+        if (dtype != torch.float32 or self.syncIndexes or self.saveChangeMap or
+                os.environ.get('CBINFER_NO_SELFCOMPACT', '0') == '1'):
+            return None
+        if (K <= int(os.environ.get('CBINFER_ROWCONV_MAXK', '16')) and
+                os.environ.get('CBINFER_NO_ROWCONV', '0') != '1' and C.cbinfer_rowconv_supported(Cin, K, kH, kW)):
+            return 'rows'
+        if (K <= int(os.environ.get('CBINFER_BLOCKCONV_MAXK', '64')) and self._arith_code(dtype) == _lib.CB_F32S and
+                os.environ.get('CBINFER_NO_BLOCKCONV', '0') != '1' and
+                C.cbinfer_blockconv_supported(Cin, K, kH, kW)):
+            return 'blocks'
+        return None
+
+    def _masked_call(self, path):
+        """(library entry point, prepared weights) of a mask-driven path."""
+        w = self.weight
+        key = (path, w.data_ptr(), w._version, w.device)
+        if self._wrows is None or self._wrows[0] != key:
+            K, Cin, kH, kW = w.size()
+            if path == 'rows':
+                nbytes, prep = C.cbinfer_rowconv_prepared_bytes(Cin, K, kH, kW), C.cbinfer_rowconv_prep_weights
+            else:
+                nbytes, prep = C.cbinfer_blockconv_prepared_bytes(Cin, K, kH, kW), C.cbinfer_blockconv_prep_weights
+            wp = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+            check(prep(ptr(w.detach().contiguous()), ptr(wp), K, Cin, kH, kW, stream_ptr(w)))
+            self._wrows = (key, wp)
+        fn = C.cbinfer_cbconv2d_forward_rows if path == 'rows' else C.cbinfer_cbconv2d_forward_blocks
+        return fn, self._wrows[1]
 
     def _rows_workspace(self, work, H, W, dev):
         if work['rows'] is None:
@@ -242,25 +267,19 @@ class CBConv2d(nn.Module):
                                 copy=torch.zeros(words, dtype=torch.int64, device=dev))
         return work['rows']
 
-    def _prepared_row_weights(self):
-        w = self.weight
-        key = (w.data_ptr(), w._version, w.device)
-        if self._wrows is None or self._wrows[0] != key:
-            K, Cin, kH, kW = w.size()
-            wp = torch.empty(C.cbinfer_rowconv_prepared_bytes(Cin, K, kH, kW), dtype=torch.uint8, device=w.device)
-            check(C.cbinfer_rowconv_prep_weights(ptr(w.detach().contiguous()), ptr(wp), K, Cin, kH, kW,
-                                                 stream_ptr(w)))
-            self._wrows = (key, wp)
-        return self._wrows[1]
+    def _arith_code(self, dtype):
+        if dtype == torch.float16:
+            return _lib.CB_F16
+        if not self.exactF32 and os.environ.get('CBINFER_EXACT_F32', '0') != '1':
+            return _lib.CB_F32S
+        return _lib.CB_F32
 
     def _arith(self, t):
         """Arithmetic of the fused contraction: fp16 as is; fp32 as bf16x3 split products on the bf16 MFMA
         (CB_F32S: every operand as three bf16 terms, the six cross products above 2^-24, f32 accumulation
         -- f32-level accuracy at 2.7x the f32 MFMA's rate) unless exactF32 asks for the exact f32 fma chain."""
-        code = dtype_code(t)
-        if code == _lib.CB_F32 and not self.exactF32 and os.environ.get('CBINFER_EXACT_F32', '0') != '1':
-            return _lib.CB_F32S
-        return code
+        dtype_code(t)     # (rejects anything but fp32 / fp16)
+        return self._arith_code(t.dtype)
 
     def _prepared_weights(self, H=1, W=1, arith=None):
         w = self.weight
@@ -458,14 +477,16 @@ class CBConv2d(nn.Module):
         if not work['selfc']:
             return self.forward_normal(lazy.tensor())
         K, Cin, kH, kW = self.weight.size()
-        if self._rows_path(src.dtype, H, W):
+        path = self._rows_path(src.dtype, H, W)
+        if path:
             rows = self._rows_workspace(work, H, W, src.device)
+            fn, wprep = self._masked_call(path)
             args = (None, ptr(src), src.size(-2), src.size(-1), ptr(self.prevInput), ptr(self.prevOutput),
-                    ptr(rows['bits']), ptr(rows['arrive']), ptr(rows['copy']), ptr(self._prepared_row_weights()),
+                    ptr(rows['bits']), ptr(rows['arrive']), ptr(rows['copy']), ptr(wprep),
                     ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold), 1, 0,
                     int(bool(self.withReLU)), stream_ptr(src))
-            check(C.cbinfer_cbconv2d_forward_rows(*args))
-            self._make_plan(True, src, C.cbinfer_cbconv2d_forward_rows, args, 1, rows=True)
+            check(fn(*args))
+            self._make_plan(True, src, fn, args, 1, rows=True)
             self._lastIndexes = MaskChangeIndexes(rows['copy'], (H, W), work['idx'], work['count'])
             if self.propChangeIndexes:
                 return 'changeIndexes', self.prevOutput, self._lastIndexes
@@ -519,16 +540,18 @@ class CBConv2d(nn.Module):
         if not prev.is_contiguous():
             prev = self.prevInput = prev.contiguous()
         mapOut = work['map'] if (self.saveChangeMap and not have) else None
-        if not have and work['selfc'] and self._rows_path(input.dtype, H, W):
+        path = self._rows_path(input.dtype, H, W) if (not have and work['selfc']) else None
+        if path:
             rows = self._rows_workspace(work, H, W, input.device)
+            fn, wprep = self._masked_call(path)
             args = (ptr(input), None, 0, 0, ptr(prev), ptr(self.prevOutput), ptr(rows['bits']),
-                    ptr(rows['arrive']), ptr(rows['copy']), ptr(self._prepared_row_weights()),
+                    ptr(rows['arrive']), ptr(rows['copy']), ptr(wprep),
                     ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold),
                     int(bool(self.feedbackLoop)), int(bool(self.copyInput)), int(bool(self.withReLU)),
                     stream_ptr(input))
-            check(C.cbinfer_cbconv2d_forward_rows(*args))
+            check(fn(*args))
             if not self._inputIsLiveState:
-                self._make_plan(False, input, C.cbinfer_cbconv2d_forward_rows, args, 0, rows=True)
+                self._make_plan(False, input, fn, args, 0, rows=True)
             result = MaskChangeIndexes(rows['copy'], (H, W), work['idx'], work['count'])
             cap = 0      # (done)
         if cap > 0:

@@ -164,6 +164,7 @@ struct ConvParams {
     int32_t* countOut;
     void* reluOut;                    // EPI_SCATTER_ACC: optional second plane set receiving relu(out)
     int dbg;                          // diagnostic ablations (CBINFER_CONV_DBG): 1 no gather loads, 2 no weight loads
+    int xcdMap;                       // XCD-aware item order (CBINFER_XCD_MAP=0 switches it off)
 };
 
 #define CB_SELFC_MAXW 4096
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
             SK = max(1, min(cap, cus / T));
     }
     const int items = T * SK;
-    if (!SELFC && (int)blockIdx.x >= items) return;
+    if (!SELFC && (int)blockIdx.x >= ((items + 7) & ~7)) return;
 
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_STAGE + B_STAGE)];
     __shared__ int s_last;
@@ -380,8 +381,28 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
     const int br = MODE == CB_MODE_GATHER ? __builtin_amdgcn_readfirstlane(t / BN) * B_PER_T : t % BK;
 
     CB_STAMP_AT(1);
-    for (int item = blockIdx.x; item < items; item += gridDim.x) {
-        const int tile = item / SK, slice = item - tile * SK;
+    // XCD-aware item order.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx.x % 8 names the
+    // XCD's peers; gridDim.x is a multiple of 8), and each XCD has its own 4 MB L2.  With the natural order
+    // every XCD works on every output-channel tile and streams the WHOLE filter bank (3.2 MB f32 / 4.8 MB
+    // split: it does not stay in one L2); here the m-tile is a function of item % 8, so an XCD only ever
+    // touches the weights of 8/MT... of its own m-tile(s) and finds them in its L2.  Pure re-indexing: item
+    // <-> (n-tile, m-tile, slice) stays a bijection, nothing is assumed about placement for correctness.
+    const bool xmap = p.xcdMap && (MT == 1 || MT == 2 || MT == 4 || MT == 8) && (gridDim.x & 7) == 0;
+    const int itemsP = xmap ? (items + 7) & ~7 : items;
+    for (int itemL = blockIdx.x; itemL < itemsP; itemL += gridDim.x) {
+        int tile, slice;
+        if (xmap) {
+            const int q = itemL & 7, u = itemL >> 3;
+            const int mtl = q % MT, r = u * (8 / MT) + q / MT;   // r enumerates (n-tile, slice)
+            const int ntl = r / SK;
+            slice = r - ntl * SK;
+            tile = ntl * MT + mtl;
+            if (tile >= T) continue;
+        } else {
+            tile = itemL / SK;
+            slice = itemL - tile * SK;
+        }
+        const int item = tile * SK + slice;   // canonical index (slab slot)
         const int n0 = (tile / MT) * BN, m0 = (tile % MT) * BM;
         const int kBeg = (P * slice / SK) * 4 * BK, kEnd = min((P * (slice + 1) / SK) * 4 * BK, p.CkkP);
         const int kLast = kEnd - BK;
@@ -1236,6 +1257,14 @@ template <int MODE, int EPI>
 int launch_mfma(const ConvParams& p0, int dtype, hipStream_t s) {
     ConvParams p = p0;
     p.dbg = conv_dbg();
+    {
+        static int xm = -1;
+        if (xm < 0) {
+            const char* e = getenv("CBINFER_XCD_MAP");
+            xm = e ? atoi(e) : 1;
+        }
+        p.xcdMap = xm;
+    }
     const bool narrow = p.KP <= 32;
     if (dtype == CB_F32S) {   // f32 tensors, bf16x3 split products (gather modes only)
         if constexpr (MODE == CB_MODE_GATHER && EPI >= CB_EPI_SCATTER) {

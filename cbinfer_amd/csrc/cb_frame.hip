@@ -105,20 +105,24 @@ extern "C" int cbinfer_cbconv2d_forward_fg(const float* input, float* prevInput,
 // mask.  prePool != NULL: the layer sits behind a 2x2/stride-2 max pool folded into its detection
 // (cbinfer_cbconv2d_forward_pooled's contract; feedback mode).  maskCopy keeps the frame's mask: the
 // change list is made from it on demand (cbinfer_compact_bits), no launch of this frame depends on it.
-extern "C" int cbinfer_cbconv2d_forward_rows(const float* input, const float* prePool, int pH, int pW,
-                                             float* prevInput, float* prevOutput, uint64_t* bits,
-                                             int32_t* arrive, uint64_t* maskCopy, const void* rowWeights,
-                                             const float* bias, int C, int H, int W, int K, int kH, int kW,
-                                             float threshold, int feedbackLoop, int copyInput, int relu,
-                                             cbStream_t stream) {
-    CB_REQUIRE((input || prePool) && prevInput && prevOutput && bits && arrive && maskCopy && rowWeights);
+static int cb_forward_masked(int blocks, const float* input, const float* prePool, int pH, int pW,
+                             float* prevInput, float* prevOutput, uint64_t* bits, int32_t* arrive,
+                             uint64_t* maskCopy, const void* weights, const float* bias, int C, int H, int W,
+                             int K, int kH, int kW, float threshold, int feedbackLoop, int copyInput, int relu,
+                             cbStream_t stream) {
+    CB_REQUIRE((input || prePool) && prevInput && prevOutput && bits && arrive && maskCopy && weights);
+    auto contract = [&](const float* src) {
+        return blocks ? cbinfer_conv_changed_blocks(src, bits, arrive, maskCopy, weights, bias, prevOutput, C, H,
+                                                    W, K, kH, kW, relu, stream)
+                      : cbinfer_conv_changed_rows(src, bits, arrive, maskCopy, weights, bias, prevOutput, C, H, W,
+                                                  K, kH, kW, relu, stream);
+    };
     int st;
     if (prePool) {
         st = cbinfer_change_detection_bits_pooled(prePool, pH, pW, prevInput, bits, W, H, C, (kH - 1) / 2,
                                                   (kW - 1) / 2, threshold, CB_F32, stream);
         if (st != CB_OK) return st;
-        return cbinfer_conv_changed_rows(prevInput, bits, arrive, maskCopy, rowWeights, bias, prevOutput, C, H,
-                                         W, K, kH, kW, relu, stream);
+        return contract(prevInput);
     }
     st = cbinfer_change_detection_bits(input, prevInput, bits, W, H, C, (kH - 1) / 2, (kW - 1) / 2, threshold,
                                        feedbackLoop, CB_F32, stream);
@@ -128,7 +132,28 @@ extern "C" int cbinfer_cbconv2d_forward_rows(const float* input, const float* pr
                                       (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
     }
-    const float* src = (feedbackLoop || copyInput) ? prevInput : input;
-    return cbinfer_conv_changed_rows(src, bits, arrive, maskCopy, rowWeights, bias, prevOutput, C, H, W, K, kH,
-                                     kW, relu, stream);
+    return contract((feedbackLoop || copyInput) ? prevInput : input);
+}
+
+extern "C" int cbinfer_cbconv2d_forward_rows(const float* input, const float* prePool, int pH, int pW,
+                                             float* prevInput, float* prevOutput, uint64_t* bits,
+                                             int32_t* arrive, uint64_t* maskCopy, const void* rowWeights,
+                                             const float* bias, int C, int H, int W, int K, int kH, int kW,
+                                             float threshold, int feedbackLoop, int copyInput, int relu,
+                                             cbStream_t stream) {
+    return cb_forward_masked(0, input, prePool, pH, pW, prevInput, prevOutput, bits, arrive, maskCopy, rowWeights,
+                             bias, C, H, W, K, kH, kW, threshold, feedbackLoop, copyInput, relu, stream);
+}
+
+// The same frame with the patch-staged contraction (cbinfer_conv_changed_blocks; weights from
+// cbinfer_blockconv_prep_weights; bf16x3 arithmetic).
+extern "C" int cbinfer_cbconv2d_forward_blocks(const float* input, const float* prePool, int pH, int pW,
+                                               float* prevInput, float* prevOutput, uint64_t* bits,
+                                               int32_t* arrive, uint64_t* maskCopy, const void* blockWeights,
+                                               const float* bias, int C, int H, int W, int K, int kH, int kW,
+                                               float threshold, int feedbackLoop, int copyInput, int relu,
+                                               cbStream_t stream) {
+    return cb_forward_masked(1, input, prePool, pH, pW, prevInput, prevOutput, bits, arrive, maskCopy,
+                             blockWeights, bias, C, H, W, K, kH, kW, threshold, feedbackLoop, copyInput, relu,
+                             stream);
 }

@@ -226,6 +226,25 @@ int cbinfer_cbconv2d_forward_rows(const float* input, const float* prePool, int 
                                   int kH, int kW, float threshold, int feedbackLoop, int copyInput, int relu,
                                   cbStream_t stream);
 
+/* ---- a5..a8 fused, patch-staged form (fp32 tensors, CB_F32S arithmetic, wide layers) -----------
+ * Same contract, buffers and mask protocol as cbinfer_conv_changed_rows for the layers with many channels
+ * (16->64, 64->256 7x7): one workgroup per unit of R rows x 64 columns and 64 output channels; the input rows
+ * under the unit are staged once per 8-channel chunk in LDS, pre-split into three bf16 planes, every tap reads
+ * its 16-byte B fragment from there, the pre-split weights stream from L2 in MFMA fragment order
+ * (cbinfer_blockconv_prep_weights, cbinfer_blockconv_prepared_bytes bytes). */
+int cbinfer_blockconv_supported(int C, int K, int kH, int kW);
+long cbinfer_blockconv_prepared_bytes(int C, int K, int kH, int kW);
+int cbinfer_blockconv_prep_weights(const float* weight, void* prepared, int K, int C, int kH, int kW,
+                                   cbStream_t stream);
+int cbinfer_conv_changed_blocks(const float* state, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
+                                const void* prepared, const float* bias, float* output, int C, int H, int W,
+                                int K, int kH, int kW, int relu, cbStream_t stream);
+int cbinfer_cbconv2d_forward_blocks(const float* input, const float* prePool, int pH, int pW, float* prevInput,
+                                    float* prevOutput, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
+                                    const void* blockWeights, const float* bias, int C, int H, int W, int K,
+                                    int kH, int kW, float threshold, int feedbackLoop, int copyInput, int relu,
+                                    cbStream_t stream);
+
 /* ---- a9: change-based 2x2/stride-2 max pooling -----------------------------------------------
  * replaces maxPool2d, conv2d_cg.py:58-82 -> cbconv2d_cg_backend.cu:229-240 (kernel :199-227).
  * changeIndexes are INPUT-resolution pixel indices.  Unlike the reference, windows with

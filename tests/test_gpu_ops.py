@@ -717,3 +717,52 @@ def test_split_contraction_accuracy(cb, oracle, C, K, H, W, filt, frac):
     # per-element bound: a few 2^-24 of the accumulated magnitude (each product is off by < 3 * 2^-24, plus
     # the f32 roundings of the running sum) -- i.e. no worse than the exact chain's own rounding error bound
     assert np.all(err_s <= 64 * 2.0 ** -24 * mag.T + 1e-30)
+
+
+@pytest.mark.parametrize("C,K,kH,kW,H,W,frac", [
+    (16, 64, 7, 7, 40, 60, 0.03), (64, 256, 7, 7, 20, 30, 0.05), (5, 20, 3, 5, 37, 83, 0.02),
+    (8, 16, 3, 3, 9, 130, 0.1), (33, 70, 5, 3, 21, 64, 0.02), (16, 64, 7, 7, 160, 240, 0.02),
+    (64, 256, 7, 7, 80, 120, 0.02), (3, 130, 2, 7, 18, 200, 0.05)])
+def test_blockconv_vs_oracle(cb, oracle, C, K, kH, kW, H, W, frac):
+    """Patch-staged contraction (cbinfer_conv_changed_blocks, bf16x3 arithmetic) behind the single-mask
+    detection: same checks as test_rowconv_vs_oracle -- outputs at the changed pixels <= 1e-4 from the
+    double-accumulated dense convolution of the state (image borders, partial last mask word, odd row count
+    against the 2-row units, C not a multiple of 8, K not a multiple of 64), everything else untouched, mask
+    copy / clearing protocol."""
+    from cbinfer_amd._lib import C as lib, check, ptr
+    assert lib.cbinfer_blockconv_supported(C, K, kH, kW)
+    rng = np.random.default_rng(C * 131 + K)
+    x, st_np = rand_case(rng, C, H, W, frac, th=0.1, blocks=True)
+    w = (rng.standard_normal((K, C, kH, kW)) / np.sqrt(C * kH * kW)).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    st_o = st_np.copy()
+    cm_o = oracle.changeDetection(x, st_o, (kH, kW), 0.1, updateInputState=True)
+    idx_o = oracle.changeIndexesExtr(cm_o)
+    assert idx_o.size > 0
+    dense = oracle.conv2d_dense(st_o, w, b, relu=True)
+    words = lib.cbinfer_mask_words(H, W)
+    bits = torch.zeros(words, dtype=torch.int64, device="cuda")
+    arrive = torch.zeros(words, dtype=torch.int32, device="cuda")
+    copy = torch.full((words,), -1, dtype=torch.int64, device="cuda")
+    wq = torch.empty(lib.cbinfer_blockconv_prepared_bytes(C, K, kH, kW), dtype=torch.uint8, device="cuda")
+    dw, db = dev(w), dev(b)
+    check(lib.cbinfer_blockconv_prep_weights(ptr(dw), ptr(wq), K, C, kH, kW, None))
+    dx, st = dev(x), dev(st_np)
+    out = torch.full((1, K, H, W), 77.0, device="cuda")
+    check(lib.cbinfer_change_detection_bits(ptr(dx), ptr(st), ptr(bits), W, H, C, (kH - 1) // 2, (kW - 1) // 2,
+                                            0.1, 1, 0, None))
+    mask = bits.clone()
+    check(lib.cbinfer_conv_changed_blocks(ptr(st), ptr(bits), ptr(arrive), ptr(copy), ptr(wq), ptr(db), ptr(out),
+                                          C, H, W, K, kH, kW, 1, None))
+    torch.cuda.synchronize()
+    assert torch.equal(copy, mask) and int(bits.abs().sum()) == 0 and int(arrive.abs().sum()) == 0
+    got = out.cpu().numpy().reshape(K, -1)
+    err = np.abs(got[:, idx_o] - dense.reshape(K, -1)[:, idx_o]).max()
+    assert err <= FP32_TOL, err
+    rest = np.setdiff1d(np.arange(H * W), idx_o)
+    assert np.all(got[:, rest] == 77.0)
+    before = out.clone()
+    check(lib.cbinfer_conv_changed_blocks(ptr(st), ptr(bits), ptr(arrive), ptr(copy), ptr(wq), ptr(db), ptr(out),
+                                          C, H, W, K, kH, kW, 1, None))
+    torch.cuda.synchronize()
+    assert torch.equal(out, before) and int(copy.abs().sum()) == 0

@@ -4,10 +4,12 @@
 #   stats/                     rocprofv3 --kernel-trace --stats of the same command (+ its bench line)
 #   pmc_fetch/, pmc_write/     FETCH_SIZE / WRITE_SIZE passes (counters only, eager launches so that every
 #                              kernel is its own dispatch), summarised by tools/pmc_traffic.py
-# Every step is bounded; a step that is killed stops the script.
+#   fg_stats/, fg_pmc_*        the same for the fine-grained experiment 7 (in-place form)
+# usage: collect_profiles.sh <commit>        Every step is bounded; a step that is killed stops the script.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof
+COMMIT=${1:-unknown}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 run() { "$@"; rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "killed: $*"; exit 1; fi; return $rc; }
@@ -19,9 +21,18 @@ echo "stats done"
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$O/pmc_$(echo $c | tr A-Z a-z | sed 's/_size//')
   run timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d $d -o p --output-format csv -- \
-      python3 $R/bench.py --mode eager --steps 40 --warmup 5 --no-cpu-baseline --no-dense --multi 0 \
+      python3 $R/bench.py --mode eager --steps 40 --warmup 5 --min-seconds 0 --no-cpu-baseline --no-dense --multi 0 \
       > $d.json 2> $d.err || exit 1
   echo "$c done"
 done
-python3 $R/tools/pmc_traffic.py $O > $O/pmc_traffic.txt
+python3 $R/tools/pmc_traffic.py $O --json $O/pmc_traffic.json --commit $COMMIT > $O/pmc_traffic.txt
 cat $O/pmc_traffic.txt
+# fine-grained experiment 7, in-place form, 10 % change
+run timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/fg_stats -o s --output-format csv -- \
+    python3 $R/tools/fg_target.py > $O/fg_target.txt 2> $O/fg_stats.err || exit 1
+for c in FETCH_SIZE WRITE_SIZE; do
+  d=$O/fg_pmc_$(echo $c | tr A-Z a-z | sed 's/_size//')
+  run timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d $d -o p --output-format csv -- \
+      python3 $R/tools/fg_target.py > $d.txt 2> $d.err || exit 1
+done
+echo "fg done"

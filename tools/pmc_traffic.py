@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
-"""Median FETCH_SIZE / WRITE_SIZE (KB as rocprofv3 reports them) per kernel and per value cluster from the
-pmc_fetch/ and pmc_write/ passes of tools/collect_profiles.sh.  The same contraction kernel serves several
-layers; its dispatches separate cleanly into clusters by traffic (L2 < L3)."""
+"""Median FETCH_SIZE / WRITE_SIZE (KB as rocprofv3 reports them) per kernel from the pmc_fetch/ and pmc_write/
+passes of tools/collect_profiles.sh.  Prints a text summary and, with --json OUT, writes the file bench.py reads
+for `roofline.traffic` (keyed by the bench's layer labels, stamped with the hash of the kernel sources the
+passes ran on).  In the bench workload every layer has a contraction kernel of its own: cb_rowconv (3->16),
+cb_blockconv (16->64), cb_mfma_f32_kernel (64->256), so no clustering by value is needed."""
 import csv
 import glob
+import json
 import os
 import statistics
 import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+commit = sys.argv[sys.argv.index("--commit") + 1] if "--commit" in sys.argv else "?"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def load(sub, counter):
@@ -21,26 +27,37 @@ def load(sub, counter):
     return by
 
 
-def clusters(v):
-    v = sorted(v)
-    out, cur = [], [v[0]]
-    for x in v[1:]:
-        if x > cur[-1] * 1.3 + 8 and len(cur) >= 3:
-            out.append(cur)
-            cur = [x]
-        else:
-            cur.append(x)
-    out.append(cur)
-    return [c for c in out if len(c) >= 5]
-
-
 fetch, write = load("pmc_fetch", "FETCH_SIZE"), load("pmc_write", "WRITE_SIZE")
+LAYER = [("cb_rowconv_f32_kernel", "cb_mfma_f32_kernel conv 3->16 k7 @320x480"),
+         ("cb_blockconv_kernel", "cb_mfma_f32_kernel conv 16->64 k7 @160x240"),
+         ("cb_mfma_f32_kernel", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),
+         ("cb_tail1x1_kernel", "cb_tail1x1_kernel 256->64->8 @80x120")]
+table = {}
 for name in sorted(set(fetch) | set(write)):
-    if not ("cb_" in name):
+    if "cb_" not in name:
         continue
-    short = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:80]
-    print(short)
-    for label, d in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
-        if name in d:
-            for c in clusters(d[name]):
-                print("    %-10s n=%4d median %10.2f KB  (min %.1f max %.1f)" % (label, len(c), statistics.median(c), c[0], c[-1]))
+    short = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:90]
+    # steady state: drop the first dispatches (100 %-change first frame, priming)
+    f = fetch.get(name, [])[3:] or fetch.get(name, [])
+    w = write.get(name, [])[3:] or write.get(name, [])
+    fm = statistics.median(f) if f else 0.0
+    wm = statistics.median(w) if w else 0.0
+    print("%-92s n=%4d  FETCH_SIZE median %10.2f KB   WRITE_SIZE median %10.2f KB" % (short, max(len(f), len(w)), fm, wm))
+    for pat, label in LAYER:
+        if pat in name and label not in table:
+            table[label] = {"kernel": short, "fetch_kb": fm, "write_kb": wm,
+                            "bytes_per_launch": int((fm + wm) * 1024),
+                            "bytes_per_launch_fetch_x2": int((2 * fm + wm) * 1024)}
+if out_json:
+    import bench
+    table["_note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, counters + kernel trace only; "
+                      "tools/collect_profiles.sh) over `python3 bench.py --mode eager --steps 40 --warmup 5 "
+                      "--no-cpu-baseline --no-dense --multi 0`, MI355X.  Per-dispatch medians in KB as reported "
+                      "(x1024 = bytes).  FETCH_SIZE counts L2->fabric read requests: bytes still resident in the "
+                      "XCD's L2 are not counted, and on gfx950 it under-reports wide 16-B/lane streaming reads by 2x "
+                      "(MI355X_MICROARCH.md, HBM section): `bytes_per_launch` is the raw sum, "
+                      "`bytes_per_launch_fetch_x2` the upper bound.")
+    table["kernel_source_sha256"] = bench.kernel_source_hash()
+    table["commit"] = commit
+    json.dump(table, open(out_json, "w"), indent=1)
+    print("wrote", out_json)

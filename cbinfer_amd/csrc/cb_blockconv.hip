@@ -403,7 +403,7 @@ BlkGeom blk_geom(int C, int K, int kH, int kW) {
     g.SPC = kH * g.KXQ;
     g.MT = (K + 15) / 16;
     g.ZM = (g.MT + 3) / 4;
-    g.R = g.ZM >= 4 ? 2 : 1;   // few channel groups: finer spatial units keep all CUs busy
+    g.R = 2;   // measured on 16->64 @160x240, 18 % changed: 18.7 us with two-row units, 22 with one-row units
     {
         static int rr = -1;
         if (rr < 0) {

@@ -59,20 +59,43 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cb_tail1x1_kernel(
         // 16 pixels of one channel plane (contiguous where the changed pixels are)
         const int px = t & 15;
         const int mypix = s_pix[px];
-        for (int c = t >> 4; c < C0P; c += NT >> 4)
-            Xs[c * CB_TAIL_PX + px] = (mypix >= 0 && c < C0) ? x[(long)c * HW + mypix] : 0.f;
-        __syncthreads();
+        const int cstep = NT >> 4;
+        for (int c0 = t >> 4; c0 < C0P; c0 += 16 * cstep) {   // sixteen loads in flight per lane
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = c0 + u * cstep;
+                v[u] = (mypix >= 0 && c < C0) ? x[(long)c * HW + mypix] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = c0 + u * cstep;
+                if (c < C0P) Xs[c * CB_TAIL_PX + px] = v[u];
+            }
+        }
 
         // H tile of this wave: rows 16 wave .. +15, cols = 16 px.  A: lane holds W1[16w + l%16][4s + l/16],
-        // B: lane holds X[4s + l/16][l%16]
+        // B: lane holds X[4s + l/16][l%16].  The weight fragments of up to 256 input channels are requested in
+        // one go (16 x 16 B per lane), before the gathered tile is even waited for: fetched one by one in the
+        // MFMA loop they cost sixteen L2 round trips per tile (15.8 us per launch in the frame, round 2).
         floatx4 acc = {0.f, 0.f, 0.f, 0.f};
         const floatx4* ap = (const floatx4*)w1p + ((long)wave * (C0P / 16)) * 64 + lane;
         const float* bp = Xs + (lane >> 4) * CB_TAIL_PX + (lane & 15);
-        for (int s4 = 0; s4 < C0P / 16; ++s4) {
-            const floatx4 a = ap[(long)s4 * 64];
+        const int groups = C0P / 16;
+        for (int g0 = 0; g0 < groups; g0 += 16) {
+            floatx4 a[16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bp[(16 * s4 + 4 * j) * CB_TAIL_PX], acc, 0, 0, 0);
+            for (int i = 0; i < 16; ++i) a[i] = ap[(long)min(g0 + i, groups - 1) * 64];
+            if (g0 == 0) __syncthreads();   // the X tile is complete
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (g0 + i < groups) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], bp[(16 * (g0 + i) + 4 * j) * CB_TAIL_PX], acc,
+                                                                   0, 0, 0);
+                }
+            }
         }
         // C/D map of the 16x16 tile: col = lane%16, row = 4*(lane/16) + r
 #pragma unroll

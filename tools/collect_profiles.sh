@@ -26,7 +26,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "$c done"
 done
 python3 $R/tools/pmc_traffic.py $O --json $O/pmc_traffic.json --commit $COMMIT > $O/pmc_traffic.txt
-cat $O/pmc_traffic.txt
+cat $O/pmc_traffic.txt | cut -c1-160
 # fine-grained experiment 7, in-place form, 10 % change
 run timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/fg_stats -o s --output-format csv -- \
     python3 $R/tools/fg_target.py > $O/fg_target.txt 2> $O/fg_stats.err || exit 1
@@ -35,4 +35,24 @@ for c in FETCH_SIZE WRITE_SIZE; do
   run timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d $d -o p --output-format csv -- \
       python3 $R/tools/fg_target.py > $d.txt 2> $d.err || exit 1
 done
+python3 - <<PY
+import csv, glob, collections, statistics
+for sub, c in (("fg_pmc_fetch", "FETCH_SIZE"), ("fg_pmc_write", "WRITE_SIZE")):
+    by = collections.defaultdict(list)
+    for f in glob.glob("$O/%s/**/*counter_collection.csv" % sub, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == c and "cb_" in r["Kernel_Name"]:
+                by[r["Kernel_Name"].replace("void (anonymous namespace)::", "")[:70]].append(float(r["Counter_Value"]))
+    for k, v in sorted(by.items()):
+        print("fg %-72s n=%4d %s median %10.2f KB" % (k, len(v), c, statistics.median(v[3:] or v)))
+PY
 echo "fg done"
+# keep the summaries, drop the bulky raw traces (gpurun merges at most 64 MiB back)
+mkdir -p $O/keep
+cp $O/bench.json $O/bench_under_rocprof.json $O/pmc_traffic.json $O/pmc_traffic.txt $O/fg_target.txt $O/keep/ 2>/dev/null
+for d in stats fg_stats; do
+  f=$(find $O/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/keep/${d}_kernel_stats.csv
+done
+f=$(find $O/stats -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 $R/tools/trace_summary.py $f > $O/keep/kernel_trace_summary.txt 2>/dev/null
+rm -rf $O/stats $O/fg_stats $O/pmc_fetch $O/pmc_write $O/fg_pmc_fetch $O/fg_pmc_write
+ls -la $O/keep

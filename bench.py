@@ -303,8 +303,12 @@ def inframe_conv_times(test, frames, start, reps=40):
                 if lazy is not None:
                     det = lib.cbinfer_change_detection_bits_pooled if rows is not None else \
                         lib.cbinfer_change_detection_frame_pooled
-                    check(det(ptr(src), src.shape[-2], src.shape[-1], ptr(m.prevInput), ptr(bits), Ww, Hh, C,
-                              (kH - 1) // 2, (kW - 1) // 2, float(m.threshold), dt, st))
+                    if rows is not None:
+                        check(det(ptr(src), src.shape[-2], src.shape[-1], ptr(lazy.producerMask()), ptr(m.prevInput),
+                                  ptr(bits), Ww, Hh, C, (kH - 1) // 2, (kW - 1) // 2, float(m.threshold), dt, st))
+                    else:
+                        check(det(ptr(src), src.shape[-2], src.shape[-1], ptr(m.prevInput), ptr(bits), Ww, Hh, C,
+                                  (kH - 1) // 2, (kW - 1) // 2, float(m.threshold), dt, st))
                 else:
                     det = lib.cbinfer_change_detection_bits if rows is not None else \
                         lib.cbinfer_change_detection_frame

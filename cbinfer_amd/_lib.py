@@ -65,11 +65,11 @@ _SIGNATURES = {
     "cbinfer_rowconv_prepared_bytes": (_l, [_i, _i, _i, _i]),
     "cbinfer_rowconv_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "cbinfer_conv_changed_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "cbinfer_change_detection_bits_pooled": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
-    "cbinfer_cbconv2d_forward_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
+    "cbinfer_change_detection_bits_pooled": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "cbinfer_cbconv2d_forward_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
                                            _i, _i, _i, _f, _i, _i, _i, _vp]),
-    "cbinfer_cbconv2d_forward_blocks": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
-                                             _i, _i, _i, _f, _i, _i, _i, _vp]),
+    "cbinfer_cbconv2d_forward_blocks": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                                             _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
     "cbinfer_blockconv_supported": (_i, [_i, _i, _i, _i]),
     "cbinfer_blockconv_prepared_bytes": (_l, [_i, _i, _i, _i]),
     "cbinfer_blockconv_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -38,10 +38,19 @@ class LazyPool(object):
     INPUT and the pooled size.  A feedback-mode CBConv2d folds the pooling into its change detection
     (cbinfer_cbconv2d_forward_pooled) and never needs the pooled map; anything else calls tensor()."""
 
-    def __init__(self, source, outSize, ceil_mode):
+    def __init__(self, source, outSize, ceil_mode, indexes=None):
         self.source = source
         self.outSize = tuple(outSize)
         self.ceil_mode = ceil_mode
+        self.indexes = indexes      # the producer's change indexes of this frame (pre-pool resolution)
+
+    def producerMask(self):
+        """The producing layer's change bit mask of this frame, if it ran a mask-driven contraction: the
+        consumer's pooled detection then only looks where that layer rewrote something."""
+        ix = self.indexes
+        if isinstance(ix, MaskChangeIndexes) and ix.size == tuple(self.source.shape[-2:]):
+            return ix._mask
+        return None
 
     def tensor(self):
         return F.max_pool2d(self.source, 2, 2, ceil_mode=self.ceil_mode)
@@ -94,7 +103,7 @@ class CBPoolMax2d(nn.Module):
         if getattr(self, 'lazy', False) and not self.propChangeIndexes:
             nc, h, w = input.size(-3), input.size(-2), input.size(-1)
             oh, ow = ((h - 1) // 2 + 1, (w - 1) // 2 + 1) if self.ceil_mode else (h // 2, w // 2)
-            return LazyPool(input, (1, nc, oh, ow), self.ceil_mode)
+            return LazyPool(input, (1, nc, oh, ow), self.ceil_mode, changeIndexes)
         exact = isinstance(changeIndexes, torch.Tensor)
         if exact:
             changeIndexes = changeIndexes.detach().contiguous()
@@ -464,8 +473,9 @@ class CBConv2d(nn.Module):
         require_device(src)
         if C.cbinfer_mask_words(H, W) > C.cbinfer_frame_mask_max_words():
             return self.forward_normal(lazy.tensor())
-        if (tuple(self.prevInput.size()) != tuple(size) or self.prevInput.dtype != src.dtype or
-                self.prevInput.device != src.device):
+        fresh = (tuple(self.prevInput.size()) != tuple(size) or self.prevInput.dtype != src.dtype or
+                 self.prevInput.device != src.device)
+        if fresh:
             self.prevInput = torch.full(size, float('inf'), dtype=src.dtype, device=src.device)
         outpSize = list(size)
         outpSize[-3] = self.out_channels
@@ -481,12 +491,14 @@ class CBConv2d(nn.Module):
         if path:
             rows = self._rows_workspace(work, H, W, src.device)
             fn, wprep = self._masked_call(path)
-            args = (None, ptr(src), src.size(-2), src.size(-1), ptr(self.prevInput), ptr(self.prevOutput),
-                    ptr(rows['bits']), ptr(rows['arrive']), ptr(rows['copy']), ptr(wprep),
+            # (a state that was just (re)allocated must see every pixel, whatever the producer rewrote)
+            pmask = None if fresh else lazy.producerMask()
+            args = (None, ptr(src), src.size(-2), src.size(-1), ptr(pmask), ptr(self.prevInput),
+                    ptr(self.prevOutput), ptr(rows['bits']), ptr(rows['arrive']), ptr(rows['copy']), ptr(wprep),
                     ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold), 1, 0,
                     int(bool(self.withReLU)), stream_ptr(src))
             check(fn(*args))
-            self._make_plan(True, src, fn, args, 1, rows=True)
+            self._make_plan(True, src, fn, args, 1, rows=True, pmask=ptr(pmask))
             self._lastIndexes = MaskChangeIndexes(rows['copy'], (H, W), work['idx'], work['count'])
             if self.propChangeIndexes:
                 return 'changeIndexes', self.prevOutput, self._lastIndexes
@@ -544,7 +556,7 @@ class CBConv2d(nn.Module):
         if path:
             rows = self._rows_workspace(work, H, W, input.device)
             fn, wprep = self._masked_call(path)
-            args = (ptr(input), None, 0, 0, ptr(prev), ptr(self.prevOutput), ptr(rows['bits']),
+            args = (ptr(input), None, 0, 0, None, ptr(prev), ptr(self.prevOutput), ptr(rows['bits']),
                     ptr(rows['arrive']), ptr(rows['copy']), ptr(wprep),
                     ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold),
                     int(bool(self.feedbackLoop)), int(bool(self.copyInput)), int(bool(self.withReLU)),
@@ -622,7 +634,7 @@ class CBConv2d(nn.Module):
                 self.syncIndexes, self.saveChangeMap, self.gatherComputationStats, self.finegrained,
                 self.atomicFG, self.fgInPlace, self.exactF32)
 
-    def _make_plan(self, pooled, src, fn, args, srcSlot, result=None, rows=False):
+    def _make_plan(self, pooled, src, fn, args, srcSlot, result=None, rows=False, pmask=None):
         """Remember a finished sync-free call: fn(*args) with args[srcSlot] = source pointer, args[-1] =
         stream.  Only for configurations whose call does not depend on per-frame host state."""
         if self.syncIndexes or self.saveChangeMap or self.gatherComputationStats:
@@ -637,7 +649,7 @@ class CBConv2d(nn.Module):
             pooled=pooled, shape=tuple(src.shape), dtype=src.dtype, device=src.device, flags=self._flags(),
             w=(w.data_ptr(), w._version), b=(b.data_ptr(), b._version),
             state=(self._buffers['prevInput'].data_ptr(), self._buffers['prevOutput'].data_ptr()),
-            stream=args[-1], work=work, fn=fn, args=list(args), srcSlot=srcSlot, result=result, rows=rows,
+            stream=args[-1], work=work, fn=fn, args=list(args), srcSlot=srcSlot, result=result, rows=rows, pmask=pmask,
             indexes=ChangeIndexes(work['idx'], work['count'], work['key'][:2]))
 
     def _run_plan(self, inp):
@@ -646,6 +658,10 @@ class CBConv2d(nn.Module):
             if type(inp) is not LazyPool:
                 return None
             src = inp.source
+            if plan['rows']:      # the producer's mask is baked into the call: it must still be the one offered
+                pm = inp.producerMask()
+                if (pm.data_ptr() if pm is not None else None) != plan['pmask']:
+                    return None
         else:
             if type(inp) is not torch.Tensor:
                 return None

@@ -315,7 +315,11 @@ __global__ __launch_bounds__(CB_BLK_THREADS) void cb_blockconv_kernel(BlkParams 
         if (!active) {   // a wave without a channel tile only keeps the barrier count
             for (int c = 0; c < p.CH; ++c) __syncthreads();
         } else {
-            int c = 0, sin = kh;
+            int c = 0, sin = kh, ky = 0, q = kh;   // sin = ky * KXQ + q; this wave advances by two steps
+            while (q >= p.KXQ) {
+                q -= p.KXQ;
+                ++ky;
+            }
             const int own = p.CH * ((p.SPC - kh + 1) >> 1);   // steps of this wave
             const char* pat = lds;
             bool fresh = true;                                // first own step of a chunk: wait for its barrier
@@ -327,11 +331,21 @@ __global__ __launch_bounds__(CB_BLK_THREADS) void cb_blockconv_kernel(BlkParams 
             pat = lds + (c & 1) * bufBytes;                                                         \
             fresh = false;                                                                          \
         }                                                                                           \
-        const int ky = sin / p.KXQ, q = sin - ky * p.KXQ;                                           \
         mul(A, pat, (ky * p.PC + 4 * q) * 16);                                                      \
         sin += 2;                                                                                   \
+        q += 2;                                                                                     \
+        while (q >= p.KXQ) {                                                                        \
+            q -= p.KXQ;                                                                             \
+            ++ky;                                                                                   \
+        }                                                                                           \
         if (sin >= p.SPC) {                                                                         \
             sin = kh;                                                                               \
+            ky = 0;                                                                                 \
+            q = kh;                                                                                 \
+            while (q >= p.KXQ) {                                                                    \
+                q -= p.KXQ;                                                                         \
+                ++ky;                                                                               \
+            }                                                                                       \
             ++c;                                                                                    \
             fresh = true;                                                                           \
         }                                                                                           \
@@ -416,6 +430,8 @@ BlkGeom blk_geom(int C, int K, int kH, int kW) {
     g.PC = 64 + 4 * g.KXQ;
     g.PLANE = g.PR * g.PC * 16;
     g.ldsBytes = 2l * 3 * g.PLANE;
+    // (the same LDS holds the k-halves' partial sums at the end: 4 tiles x 4R pixel tiles x 64 lanes x 16 B)
+    if (g.ldsBytes < 4l * 4 * g.R * 1024) g.ldsBytes = 4l * 4 * g.R * 1024;
     g.wbBytes = (long)g.ZM * 4 * g.CH * g.SPC * 3 * 64 * 16;
     return g;
 }

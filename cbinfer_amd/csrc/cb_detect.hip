@@ -29,7 +29,23 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
                                                         int H, int C, int kHH, int kWH, float thf,
                                                         int update, int wpr,
                                                         const int* __restrict__ parity, long altWords,
-                                                        int pH = 0, int pW = 0) {
+                                                        int pH = 0, int pW = 0,
+                                                        const unsigned long long* __restrict__ prodMask = nullptr) {
+    // POOL with the producer's change mask (pre-pool resolution, this frame): a pooled pixel none of whose
+    // window pixels was rewritten by the producing layer compares exactly as it did last frame, i.e. not
+    // above the threshold -- the 64 pooled pixels of this workgroup lie under four words of that mask
+    if (POOL && prodMask) {
+        const int pwpr = (pW + 63) >> 6;
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int yy = 2 * (int)blockIdx.y + j, ww = 2 * (int)blockIdx.x + i;
+                if (yy < pH && ww < pwpr) any |= prodMask[(long)yy * pwpr + ww];
+            }
+        if (__builtin_amdgcn_readfirstlane((int)(any != 0ull)) == 0) return;
+    }
     // frame pipeline: two masks alternate by a device-side parity (flipped by the consumer kernel)
     if (BITS && parity && *parity) bits += altWords;
     const int lane = threadIdx.x & 63;
@@ -315,13 +331,13 @@ int detect_groups(int C) {
 template <typename T, bool BITS, bool POOL = false>
 int launch_detect(const void* input, void* state, int8_t* map, uint64_t* bits, int W, int H, int C,
                   int kHH, int kWH, float th, int update, hipStream_t s, const int* parity = nullptr,
-                  long altWords = 0, int pH = 0, int pW = 0) {
+                  long altWords = 0, int pH = 0, int pW = 0, const uint64_t* prodMask = nullptr) {
     const int wpr = cbinfer_mask_words_per_row(W);
     const int G = detect_groups(C);
     dim3 grid(wpr, H), block(64 * G);
     hipLaunchKernelGGL((cb_detect_kernel<T, BITS, POOL>), grid, block, 0, s, (const T*)input, (T*)state,
                        map, (unsigned long long*)bits, W, H, C, kHH, kWH, th, update, wpr, parity, altWords,
-                       pH, pW);
+                       pH, pW, (const unsigned long long*)prodMask);
     return cb_launch_status();
 }
 
@@ -365,19 +381,19 @@ int cbinfer_change_detection_bits(const void* input, void* state, uint64_t* bits
 }
 
 // Single-mask form of the pooled detection (see cbinfer_change_detection_frame_pooled): ORs into bitsOut.
-int cbinfer_change_detection_bits_pooled(const void* prePool, int pH, int pW, void* state, uint64_t* bitsOut,
-                                         int W, int H, int C, int kHHalf, int kWHalf, float threshold,
-                                         int dtype, cbStream_t stream) {
+int cbinfer_change_detection_bits_pooled(const void* prePool, int pH, int pW, const uint64_t* producerMask,
+                                         void* state, uint64_t* bitsOut, int W, int H, int C, int kHHalf,
+                                         int kWHalf, float threshold, int dtype, cbStream_t stream) {
     CB_REQUIRE(prePool && state && bitsOut && W > 0 && H > 0 && C > 0 && kHHalf >= 0 && kWHalf >= 0);
     CB_REQUIRE((H == pH / 2 || H == (pH + 1) / 2) && (W == pW / 2 || W == (pW + 1) / 2));
     if (kWHalf > 63 || H > 65535) return CB_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CB_F32)
         return launch_detect<float, true, true>(prePool, state, nullptr, bitsOut, W, H, C, kHHalf, kWHalf,
-                                                threshold, 1, s, nullptr, 0, pH, pW);
+                                                threshold, 1, s, nullptr, 0, pH, pW, producerMask);
     if (dtype == CB_F16)
         return launch_detect<cb_half, true, true>(prePool, state, nullptr, bitsOut, W, H, C, kHHalf, kWHalf,
-                                                  threshold, 1, s, nullptr, 0, pH, pW);
+                                                  threshold, 1, s, nullptr, 0, pH, pW, producerMask);
     return CB_ERR_BADARG;
 }
 

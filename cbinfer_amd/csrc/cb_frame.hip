@@ -103,10 +103,12 @@ extern "C" int cbinfer_cbconv2d_forward_fg(const float* input, float* prevInput,
 // The frame of a layer whose contraction runs on the row-segment kernel (cbinfer_conv_changed_rows, fp32,
 // cbinfer_rowconv_supported): detection -> [state copy] -> row-segment contraction, two launches, single
 // mask.  prePool != NULL: the layer sits behind a 2x2/stride-2 max pool folded into its detection
-// (cbinfer_cbconv2d_forward_pooled's contract; feedback mode).  maskCopy keeps the frame's mask: the
+// (cbinfer_cbconv2d_forward_pooled's contract; feedback mode); producerMask (optional): the maskCopy the layer
+// that PRODUCED prePool left this frame (pre-pool resolution) -- the detection then skips every 64-pixel
+// segment none of whose window pixels that layer rewrote (they compare exactly as they did last frame).  maskCopy keeps the frame's mask: the
 // change list is made from it on demand (cbinfer_compact_bits), no launch of this frame depends on it.
 static int cb_forward_masked(int blocks, const float* input, const float* prePool, int pH, int pW,
-                             float* prevInput, float* prevOutput, uint64_t* bits, int32_t* arrive,
+                             const uint64_t* producerMask, float* prevInput, float* prevOutput, uint64_t* bits, int32_t* arrive,
                              uint64_t* maskCopy, const void* weights, const float* bias, int C, int H, int W,
                              int K, int kH, int kW, float threshold, int feedbackLoop, int copyInput, int relu,
                              cbStream_t stream) {
@@ -119,8 +121,8 @@ static int cb_forward_masked(int blocks, const float* input, const float* prePoo
     };
     int st;
     if (prePool) {
-        st = cbinfer_change_detection_bits_pooled(prePool, pH, pW, prevInput, bits, W, H, C, (kH - 1) / 2,
-                                                  (kW - 1) / 2, threshold, CB_F32, stream);
+        st = cbinfer_change_detection_bits_pooled(prePool, pH, pW, producerMask, prevInput, bits, W, H, C,
+                                                  (kH - 1) / 2, (kW - 1) / 2, threshold, CB_F32, stream);
         if (st != CB_OK) return st;
         return contract(prevInput);
     }
@@ -136,24 +138,26 @@ static int cb_forward_masked(int blocks, const float* input, const float* prePoo
 }
 
 extern "C" int cbinfer_cbconv2d_forward_rows(const float* input, const float* prePool, int pH, int pW,
+                                             const uint64_t* producerMask,
                                              float* prevInput, float* prevOutput, uint64_t* bits,
                                              int32_t* arrive, uint64_t* maskCopy, const void* rowWeights,
                                              const float* bias, int C, int H, int W, int K, int kH, int kW,
                                              float threshold, int feedbackLoop, int copyInput, int relu,
                                              cbStream_t stream) {
-    return cb_forward_masked(0, input, prePool, pH, pW, prevInput, prevOutput, bits, arrive, maskCopy, rowWeights,
+    return cb_forward_masked(0, input, prePool, pH, pW, producerMask, prevInput, prevOutput, bits, arrive, maskCopy, rowWeights,
                              bias, C, H, W, K, kH, kW, threshold, feedbackLoop, copyInput, relu, stream);
 }
 
 // The same frame with the patch-staged contraction (cbinfer_conv_changed_blocks; weights from
 // cbinfer_blockconv_prep_weights; bf16x3 arithmetic).
 extern "C" int cbinfer_cbconv2d_forward_blocks(const float* input, const float* prePool, int pH, int pW,
+                                             const uint64_t* producerMask,
                                                float* prevInput, float* prevOutput, uint64_t* bits,
                                                int32_t* arrive, uint64_t* maskCopy, const void* blockWeights,
                                                const float* bias, int C, int H, int W, int K, int kH, int kW,
                                                float threshold, int feedbackLoop, int copyInput, int relu,
                                                cbStream_t stream) {
-    return cb_forward_masked(1, input, prePool, pH, pW, prevInput, prevOutput, bits, arrive, maskCopy,
+    return cb_forward_masked(1, input, prePool, pH, pW, producerMask, prevInput, prevOutput, bits, arrive, maskCopy,
                              blockWeights, bias, C, H, W, K, kH, kW, threshold, feedbackLoop, copyInput, relu,
                              stream);
 }

@@ -38,13 +38,19 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cb_tail1x1_kernel(
     const int32_t* __restrict__ countDev, const float* __restrict__ w1p, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, float* out, int C0, int C0P, int C1, int C2,
     int HW, int relu1, int relu2) {
-    extern __shared__ float sm[];   // Xs[C0P][16] | Hs[C1P][17]
+    extern __shared__ float sm[];   // Xs[C0P][16] | Hs[C1P][17] | W2s[C2][C1] | b2s[C2]
     const int N = countDev ? min(*countDev, nHost) : nHost;
     const int t = threadIdx.x, NT = blockDim.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     float* Xs = sm;
     float* Hs = sm + (long)C0P * CB_TAIL_PX;
+    float* W2s = Hs + (NT >> 6) * 16 * (CB_TAIL_PX + 1);
+    float* b2s = W2s + C2 * C1;
     __shared__ int s_pix[CB_TAIL_PX];
+    if ((int)blockIdx.x * CB_TAIL_PX >= N) return;
+    // the second layer's (small) matrix and bias live in LDS for the life of the workgroup
+    for (int i = t; i < C2 * C1; i += NT) W2s[i] = w2[i];
+    for (int i = t; i < C2; i += NT) b2s[i] = b2[i];
 
     for (int tile = blockIdx.x; tile * CB_TAIL_PX < N; tile += gridDim.x) {
         const int n0 = tile * CB_TAIL_PX;
@@ -111,8 +117,9 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cb_tail1x1_kernel(
             const int c2 = o >> 4, p2 = o & 15;
             const int pix = s_pix[p2];
             if (pix < 0) continue;
-            float v = b2[c2];
-            const float* wr = w2 + (long)c2 * C1;
+            float v = b2s[c2];
+            const float* wr = W2s + c2 * C1;
+#pragma unroll 8
             for (int j = 0; j < C1; ++j) v = fmaf(wr[j], Hs[j * (CB_TAIL_PX + 1) + p2], v);
             if (relu2) v = v <= 0.f ? 0.f : v;
             out[(long)c2 * HW + pix] = v;
@@ -151,7 +158,7 @@ int cbinfer_tail1x1(const float* input, const int32_t* changeList, int numChange
     if (numChanges == 0) return CB_OK;
     const int C0P = (C0 + 15) / 16 * 16;
     const int waves = (C1 + 15) / 16;
-    const size_t lds = ((size_t)C0P * CB_TAIL_PX + (size_t)waves * 16 * (CB_TAIL_PX + 1)) * 4;
+    const size_t lds = ((size_t)C0P * CB_TAIL_PX + (size_t)waves * 16 * (CB_TAIL_PX + 1) + (size_t)C2 * C1 + C2) * 4;
     if (lds > 60 * 1024) return CB_ERR_UNSUPPORTED;   // stays below the 64 KB that needs no opt-in
     long tiles = ((long)numChanges + CB_TAIL_PX - 1) / CB_TAIL_PX;
     if (tiles > 2048) tiles = 2048;   // grid-stride beyond: the capacity is H*W when the count is on the device

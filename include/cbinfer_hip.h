@@ -217,10 +217,13 @@ int cbinfer_rowconv_prep_weights(const float* weight, void* prepared, int K, int
 int cbinfer_conv_changed_rows(const float* state, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
                               const void* prepared, const float* bias, float* output, int C, int H, int W,
                               int K, int kH, int kW, int relu, cbStream_t stream);
-int cbinfer_change_detection_bits_pooled(const void* prePool, int pH, int pW, void* state, uint64_t* bitsOut,
-                                         int W, int H, int C, int kHHalf, int kWHalf, float threshold,
-                                         int dtype, cbStream_t stream);
-int cbinfer_cbconv2d_forward_rows(const float* input, const float* prePool, int pH, int pW, float* prevInput,
+/* producerMask (may be NULL): the change mask (cbinfer_mask_words(pH,pW) words, this frame) of the layer that
+ * wrote prePool; pooled pixels none of whose window pixels it rewrote are not even read. */
+int cbinfer_change_detection_bits_pooled(const void* prePool, int pH, int pW, const uint64_t* producerMask,
+                                         void* state, uint64_t* bitsOut, int W, int H, int C, int kHHalf,
+                                         int kWHalf, float threshold, int dtype, cbStream_t stream);
+int cbinfer_cbconv2d_forward_rows(const float* input, const float* prePool, int pH, int pW,
+                                  const uint64_t* producerMask, float* prevInput,
                                   float* prevOutput, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
                                   const void* rowWeights, const float* bias, int C, int H, int W, int K,
                                   int kH, int kW, float threshold, int feedbackLoop, int copyInput, int relu,
@@ -239,7 +242,8 @@ int cbinfer_blockconv_prep_weights(const float* weight, void* prepared, int K, i
 int cbinfer_conv_changed_blocks(const float* state, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
                                 const void* prepared, const float* bias, float* output, int C, int H, int W,
                                 int K, int kH, int kW, int relu, cbStream_t stream);
-int cbinfer_cbconv2d_forward_blocks(const float* input, const float* prePool, int pH, int pW, float* prevInput,
+int cbinfer_cbconv2d_forward_blocks(const float* input, const float* prePool, int pH, int pW,
+                                    const uint64_t* producerMask, float* prevInput,
                                     float* prevOutput, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
                                     const void* blockWeights, const float* bias, int C, int H, int W, int K,
                                     int kH, int kW, float threshold, int feedbackLoop, int copyInput, int relu,

@@ -295,13 +295,27 @@ def test_pooling_fused_into_detection_is_bit_identical(pkg, dtype, size):
     with torch.no_grad():
         for f in vid.frames(5):
             ya, yb = a(f), b(f)
-            if dtype == torch.float32:   # (the dense fp16 1x1 tail of experiment 6 is torch/MIOpen code
-                assert torch.equal(ya, yb)   # whose split-K reduction is not run-to-run deterministic)
+            # (the dense 1x1 tail of experiment 6 is torch/MIOpen code: its solver choice and split-K reduction
+            # are not reproducible from one module instance to the next, so the network outputs are only
+            # compared to the last bits; the change-based layers' own states below must be identical)
+            if dtype == torch.float32:
+                assert torch.allclose(ya, yb, rtol=0, atol=1e-6)
             ca = [m for m in a.modules() if type(m) is pkg.CBConv2d]
             cb = [m for m in b.modules() if type(m) is pkg.CBConv2d]
             for ma, mb in zip(ca, cb):
                 assert torch.equal(ma.prevOutput, mb.prevOutput)
                 assert torch.equal(ma.prevInput, mb.prevInput)
+        # a consumer whose state alone is cleared must see EVERY pixel on its next frame, although the layer
+        # in front of it rewrites (and reports in its change mask) only a few: the pooled detection may use the
+        # producer's mask only against a state it has compared before
+        ca[1].clearMemory()
+        cb[1].clearMemory()
+        for f in [vid.next(), vid.next()]:
+            ya, yb = a(f), b(f)
+            for ma, mb in zip(ca, cb):
+                assert torch.equal(ma.prevOutput, mb.prevOutput)
+                assert torch.equal(ma.prevInput, mb.prevInput)
+            assert torch.isfinite(cb[1].prevInput).all()
 
 
 def test_call_plan_is_dropped_when_its_assumptions_change(pkg, oracle):

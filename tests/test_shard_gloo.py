@@ -57,3 +57,31 @@ def test_single_process_is_identity():
     assert s.world == 1 and s.aggregate(7, 0.5) == (7, 0.5) and s.sequence_seed(3) == 3
     s.barrier()
     s.finish()
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` without a launcher starts its own ranks -- and must refuse, loudly and
+    before touching a GPU, when fewer than N are visible (round 1 silently ran a single rank and reported
+    n_gpus = 1).  This container has none."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode != 0
+    assert b"--gpus 2 requested but only 0 GPU(s) are visible" in out.stderr
+    assert out.stdout.strip() == b""       # no JSON line pretending to be a result
+
+
+def test_bench_rejects_world_size_mismatch():
+    """Launched by a launcher with another world size than --gpus says: refuse instead of mislabelling."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "4", "--steps", "1"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode != 0 and b"--gpus 4 but WORLD_SIZE=1" in out.stderr

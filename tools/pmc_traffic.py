@@ -30,7 +30,7 @@ def load(sub, counter):
 fetch, write = load("pmc_fetch", "FETCH_SIZE"), load("pmc_write", "WRITE_SIZE")
 LAYER = [("cb_rowconv_f32_kernel", "cb_mfma_f32_kernel conv 3->16 k7 @320x480"),
          ("cb_blockconv_kernel", "cb_mfma_f32_kernel conv 16->64 k7 @160x240"),
-         ("cb_mfma_f32_kernel", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),
+         ("cb_mfma_f32_kernel<2, 2, 2, 1, 2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),   # in-frame form
          ("cb_tail1x1_kernel", "cb_tail1x1_kernel 256->64->8 @80x120")]
 table = {}
 for name in sorted(set(fetch) | set(write)):

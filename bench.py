@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--no-fuse-tail", action="store_true",
                     help="keep the dense 1x1 tail as torch modules (default: pycbinfer.fuseTail1x1, one "
                          "change-based launch for conv1x1->ReLU->conv1x1; results within 1e-4)")
+    ap.add_argument("--no-pipelined", action="store_true",
+                    help="skip the extra measurement with frame pipelining (pycbinfer.FramePipeline: the 64->256 "
+                         "layer + tail of frame t on a side stream while the first two layers of frame t+1 run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="(internal) run only the CPU baseline leg and print its JSON object")
@@ -80,6 +83,24 @@ def parse():
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+class PipelinedRunner(object):
+    """Feeds frames to a pycbinfer.FramePipeline (eager, one sequence, two streams)."""
+
+    def __init__(self, model, cut):
+        import pycbinfer
+        self.pipe = pycbinfer.FramePipeline(model, cut)
+        self.model, self.mode, self.graph = model, "eager", None
+        self.out = None
+
+    def prime(self, frames):
+        for f in frames:
+            self.out = self.pipe(f)
+
+    def step(self, frame):
+        self.out = self.pipe.submit(frame)
+        return self.out
 
 
 class FrameRunner(object):
@@ -501,7 +522,7 @@ def main():
     # do not overlap (measured: 7.4k instead of 8.9k frames/s with 4 sequences).
     stream_pool = [torch.cuda.Stream() for _ in range(max(args.sequences, args.multi, 1))]
 
-    def build_sequences(S, nframes, seq0, mode):
+    def build_sequences(S, nframes, seq0, mode, pipelined=False):
         """S independent sequences (model + state + synthetic video + runner), primed on two frames."""
         seqs = []
         for q in range(S):
@@ -517,17 +538,21 @@ def main():
             # 2 priming frames + a walk of nframes frames, all resident in HBM (1.8 MB each); the timed
             # loop goes back and forth over the walk, so any number of steps sees the same change per step
             allframes = vid.frames(2 + nframes)
-            runner = FrameRunner(test, allframes[0], mode, stream_pool[q] if S > 1 else None)
+            if pipelined:     # cut behind the second pool: [conv, pool, conv, pool | conv, tail ...]
+                cut = [i for i, m in enumerate(test.children()) if type(m) is pycbinfer.CBPoolMax2d][-1] + 1
+                runner = PipelinedRunner(test, cut)
+            else:
+                runner = FrameRunner(test, allframes[0], mode, stream_pool[q] if S > 1 else None)
             runner.prime(allframes[:2])
             seqs.append(dict(base=base, test=test, vid=vid, runner=runner, frames=allframes[2:]))
         torch.cuda.synchronize()
         return seqs
 
-    def run_sequences(S, steps, warmup, seq0, bar, mode, min_seconds=0.0, agree=None):
+    def run_sequences(S, steps, warmup, seq0, bar, mode, min_seconds=0.0, agree=None, pipelined=False):
         """Warm up, then time `steps` steps (x an integer repeat count that makes the region last
         min_seconds; all ranks agree on it through `agree`).  Returns (elapsed, steps timed, sequences)."""
         nframes = max(8, min(max(steps, warmup), 256))
-        seqs = build_sequences(S, nframes, seq0, mode)
+        seqs = build_sequences(S, nframes, seq0, mode, pipelined)
         runners, frs = [q['runner'] for q in seqs], [q['frames'] for q in seqs]
         t_warm = timed_loop(runners, frs, max(warmup, 1), lambda: None)
         reps = 1
@@ -649,6 +674,15 @@ def main():
 
     if multi_result is not None:
         result["multi_sequence"] = multi_result
+    if world == 1 and S == 1 and not args.no_pipelined and args.experiment in (5, 6):
+        pel, psteps, pseqs = run_sequences(1, args.steps, args.warmup, 50, lambda: None, "eager",
+                                           min_seconds=args.min_seconds, pipelined=True)
+        result["pipelined"] = {"value": psteps / pel, "unit": "frames/s", "steps": psteps,
+                               "what": "the same single sequence with frame pipelining (pycbinfer.FramePipeline): "
+                                       "stage 2 (64->256 layer + tail) of frame t on a side stream while stage 1 of "
+                                       "frame t+1 runs; outputs identical to the serial execution"}
+        del pseqs
+        torch.cuda.synchronize()
 
     # dense network on the same GPU, timed the same way (eval01.py:68)
     if not args.no_dense and world == 1:

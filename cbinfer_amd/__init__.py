@@ -14,6 +14,7 @@ from .conv2d import CBConv2d
 from .conv2d import CBPoolMax2d
 from .conv2d import CBTail1x1
 from .conv2d_cg import ChangeIndexes
+from .pipeline import FramePipeline
 
 __version__ = "0.1.0"
 
@@ -271,7 +272,7 @@ def tuneThresholdParameters(vidSeqReader, evalSequences, numFramesPerSeq, target
         anchor = measure()
 
 
-__all__ = ['CBConv2d', 'CBPoolMax2d', 'CBTail1x1', 'ChangeIndexes', 'convert', 'convertRecur', 'subsitute',
+__all__ = ['CBConv2d', 'CBPoolMax2d', 'CBTail1x1', 'ChangeIndexes', 'FramePipeline', 'convert', 'convertRecur', 'subsitute',
            'mergeReLURecur', 'propChangeIndexesOf1x1', 'insertCBPooling', 'fusePoolingIntoDetection', 'fuseTail1x1',
            'clearMemory', 'getStateTensors',
            'setSyncIndexes', 'tuneThresholdParameters']

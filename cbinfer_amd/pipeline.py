@@ -1,0 +1,69 @@
+"""Frame pipelining for ONE video sequence (execution level, results unchanged).
+
+The layers of a converted network form a chain, but consecutive FRAMES only meet in each layer's own state:
+layer i of frame t+1 needs layer i of frame t and layer i-1 of frame t+1, nothing else.  `FramePipeline` cuts
+an nn.Sequential in two stages and runs stage 2 (the deep, expensive layers) of frame t on a side HIP stream
+while stage 1 of frame t+1 runs on the caller's stream -- the small kernels, detection latencies and launch
+ramps of one stage fill the idle CUs of the other, which is what several concurrent sequences do for
+throughput (bench.py --sequences), here for a single one.  Frames stay in order, every module sees exactly the
+calls it would see serially, so outputs and states are those of the serial execution.
+
+The tensor handed from stage 1 to stage 2 is private to its frame (a lazily pooled tensor is materialised
+densely at the cut, anything else is cloned), so stage 1 never has to wait for stage 2; its memory is tied
+to the side stream with record_stream().  The reference has nothing of the kind (single stream, one blocking
+sync per layer, conv2d_cg.py:202).
+"""
+import torch
+
+from .conv2d import LazyPool
+
+
+class FramePipeline(object):
+    def __init__(self, net, cut):
+        mods = list(net.children())
+        assert 0 < cut < len(mods), "cut must leave at least one module on each side"
+        self.stage1, self.stage2 = mods[:cut], mods[cut:]
+        self.side = None
+        self._done = None       # event: stage 2 of the most recently submitted frame
+
+    def _private(self, h):
+        """What stage 2 receives: a tensor (or tuple) no later frame's stage 1 will write to."""
+        if isinstance(h, LazyPool):
+            return h.tensor()                       # dense pooling: a fresh tensor per frame
+        if isinstance(h, tuple):
+            idx = h[2].clone() if hasattr(h[2], 'clone') else h[2]
+            return (h[0], h[1].clone(), idx)
+        return h.clone()
+
+    def submit(self, frame):
+        """Enqueue one frame; returns the network output, valid once wait() (or a sync) has passed."""
+        cur = torch.cuda.current_stream(frame.device)
+        if self.side is None:
+            self.side = torch.cuda.Stream(frame.device)
+        with torch.no_grad():
+            h = frame
+            for m in self.stage1:
+                h = m(h)
+            h = self._private(h)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            for t in ([h[1]] if isinstance(h, tuple) else [h]):
+                t.record_stream(self.side)
+            self.side.wait_event(ready)
+            with torch.cuda.stream(self.side):
+                y = h
+                for m in self.stage2:
+                    y = m(y)
+                self._done = torch.cuda.Event()
+                self._done.record(self.side)
+        return y
+
+    def wait(self):
+        """Make the caller's stream wait for everything submitted so far."""
+        if self._done is not None:
+            torch.cuda.current_stream().wait_event(self._done)
+
+    def __call__(self, frame):
+        y = self.submit(frame)
+        self.wait()
+        return y

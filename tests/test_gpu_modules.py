@@ -950,3 +950,45 @@ def test_power_logger_and_power_measurement(pkg):
         print("no readable amdgpu hwmon power sensor on this box: sampling thread exercised, values NaN")
     pl.recordEvent("done")
     assert pl.events and pl.events[-1][1] == "done"
+
+
+def test_frame_pipeline_equals_serial_execution(pkg):
+    """pycbinfer.FramePipeline: stage 2 of frame t on a side stream while stage 1 of frame t+1 runs.  Every
+    frame's output and every layer state after the sequence must be those of the serial execution (the only
+    difference allowed: the layer behind the cut detects on a densely pooled tensor instead of pooling inside
+    its detection, which is bit-identical by test_pooling_fused_into_detection_is_bit_identical)."""
+    from cbinfer_amd import workloads
+    def build():
+        _, net = workloads.sceneLabelingModels(experimentIdx=6, threshold=0.03, seed=5)
+        for m in net.modules():
+            if type(m) is pkg.CBPoolMax2d:
+                m.cloneOutput = False
+        pkg.fuseTail1x1(net)
+        pkg.fusePoolingIntoDetection(net)
+        return net
+    serial, piped = build(), build()
+    pipe = pkg.FramePipeline(piped, cut=4)          # conv, pool, conv, pool | conv, tail
+    vid = workloads.SyntheticVideo(H=96, W=160, ratio=0.1, block=16, seed=31)
+    frames = vid.frames(12)
+    outs_p = []
+    with torch.no_grad():
+        for f in frames:                            # submitted back to back, nothing waited for in between
+            y = pipe.submit(f)
+            outs_p.append((y, torch.cuda.Event()))
+        pipe.wait()
+        torch.cuda.synchronize()
+        last = y.clone()
+        for f in frames:
+            ys = serial(f)
+        assert torch.equal(last, ys)
+    for ms, mp_ in zip([m for m in serial.modules() if type(m) in (pkg.CBConv2d, pkg.CBTail1x1)],
+                       [m for m in piped.modules() if type(m) in (pkg.CBConv2d, pkg.CBTail1x1)]):
+        assert torch.equal(ms.prevOutput, mp_.prevOutput)
+    # used as a plain callable it waits per frame and returns each frame's output
+    serial2, piped2 = build(), build()
+    pipe2 = pkg.FramePipeline(piped2, cut=4)
+    with torch.no_grad():
+        for f in frames[:5]:
+            a, b = serial2(f).clone(), pipe2(f)
+            torch.cuda.synchronize()
+            assert torch.equal(a, b)

@@ -88,9 +88,9 @@ def log(*a):
 class PipelinedRunner(object):
     """Feeds frames to a pycbinfer.FramePipeline (eager, one sequence, two streams)."""
 
-    def __init__(self, model, cut):
+    def __init__(self, model, cut, side_stream=None):
         import pycbinfer
-        self.pipe = pycbinfer.FramePipeline(model, cut)
+        self.pipe = pycbinfer.FramePipeline(model, cut, side_stream)
         self.model, self.mode, self.graph = model, "eager", None
         self.out = None
 
@@ -540,7 +540,7 @@ def main():
             allframes = vid.frames(2 + nframes)
             if pipelined:     # cut behind the second pool: [conv, pool, conv, pool | conv, tail ...]
                 cut = [i for i, m in enumerate(test.children()) if type(m) is pycbinfer.CBPoolMax2d][-1] + 1
-                runner = PipelinedRunner(test, cut)
+                runner = PipelinedRunner(test, cut, stream_pool[0])
             else:
                 runner = FrameRunner(test, allframes[0], mode, stream_pool[q] if S > 1 else None)
             runner.prime(allframes[:2])

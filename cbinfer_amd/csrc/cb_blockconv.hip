@@ -91,11 +91,13 @@ __device__ unsigned long long cb_blk_stamps[2048 * 32];
 #else
 #define CB_BSTAMP(who, i)
 #endif
-#define CB_BLK_THREADS 768   // 8 multiplier waves (4 channel tiles x 2 k-halves) + 4 stager waves
+#define CB_BLK_THREADS 768   // at most: 8 multiplier waves (4 channel tiles x 2 k-halves) + 4 stager waves
 #define CB_BLK_SPT 3         // patch pixels per stager thread (PR*PC <= 768)
 
-template <int R>
-__global__ __launch_bounds__(CB_BLK_THREADS) void cb_blockconv_kernel(BlkParams p) {
+// MG = 16-channel tiles per workgroup (2 MG multiplier waves + 4 stager waves): 4 for wide layers; 2 for layers
+// of at most 64 output channels, whose units are too few to fill the chip with four tiles each
+template <int R, int MG>
+__global__ __launch_bounds__(64 * (2 * MG + 4)) void cb_blockconv_kernel(BlkParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // patch [2 buffers][3 planes][PR][PC] x 16 B
     constexpr int NTMAX = 4 * R;
     CB_BSTAMP(0, 0);
@@ -136,14 +138,14 @@ __global__ __launch_bounds__(CB_BLK_THREADS) void cb_blockconv_kernel(BlkParams 
         nTt += nT[r];
     }
 
-    if (wave >= 8) {
+    if (wave >= 2 * MG) {
         // ================= stager waves: patch of chunk c -> buffer c & 1, one chunk ahead of the multipliers
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void*)p.state, 0, p.C * HW * 4, 0x00020000);
         const int x0 = tx * 64 - pw;
         // the patch's PR x PC pixels flattened over the 256 stager threads, CB_BLK_SPT per thread; a thread
         // gathers the 8 channels of its pixels (all loads of a chunk in flight at once), splits and writes them
-        const int ts = t - 512;
+        const int ts = t - 128 * MG;
         int pixoff[CB_BLK_SPT], dstoff[CB_BLK_SPT];
 #pragma unroll
         for (int i = 0; i < CB_BLK_SPT; ++i) {
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(CB_BLK_THREADS) void cb_blockconv_kernel(BlkParams 
         __syncthreads();
     } else {
         // ================= multiplier waves: one 16-channel tile each
-        const int mt = 4 * mg + (wave & 3), kh = wave >> 2;   // channel tile, k-half (steps kh, kh+2, ...)
+        const int mt = MG * mg + wave % MG, kh = wave / MG;   // channel tile, k-half (steps kh, kh+2, ...)
         const bool active = mt < p.MT;
         const int kg = lane >> 4;
         // per tile: LDS byte offset of this lane's pixel (patch row = row in unit, column = x in word) + quarter
@@ -366,13 +368,13 @@ __global__ __launch_bounds__(CB_BLK_THREADS) void cb_blockconv_kernel(BlkParams 
         if (active && kh == 1) {
 #pragma unroll
             for (int s = 0; s < NTMAX; ++s)
-                if (s < nTt) *(floatx4*)(lds + (((wave & 3) * NTMAX + s) * 64 + lane) * 16) = acc[s];
+                if (s < nTt) *(floatx4*)(lds + (((wave % MG) * NTMAX + s) * 64 + lane) * 16) = acc[s];
         }
         __syncthreads();
         if (active && kh == 0) {
 #pragma unroll
             for (int s = 0; s < NTMAX; ++s)
-                if (s < nTt) acc[s] += *(const floatx4*)(lds + (((wave & 3) * NTMAX + s) * 64 + lane) * 16);
+                if (s < nTt) acc[s] += *(const floatx4*)(lds + (((wave % MG) * NTMAX + s) * 64 + lane) * 16);
         }
         CB_BSTAMP(0, 14);
         // ---- bias / ReLU / scatter: D tile col = lane % 16 (pixel), rows 4 (lane/16) + r (channel) ----------
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(CB_BLK_THREADS) void cb_blockconv_kernel(BlkParams 
 }
 
 struct BlkGeom {
-    int CH, KXQ, SPC, R, PR, PC, PLANE, MT, ZM;
+    int CH, KXQ, SPC, R, PR, PC, PLANE, MT, MG, ZM;
     long ldsBytes, wbBytes;
 };
 BlkGeom blk_geom(int C, int K, int kH, int kW) {
@@ -416,7 +418,16 @@ BlkGeom blk_geom(int C, int K, int kH, int kW) {
     g.KXQ = (kW + 3) / 4;
     g.SPC = kH * g.KXQ;
     g.MT = (K + 15) / 16;
-    g.ZM = (g.MT + 3) / 4;
+    g.MG = 2;   // two tiles per workgroup, two workgroups per CU: 65 vs 68 us (64->256, 27 %), 117 vs 131 (100 %)
+    {
+        static int mgo = -1;
+        if (mgo < 0) {
+            const char* e = getenv("CBINFER_BLK_MG");   // tuning aid
+            mgo = e ? atoi(e) : 0;
+        }
+        if (mgo == 2 || mgo == 4) g.MG = mgo;
+    }
+    g.ZM = (g.MT + g.MG - 1) / g.MG;
     g.R = 2;   // measured on 16->64 @160x240, 18 % changed: 18.7 us with two-row units, 22 with one-row units
     {
         static int rr = -1;
@@ -432,7 +443,7 @@ BlkGeom blk_geom(int C, int K, int kH, int kW) {
     g.ldsBytes = 2l * 3 * g.PLANE;
     // (the same LDS holds the k-halves' partial sums at the end: 4 tiles x 4R pixel tiles x 64 lanes x 16 B)
     if (g.ldsBytes < 4l * 4 * g.R * 1024) g.ldsBytes = 4l * 4 * g.R * 1024;
-    g.wbBytes = (long)g.ZM * 4 * g.CH * g.SPC * 3 * 64 * 16;
+    g.wbBytes = (long)g.ZM * g.MG * g.CH * g.SPC * 3 * 64 * 16;
     return g;
 }
 
@@ -484,9 +495,9 @@ int cbinfer_blockconv_prep_weights(const float* weight, void* prepared, int K, i
     CB_REQUIRE(weight && prepared);
     if (!cbinfer_blockconv_supported(C, K, kH, kW)) return CB_ERR_UNSUPPORTED;
     const BlkGeom g = blk_geom(C, K, kH, kW);
-    const long total = (long)g.ZM * 4 * g.CH * g.SPC * 64 * 8;
+    const long total = (long)g.ZM * g.MG * g.CH * g.SPC * 64 * 8;
     hipLaunchKernelGGL(cb_blockconv_prep_kernel, dim3(cb_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       weight, (unsigned short*)prepared, K, C, kH, kW, g.CH, g.KXQ, g.ZM * 4);
+                       weight, (unsigned short*)prepared, K, C, kH, kW, g.CH, g.KXQ, g.ZM * g.MG);
     return cb_launch_status();
 }
 
@@ -522,11 +533,15 @@ int cbinfer_conv_changed_blocks(const float* state, uint64_t* bits, int32_t* arr
     p.pcMagic = (65536 + g.PC - 1) / g.PC;
     p.relu = relu;
     p.wpr = cbinfer_mask_words_per_row(W);
-    dim3 grid(p.wpr, (H + g.R - 1) / g.R, g.ZM), block(CB_BLK_THREADS);
-    if (g.R == 2)
-        hipLaunchKernelGGL((cb_blockconv_kernel<2>), grid, block, (size_t)g.ldsBytes, (hipStream_t)stream, p);
+    dim3 grid(p.wpr, (H + g.R - 1) / g.R, g.ZM), block(64 * (2 * g.MG + 4));
+    if (g.R == 2 && g.MG == 4)
+        hipLaunchKernelGGL((cb_blockconv_kernel<2, 4>), grid, block, (size_t)g.ldsBytes, (hipStream_t)stream, p);
+    else if (g.R == 2)
+        hipLaunchKernelGGL((cb_blockconv_kernel<2, 2>), grid, block, (size_t)g.ldsBytes, (hipStream_t)stream, p);
+    else if (g.MG == 4)
+        hipLaunchKernelGGL((cb_blockconv_kernel<1, 4>), grid, block, (size_t)g.ldsBytes, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL((cb_blockconv_kernel<1>), grid, block, (size_t)g.ldsBytes, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((cb_blockconv_kernel<1, 2>), grid, block, (size_t)g.ldsBytes, (hipStream_t)stream, p);
     return cb_launch_status();
 }
 

@@ -32,6 +32,17 @@ __device__ __forceinline__ void cb_split3(float x, unsigned& hi, unsigned& mid, 
     mid = __builtin_bit_cast(unsigned short, m);
     lo = __builtin_bit_cast(unsigned short, l);
 }
+// The same decomposition for the inner loops, cheaper: hi and mid by truncation (a mask instead of a
+// conversion and a shift each), lo rounded to nearest; |x - (hi + mid + lo)| <= 2^-24 |x| still.  The terms
+// are returned as f32 bit patterns with the bf16 in the TOP half, so two of them pack with one shift-or.
+__device__ __forceinline__ void cb_split3t(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, hi);
+    mid = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, mid);
+    lo = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)r2) << 16;
+}
+#define CB_PK2(a, b) (((a) >> 16) | (b))
 typedef __attribute__((address_space(4))) int cb_const_int;   // constant address space: scalar loads
 
 __device__ __forceinline__ float cb_relu(float v) { return v <= 0.f ? 0.f : v; }
@@ -544,11 +555,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
                 for (int q = 0; q < B_PER_T / 4; ++q) {
                     unsigned h[4], m[4], l[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) cb_split3(breg[q * 4 + e], h[e], m[e], l[e]);
+                    for (int e = 0; e < 4; ++e) cb_split3t(breg[q * 4 + e], h[e], m[e], l[e]);
                     char* row = (char*)(bs + bj * LDK) + (br + q * 4) * 2;
-                    *(uint2*)(row) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                    *(uint2*)(row + 64) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-                    *(uint2*)(row + 128) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                    *(uint2*)(row) = make_uint2(CB_PK2(h[0], h[1]), CB_PK2(h[2], h[3]));
+                    *(uint2*)(row + 64) = make_uint2(CB_PK2(m[0], m[1]), CB_PK2(m[2], m[3]));
+                    *(uint2*)(row + 128) = make_uint2(CB_PK2(l[0], l[1]), CB_PK2(l[2], l[3]));
                 }
             } else if (MODE == CB_MODE_GATHER && B_PER_T % 4 == 0) {   // the thread's taps are k-consecutive
 #pragma unroll

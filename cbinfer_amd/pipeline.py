@@ -19,11 +19,14 @@ from .conv2d import LazyPool
 
 
 class FramePipeline(object):
-    def __init__(self, net, cut):
+    def __init__(self, net, cut, side_stream=None):
+        """side_stream: the HIP stream of stage 2 (default: a new one on first use).  HIP maps streams onto
+        its few hardware queues in creation order; a side stream that shares a queue with the caller's stream
+        does not overlap with it, so a process that creates many streams should create this one early."""
         mods = list(net.children())
         assert 0 < cut < len(mods), "cut must leave at least one module on each side"
         self.stage1, self.stage2 = mods[:cut], mods[cut:]
-        self.side = None
+        self.side = side_stream
         self._done = None       # event: stage 2 of the most recently submitted frame
 
     def _private(self, h):

@@ -8,46 +8,41 @@ import math
 import os
 import threading
 import time
-import timeit
 
 import torch
 
 from . import CBConv2d, CBPoolMax2d, clearMemory
 
 
+def _staged(frameset, cuda, preprocessor):
+    """The frame list after the optional per-frame preprocessor, resident on the device if asked."""
+    frames = [preprocessor(f) for f in frameset] if preprocessor is not None else list(frameset)
+    return [f.cuda() for f in frames] if cuda else frames
+
+
 def inferFramesetBenchmark(m, frameset, cuda=True, numIter=3, preprocessor=None):
-    """Seconds for the last frame of `frameset` (reference: evalTools.py:7-35): state cleared, frames
-    [:-1] run untimed, device synchronised, then the last frame + synchronise is timed; repeated numIter
-    times, minimum returned.  Frames are moved to the device before timing."""
-    if preprocessor is not None:
-        frameset = list(map(preprocessor, frameset))
-    if cuda:
-        frameset = [frm.cuda() for frm in frameset]
-
-    def prepBenchm():
-        clearMemory(m)
-        with torch.no_grad():
-            for frame in frameset[:-1]:
+    """Seconds for the last frame of `frameset` (protocol of the reference's evalTools.py:7-35): state
+    cleared, frames [:-1] run untimed, device synchronised, then the last frame + synchronise is timed;
+    repeated numIter times, minimum returned.  Frames are moved to the device before timing."""
+    frames = _staged(frameset, cuda, preprocessor)
+    wait = torch.cuda.synchronize if cuda else (lambda: None)
+    best = float('inf')
+    with torch.no_grad():
+        for _ in range(numIter):
+            clearMemory(m)
+            for frame in frames[:-1]:
                 m(frame)
-        if cuda:
-            torch.cuda.synchronize()
-
-    def coreBenchm():
-        with torch.no_grad():
-            m(frameset[-1])
-        if cuda:
-            torch.cuda.synchronize()
-
-    tmr = timeit.Timer(stmt=coreBenchm, setup=prepBenchm)
-    return min(tmr.repeat(repeat=numIter, number=1))
+            wait()
+            t0 = time.perf_counter()
+            m(frames[-1])
+            wait()
+            best = min(best, time.perf_counter() - t0)
+    return best
 
 
 def inferFrameset(m, frameset, cuda=True, preprocessor=None, postproc=None):
     """Output for the last frame after feeding the whole list (reference: evalTools.py:37-49)."""
-    if preprocessor is not None:
-        frameset = list(map(preprocessor, frameset))
-    if cuda:
-        frameset = [frm.cuda() for frm in frameset]
+    frameset = _staged(frameset, cuda, preprocessor)
     clearMemory(m)
     y = None
     with torch.no_grad():
@@ -133,10 +128,7 @@ class PowerLogger(object):
 
 def inferFramesetPowerMeasurement(m, frameset, cuda=True, numFrames=0, preprocessor=None, interval=0.05):
     """Run a (back-and-forth extended) sequence under a PowerLogger (reference: evalTools.py:54-83)."""
-    if preprocessor is not None:
-        frameset = list(map(preprocessor, frameset))
-    if cuda:
-        frameset = [frm.cuda() for frm in frameset]
+    frameset = _staged(frameset, cuda, preprocessor)
     if numFrames > 0:
         frameset = frameset + frameset[-2:0:-1]
         frameset = int(math.ceil(numFrames / float(len(frameset)))) * frameset

@@ -249,18 +249,31 @@ __device__ unsigned long long cb_stamp_clk[1024 * 2];   // s_memtime (shader clo
 #define CB_STAMP_AT(i)
 #endif
 #define CB_SKMAX 8
+// diagnostic ablations of the X3 kernel are a build option (make EXTRA=-DCB_CONV_DBG): as run-time
+// branches around the stage loads they would cost the loop its counted vmcnt waits
+#ifdef CB_CONV_DBG
+#define CB_DBG(bit) (p.dbg & (bit))
+#else
+#define CB_DBG(bit) false
+#endif
 // X3: the same kernel with every f32 operand split into three bf16 terms (cb_split3) and the six cross
 // products that matter -- hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi; the dropped ones are below 2^-24
 // of the product -- issued on v_mfma_f32_32x32x16_bf16 with f32 accumulation: f32-level accuracy at 16/6
 // of the f32 MFMA's rate (the f32-input MFMA runs at 1/16 of the bf16 one on gfx950).  Weights come
 // pre-split (cb_prep_w_f32s_kernel); gathered values are split on their way into LDS.  LDS row = the
 // stage's 32 k as hi | mid | lo (192 B + 16 B pad: 16-byte fragment reads of any 16 rows are conflict-free).
-template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false, bool X3 = false>
+// MS = 2 (X3 only, output channels in multiples of 128): every wave owns TWO 32-row tiles of output channels
+// for its 32 pixels.  Used as <2, 4, 2, ..., MS = 2>: a 1024-thread workgroup, one per CU, on a 128 x 128 tile.
+// The vector-memory pipe of a CU (~70 GB/s: MI355X_MICROARCH.md, "Indexed rows") is what bounds this
+// contraction -- a 64 x 64 tile moves 20 KB of weights and gathered values per stage and MFMA unit through it,
+// the 128 x 128 tile half of that, with the same registers per wave.
+template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false, bool X3 = false, int MS = 1>
 __global__ __launch_bounds__(64 * WM * WN * KS)
     __attribute__((amdgpu_waves_per_eu((WM * WN * KS >= 8 ? 4 : WM * WN * KS >= 4 ? 2 : 1)))) void cb_mfma_f32_kernel(
         ConvParams p) {
     constexpr int NT = 64 * WM * WN * KS;
-    constexpr int BM = 32 * WM;
+    constexpr int GPC = NT > 512 ? 1 : CB_CONV_GRID_PER_CU;   // workgroups per CU in the persistent grid
+    constexpr int BM = 32 * WM * MS;
     constexpr int BN = 32 * WN;
     constexpr int BK = 32;
     constexpr int LDK = X3 ? 52 : BK + 4;   // LDS row in floats: 32 k of one m / one pixel + 16 B pad
@@ -272,10 +285,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
     constexpr int S = KSTEP / 2;        // ... = MFMA steps per wave and stage (two k per step)
     constexpr int A_STAGE = BM * LDK, B_STAGE = BN * LDK;
     constexpr int TILE = BM * BN;
+    constexpr int RED = KS > 1 ? WM * WN * MS * 64 * 16 : 0;   // floats of the k-group reduction buffer
+    static_assert(MS == 1 || (MS == 2 && X3), "two row tiles per wave: X3 only");
     static_assert(BN % 64 == 0, "gather rows must be wave-uniform");
     static_assert(BK * BN % NT == 0 && S % 4 == 0, "bad decomposition");
     static_assert(!X3 || (KS == 2 && MODE == CB_MODE_GATHER && (BK * BN / NT) % 4 == 0), "X3: 16 k per wave group");
-    static_assert(KS == 1 || 2 * (A_STAGE + B_STAGE) >= WM * WN * 64 * 16, "reduce buffer");
+    static_assert(2 * (A_STAGE + B_STAGE) >= RED, "reduce buffer");
 
 #ifdef CB_STAMP
     bool cb_stamp_first = true;
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
     const int P = (p.CkkP + 4 * BK - 1) / (4 * BK);          // groups of four stages along k (last: partial)
     // Split-K slice count (at most ~sqrt(3.4 P) <= 8: the reducer costs ~4 us of fences + ~1 us per slab)
     int SK = 1;
-    const int cus = (int)gridDim.x / CB_CONV_GRID_PER_CU;
+    const int cus = (int)gridDim.x / GPC;
 #ifndef CB_SK_TARGET
 #define CB_SK_TARGET 2
 #endif
@@ -357,7 +372,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
     // the idle CUs, above it slices of co-resident workgroups just slow each other down.
     if (p.slabs && T > 0 && P >= 4) {
         const int cap = min(CB_SKMAX, min(P, (int)sqrtf(3.4f * (float)P)));
-        if (P >= 8 && T * 2 >= cus)
+        if (GPC == 2 && P >= 8 && T * 2 >= cus)
             SK = max(1, min(cap, (CB_SK_TARGET * cus) / T));
         else
             SK = max(1, min(cap, cus / T));
@@ -496,7 +511,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
                 const int f = X3 ? min(t + i * NT, A_F4 - 1) : t + i * NT;   // (X3: every thread loads, the
                 if (A_F4 % NT == 0 || f < A_F4) {                            //  surplus is not stored)
                     float4 v;
-                    if (X3 && (p.dbg & 2)) {
+                    if (X3 && CB_DBG(2)) {
                         v = make_float4(1.f, 1.f, 1.f, 1.f);
                     } else if (X3) {   // 12 chunks per row and stage in the pre-split layout
                         const int row = f / 12, c = f % 12;
@@ -511,7 +526,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
                     areg[4 * i + 3] = v.w;
                 }
             }
-            if (X3 && (p.dbg & 1)) {
+            if (X3 && CB_DBG(1)) {
 #pragma unroll
                 for (int i = 0; i < B_PER_T; ++i) breg[i] = 1.0f;
             } else if (MODE == CB_MODE_GATHER && FAST) {
@@ -577,14 +592,39 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
             }
         };
 
-        floatx16 acc;
+        floatx16 acc, acc1;   // (acc1: second row tile, MS == 2)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f, acc1[i] = 0.f;
 
         // MFMA step s of wave group ks multiplies k-slots {ks*S + s, BK/2 + ks*S + s} of the stage (lane
         // half h takes the second); any pairing works as long as both operands use it, and this one
         // makes a lane's S values per operand contiguous: S/4 ds_read_b128 instead of S ds_read_b32.
         auto compute = [&](int buf) {
+            if (MS == 2) {
+                const char* ap = (const char*)(As + buf * A_STAGE + (wm * 64 + l31) * LDK) + ks * 32 + h * 16;
+                const char* bp = (const char*)(Bs + buf * B_STAGE + (wn * 32 + l31) * LDK) + ks * 32 + h * 16;
+                const bf16x8 bh = *(const bf16x8*)bp, bm = *(const bf16x8*)(bp + 64), bl = *(const bf16x8*)(bp + 128);
+                {
+                    const bf16x8 ah = *(const bf16x8*)ap, am = *(const bf16x8*)(ap + 64), al = *(const bf16x8*)(ap + 128);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                }
+                {
+                    const char* ap1 = ap + 32 * LDK * 4;
+                    const bf16x8 ah = *(const bf16x8*)ap1, am = *(const bf16x8*)(ap1 + 64), al = *(const bf16x8*)(ap1 + 128);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc1, 0, 0, 0);
+                }
+                return;
+            }
             if (X3) {
                 // wave group ks owns k 16 ks .. 16 ks + 15 of the stage; a lane's fragment = 8 consecutive k
                 const char* ap = (const char*)(As + buf * A_STAGE + (wm * 32 + l31) * LDK) + ks * 32 + h * 16;
@@ -626,6 +666,34 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
         CB_STAMP_AT(2);
         auto main_loop = [&](auto FASTC, auto MFC) {
             constexpr bool MF = decltype(MFC)::value;
+            if (MS == 2) {
+                // the 16-wave form has the registers for TWO staging sets: loads run two stages ahead
+                load_stage(FASTC, kBeg, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_stage(FASTC, min(kBeg + BK, kLast), a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                store_stage(0, a0, b0);
+                load_stage(FASTC, min(kBeg + 2 * BK, kLast), a0, b0);
+                __syncthreads();
+#define CB_STAGE2(BUF, AREG, BREG, KNEXT)                         \
+                if (MF) {                                             \
+                    compute(BUF);                                     \
+                    store_stage((BUF) ^ 1, AREG, BREG);               \
+                    load_stage(FASTC, min(KNEXT, kLast), AREG, BREG); \
+                } else {                                              \
+                    store_stage((BUF) ^ 1, AREG, BREG);               \
+                    load_stage(FASTC, min(KNEXT, kLast), AREG, BREG); \
+                    compute(BUF);                                     \
+                }                                                     \
+                __syncthreads();
+                for (int k0 = kBeg; k0 < kEnd; k0 += 2 * BK) {
+                    CB_STAGE2(0, a1, b1, k0 + 3 * BK)
+                    if (k0 + BK >= kEnd) break;
+                    CB_STAGE2(1, a0, b0, k0 + 4 * BK)
+                }
+#undef CB_STAGE2
+                return;
+            }
             // (scheduling fences: the prologue must issue the sets in ring order, otherwise the loop
             // header inherits "set 0 is the youngest" and drains the queue every iteration)
             load_stage(FASTC, kBeg, a0, b0);
@@ -687,41 +755,87 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
         CB_STAMP_AT(3);
 
         if (KS > 1) {   // sum the wave groups' partial tiles through LDS (fixed order: deterministic)
-            float* red = smem + (wq * 16) * 64 + lane;
+            float* red = smem + (wq * MS * 16) * 64 + lane;
 #pragma unroll
             for (int g = 1; g < KS; ++g) {
                 if (ks == g) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) red[r * 64] = acc[r];
+                    if (MS == 2) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) red[(16 + r) * 64] = acc1[r];
+                    }
                 }
                 __syncthreads();
                 if (ks == 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] += red[r * 64];
+                    if (MS == 2) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc1[r] += red[(16 + r) * 64];
+                    }
                 }
                 __syncthreads();
             }
         }
 
         CB_STAMP_AT(4);
-        if (SK > 1) {
-            // publish this slice's partial tile, take a ticket; the last arriver reduces
-            float* slab = p.slabs + (long)item * TILE + (wq * 16) * 64 + lane;
-            if (ks == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) slab[r * 64] = acc[r];
+        // one output value: bias / ReLU / the form of the store
+        auto emit = [&](int m, int n, int pix, float v) {
+            if (EPI != CB_EPI_SCATTER_ACC) {
+                if (bias) v += bias[m];
+                if (p.relu) v = cb_relu(v);
             }
+            if (EPI == CB_EPI_Y)
+                out[(long)n * p.K + m] = v;
+            else if (EPI == CB_EPI_YT)
+                out[(long)m * p.nHost + n] = v;
+            else if (EPI == CB_EPI_SCATTER)
+                out[(long)m * HW + pix] = v;
+            else {
+                const float nv = out[(long)m * HW + pix] + v;
+                out[(long)m * HW + pix] = nv;
+                if (p.reluOut) ((float*)p.reluOut)[(long)m * HW + pix] = cb_relu(nv);
+            }
+        };
+        if (SK > 1) {
+            // Publish this slice's partial tile, take a ticket; the last arriver sums the slices and stores.
+            // Slab = [BM/4][BN] float4: four consecutive output channels of one pixel -- the registers
+            // 4q..4q+3 of a lane's 32x32 accumulator as they stand -- so both sides move 16 bytes per lane in
+            // 512-byte runs.  The stores are write-through (sc1) and drained before the workgroup's ticket,
+            // which replaces the agent-scope release (an L2 write-back per workgroup); with one workgroup
+            // per CU the reducer's sc1 loads also replace the acquire (MI355X_MICROARCH.md, "Inter-workgroup
+            // visibility": publish-large / splitk-seam), otherwise it invalidates its L1 first.
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)p.slabs, 0, (int)min((long)gridDim.x * TILE * 4, (long)0x7fffffff), 0x00020000);
+#define CB_PUBLISH(A, J)                                                                            \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                            \
+                const f32x4 f = {A[4 * q], A[4 * q + 1], A[4 * q + 2], A[4 * q + 3]};                   \
+                const u32x4 v = __builtin_bit_cast(u32x4, f);                                           \
+                const int mq = (wm * MS + (J)) * 8 + 2 * q + h;                                         \
+                __builtin_amdgcn_raw_buffer_store_b128(                                                 \
+                    v, srsrc, (item * (TILE / 4) + mq * BN + wn * 32 + l31) * 16, 0, 16 /* sc1 */);     \
+            }
+            if (ks == 0) {
+                CB_PUBLISH(acc, 0)
+                if (MS == 2) {
+                    CB_PUBLISH(acc1, 1)
+                }
+            }
+#undef CB_PUBLISH
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (t == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const int ticket = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED,
                                                           __HIP_MEMORY_SCOPE_AGENT);
                 const int last = ticket == SK - 1;
                 if (last) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (GPC != 1) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
                     __hip_atomic_store(p.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 s_last = last;
@@ -734,15 +848,38 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
             if (!last) cb_stamp_first = false;
 #endif
             if (!last) continue;
-            if (ks == 0) {
-                const float* sl = p.slabs + (long)tile * SK * TILE + (wq * 16) * 64 + lane;
+            // every thread: TILE / 4 / NT chunks, all slices of a chunk in flight together
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int c0 = 0; c0 < TILE / 4; c0 += NT) {
+                const int c = c0 + t;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
                 for (int j = 0; j < SK; ++j) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] += sl[(long)j * TILE + r * 64];
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                        srsrc, ((tile * SK + j) * (TILE / 4) + c) * 16, 0, 16 /* sc1 */);
+                    const f32x4 f = __builtin_bit_cast(f32x4, v);   // (whole-vector casts: element-wise
+                    s0 += f.x;                                     //  ones on these types came out as splats)
+                    s1 += f.y;
+                    s2 += f.z;
+                    s3 += f.w;
+                }
+                const int nl = c % BN, mq = c / BN;
+                const int n = n0 + nl;
+                int pix = 0;
+                if (EPI >= CB_EPI_SCATTER && n < N) pix = SELFC ? s_tilePix[nl] : p.list[n];
+                if (n < N && (unsigned)pix < (unsigned)HW) {
+                    const int m = m0 + 4 * mq;
+                    if (m < p.K) emit(m, n, pix, s0);
+                    if (m + 1 < p.K) emit(m + 1, n, pix, s1);
+                    if (m + 2 < p.K) emit(m + 2, n, pix, s2);
+                    if (m + 3 < p.K) emit(m + 3, n, pix, s3);
                 }
             }
+            CB_STAMP_AT(6);
+#ifdef CB_STAMP
+            cb_stamp_first = false;
+#endif
+            continue;
         }
 
         // epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -753,25 +890,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
         // written through: the reference's scatter would corrupt a neighbouring plane, .cu:187)
         if (ks == 0 && n < N && (unsigned)pix < (unsigned)HW) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            for (int rr = 0; rr < 16 * MS; ++rr) {
+                const int r = rr & 15;
+                const int m = m0 + (wm * MS + (rr >> 4)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m >= p.K) continue;
-                float v = acc[r];
-                if (EPI != CB_EPI_SCATTER_ACC) {
-                    if (bias) v += bias[m];
-                    if (p.relu) v = cb_relu(v);
-                }
-                if (EPI == CB_EPI_Y)
-                    out[(long)n * p.K + m] = v;
-                else if (EPI == CB_EPI_YT)
-                    out[(long)m * p.nHost + n] = v;
-                else if (EPI == CB_EPI_SCATTER)
-                    out[(long)m * HW + pix] = v;
-                else {
-                    const float nv = out[(long)m * HW + pix] + v;
-                    out[(long)m * HW + pix] = nv;
-                    if (p.reluOut) ((float*)p.reluOut)[(long)m * HW + pix] = cb_relu(nv);
-                }
+                emit(m, n, pix, rr < 16 ? acc[r] : acc1[r]);
             }
         }
         CB_STAMP_AT(6);
@@ -1221,16 +1344,16 @@ int cb_num_cus() {
     return cus;
 }
 
-template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false, bool X3 = false>
+template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false, bool X3 = false, int MS = 1>
 int launch_f32(const ConvParams& p, hipStream_t s) {
-    const long tilesCap = (long)cb_div_up(p.nHost, 32 * WN) * (p.KP / (32 * WM));
+    const long tilesCap = (long)cb_div_up(p.nHost, 32 * WN) * (p.KP / (32 * WM * MS));
     if (tilesCap == 0) return CB_OK;
-    // persistent grid: 2 workgroups per CU (fewer only if the capacity itself is smaller and there is
-    // no split-K workspace to spread it with)
-    long g = CB_CONV_GRID_PER_CU * (long)cb_num_cus();
+    // persistent grid: 2 workgroups per CU, 1 of the 1024-thread form (fewer only if the capacity itself is
+    // smaller and there is no split-K workspace to spread it with)
+    long g = (WM * WN * KS > 8 ? 1 : CB_CONV_GRID_PER_CU) * (long)cb_num_cus();
     if (!p.slabs && tilesCap < g && !SELFC) g = tilesCap;
     dim3 grid((unsigned)g), block(64 * WM * WN * KS);
-    hipLaunchKernelGGL((cb_mfma_f32_kernel<WM, WN, KS, MODE, EPI, SELFC, X3>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((cb_mfma_f32_kernel<WM, WN, KS, MODE, EPI, SELFC, X3, MS>), grid, block, 0, s, p);
     return cb_launch_status();
 }
 
@@ -1249,6 +1372,16 @@ int launch_f16(const ConvParams& p, hipStream_t s) {
 int cb_ckkpad(int Ckk, int dtype) {
     const int q = dtype == CB_F16 ? 128 : 32;   // fp32 (both layouts): whole 32-deep stages; fp16: stage pairs of 2 x 64
     return (Ckk + q - 1) / q * q;
+}
+
+// bf16x3 arithmetic with output channels in multiples of 128: the 128 x 128 form (CBINFER_X3_WIDE=0: 64 x 64)
+bool cb_x3_wide(int KP) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("CBINFER_X3_WIDE");
+        on = e ? atoi(e) != 0 : 1;
+    }
+    return on && KP % 128 == 0;
 }
 
 int conv_cfg_override() {
@@ -1281,9 +1414,11 @@ int launch_mfma(const ConvParams& p0, int dtype, hipStream_t s) {
         if constexpr (MODE == CB_MODE_GATHER && EPI >= CB_EPI_SCATTER) {
             if (p.frameMasks) {
                 if (narrow) return launch_f32<1, 4, 2, CB_MODE_GATHER, EPI, true, true>(p, s);
+                if (cb_x3_wide(p.KP)) return launch_f32<2, 4, 2, CB_MODE_GATHER, EPI, true, true, 2>(p, s);
                 return launch_f32<2, 2, 2, CB_MODE_GATHER, EPI, true, true>(p, s);
             }
             if (narrow) return launch_f32<1, 4, 2, CB_MODE_GATHER, EPI, false, true>(p, s);
+            if (cb_x3_wide(p.KP)) return launch_f32<2, 4, 2, CB_MODE_GATHER, EPI, false, true, 2>(p, s);
             return launch_f32<2, 2, 2, CB_MODE_GATHER, EPI, false, true>(p, s);
         } else {
             return CB_ERR_UNSUPPORTED;
@@ -1329,7 +1464,7 @@ int cbinfer_weights_kpad(int K) { return K <= CB_MFMA_M ? CB_MFMA_M : (K + 63) /
 int cbinfer_weights_ckkpad(int Ckk, int dtype) { return cb_ckkpad(Ckk, dtype); }
 
 long cbinfer_conv_workspace_bytes(void) {
-    return 4096 + (long)CB_CONV_GRID_PER_CU * cb_num_cus() * 64 * 64 * 4;
+    return 4096 + (long)CB_CONV_GRID_PER_CU * cb_num_cus() * 128 * 64 * 4;   // (= one 128 x 128 tile per CU)
 }
 
 long cbinfer_prepared_weights_bytes(int K, int C, int kH, int kW, int dtype) {
@@ -1457,7 +1592,7 @@ int cbinfer_conv_changed(const void* input, const int32_t* changeList, int numCh
     p.relu = relu;
     p.clearBits = (unsigned long long*)clearBits;
     p.clearWords = clearBits ? clearWords : 0;
-    if (workspace) {   // [tickets: grid ints, padded to 4 KB][slabs: grid x 64x64 floats]
+    if (workspace) {   // [tickets: grid ints, padded to 4 KB][slabs: one partial tile per workgroup of the grid]
         p.tickets = (int*)workspace;
         p.slabs = (float*)((char*)workspace + 4096);
     }

@@ -12,15 +12,17 @@ raw = ctypes.CDLL(_lib.LIB_PATH)
 C, K, k, H, W = LAYERS[int(sys.argv[1]) if len(sys.argv) > 1 else 2]
 gen = torch.Generator().manual_seed(0)
 x = torch.randn(1, C, H, W, device="cuda"); w = torch.randn(K, C, k, k, device="cuda") / (C*k*k)**0.5
-b = torch.randn(K, device="cuda"); out = torch.zeros(1, K, H, W, device="cuda"); wp = cg.prepWeights(w, H, W)
+ARITH = _lib.CB_F32S if os.environ.get('STAMP_SPLIT', '1') != '0' else None
+b = torch.randn(K, device="cuda"); out = torch.zeros(1, K, H, W, device="cuda"); wp = cg.prepWeights(w, H, W, arith=ARITH)
 for ratio in ([float(a) for a in sys.argv[2:]] or [0.1, 0.36, 1.0]):
     idx = blocks_list(H, W, ratio, 8, gen)
     for _ in range(5):
-        cg.convChanged(x, idx, w, b, out, withReLU=True, weightsPrepared=wp)
+        cg.convChanged(x, idx, w, b, out, withReLU=True, weightsPrepared=wp, arith=ARITH)
     torch.cuda.synchronize()
     buf = np.zeros(1024 * 8, dtype=np.uint64)
     raw.cbinfer_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(buf.nbytes))
     st = buf.reshape(1024, 8)[:512].astype(np.int64)
+    st = st[st[:, 0] > 0]          # workgroups of this launch's grid
     t0 = st[:, 0].min()
     us = (st - t0) / 100.0
     names = ['entry', 'prologue done', 'item setup done', 'stage loop done', 'KS reduce done', 'ticket done', 'epilogue done', 'exit']
@@ -29,9 +31,13 @@ for ratio in ([float(a) for a in sys.argv[2:]] or [0.1, 0.36, 1.0]):
         col = us[:, i]; valid = st[:, i] >= t0
         if valid.sum() == 0: continue
         print("  %-18s min %7.2f  mean %7.2f  max %7.2f us (%d wgs)" % (n, col[valid].min(), col[valid].mean(), col[valid].max(), valid.sum()))
+    ok2 = (st[:, 2] >= t0) & (st[:, 3] >= st[:, 2])
+    if ok2.sum():
+        d = (st[ok2, 3] - st[ok2, 2]) / 100.0
+        print("  stage loop of the first item: min %.2f mean %.2f max %.2f us over %d wgs" % (d.min(), d.mean(), d.max(), ok2.sum()))
     clk = np.zeros(1024 * 2, dtype=np.uint64)
     raw.cbinfer_debug_clocks(clk.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(clk.nbytes))
-    ck = clk.reshape(1024, 2)[:512].astype(np.int64)
+    ck = clk.reshape(1024, 2)[:len(st)].astype(np.int64)
     dcyc = ck[:, 1] - ck[:, 0]; dus = (st[:, 7] - st[:, 0]) / 100.0
     ok = dus > 5
     print("  shader clock: s_memtime ticks per us  min %.0f mean %.0f max %.0f" % ((dcyc[ok] / dus[ok]).min(), (dcyc[ok] / dus[ok]).mean(), (dcyc[ok] / dus[ok]).max()))

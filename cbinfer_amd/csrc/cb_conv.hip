@@ -1249,18 +1249,41 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
             }
         }
 
+        auto emit = [&](int m, int n, int pix, float v) {
+            if (EPI != CB_EPI_SCATTER_ACC) {
+                if (bias) v += (float)bias[m];
+                if (p.relu) v = cb_relu(v);
+            }
+            if (EPI == CB_EPI_Y)
+                out[(long)n * p.K + m] = (cb_half)v;
+            else if (EPI == CB_EPI_YT)
+                out[(long)m * p.nHost + n] = (cb_half)v;
+            else if (EPI == CB_EPI_SCATTER)
+                out[(long)m * HW + pix] = (cb_half)v;
+            else
+                out[(long)m * HW + pix] = (cb_half)((float)out[(long)m * HW + pix] + v);
+        };
         if (SK > 1) {
-            // publish this slice's partial tile, take a ticket; the last arriver reduces
-            float* slab = p.slabs + (long)item * TILE + (wq * 16) * 64 + lane;
+            // publish this slice's partial tile, take a ticket; the last arriver sums and stores -- the
+            // protocol and slab layout of cb_mfma_f32_kernel ([BM/4][BN] float4, write-through stores, no
+            // release; two workgroups per CU: the reducer invalidates its L1 before its sc1 loads)
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)p.slabs, 0, (int)min((long)gridDim.x * TILE * 4, (long)0x7fffffff), 0x00020000);
             if (ks == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) slab[r * 64] = acc[r];
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 f = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                    const u32x4 v = __builtin_bit_cast(u32x4, f);
+                    const int mq = wm * 8 + 2 * q + h;
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        v, srsrc, (item * (TILE / 4) + mq * BN + wn * 32 + l31) * 16, 0, 16 /* sc1 */);
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (t == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const int ticket = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED,
                                                           __HIP_MEMORY_SCOPE_AGENT);
                 const int last = ticket == SK - 1;
@@ -1275,15 +1298,33 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
             const bool last = s_last != 0;
             __syncthreads();   // s_last may be rewritten by the next item
             if (!last) continue;
-            if (ks == 0) {
-                const float* sl = p.slabs + (long)tile * SK * TILE + (wq * 16) * 64 + lane;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int c0 = 0; c0 < TILE / 4; c0 += NT) {
+                const int c = c0 + t;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
                 for (int j = 0; j < SK; ++j) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] += sl[(long)j * TILE + r * 64];
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                        srsrc, ((tile * SK + j) * (TILE / 4) + c) * 16, 0, 16 /* sc1 */);
+                    const f32x4 f = __builtin_bit_cast(f32x4, v);
+                    s0 += f.x;
+                    s1 += f.y;
+                    s2 += f.z;
+                    s3 += f.w;
+                }
+                const int nl = c % BN, mq = c / BN;
+                const int n = n0 + nl;
+                int pix = 0;
+                if (EPI >= CB_EPI_SCATTER && n < N) pix = SELFC ? s_tilePix[nl] : p.list[n];
+                if (n < N && (unsigned)pix < (unsigned)HW) {
+                    const int m = m0 + 4 * mq;
+                    if (m < p.K) emit(m, n, pix, s0);
+                    if (m + 1 < p.K) emit(m + 1, n, pix, s1);
+                    if (m + 2 < p.K) emit(m + 2, n, pix, s2);
+                    if (m + 3 < p.K) emit(m + 3, n, pix, s3);
                 }
             }
+            continue;
         }
 
         // epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -1297,19 +1338,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m >= p.K) continue;
-                float v = acc[r];
-                if (EPI != CB_EPI_SCATTER_ACC) {
-                    if (bias) v += (float)bias[m];
-                    if (p.relu) v = cb_relu(v);
-                }
-                if (EPI == CB_EPI_Y)
-                    out[(long)n * p.K + m] = (cb_half)v;
-                else if (EPI == CB_EPI_YT)
-                    out[(long)m * p.nHost + n] = (cb_half)v;
-                else if (EPI == CB_EPI_SCATTER)
-                    out[(long)m * HW + pix] = (cb_half)v;
-                else
-                    out[(long)m * HW + pix] = (cb_half)((float)out[(long)m * HW + pix] + v);
+                emit(m, n, pix, acc[r]);
             }
         }
     }

@@ -240,6 +240,14 @@ __device__ __forceinline__ void cb_clear_mask(const ConvParams& p) {
 // diagnostic build only (make EXTRA=-DCB_STAMP): per-workgroup phase time stamps (100 MHz constant clock)
 __device__ unsigned long long cb_stamp_buf[1024 * 8];
 __device__ unsigned long long cb_stamp_clk[1024 * 2];   // s_memtime (shader clock) at entry / exit
+// wide (MS = 2) kernel: shader-clock stamps of waves 0 (store first) and 8 (MFMA first) of workgroup 8 over
+// its first 24 stages: [wave][stage][after barrier, after first segment, after second, after third]
+__device__ unsigned long long cb_stage_clk[2 * 24 * 4];
+#define CB_STAGE_STAMP(pt)                                                                          \
+    do {                                                                                            \
+        if (blockIdx.x == 8 && (t == 0 || t == 512) && cb_stage_no < 24 && cb_stamp_first)          \
+            cb_stage_clk[((t >> 9) * 24 + cb_stage_no) * 4 + (pt)] = __builtin_amdgcn_s_memtime();  \
+    } while (0)
 #define CB_STAMP_AT(i)                                                                        \
     do {                                                                                      \
         if (threadIdx.x == 0 && blockIdx.x < 1024 && cb_stamp_first)                          \
@@ -247,6 +255,7 @@ __device__ unsigned long long cb_stamp_clk[1024 * 2];   // s_memtime (shader clo
     } while (0)
 #else
 #define CB_STAMP_AT(i)
+#define CB_STAGE_STAMP(pt)
 #endif
 #define CB_SKMAX 8
 // diagnostic ablations of the X3 kernel are a build option (make EXTRA=-DCB_CONV_DBG): as run-time
@@ -602,27 +611,28 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
         auto compute = [&](int buf) {
             if (MS == 2) {
                 const char* ap = (const char*)(As + buf * A_STAGE + (wm * 64 + l31) * LDK) + ks * 32 + h * 16;
+                const char* ap1 = ap + 32 * LDK * 4;
                 const char* bp = (const char*)(Bs + buf * B_STAGE + (wn * 32 + l31) * LDK) + ks * 32 + h * 16;
-                const bf16x8 bh = *(const bf16x8*)bp, bm = *(const bf16x8*)(bp + 64), bl = *(const bf16x8*)(bp + 128);
-                {
-                    const bf16x8 ah = *(const bf16x8*)ap, am = *(const bf16x8*)(ap + 64), al = *(const bf16x8*)(ap + 128);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-                }
-                {
-                    const char* ap1 = ap + 32 * LDK * 4;
-                    const bf16x8 ah = *(const bf16x8*)ap1, am = *(const bf16x8*)(ap1 + 64), al = *(const bf16x8*)(ap1 + 128);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc1, 0, 0, 0);
-                }
+                // all nine fragment reads first, in the order of their use (the scheduler otherwise re-uses
+                // fragment registers and leaves an exposed LDS round trip between the MFMAs)
+                const bf16x8 bh = *(const bf16x8*)bp, al = *(const bf16x8*)(ap + 128);
+                const bf16x8 bl = *(const bf16x8*)(bp + 128), ah = *(const bf16x8*)ap;
+                const bf16x8 bm = *(const bf16x8*)(bp + 64), am = *(const bf16x8*)(ap + 64);
+                const bf16x8 al1 = *(const bf16x8*)(ap1 + 128), ah1 = *(const bf16x8*)ap1, am1 = *(const bf16x8*)(ap1 + 64);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, bm, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, bh, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bm, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
                 return;
             }
             if (X3) {
@@ -666,30 +676,44 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
         CB_STAMP_AT(2);
         auto main_loop = [&](auto FASTC, auto MFC) {
             constexpr bool MF = decltype(MFC)::value;
+#ifdef CB_STAMP
+            int cb_stage_no = 0;
+#define CB_STAGE_NEXT ++cb_stage_no;
+#else
+#define CB_STAGE_NEXT
+#endif
             if (MS == 2) {
-                // the 16-wave form has the registers for TWO staging sets: loads run two stages ahead
+                // the 16-wave form keeps ONE staging set (128 registers per wave: two accumulators and nine
+                // fragment registers come first): the loads of stage s+2 are issued during stage s+1... i.e.
+                // one stage (~1.5 us) ahead of their use
                 load_stage(FASTC, kBeg, a0, b0);
                 __builtin_amdgcn_sched_barrier(0);
-                load_stage(FASTC, min(kBeg + BK, kLast), a1, b1);
-                __builtin_amdgcn_sched_barrier(0);
                 store_stage(0, a0, b0);
-                load_stage(FASTC, min(kBeg + 2 * BK, kLast), a0, b0);
+                load_stage(FASTC, min(kBeg + BK, kLast), a0, b0);
                 __syncthreads();
-#define CB_STAGE2(BUF, AREG, BREG, KNEXT)                         \
+#define CB_STAGE2(BUF, KNEXT)                                     \
+                CB_STAGE_STAMP(0);                                    \
                 if (MF) {                                             \
                     compute(BUF);                                     \
-                    store_stage((BUF) ^ 1, AREG, BREG);               \
-                    load_stage(FASTC, min(KNEXT, kLast), AREG, BREG); \
+                    CB_STAGE_STAMP(1);                                \
+                    store_stage((BUF) ^ 1, a0, b0);                   \
+                    CB_STAGE_STAMP(2);                                \
+                    load_stage(FASTC, min(KNEXT, kLast), a0, b0);     \
+                    CB_STAGE_STAMP(3);                                \
                 } else {                                              \
-                    store_stage((BUF) ^ 1, AREG, BREG);               \
-                    load_stage(FASTC, min(KNEXT, kLast), AREG, BREG); \
+                    store_stage((BUF) ^ 1, a0, b0);                   \
+                    CB_STAGE_STAMP(1);                                \
+                    load_stage(FASTC, min(KNEXT, kLast), a0, b0);     \
+                    CB_STAGE_STAMP(2);                                \
                     compute(BUF);                                     \
+                    CB_STAGE_STAMP(3);                                \
                 }                                                     \
+                CB_STAGE_NEXT                                         \
                 __syncthreads();
                 for (int k0 = kBeg; k0 < kEnd; k0 += 2 * BK) {
-                    CB_STAGE2(0, a1, b1, k0 + 3 * BK)
+                    CB_STAGE2(0, k0 + 2 * BK)
                     if (k0 + BK >= kEnd) break;
-                    CB_STAGE2(1, a0, b0, k0 + 4 * BK)
+                    CB_STAGE2(1, k0 + 3 * BK)
                 }
 #undef CB_STAGE2
                 return;
@@ -1703,6 +1727,9 @@ int cbinfer_frame_mask_max_words(void) { return CB_SELFC_MAXW; }
 #ifdef CB_STAMP
 extern "C" int cbinfer_debug_stamps(void* host, long bytes) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cb_stamp_buf), (size_t)bytes);
+}
+extern "C" int cbinfer_debug_stage_clocks(void* host, long bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cb_stage_clk), (size_t)bytes);
 }
 extern "C" int cbinfer_debug_clocks(void* host, long bytes) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cb_stamp_clk), (size_t)bytes);

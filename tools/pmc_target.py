@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cbinfer_amd import conv2d_cg as cg  # noqa: E402
+from cbinfer_amd._lib import CB_F32S  # noqa: E402
 from tools.bench_conv import LAYERS, blocks_list  # noqa: E402
 
 
@@ -22,10 +23,11 @@ def main():
     w = torch.randn(K, C, k, k, device="cuda") / (C * k * k) ** 0.5
     b = torch.randn(K, device="cuda")
     out = torch.zeros(1, K, H, W, device="cuda")
-    wp = cg.prepWeights(w, H, W)
+    arith = CB_F32S if os.environ.get('PMC_SPLIT', '1') != '0' else None   # the frame's arithmetic
+    wp = cg.prepWeights(w, H, W, arith=arith)
     idx = blocks_list(H, W, ratio, 8, gen)
     for _ in range(reps):
-        cg.convChanged(x, idx, w, b, out, withReLU=True, weightsPrepared=wp)
+        cg.convChanged(x, idx, w, b, out, withReLU=True, weightsPrepared=wp, arith=arith)
     torch.cuda.synchronize()
     print("layer", LAYERS[layer], "N", idx.numel(), "launches", reps)
 

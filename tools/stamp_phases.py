@@ -35,6 +35,17 @@ for ratio in ([float(a) for a in sys.argv[2:]] or [0.1, 0.36, 1.0]):
     if ok2.sum():
         d = (st[ok2, 3] - st[ok2, 2]) / 100.0
         print("  stage loop of the first item: min %.2f mean %.2f max %.2f us over %d wgs" % (d.min(), d.mean(), d.max(), ok2.sum()))
+    sc = np.zeros(2 * 24 * 4, dtype=np.uint64)
+    if hasattr(raw, 'cbinfer_debug_stage_clocks') and os.environ.get('CBINFER_X3_WIDE', '1') != '0':
+        raw.cbinfer_debug_stage_clocks(sc.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(sc.nbytes))
+        sc = sc.reshape(2, 24, 4).astype(np.int64)
+        for wv, nm in ((0, 'wave 0 (store, load, MFMA)'), (1, 'wave 8 (MFMA, store, load)')):
+            rows = [r for r in sc[wv] if r[0] > 0]
+            if len(rows) > 3:
+                r = np.array(rows[1:-1])
+                seg = np.diff(r, axis=1).mean(0)
+                per = np.diff(r[:, 0]).mean() if len(r) > 1 else 0
+                print("  %s: segments %s cycles; stage period %.0f cycles (%d stages)" % (nm, [int(x) for x in seg], per, len(r)))
     clk = np.zeros(1024 * 2, dtype=np.uint64)
     raw.cbinfer_debug_clocks(clk.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(clk.nbytes))
     ck = clk.reshape(1024, 2)[:len(st)].astype(np.int64)

@@ -3,7 +3,8 @@
 passes of tools/collect_profiles.sh.  Prints a text summary and, with --json OUT, writes the file bench.py reads
 for `roofline.traffic` (keyed by the bench's layer labels, stamped with the hash of the kernel sources the
 passes ran on).  In the bench workload every layer has a contraction kernel of its own: cb_rowconv (3->16),
-cb_blockconv (16->64), cb_mfma_f32_kernel (64->256), so no clustering by value is needed."""
+cb_blockconv (16->64), cb_mfma_f32_kernel (64->256: the 128 x 128 self-compacting form), so no clustering by
+value is needed."""
 import csv
 import glob
 import json
@@ -30,7 +31,8 @@ def load(sub, counter):
 fetch, write = load("pmc_fetch", "FETCH_SIZE"), load("pmc_write", "WRITE_SIZE")
 LAYER = [("cb_rowconv_f32_kernel", "cb_mfma_f32_kernel conv 3->16 k7 @320x480"),
          ("cb_blockconv_kernel", "cb_mfma_f32_kernel conv 16->64 k7 @160x240"),
-         ("cb_mfma_f32_kernel<2, 2, 2, 1, 2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),   # in-frame form
+         ("cb_mfma_f32_kernel<2, 4, 2, 1, 2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),   # in-frame form
+         ("cb_mfma_f32_kernel<2, 2, 2, 1, 2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),   # (64 x 64 tiles)
          ("cb_tail1x1_kernel", "cb_tail1x1_kernel 256->64->8 @80x120")]
 table = {}
 for name in sorted(set(fetch) | set(write)):

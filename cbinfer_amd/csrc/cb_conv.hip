@@ -258,6 +258,9 @@ __device__ unsigned long long cb_stage_clk[2 * 24 * 4];
 #define CB_STAGE_STAMP(pt)
 #endif
 #define CB_SKMAX 8
+#ifndef CB_WIDE_IL
+#define CB_WIDE_IL 0
+#endif
 // diagnostic ablations of the X3 kernel are a build option (make EXTRA=-DCB_CONV_DBG): as run-time
 // branches around the stage loads they would cost the loop its counted vmcnt waits
 #ifdef CB_CONV_DBG
@@ -276,7 +279,10 @@ __device__ unsigned long long cb_stage_clk[2 * 24 * 4];
 // The vector-memory pipe of a CU (~70 GB/s: MI355X_MICROARCH.md, "Indexed rows") is what bounds this
 // contraction -- a 64 x 64 tile moves 20 KB of weights and gathered values per stage and MFMA unit through it,
 // the 128 x 128 tile half of that, with the same registers per wave.
-template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false, bool X3 = false, int MS = 1>
+// BHALF (with MS = 2, as <4, 2, 2, ..., MS 2, BHALF>: 256 channels x 64 pixels): only the first k-group's
+// waves gather, split and store the pixel operand -- 4 values per thread as elsewhere -- so a staged pixel row
+// feeds all 256 output channels; the other k-group's waves only move weights.
+template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false, bool X3 = false, int MS = 1, bool BHALF = false>
 __global__ __launch_bounds__(64 * WM * WN * KS)
     __attribute__((amdgpu_waves_per_eu((WM * WN * KS >= 8 ? 4 : WM * WN * KS >= 4 ? 2 : 1)))) void cb_mfma_f32_kernel(
         ConvParams p) {
@@ -288,7 +294,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
     constexpr int LDK = X3 ? 52 : BK + 4;   // LDS row in floats: 32 k of one m / one pixel + 16 B pad
     constexpr int A_F4 = X3 ? 12 * BM : BK * BM / 4;   // 16-byte chunks of an A stage
     constexpr int A_PER_T = (A_F4 + NT - 1) / NT;
-    constexpr int B_PER_T = BK * BN / NT;
+    constexpr int BT = BHALF ? NT / 2 : NT;   // threads that carry the pixel operand
+    constexpr int B_PER_T = BK * BN / BT;
+    static_assert(!BHALF || (MS == 2 && KS == 2), "BHALF: the k-group 0 waves of the wide form");
     constexpr int NPP = NT / BK;        // matrix: pixel slots covered by one pass
     constexpr int KSTEP = BK / KS;     // k-depth one wave group handles per stage
     constexpr int S = KSTEP / 2;        // ... = MFMA steps per wave and stage (two k per step)
@@ -297,8 +305,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
     constexpr int RED = KS > 1 ? WM * WN * MS * 64 * 16 : 0;   // floats of the k-group reduction buffer
     static_assert(MS == 1 || (MS == 2 && X3), "two row tiles per wave: X3 only");
     static_assert(BN % 64 == 0, "gather rows must be wave-uniform");
-    static_assert(BK * BN % NT == 0 && S % 4 == 0, "bad decomposition");
-    static_assert(!X3 || (KS == 2 && MODE == CB_MODE_GATHER && (BK * BN / NT) % 4 == 0), "X3: 16 k per wave group");
+    static_assert(BK * BN % BT == 0 && S % 4 == 0, "bad decomposition");
+    static_assert(!X3 || (KS == 2 && MODE == CB_MODE_GATHER && B_PER_T % 4 == 0), "X3: 16 k per wave group");
     static_assert(2 * (A_STAGE + B_STAGE) >= RED, "reduce buffer");
 
 #ifdef CB_STAMP
@@ -513,8 +521,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
         avec a0, a1, a2, a3;
         bvec b0, b1, b2, b3;
 
-        auto load_stage = [&](auto FASTC, int k0, avec& areg, bvec& breg) {
+        auto load_stage = [&](auto FASTC, auto DOBC, int k0, avec& areg, bvec& breg) {
             constexpr bool FAST = decltype(FASTC)::value;
+            constexpr bool DOB = decltype(DOBC)::value;
 #pragma unroll
             for (int i = 0; i < A_PER_T; ++i) {
                 const int f = X3 ? min(t + i * NT, A_F4 - 1) : t + i * NT;   // (X3: every thread loads, the
@@ -535,7 +544,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
                     areg[4 * i + 3] = v.w;
                 }
             }
-            if (X3 && CB_DBG(1)) {
+            if (!DOB) {
+                return;
+            } else if (X3 && CB_DBG(1)) {
 #pragma unroll
                 for (int i = 0; i < B_PER_T; ++i) breg[i] = 1.0f;
             } else if (MODE == CB_MODE_GATHER && FAST) {
@@ -564,17 +575,21 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
             }
             fetch_pk(min(k0 + BK, kLast));   // consecutive calls load consecutive stages
         };
-        auto store_stage = [&](int buf, const avec& areg, const bvec& breg) {
+        auto store_stage = [&](auto DOBC, int buf, const avec& areg, const bvec& breg) {
+            constexpr bool DOB = decltype(DOBC)::value;
             float* as = As + buf * A_STAGE;
             float* bs = Bs + buf * B_STAGE;
 #pragma unroll
             for (int i = 0; i < A_PER_T; ++i) {
-                const int f = t + i * NT;
-                if (A_F4 % NT == 0 || f < A_F4)
+                // (MS == 2: the surplus threads re-write the last chunk -- same address, same value as its
+                //  owner -- so that the stage body stays one basic block for the scheduler)
+                const int f = MS == 2 ? min(t + i * NT, A_F4 - 1) : t + i * NT;
+                if (MS == 2 || A_F4 % NT == 0 || f < A_F4)
                     *(float4*)(as + (X3 ? (f / 12) * LDK + (f % 12) * 4 : (f / (BK / 4)) * LDK + (f % (BK / 4)) * 4)) =
                         make_float4(areg[4 * i], areg[4 * i + 1], areg[4 * i + 2], areg[4 * i + 3]);
             }
-            if (X3) {   // split the thread's k-consecutive values, 8-byte writes into the three planes
+            if (!DOB) {
+            } else if (X3) {   // split the thread's k-consecutive values, 8-byte writes into the three planes
 #pragma unroll
                 for (int q = 0; q < B_PER_T / 4; ++q) {
                     unsigned h[4], m[4], l[4];
@@ -632,7 +647,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, bh, acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bm, acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc1, 0, 0, 0);
+#if !CB_WIDE_IL
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 return;
             }
             if (X3) {
@@ -676,6 +693,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
         CB_STAMP_AT(2);
         auto main_loop = [&](auto FASTC, auto MFC) {
             constexpr bool MF = decltype(MFC)::value;
+            const std::integral_constant<bool, !(BHALF && MF)> dob;   // (BHALF: the MFMA-first waves = k-group 1)
 #ifdef CB_STAMP
             int cb_stage_no = 0;
 #define CB_STAGE_NEXT ++cb_stage_no;
@@ -686,30 +704,46 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
                 // the 16-wave form keeps ONE staging set (128 registers per wave: two accumulators and nine
                 // fragment registers come first): the loads of stage s+2 are issued during stage s+1... i.e.
                 // one stage (~1.5 us) ahead of their use
-                load_stage(FASTC, kBeg, a0, b0);
+                load_stage(FASTC, dob, kBeg, a0, b0);
                 __builtin_amdgcn_sched_barrier(0);
-                store_stage(0, a0, b0);
-                load_stage(FASTC, min(kBeg + BK, kLast), a0, b0);
+                store_stage(dob, 0, a0, b0);
+                load_stage(FASTC, dob, min(kBeg + BK, kLast), a0, b0);
                 __syncthreads();
+#if CB_WIDE_IL
+                // every wave: fragment reads, then the twelve MFMAs with the next stage's LDS writes, address
+                // arithmetic and loads dealt into the gaps between them
+#define CB_STAGE2(BUF, KNEXT)                                     \
+                compute(BUF);                                         \
+                store_stage(dob, (BUF) ^ 1, a0, b0);                       \
+                load_stage(FASTC, dob, min(KNEXT, kLast), a0, b0);         \
+                _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {   \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);\
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);\
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);\
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);\
+                }                                                     \
+                __syncthreads();
+#else
 #define CB_STAGE2(BUF, KNEXT)                                     \
                 CB_STAGE_STAMP(0);                                    \
                 if (MF) {                                             \
-                    compute(BUF);                                     \
+                    if (!CB_DBG(8)) compute(BUF);                     \
                     CB_STAGE_STAMP(1);                                \
-                    store_stage((BUF) ^ 1, a0, b0);                   \
+                    if (!CB_DBG(4)) store_stage(dob, (BUF) ^ 1, a0, b0);   \
                     CB_STAGE_STAMP(2);                                \
-                    load_stage(FASTC, min(KNEXT, kLast), a0, b0);     \
+                    if (!CB_DBG(16)) load_stage(FASTC, dob, min(KNEXT, kLast), a0, b0);     \
                     CB_STAGE_STAMP(3);                                \
                 } else {                                              \
-                    store_stage((BUF) ^ 1, a0, b0);                   \
+                    if (!CB_DBG(4)) store_stage(dob, (BUF) ^ 1, a0, b0);   \
                     CB_STAGE_STAMP(1);                                \
-                    load_stage(FASTC, min(KNEXT, kLast), a0, b0);     \
+                    if (!CB_DBG(16)) load_stage(FASTC, dob, min(KNEXT, kLast), a0, b0);     \
                     CB_STAGE_STAMP(2);                                \
-                    compute(BUF);                                     \
+                    if (!CB_DBG(8)) compute(BUF);                     \
                     CB_STAGE_STAMP(3);                                \
                 }                                                     \
                 CB_STAGE_NEXT                                         \
                 __syncthreads();
+#endif
                 for (int k0 = kBeg; k0 < kEnd; k0 += 2 * BK) {
                     CB_STAGE2(0, k0 + 2 * BK)
                     if (k0 + BK >= kEnd) break;
@@ -720,17 +754,17 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
             }
             // (scheduling fences: the prologue must issue the sets in ring order, otherwise the loop
             // header inherits "set 0 is the youngest" and drains the queue every iteration)
-            load_stage(FASTC, kBeg, a0, b0);
+            load_stage(FASTC, dob, kBeg, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            load_stage(FASTC, min(kBeg + BK, kLast), a1, b1);
+            load_stage(FASTC, dob, min(kBeg + BK, kLast), a1, b1);
             __builtin_amdgcn_sched_barrier(0);
-            load_stage(FASTC, min(kBeg + 2 * BK, kLast), a2, b2);
+            load_stage(FASTC, dob, min(kBeg + 2 * BK, kLast), a2, b2);
             __builtin_amdgcn_sched_barrier(0);
-            load_stage(FASTC, min(kBeg + 3 * BK, kLast), a3, b3);
+            load_stage(FASTC, dob, min(kBeg + 3 * BK, kLast), a3, b3);
             __builtin_amdgcn_sched_barrier(0);
             // LDS stage 0 <- set 0, which is then re-armed with stage 4
-            store_stage(0, a0, b0);
-            load_stage(FASTC, min(kBeg + 4 * BK, kLast), a0, b0);
+            store_stage(dob, 0, a0, b0);
+            load_stage(FASTC, dob, min(kBeg + 4 * BK, kLast), a0, b0);
             __syncthreads();
             // One barrier per stage.  While a wave's MFMA chain on LDS buffer BUF runs it also writes the
             // NEXT stage into the other buffer (free since the barrier just passed: every wave finished
@@ -739,11 +773,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
 #define CB_STAGE(BUF, AREG, BREG, KNEXT)                          \
             if (MF) {                                             \
                 compute(BUF);                                     \
-                store_stage((BUF) ^ 1, AREG, BREG);               \
-                load_stage(FASTC, min(KNEXT, kLast), AREG, BREG); \
+                store_stage(dob, (BUF) ^ 1, AREG, BREG);               \
+                load_stage(FASTC, dob, min(KNEXT, kLast), AREG, BREG); \
             } else {                                              \
-                store_stage((BUF) ^ 1, AREG, BREG);               \
-                load_stage(FASTC, min(KNEXT, kLast), AREG, BREG); \
+                store_stage(dob, (BUF) ^ 1, AREG, BREG);               \
+                load_stage(FASTC, dob, min(KNEXT, kLast), AREG, BREG); \
                 compute(BUF);                                     \
             }                                                     \
             __syncthreads();
@@ -762,7 +796,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
         };
         typedef std::integral_constant<bool, true> cb_true;
         typedef std::integral_constant<bool, false> cb_false;
-        const bool mfmaFirst = (KS > 1) && (__builtin_amdgcn_readfirstlane(ks) & 1);
+        bool mfmaFirst = (KS > 1) && (__builtin_amdgcn_readfirstlane(ks) & 1);
+        if (!BHALF) {   // (BHALF ties the roles to the k-group)
+            if (CB_DBG(32)) mfmaFirst = true;                      // (diagnostic: no stagger)
+            if (CB_DBG(64)) mfmaFirst = (wave >> 2) & 1;           // (diagnostic: stagger by wave quartets)
+            if (CB_DBG(128)) mfmaFirst = wave & 1;                 // (diagnostic: stagger by wave parity)
+        }
         const bool fastU = __builtin_amdgcn_readfirstlane((int)fast) != 0;
         if (fastU) {
             if (mfmaFirst)
@@ -1397,7 +1436,7 @@ int cb_num_cus() {
     return cus;
 }
 
-template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false, bool X3 = false, int MS = 1>
+template <int WM, int WN, int KS, int MODE, int EPI, bool SELFC = false, bool X3 = false, int MS = 1, bool BHALF = false>
 int launch_f32(const ConvParams& p, hipStream_t s) {
     const long tilesCap = (long)cb_div_up(p.nHost, 32 * WN) * (p.KP / (32 * WM * MS));
     if (tilesCap == 0) return CB_OK;
@@ -1406,7 +1445,7 @@ int launch_f32(const ConvParams& p, hipStream_t s) {
     long g = (WM * WN * KS > 8 ? 1 : CB_CONV_GRID_PER_CU) * (long)cb_num_cus();
     if (!p.slabs && tilesCap < g && !SELFC) g = tilesCap;
     dim3 grid((unsigned)g), block(64 * WM * WN * KS);
-    hipLaunchKernelGGL((cb_mfma_f32_kernel<WM, WN, KS, MODE, EPI, SELFC, X3, MS>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((cb_mfma_f32_kernel<WM, WN, KS, MODE, EPI, SELFC, X3, MS, BHALF>), grid, block, 0, s, p);
     return cb_launch_status();
 }
 
@@ -1427,14 +1466,22 @@ int cb_ckkpad(int Ckk, int dtype) {
     return (Ckk + q - 1) / q * q;
 }
 
-// bf16x3 arithmetic with output channels in multiples of 128: the 128 x 128 form (CBINFER_X3_WIDE=0: 64 x 64)
-bool cb_x3_wide(int KP) {
-    static int on = -1;
-    if (on < 0) {
+// bf16x3 arithmetic, 16-wave forms: 1 = 128 x 128 (output channels in multiples of 128), 0 = the 64 x 64
+// form; 2 = 256 channels x 64 pixels (multiples of 256; builds with -DCB_X3_BHALF only).  CBINFER_X3_WIDE caps
+// the choice.
+int cb_x3_wide(int KP) {
+    static int cap = -1;
+    if (cap < 0) {
         const char* e = getenv("CBINFER_X3_WIDE");
-        on = e ? atoi(e) != 0 : 1;
+#ifdef CB_X3_BHALF
+        cap = e ? atoi(e) : 2;
+#else
+        cap = e ? min(atoi(e), 1) : 1;
+#endif
     }
-    return on && KP % 128 == 0;
+    if (cap >= 2 && KP % 256 == 0) return 2;
+    if (cap >= 1 && KP % 128 == 0) return 1;
+    return 0;
 }
 
 int conv_cfg_override() {
@@ -1467,11 +1514,17 @@ int launch_mfma(const ConvParams& p0, int dtype, hipStream_t s) {
         if constexpr (MODE == CB_MODE_GATHER && EPI >= CB_EPI_SCATTER) {
             if (p.frameMasks) {
                 if (narrow) return launch_f32<1, 4, 2, CB_MODE_GATHER, EPI, true, true>(p, s);
-                if (cb_x3_wide(p.KP)) return launch_f32<2, 4, 2, CB_MODE_GATHER, EPI, true, true, 2>(p, s);
+#ifdef CB_X3_BHALF   // (measured: 63 vs 60 us in the frame -- twice the weight bytes through the LDS store path)
+                if (cb_x3_wide(p.KP) == 2) return launch_f32<4, 2, 2, CB_MODE_GATHER, EPI, true, true, 2, true>(p, s);
+#endif
+                if (cb_x3_wide(p.KP) >= 1) return launch_f32<2, 4, 2, CB_MODE_GATHER, EPI, true, true, 2>(p, s);
                 return launch_f32<2, 2, 2, CB_MODE_GATHER, EPI, true, true>(p, s);
             }
             if (narrow) return launch_f32<1, 4, 2, CB_MODE_GATHER, EPI, false, true>(p, s);
-            if (cb_x3_wide(p.KP)) return launch_f32<2, 4, 2, CB_MODE_GATHER, EPI, false, true, 2>(p, s);
+#ifdef CB_X3_BHALF
+            if (cb_x3_wide(p.KP) == 2) return launch_f32<4, 2, 2, CB_MODE_GATHER, EPI, false, true, 2, true>(p, s);
+#endif
+            if (cb_x3_wide(p.KP) >= 1) return launch_f32<2, 4, 2, CB_MODE_GATHER, EPI, false, true, 2>(p, s);
             return launch_f32<2, 2, 2, CB_MODE_GATHER, EPI, false, true>(p, s);
         } else {
             return CB_ERR_UNSUPPORTED;

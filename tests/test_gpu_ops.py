@@ -688,7 +688,11 @@ def test_rowconv_vs_oracle(cb, oracle, C, K, kH, kW, H, W, frac):
 
 @pytest.mark.parametrize("C,K,H,W,filt,frac", [(64, 256, 80, 120, (7, 7), 0.3), (16, 64, 160, 240, (7, 7), 0.1),
                                                (185, 128, 46, 81, (7, 7), 0.2), (5, 20, 33, 70, (3, 5), 0.5),
-                                               (3, 16, 64, 96, (7, 7), 0.2)])
+                                               (3, 16, 64, 96, (7, 7), 0.2),
+                                               # the 128 x 128 form off its comfortable shapes: three row tiles
+                                               # (no XCD-aware order), 129 and 1 changed pixels, every pixel
+                                               (9, 384, 20, 33, (3, 3), 0.9), (64, 128, 17, 40, (5, 5), 0.19),
+                                               (40, 256, 12, 31, (7, 7), 0.003), (12, 128, 31, 67, (3, 7), 1.0)])
 def test_split_contraction_accuracy(cb, oracle, C, K, H, W, filt, frac):
     """CB_F32S: the fused contraction with every f32 operand split into three bf16 terms and six cross
     products on the bf16 MFMA.  Against the double-accumulated oracle it must meet the fp32 bar (1e-4) with a

@@ -447,7 +447,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
         }
         const int item = tile * SK + slice;   // canonical index (slab slot)
         const int n0 = (tile / MT) * BN, m0 = (tile % MT) * BM;
-        const int kBeg = (P * slice / SK) * 4 * BK, kEnd = min((P * (slice + 1) / SK) * 4 * BK, p.CkkP);
+        // slices are cut at STAGE granularity (the stage loops leave at any stage): 98 stages over 4 slices are
+        // 24/25/24/25, not 24/24/24/26 -- the longest slice is what a tile waits for
+        const int nStg = p.CkkP / BK;
+        const int kBeg = (nStg * slice / SK) * BK, kEnd = (nStg * (slice + 1) / SK) * BK;
         const int kLast = kEnd - BK;
 
         // per-thread B-load coordinates; a slot past the list is "outside the image"
@@ -584,6 +587,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
                 // (MS == 2: the surplus threads re-write the last chunk -- same address, same value as its
                 //  owner -- so that the stage body stays one basic block for the scheduler)
                 const int f = MS == 2 ? min(t + i * NT, A_F4 - 1) : t + i * NT;
+                if (X3 && CB_DBG(256)) continue;   // (diagnostic: no weight LDS writes)
                 if (MS == 2 || A_F4 % NT == 0 || f < A_F4)
                     *(float4*)(as + (X3 ? (f / 12) * LDK + (f % 12) * 4 : (f / (BK / 4)) * LDK + (f % (BK / 4)) * 4)) =
                         make_float4(areg[4 * i], areg[4 * i + 1], areg[4 * i + 2], areg[4 * i + 3]);
@@ -596,6 +600,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) cb_split3t(breg[q * 4 + e], h[e], m[e], l[e]);
                     char* row = (char*)(bs + bj * LDK) + (br + q * 4) * 2;
+                    if (CB_DBG(512)) continue;   // (diagnostic: split, but no pixel-operand LDS writes)
                     *(uint2*)(row) = make_uint2(CB_PK2(h[0], h[1]), CB_PK2(h[2], h[3]));
                     *(uint2*)(row + 64) = make_uint2(CB_PK2(m[0], m[1]), CB_PK2(m[2], m[3]));
                     *(uint2*)(row + 128) = make_uint2(CB_PK2(l[0], l[1]), CB_PK2(l[2], l[3]));
@@ -781,8 +786,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
                 compute(BUF);                                     \
             }                                                     \
             __syncthreads();
-            // (only the slice that ends the k-range can stop inside a group of four: CkkP is a multiple
-            // of BK, not of 4 BK -- the exits leave the straight-line body, and its counted waits, alone)
+            // (a slice is a whole number of stages, not of groups of four -- the exits leave the
+            // straight-line body, and its counted waits, alone)
             for (int k0 = kBeg; k0 < kEnd; k0 += 4 * BK) {
                 CB_STAGE(0, a1, b1, k0 + 5 * BK)
                 if (k0 + BK >= kEnd) break;

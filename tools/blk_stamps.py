@@ -15,7 +15,11 @@ raw = ctypes.CDLL(LIB_PATH)
 
 def main():
     gen = torch.Generator().manual_seed(0)
-    for (C, K, k, H, W, blk, ratio) in [(64, 256, 7, 80, 120, 8, 0.01), (64, 256, 7, 80, 120, 8, 0.10)]:
+    shapes = [(64, 256, 7, 80, 120, 8, 0.01), (64, 256, 7, 80, 120, 8, 0.10)]
+    if len(sys.argv) > 1 and sys.argv[1] == 'l2':      # the 16->64 layer at the bench's change ratio
+        shapes = [(16, 64, 7, 160, 240, 16, 0.10), (16, 64, 7, 160, 240, 16, 0.14)]
+    for (C, K, k, H, W, blk, ratio) in shapes:
+        CH = (C + 7) // 8
         x = torch.randn(1, C, H, W, device="cuda")
         w = torch.randn(K, C, k, k, device="cuda") / (C * k * k) ** 0.5
         b = torch.randn(K, device="cuda")
@@ -61,11 +65,11 @@ def main():
         med = lambda v: float(np.median(v)) / 100.0
         print("   multiplier: prologue %.2f | wait first chunk %.2f | per chunk %s | loop tail %.2f | store %.2f | lifetime %.2f (max %.2f)" % (
             med(a[:, 1] - a[:, 0]), med(a[:, 2] - a[:, 1]),
-            " ".join("%.2f" % med(a[:, 3 + i] - a[:, 2 + i]) for i in range(7)),
-            med(a[:, 14] - a[:, 9]), med(a[:, 15] - a[:, 14]), med(a[:, 15] - a[:, 0]),
+            " ".join("%.2f" % med(a[:, 3 + i] - a[:, 2 + i]) for i in range(min(CH, 8) - 1)),
+            med(a[:, 14] - a[:, 1 + min(CH, 8)]), med(a[:, 15] - a[:, 14]), med(a[:, 15] - a[:, 0]),
             float((a[:, 15] - a[:, 0]).max()) / 100.0))
         print("   stager: start %.2f after entry | chunk staged at (rel. to its start) %s" % (
-            med(a[:, 16] - a[:, 0]), " ".join("%.2f" % med(a[:, 17 + i] - a[:, 16]) for i in range(8))))
+            med(a[:, 16] - a[:, 0]), " ".join("%.2f" % med(a[:, 17 + i] - a[:, 16]) for i in range(min(CH, 8)))))
 
 
 if __name__ == "__main__":

@@ -43,6 +43,32 @@ __device__ __forceinline__ void cb_split3t(float x, unsigned& hi, unsigned& mid,
     lo = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)r2) << 16;
 }
 #define CB_PK2(a, b) (((a) >> 16) | (b))
+// Four values at once for the stage stores: the three planes as packed pairs {x0 x1}, {x2 x3}.  The top halves
+// of two registers are packed by ONE v_perm_b32 (no mask, shift, or); the subtractions are scalar v_sub_f32 on
+// purpose -- the packed f32 form the compiler would choose costs three times as much beside MFMAs.
+__device__ __forceinline__ float cb_sub_f32(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void cb_split3t_x4(const float (&x)[4], uint2& hi, uint2& mid, uint2& lo) {
+    unsigned u[4], v[4];
+    float r1[4], r2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        u[e] = __builtin_bit_cast(unsigned, x[e]);
+        r1[e] = cb_sub_f32(x[e], __builtin_bit_cast(float, u[e] & 0xffff0000u));
+        v[e] = __builtin_bit_cast(unsigned, r1[e]);
+        r2[e] = cb_sub_f32(r1[e], __builtin_bit_cast(float, v[e] & 0xffff0000u));
+    }
+    hi = make_uint2(__builtin_amdgcn_perm(u[1], u[0], 0x07060302u), __builtin_amdgcn_perm(u[3], u[2], 0x07060302u));
+    mid = make_uint2(__builtin_amdgcn_perm(v[1], v[0], 0x07060302u), __builtin_amdgcn_perm(v[3], v[2], 0x07060302u));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 p0 = {r2[0], r2[1]}, p1 = {r2[2], r2[3]};
+    lo = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(p0, bf16x2)),
+                    __builtin_bit_cast(unsigned, __builtin_convertvector(p1, bf16x2)));
+}
 typedef __attribute__((address_space(4))) int cb_const_int;   // constant address space: scalar loads
 
 __device__ __forceinline__ float cb_relu(float v) { return v <= 0.f ? 0.f : v; }
@@ -417,6 +443,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
     const int HW = p.H * p.W;
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.B, 0, MODE == CB_MODE_GATHER ? p.C * HW * 4 : 0, 0x00020000);
+    // (X3: the pre-split weights through a buffer descriptor -- 32-bit offsets, the stage as scalar offset)
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.A, 0, X3 ? (int)min((long)p.KP * p.CkkP * 6, (long)0x7fffffff) : 0, 0x00020000);
     float* __restrict__ out = (float*)p.out;
     const float* __restrict__ bias = (const float*)p.bias;
 
@@ -524,6 +553,15 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
         avec a0, a1, a2, a3;
         bvec b0, b1, b2, b3;
 
+        // X3 weight loads: byte offset of the thread's chunk(s) in stage 0 of this item's row tile
+        int aoff[A_PER_T ? A_PER_T : 1];
+        if (X3) {
+#pragma unroll
+            for (int i = 0; i < A_PER_T; ++i) {
+                const int f = min(t + i * NT, A_F4 - 1);
+                aoff[i] = (((m0 + f / 12) * (p.CkkP / 32)) * 12 + f % 12) * 16;
+            }
+        }
         auto load_stage = [&](auto FASTC, auto DOBC, int k0, avec& areg, bvec& breg) {
             constexpr bool FAST = decltype(FASTC)::value;
             constexpr bool DOB = decltype(DOBC)::value;
@@ -534,9 +572,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
                     float4 v;
                     if (X3 && CB_DBG(2)) {
                         v = make_float4(1.f, 1.f, 1.f, 1.f);
-                    } else if (X3) {   // 12 chunks per row and stage in the pre-split layout
-                        const int row = f / 12, c = f % 12;
-                        v = *((const float4*)Ag + ((long)(m0 + row) * (p.CkkP / 32) + k0 / 32) * 12 + c);
+                    } else if (X3) {   // 12 chunks per row and stage in the pre-split layout: the thread's
+                        // byte offset is fixed per item (aoff), the stage goes in as the scalar offset
+                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                        typedef float f32x4 __attribute__((ext_vector_type(4)));
+                        const f32x4 w4 = __builtin_bit_cast(
+                            f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i], k0 * 6, 0));
+                        v = make_float4(w4.x, w4.y, w4.z, w4.w);
                     } else {
                         const int row = f / (BK / 4), c4 = f % (BK / 4);
                         v = *(const float4*)(Ag + (long)(m0 + row) * p.CkkP + k0 + c4 * 4);
@@ -596,14 +638,14 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
             } else if (X3) {   // split the thread's k-consecutive values, 8-byte writes into the three planes
 #pragma unroll
                 for (int q = 0; q < B_PER_T / 4; ++q) {
-                    unsigned h[4], m[4], l[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) cb_split3t(breg[q * 4 + e], h[e], m[e], l[e]);
+                    const float x4[4] = {breg[q * 4], breg[q * 4 + 1], breg[q * 4 + 2], breg[q * 4 + 3]};
+                    uint2 h2, m2, l2;
+                    cb_split3t_x4(x4, h2, m2, l2);
                     char* row = (char*)(bs + bj * LDK) + (br + q * 4) * 2;
                     if (CB_DBG(512)) continue;   // (diagnostic: split, but no pixel-operand LDS writes)
-                    *(uint2*)(row) = make_uint2(CB_PK2(h[0], h[1]), CB_PK2(h[2], h[3]));
-                    *(uint2*)(row + 64) = make_uint2(CB_PK2(m[0], m[1]), CB_PK2(m[2], m[3]));
-                    *(uint2*)(row + 128) = make_uint2(CB_PK2(l[0], l[1]), CB_PK2(l[2], l[3]));
+                    *(uint2*)(row) = h2;
+                    *(uint2*)(row + 64) = m2;
+                    *(uint2*)(row + 128) = l2;
                 }
             } else if (MODE == CB_MODE_GATHER && B_PER_T % 4 == 0) {   // the thread's taps are k-consecutive
 #pragma unroll
@@ -640,6 +682,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
                 const bf16x8 bm = *(const bf16x8*)(bp + 64), am = *(const bf16x8*)(ap + 64);
                 const bf16x8 al1 = *(const bf16x8*)(ap1 + 128), ah1 = *(const bf16x8*)ap1, am1 = *(const bf16x8*)(ap1 + 64);
                 __builtin_amdgcn_sched_barrier(0);
+                if (CB_DBG(8192)) __builtin_amdgcn_s_setprio(2);   // (diagnostic: MFMA chains win issue)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
@@ -652,6 +695,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, bh, acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bm, acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc1, 0, 0, 0);
+                if (CB_DBG(8192)) __builtin_amdgcn_s_setprio(0);
 #if !CB_WIDE_IL
                 __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -705,6 +749,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
 #else
 #define CB_STAGE_NEXT
 #endif
+            if (MS == 2 && MF && CB_DBG(4096)) __builtin_amdgcn_s_setprio(1);   // (diagnostic: younger half wins issue)
+            if (MS == 2 && !MF && CB_DBG(16384)) __builtin_amdgcn_s_setprio(1);  // (diagnostic: older half wins)
             if (MS == 2) {
                 // the 16-wave form keeps ONE staging set (128 registers per wave: two accumulators and nine
                 // fragment registers come first): the loads of stage s+2 are issued during stage s+1... i.e.
@@ -731,19 +777,19 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
 #else
 #define CB_STAGE2(BUF, KNEXT)                                     \
                 CB_STAGE_STAMP(0);                                    \
-                if (MF) {                                             \
-                    if (!CB_DBG(8)) compute(BUF);                     \
+                if (MF) {   /* (diagnostic bits 1024 / 2048: these waves ONLY multiply / only stage) */ \
+                    if (!CB_DBG(8 | 2048)) compute(BUF);              \
                     CB_STAGE_STAMP(1);                                \
-                    if (!CB_DBG(4)) store_stage(dob, (BUF) ^ 1, a0, b0);   \
+                    if (!CB_DBG(4 | 1024)) store_stage(dob, (BUF) ^ 1, a0, b0);   \
                     CB_STAGE_STAMP(2);                                \
-                    if (!CB_DBG(16)) load_stage(FASTC, dob, min(KNEXT, kLast), a0, b0);     \
+                    if (!CB_DBG(16 | 1024)) load_stage(FASTC, dob, min(KNEXT, kLast), a0, b0);     \
                     CB_STAGE_STAMP(3);                                \
-                } else {                                              \
-                    if (!CB_DBG(4)) store_stage(dob, (BUF) ^ 1, a0, b0);   \
+                } else {    /* (1024: these waves only stage; 2048: only multiply) */ \
+                    if (!CB_DBG(4 | 2048)) store_stage(dob, (BUF) ^ 1, a0, b0);   \
                     CB_STAGE_STAMP(1);                                \
-                    if (!CB_DBG(16)) load_stage(FASTC, dob, min(KNEXT, kLast), a0, b0);     \
+                    if (!CB_DBG(16 | 2048)) load_stage(FASTC, dob, min(KNEXT, kLast), a0, b0);     \
                     CB_STAGE_STAMP(2);                                \
-                    if (!CB_DBG(8)) compute(BUF);                     \
+                    if (!CB_DBG(8 | 1024)) compute(BUF);              \
                     CB_STAGE_STAMP(3);                                \
                 }                                                     \
                 CB_STAGE_NEXT                                         \

@@ -202,7 +202,10 @@ struct ConvParams {
     void* reluOut;                    // EPI_SCATTER_ACC: optional second plane set receiving relu(out)
     int dbg;                          // diagnostic ablations (CBINFER_CONV_DBG): 1 no gather loads, 2 no weight loads
     int xcdMap;                       // XCD-aware item order (CBINFER_XCD_MAP=0 switches it off)
+    int seam;                         // split-K slices are summed by a second launch (cb_splitk_reduce_kernel)
 };
+// the split-K geometry of a launch, left behind the tickets for cb_splitk_reduce_kernel: {SK, tiles, N}
+#define CB_SEAM_INFO 1020
 
 #define CB_SELFC_MAXW 4096
 
@@ -421,6 +424,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
             SK = max(1, min(cap, cus / T));
     }
     const int items = T * SK;
+    if (p.seam && blockIdx.x == 0 && threadIdx.x == 0) {
+        p.tickets[CB_SEAM_INFO] = SK;
+        p.tickets[CB_SEAM_INFO + 1] = T;
+        p.tickets[CB_SEAM_INFO + 2] = N;
+    }
     if (!SELFC && (int)blockIdx.x >= ((items + 7) & ~7)) return;
 
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_STAGE + B_STAGE)];
@@ -523,11 +531,19 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
             }
         }
         // wave-uniform: every tap of every pixel of this wave lies inside the image -> no bounds test
+        // ... and no padded k in this slice: then the pixel's byte offset (minus the most negative tap's) is
+        // the load's vector offset for the whole item and the tap goes in as the SCALAR offset -- no per-tap
+        // address arithmetic at all.  (The scalar offset is not range-checked by the hardware, hence the
+        // conditions; it is unsigned, hence the bias.)
         bool fast = false;
+        int tapBias = 0, pfast = 0;
         if (MODE == CB_MODE_GATHER) {
             const int phh = (p.kH - 1) / 2, pww = (p.kW - 1) / 2;
             fast = __all(py >= phh && py + (p.kH - 1 - phh) < p.H && px >= pww &&
-                         px + (p.kW - 1 - pww) < p.W);
+                         px + (p.kW - 1 - pww) < p.W) &&
+                   kEnd <= (p.Ckk / BK) * BK;
+            tapBias = (phh * p.W + pww) * 4;
+            pfast = pbase4 - tapBias;
         }
         // taps of the NEXT stage to load, B_PER_T consecutive table entries per array: ONE scalar load
         // each (s_load_dwordx4), kept in scalar registers across the stage
@@ -596,9 +612,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
                 for (int i = 0; i < B_PER_T; ++i) breg[i] = 1.0f;
             } else if (MODE == CB_MODE_GATHER && FAST) {
 #pragma unroll
-                for (int i = 0; i < B_PER_T; ++i)   // (a padded k-row has offset 2^30 -> reads 0)
+                for (int i = 0; i < B_PER_T; ++i)
                     breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                            brsrc, pbase4 + pkOff[i], 0, 0));
+                                                            brsrc, pfast, pkOff[i] + tapBias, 0));
             } else
 #pragma unroll
             for (int i = 0; i < B_PER_T; ++i) {
@@ -939,6 +955,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
                 }
             }
 #undef CB_PUBLISH
+            if (p.seam) {   // the slices meet in the next launch: nothing to wait for here
+                CB_STAMP_AT(5);
+#ifdef CB_STAMP
+                cb_stamp_first = false;
+#endif
+                continue;
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (t == 0) {
@@ -1031,6 +1054,58 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
             if (d == (int)gridDim.x - 1) {
                 __hip_atomic_store(ctl + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(ctl, par ^ 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// Second launch of a split-K contraction ("cut the seam"): every thread sums one float4 of a tile over its SK
+// slabs, in slice order, and stores it -- all CUs at once instead of each tile's last workgroup pulling SK x 64 KB
+// through one CU behind a ticket (10-11 us at the end of the 64->256 launch; here ~3 us plus the launch
+// boundary).  The first launch leaves {SK, tiles, N} behind the tickets; SK <= 1 (every tile was stored by its
+// own workgroup): nothing to do.  Slab layout and summation order as in cb_mfma_f32_kernel: same bits.
+template <int EPI, bool SELFC>
+__global__ __launch_bounds__(256) void cb_splitk_reduce_kernel(ConvParams p, int BM, int BN) {
+    const int SK = p.tickets[CB_SEAM_INFO];
+    if (SK <= 1) return;
+    const int T = p.tickets[CB_SEAM_INFO + 1], N = p.tickets[CB_SEAM_INFO + 2];
+    const int MT = p.KP / BM, TILE4 = BM * BN / 4, HW = p.H * p.W;
+    const float4* __restrict__ slabs = (const float4*)p.slabs;
+    float* __restrict__ out = (float*)p.out;
+    const float* __restrict__ bias = (const float*)p.bias;
+    const long total = (long)T * TILE4;
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+        const int tile = (int)(g / TILE4), c = (int)(g - (long)tile * TILE4);
+        const int nl = c % BN, mq = c / BN;
+        const int n = (tile / MT) * BN + nl;
+        if (n >= N) continue;
+        const int pix = SELFC ? p.listOut[n] : p.list[n];
+        if ((unsigned)pix >= (unsigned)HW) continue;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const float4* sl = slabs + (long)tile * SK * TILE4 + c;
+#pragma unroll 4
+        for (int j = 0; j < SK; ++j) {
+            const float4 v = sl[(long)j * TILE4];
+            s0 += v.x;
+            s1 += v.y;
+            s2 += v.z;
+            s3 += v.w;
+        }
+        const int m = (tile % MT) * BM + 4 * mq;
+        const float sv[4] = {s0, s1, s2, s3};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (m + e >= p.K) continue;
+            float v = sv[e];
+            float* o = out + (long)(m + e) * HW + pix;
+            if (EPI == CB_EPI_SCATTER) {
+                if (bias) v += bias[m + e];
+                if (p.relu) v = cb_relu(v);
+                *o = v;
+            } else {
+                const float nv = *o + v;
+                *o = nv;
+                if (p.reluOut) ((float*)p.reluOut)[(long)(m + e) * HW + pix] = cb_relu(nv);
             }
         }
     }
@@ -1497,6 +1572,14 @@ int launch_f32(const ConvParams& p, hipStream_t s) {
     if (!p.slabs && tilesCap < g && !SELFC) g = tilesCap;
     dim3 grid((unsigned)g), block(64 * WM * WN * KS);
     hipLaunchKernelGGL((cb_mfma_f32_kernel<WM, WN, KS, MODE, EPI, SELFC, X3, MS, BHALF>), grid, block, 0, s, p);
+    if constexpr (EPI >= CB_EPI_SCATTER) {
+        if (p.seam) {
+            const int st = cb_launch_status();
+            if (st != CB_OK) return st;
+            hipLaunchKernelGGL((cb_splitk_reduce_kernel<EPI, SELFC>), dim3(4 * cb_num_cus()), dim3(256), 0, s, p,
+                               32 * WM * MS, 32 * WN);
+        }
+    }
     return cb_launch_status();
 }
 
@@ -1517,18 +1600,15 @@ int cb_ckkpad(int Ckk, int dtype) {
     return (Ckk + q - 1) / q * q;
 }
 
-// bf16x3 arithmetic, 16-wave forms: 1 = 128 x 128 (output channels in multiples of 128), 0 = the 64 x 64
-// form; 2 = 256 channels x 64 pixels (multiples of 256; builds with -DCB_X3_BHALF only).  CBINFER_X3_WIDE caps
-// the choice.
+// bf16x3 arithmetic, 16-wave forms: 2 = 256 channels x 64 pixels (output channels in multiples of 256: a
+// staged pixel row feeds all of them, and per-value work on the vector ALU -- which does NOT hide under other
+// waves' MFMAs here -- is what the stage pays for), 1 = 128 x 128 (multiples of 128), 0 = the 64 x 64 form.
+// CBINFER_X3_WIDE caps the choice.
 int cb_x3_wide(int KP) {
     static int cap = -1;
     if (cap < 0) {
         const char* e = getenv("CBINFER_X3_WIDE");
-#ifdef CB_X3_BHALF
         cap = e ? atoi(e) : 2;
-#else
-        cap = e ? min(atoi(e), 1) : 1;
-#endif
     }
     if (cap >= 2 && KP % 256 == 0) return 2;
     if (cap >= 1 && KP % 128 == 0) return 1;
@@ -1552,6 +1632,15 @@ template <int MODE, int EPI>
 int launch_mfma(const ConvParams& p0, int dtype, hipStream_t s) {
     ConvParams p = p0;
     p.dbg = conv_dbg();
+    {   // split-K slices summed by a second launch (scatter epilogues with a workspace); CBINFER_SPLITK_SEAM=0:
+        // by each tile's last workgroup inside the one launch
+        static int seam = -1;
+        if (seam < 0) {
+            const char* e = getenv("CBINFER_SPLITK_SEAM");
+            seam = e ? atoi(e) : 1;
+        }
+        p.seam = seam && p.slabs && EPI >= CB_EPI_SCATTER && (dtype == CB_F32 || dtype == CB_F32S);
+    }
     {
         static int xm = -1;
         if (xm < 0) {
@@ -1565,16 +1654,12 @@ int launch_mfma(const ConvParams& p0, int dtype, hipStream_t s) {
         if constexpr (MODE == CB_MODE_GATHER && EPI >= CB_EPI_SCATTER) {
             if (p.frameMasks) {
                 if (narrow) return launch_f32<1, 4, 2, CB_MODE_GATHER, EPI, true, true>(p, s);
-#ifdef CB_X3_BHALF   // (measured: 63 vs 60 us in the frame -- twice the weight bytes through the LDS store path)
                 if (cb_x3_wide(p.KP) == 2) return launch_f32<4, 2, 2, CB_MODE_GATHER, EPI, true, true, 2, true>(p, s);
-#endif
                 if (cb_x3_wide(p.KP) >= 1) return launch_f32<2, 4, 2, CB_MODE_GATHER, EPI, true, true, 2>(p, s);
                 return launch_f32<2, 2, 2, CB_MODE_GATHER, EPI, true, true>(p, s);
             }
             if (narrow) return launch_f32<1, 4, 2, CB_MODE_GATHER, EPI, false, true>(p, s);
-#ifdef CB_X3_BHALF
             if (cb_x3_wide(p.KP) == 2) return launch_f32<4, 2, 2, CB_MODE_GATHER, EPI, false, true, 2, true>(p, s);
-#endif
             if (cb_x3_wide(p.KP) >= 1) return launch_f32<2, 4, 2, CB_MODE_GATHER, EPI, false, true, 2>(p, s);
             return launch_f32<2, 2, 2, CB_MODE_GATHER, EPI, false, true>(p, s);
         } else {

@@ -1571,8 +1571,12 @@ int launch_f32(const ConvParams& p, hipStream_t s) {
     long g = (WM * WN * KS > 8 ? 1 : CB_CONV_GRID_PER_CU) * (long)cb_num_cus();
     if (!p.slabs && tilesCap < g && !SELFC) g = tilesCap;
     dim3 grid((unsigned)g), block(64 * WM * WN * KS);
-    hipLaunchKernelGGL((cb_mfma_f32_kernel<WM, WN, KS, MODE, EPI, SELFC, X3, MS, BHALF>), grid, block, 0, s, p);
-    if constexpr (EPI >= CB_EPI_SCATTER) {
+    // (the second launch pays where a tile's slices are 64 KB each -- the 16-wave forms; with 16 KB slabs the
+    //  last workgroup's reduce is cheaper than a launch boundary: OpenPose's 36 small layers lost 5 % to it)
+    ConvParams q = p;
+    if (MS != 2) q.seam = 0;
+    hipLaunchKernelGGL((cb_mfma_f32_kernel<WM, WN, KS, MODE, EPI, SELFC, X3, MS, BHALF>), grid, block, 0, s, q);
+    if constexpr (EPI >= CB_EPI_SCATTER && MS == 2) {
         if (p.seam) {
             const int st = cb_launch_status();
             if (st != CB_OK) return st;

@@ -1078,19 +1078,23 @@ __global__ __launch_bounds__(256) void cb_splitk_reduce_kernel(ConvParams p, int
         const int tile = (int)(g / TILE4), c = (int)(g - (long)tile * TILE4);
         const int nl = c % BN, mq = c / BN;
         const int n = (tile / MT) * BN + nl;
-        if (n >= N) continue;
-        const int pix = SELFC ? p.listOut[n] : p.list[n];
-        if ((unsigned)pix >= (unsigned)HW) continue;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        // the slab loads do not wait for the pixel index (a slot past the list holds zeros or stale sums: never stored)
         const float4* sl = slabs + (long)tile * SK * TILE4 + c;
-#pragma unroll 4
-        for (int j = 0; j < SK; ++j) {
-            const float4 v = sl[(long)j * TILE4];
-            s0 += v.x;
-            s1 += v.y;
-            s2 += v.z;
-            s3 += v.w;
-        }
+        float4 v[CB_SKMAX];
+#pragma unroll
+        for (int j = 0; j < CB_SKMAX; ++j)
+            if (j < SK) v[j] = sl[(long)j * TILE4];
+        const int pix = n < N ? (SELFC ? p.listOut[n] : p.list[n]) : -1;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int j = 0; j < CB_SKMAX; ++j)
+            if (j < SK) {
+                s0 += v[j].x;
+                s1 += v[j].y;
+                s2 += v[j].z;
+                s3 += v[j].w;
+            }
+        if ((unsigned)pix >= (unsigned)HW) continue;
         const int m = (tile % MT) * BM + 4 * mq;
         const float sv[4] = {s0, s1, s2, s3};
 #pragma unroll

@@ -738,6 +738,11 @@ def main():
                                       "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                                       "traffic_source": traffic_src, "avg_duration_us": ms * 1e3,
                                       "duration_timing": timing, "units_per_launch": r["N"]}
+                if "cb_mfma" in r.get("conv_kernel", ""):
+                    result["roofline"]["launches"] = (
+                        "the contraction is two launches when its k-range is split over workgroups (16-wave forms): "
+                        "cb_mfma_f32_kernel and cb_splitk_reduce_kernel, which sums the slices; avg_duration_us and "
+                        "traffic cover both")
             else:
                 ach = r[kname + "_bytes"] / (ms * 1e-3) / 1e9
                 result["roofline"] = {"kernel": kname + ", " + r["layer"], "bound": "hbm", "achieved": ach,

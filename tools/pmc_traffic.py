@@ -31,10 +31,15 @@ def load(sub, counter):
 fetch, write = load("pmc_fetch", "FETCH_SIZE"), load("pmc_write", "WRITE_SIZE")
 LAYER = [("cb_rowconv_f32_kernel", "cb_mfma_f32_kernel conv 3->16 k7 @320x480"),
          ("cb_blockconv_kernel", "cb_mfma_f32_kernel conv 16->64 k7 @160x240"),
-         ("cb_mfma_f32_kernel<2, 4, 2, 1, 2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),   # in-frame form
-         ("cb_mfma_f32_kernel<2, 2, 2, 1, 2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),   # (64 x 64 tiles)
+         # in-frame forms of the 64->256 contraction (the first that occurs), plus its split-K reduce launch
+         ("cb_mfma_f32_kernel<4, 2, 2, 1, 2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),
+         ("cb_mfma_f32_kernel<2, 4, 2, 1, 2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),
+         ("cb_mfma_f32_kernel<2, 2, 2, 1, 2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),
          ("cb_tail1x1_kernel", "cb_tail1x1_kernel 256->64->8 @80x120")]
+ADDS = [("cb_splitk_reduce_kernel<float, 2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),
+        ("cb_splitk_reduce_kernel<2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120")]
 table = {}
+extra = {}
 for name in sorted(set(fetch) | set(write)):
     if "cb_" not in name:
         continue
@@ -50,6 +55,17 @@ for name in sorted(set(fetch) | set(write)):
             table[label] = {"kernel": short, "fetch_kb": fm, "write_kb": wm,
                             "bytes_per_launch": int((fm + wm) * 1024),
                             "bytes_per_launch_fetch_x2": int((2 * fm + wm) * 1024)}
+    for pat, label in ADDS:
+        if pat in name:
+            extra.setdefault(label, (short, fm, wm))
+for label, (short, fm, wm) in extra.items():      # second launch of the same contraction: add its bytes
+    if label in table:
+        t = table[label]
+        t["kernel"] += " + " + short
+        t["fetch_kb"] += fm
+        t["write_kb"] += wm
+        t["bytes_per_launch"] = int((t["fetch_kb"] + t["write_kb"]) * 1024)
+        t["bytes_per_launch_fetch_x2"] = int((2 * t["fetch_kb"] + t["write_kb"]) * 1024)
 if out_json:
     import bench
     table["_note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, counters + kernel trace only; "

@@ -62,6 +62,16 @@ def main():
         print("N=%d: %d workgroups started, %d active; start spread %.2f us, span %.2f us" % (
             int(cm.sum()), ran.sum(), act.sum(), (st[ran, 0].max() - t0) / 100.0, (st[act, 15].max() - t0) / 100.0))
         a = st[act]
+        # when do the active workgroups start and end (deciles, us after the first workgroup's entry)
+        q = [0, 10, 25, 50, 75, 90, 100]
+        print("   active workgroups: start deciles %s | end deciles %s" % (
+            " ".join("%.1f" % ((np.percentile(a[:, 0], x) - t0) / 100.0) for x in q),
+            " ".join("%.1f" % ((np.percentile(a[:, 15], x) - t0) / 100.0) for x in q)))
+        idle = st[ran & ~act]
+        if len(idle):
+            print("   inactive workgroups: %d, lifetime median %.2f us, last start %.1f us" % (
+                len(idle), float(np.median(idle[:, 15] - idle[:, 0])) / 100.0 if (idle[:, 15] > 0).any() else -1,
+                (idle[:, 0].max() - t0) / 100.0))
         med = lambda v: float(np.median(v)) / 100.0
         print("   multiplier: prologue %.2f | wait first chunk %.2f | per chunk %s | loop tail %.2f | store %.2f | lifetime %.2f (max %.2f)" % (
             med(a[:, 1] - a[:, 0]), med(a[:, 2] - a[:, 1]),

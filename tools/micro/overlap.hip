@@ -1,4 +1,5 @@
 // Micro-benchmark: do a workgroup's MFMA waves and its VALU/LDS/VMEM waves overlap on a CU?
+// Build and run on the GPU box:  hipcc -O3 --offload-arch=gfx950 -o tools/micro/overlap tools/micro/overlap.hip
 // 1024-thread workgroups, one per CU, one barrier per iteration.  mode bit 0: waves 8-15 run an MFMA chain of
 // 12 v_mfma_f32_32x32x16_bf16 after 9 ds_read_b128; bit 1: waves 0-7 run ~60 VALU + 4 LDS stores + 6 loads.
 #include <hip/hip_runtime.h>

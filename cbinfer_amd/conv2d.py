@@ -578,6 +578,8 @@ class CBConv2d(nn.Module):
             if not have and not self._inputIsLiveState:
                 self._make_plan(False, input, C.cbinfer_cbconv2d_forward, args, 0)
         if mapOut is not None:
+            # (a view of the module's work buffer, rewritten by the next frame -- clone it to keep it; the
+            #  reference allocates a fresh map per frame)
             self.changeMap = mapOut
         if not self.feedbackLoop and not self.copyInput:
             # alias, conv2d.py:237-238 (a producer's in-place-updated state is copied first)

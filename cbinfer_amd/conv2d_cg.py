@@ -42,6 +42,9 @@ class ChangeIndexes(object):
         return 1
 
     def tensor(self):
+        """The exact list as the reference passes it (one host sync for the length).  It is a VIEW of the
+        module's index buffer, which the next frame overwrites: `.clone()` (or `self.clone()`) what must
+        outlive the frame -- the reference returns a fresh tensor every frame."""
         n = int(self.count.item())
         return self.buffer[:n]
 

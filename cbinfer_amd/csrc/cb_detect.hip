@@ -77,6 +77,10 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
     };
 
     bool chg = false;
+    // (a wave that owns exactly four channels -- C == 4 G, the 16- and 64-channel layers -- keeps their input
+    //  values for the state refresh below instead of loading them again)
+    const bool keep = C <= 4 * G;
+    T k0 = T(0), k1 = T(0), k2 = T(0), k3 = T(0);
     if (valid) {
         int c = g;
 #pragma unroll 1
@@ -87,8 +91,18 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
             const T s3 = state[(long)(c + 3 * G) * HW + p], x3 = ldin(c + 3 * G);
             chg |= cb_changed(s0, x0, th) | cb_changed(s1, x1, th) | cb_changed(s2, x2, th) |
                    cb_changed(s3, x3, th);
+            k0 = x0, k1 = x1, k2 = x2, k3 = x3;
         }
-        for (; c < C; c += G) chg |= cb_changed(state[(long)c * HW + p], ldin(c), th);
+        if (keep && c == g) {   // fewer than four channels for this wave: the same, value by value
+            if (c < C) k0 = ldin(c);
+            if (c + G < C) k1 = ldin(c + G);
+            if (c + 2 * G < C) k2 = ldin(c + 2 * G);
+            if (c < C) chg |= cb_changed(state[(long)c * HW + p], k0, th);
+            if (c + G < C) chg |= cb_changed(state[(long)(c + G) * HW + p], k1, th);
+            if (c + 2 * G < C) chg |= cb_changed(state[(long)(c + 2 * G) * HW + p], k2, th);
+        } else {
+            for (; c < C; c += G) chg |= cb_changed(state[(long)c * HW + p], ldin(c), th);
+        }
     }
 
     __shared__ unsigned long long sm[16];
@@ -101,7 +115,14 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
 
     // feedback: refresh the state at the (pre-dilation) changed pixels only (.cu:74-80)
     if (update && ((m >> lane) & 1ull)) {
-        for (int c = g; c < C; c += G) state[(long)c * HW + p] = ldin(c);
+        if (keep) {
+            if (g < C) state[(long)g * HW + p] = k0;
+            if (g + G < C) state[(long)(g + G) * HW + p] = k1;
+            if (g + 2 * G < C) state[(long)(g + 2 * G) * HW + p] = k2;
+            if (g + 3 * G < C) state[(long)(g + 3 * G) * HW + p] = k3;
+        } else {
+            for (int c = g; c < C; c += G) state[(long)c * HW + p] = ldin(c);
+        }
     }
 
     // horizontal dilation of the 64-pixel word, with the parts spilling into the neighbour words

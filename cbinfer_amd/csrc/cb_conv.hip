@@ -8,6 +8,7 @@
 // output channel in the accumulator registers, so the scatter epilogue writes 32 (mostly consecutive)
 // pixels of one output-channel plane per store instruction.
 //   fp32: v_mfma_f32_32x32x2_f32 (exact f32 fma chain)            -- operands A[m][k], B[n][k] in LDS
+//         or, CB_F32S, six v_mfma_f32_32x32x16_bf16 per 16 k on three bf16 terms per operand (X3)
 //   fp16: v_mfma_f32_32x32x16_f16, f32 accumulation             -- operands A[m][k], B[n][k] in LDS
 #include <stdlib.h>
 
@@ -247,9 +248,10 @@ __device__ __forceinline__ void cb_clear_mask(const ConvParams& p) {
 //   schedule  a FIXED grid (2 workgroups per CU) walks the work items (tile, k-slice) computed from the
 //             device-side list length N: the host never needs N, idle workgroups exit at once, and a
 //             short list is split along k (SK slices per tile) so that it still fills the chip.  The SK
-//             partial tiles of a tile go to a workspace slab; the workgroup whose ticket is last sums
-//             them in slice order (deterministic) and runs the epilogue -- agent-scope release by every
-//             writer, one acquire by the reducer, nobody ever waits.
+//             partial tiles of a tile go to workspace slabs (write-through 16-byte stores).  They are summed
+//             in slice order (deterministic) either by the workgroup whose ticket is last -- its sc1 loads
+//             behind one L1 invalidate; nobody ever waits -- or, for the 16-wave forms, by a second launch
+//             on all CUs (cb_splitk_reduce_kernel).
 //   pipeline  BK = 32 per stage, two LDS buffers, FOUR register staging sets: the loads of stage s+4 are
 //             issued during stage s, and stage s+1 is written to the idle LDS buffer while the MFMA
 //             chain of stage s runs; one barrier per stage.  Every stage issues the same number of loads

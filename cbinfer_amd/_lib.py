@@ -57,6 +57,11 @@ _SIGNATURES = {
                                                _vp, _i, _vp]),
     "cbinfer_cbconv2d_forward_fg": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
                                          _i, _f, _i, _vp, _i, _vp]),
+    "cbinfer_change_detection_fg_bits": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "cbinfer_conv_accumulate_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "cbinfer_conv_accumulate_blocks": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "cbinfer_cbconv2d_forward_fg_masked": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
+                                                _i, _i, _i, _f, _i, _vp]),
     "cbinfer_tail1x1_max_hidden": (_i, []),
     "cbinfer_tail1x1_prepared_bytes": (_l, [_i, _i]),
     "cbinfer_tail1x1_prep": (_i, [_vp, _vp, _i, _i, _vp]),
@@ -91,7 +96,7 @@ def _load():
         fn = getattr(lib, name)     # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.cbinfer_abi_version() != 2:
+    if lib.cbinfer_abi_version() != 3:
         raise ImportError("cbinfer_amd: libcbinfer_hip.so ABI version mismatch")
     return lib
 

@@ -366,6 +366,9 @@ class CBConv2d(nn.Module):
         fused = (x.is_cuda and not self.atomicFG and x.dtype == torch.float32 and
                  C.cbinfer_mask_words(H, W) <= C.cbinfer_frame_mask_max_words() and
                  os.environ.get('CBINFER_NO_SELFCOMPACT', '0') != '1')
+        # layers of few output channels: the frame on the mask-driven contractions (row-segment / patch-staged
+        # kernel with an accumulating epilogue), as in coarse-grained mode
+        path = self._rows_path(x.dtype, H, W) if fused else None
         if fused and self.fgInPlace:
             work = self._fg_workspace(x)
             relu = None
@@ -375,6 +378,19 @@ class CBConv2d(nn.Module):
                 relu = work['relu']
             if not self.prevInput.is_contiguous():
                 self.prevInput = self.prevInput.contiguous()
+            if path:
+                rows = self._rows_workspace(work, H, W, x.device)
+                args = (int(path == 'blocks'), ptr(x), ptr(self.prevInput), ptr(work['delta']),
+                        ptr(self.prevOutput), ptr(relu), ptr(rows['bits']), ptr(rows['arrive']), ptr(rows['copy']),
+                        ptr(self._masked_call(path)[1]), Cin, H, W, K, kH, kW, float(self.threshold), 1,
+                        stream_ptr(x))
+                check(C.cbinfer_cbconv2d_forward_fg_masked(*args))
+                result = relu if self.withReLU else self.prevOutput
+                self._lastIndexes = MaskChangeIndexes(rows['copy'], (H, W), work['idx'], work['count'])
+                if self.propChangeIndexes:
+                    result = ('changeIndexes', result, self._lastIndexes)
+                self._make_plan(False, x, C.cbinfer_cbconv2d_forward_fg_masked, args, 1, result=result, rows=True)
+                return result
             arith = self._arith(x)
             args = (ptr(x), ptr(self.prevInput), ptr(work['delta']), ptr(self.prevOutput), ptr(relu),
                     ptr(work['bits']), ptr(work['idx']), ptr(work['count']),
@@ -387,8 +403,18 @@ class CBConv2d(nn.Module):
             self._make_plan(False, x, C.cbinfer_cbconv2d_forward_fg, args, 0, result=result)
             return result
         po = self.prevOutput.clone()                                 # conv2d.py:169
-        if fused:
+        indexes = None
+        if fused and path:
             work = self._fg_workspace(x)
+            rows = self._rows_workspace(work, H, W, x.device)
+            check(C.cbinfer_cbconv2d_forward_fg_masked(
+                int(path == 'blocks'), ptr(x), ptr(self.prevInput.contiguous()), ptr(work['delta']), ptr(po), None,
+                ptr(rows['bits']), ptr(rows['arrive']), ptr(rows['copy']), ptr(self._masked_call(path)[1]),
+                Cin, H, W, K, kH, kW, float(self.threshold), 0, stream_ptr(x)))
+            indexes = MaskChangeIndexes(rows['copy'], (H, W), work['idx'], work['count'])
+        elif fused:
+            work = self._fg_workspace(x)
+            indexes = ChangeIndexes(work['idx'], work['count'], (H, W))
             arith = self._arith(x)
             check(C.cbinfer_cbconv2d_forward_fg(
                 ptr(x), ptr(self.prevInput.contiguous()), ptr(work['delta']), ptr(po), None,
@@ -404,7 +430,7 @@ class CBConv2d(nn.Module):
         self.prevInput = x                                           # conv2d.py:175
         outp = F.relu(po) if self.withReLU else po
         if self.propChangeIndexes and fused:
-            return 'changeIndexes', outp, ChangeIndexes(work['idx'], work['count'], (H, W))
+            return 'changeIndexes', outp, indexes
         return outp
 
     # ---------------------------------------------------------------- coarse-grained
@@ -682,7 +708,14 @@ class CBConv2d(nn.Module):
             check(status)
         self._inputIsLiveState = False
         if plan['result'] is not None:          # fine-grained in-place frame: prevOutput or its relu'd copy
-            return plan['result']
+            res = plan['result']
+            if plan['rows']:                    # mask-driven: this frame's list is made from its own mask copy
+                work = plan['work']
+                self._lastIndexes = MaskChangeIndexes(work['rows']['copy'], work['key'][:2], work['idx'],
+                                                      work['count'])
+                if isinstance(res, tuple):
+                    res = (res[0], res[1], self._lastIndexes)
+            return res
         if plan['rows']:                        # mask-driven frame: the list is made when somebody asks
             work = plan['work']
             self._lastIndexes = MaskChangeIndexes(work['rows']['copy'], work['key'][:2], work['idx'],

@@ -46,6 +46,8 @@ struct BlkParams {
     int MT;                 // 16-row output-channel tiles
     int pcMagic;            // ceil(65536 / PC): q / PC == (q * pcMagic) >> 16 for q < PR*PC
     int relu, wpr;
+    int accumulate;         // fine-grained frame: out += W * delta (state = delta tensor), no bias
+    float* reluOut;         // ... and optionally relu(out) into a second plane set
 };
 
 __device__ __forceinline__ void cb_split3b(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
@@ -255,7 +257,8 @@ __global__ __launch_bounds__(64 * (2 * MG + 4)) void cb_blockconv_kernel(BlkPara
         for (int s = 0; s < NTMAX; ++s) acc[s] = floatx4{0.f, 0.f, 0.f, 0.f};
         float bv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[r] = p.bias[min(min(mt, p.MT - 1) * 16 + 4 * kg + r, p.K - 1)];
+        for (int r = 0; r < 4; ++r)
+            bv[r] = p.bias ? p.bias[min(min(mt, p.MT - 1) * 16 + 4 * kg + r, p.K - 1)] : 0.f;
 
         CB_BSTAMP(0, 1);
         const uint4* Aw = p.wb + (long)min(mt, p.MT - 1) * p.CH * p.SPC * 192 + lane;   // step: 3 planes x 64 lanes
@@ -387,8 +390,14 @@ __global__ __launch_bounds__(64 * (2 * MG + 4)) void cb_blockconv_kernel(BlkPara
                         const int m = mt * 16 + 4 * kg + r;
                         if (m < p.K) {
                             float v = acc[s][r] + bv[r];
-                            if (p.relu) v = v <= 0.f ? 0.f : v;
-                            p.out[(long)m * HW + tpix[s]] = v;
+                            if (p.accumulate) {
+                                v += p.out[(long)m * HW + tpix[s]];
+                                p.out[(long)m * HW + tpix[s]] = v;
+                                if (p.reluOut) p.reluOut[(long)m * HW + tpix[s]] = v <= 0.f ? 0.f : v;
+                            } else {
+                                if (p.relu) v = v <= 0.f ? 0.f : v;
+                                p.out[(long)m * HW + tpix[s]] = v;
+                            }
                         }
                     }
                 }
@@ -502,10 +511,10 @@ int cbinfer_blockconv_prep_weights(const float* weight, void* prepared, int K, i
 }
 
 // Same buffers and protocol as cbinfer_conv_changed_rows; arrive needs cbinfer_mask_words(H,W) int32.
-int cbinfer_conv_changed_blocks(const float* state, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
-                                const void* prepared, const float* bias, float* output, int C, int H, int W,
-                                int K, int kH, int kW, int relu, cbStream_t stream) {
-    CB_REQUIRE(state && bits && arrive && maskCopy && prepared && bias && output && H > 0 && W > 0);
+static int cb_blocks_launch(const float* state, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
+                            const void* prepared, const float* bias, float* output, int C, int H, int W,
+                            int K, int kH, int kW, int relu, int accumulate, float* reluOut, cbStream_t stream) {
+    CB_REQUIRE(state && bits && arrive && maskCopy && prepared && (bias || accumulate) && output && H > 0 && W > 0);
     if (!cbinfer_blockconv_supported(C, K, kH, kW)) return CB_ERR_UNSUPPORTED;
     if ((long)C * H * W * 4 >= (1l << 30) || H > 65535) return CB_ERR_UNSUPPORTED;
     const BlkGeom g = blk_geom(C, K, kH, kW);
@@ -532,6 +541,8 @@ int cbinfer_conv_changed_blocks(const float* state, uint64_t* bits, int32_t* arr
     p.MT = g.MT;
     p.pcMagic = (65536 + g.PC - 1) / g.PC;
     p.relu = relu;
+    p.accumulate = accumulate;
+    p.reluOut = reluOut;
     p.wpr = cbinfer_mask_words_per_row(W);
     dim3 grid(p.wpr, (H + g.R - 1) / g.R, g.ZM), block(64 * (2 * g.MG + 4));
     if (g.R == 2 && g.MG == 4)
@@ -543,6 +554,21 @@ int cbinfer_conv_changed_blocks(const float* state, uint64_t* bits, int32_t* arr
     else
         hipLaunchKernelGGL((cb_blockconv_kernel<1, 2>), grid, block, (size_t)g.ldsBytes, (hipStream_t)stream, p);
     return cb_launch_status();
+}
+
+int cbinfer_conv_changed_blocks(const float* state, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
+                                const void* prepared, const float* bias, float* output, int C, int H, int W,
+                                int K, int kH, int kW, int relu, cbStream_t stream) {
+    CB_REQUIRE(bias != nullptr);
+    return cb_blocks_launch(state, bits, arrive, maskCopy, prepared, bias, output, C, H, W, K, kH, kW, relu, 0,
+                            nullptr, stream);
+}
+
+int cbinfer_conv_accumulate_blocks(const float* delta, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
+                                   const void* prepared, float* output, float* reluOut, int C, int H, int W,
+                                   int K, int kH, int kW, cbStream_t stream) {
+    return cb_blocks_launch(delta, bits, arrive, maskCopy, prepared, nullptr, output, C, H, W, K, kH, kW, 0, 1,
+                            reluOut, stream);
 }
 
 }  // extern "C"

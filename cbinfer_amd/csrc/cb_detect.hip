@@ -474,6 +474,19 @@ int cbinfer_change_detection_fg_frame(const float* input, float* prevInput, floa
     return cb_launch_status();
 }
 
+int cbinfer_change_detection_fg_bits(const float* input, float* prevInput, float* delta, uint64_t* bits, int W,
+                                     int H, int C, int kHHalf, int kWHalf, float threshold, int refreshState,
+                                     cbStream_t stream) {
+    CB_REQUIRE(input && prevInput && delta && bits && W > 0 && H > 0 && C > 0 && kHHalf >= 0 && kWHalf >= 0);
+    if (kWHalf > 63 || H > 65535) return CB_ERR_UNSUPPORTED;
+    const int wpr = cbinfer_mask_words_per_row(W);
+    dim3 grid(wpr, H), block(64 * detect_groups(C));
+    hipLaunchKernelGGL(cb_detect_fg_frame_kernel, grid, block, 0, (hipStream_t)stream, input, prevInput,
+                       delta, (unsigned long long*)bits, W, H, C, kHHalf, kWHalf, threshold, refreshState, wpr,
+                       (const int*)nullptr, 0l);
+    return cb_launch_status();
+}
+
 int cbinfer_change_propagation(const int8_t* mapIn, int8_t* mapOut, int W, int H, int kHHalf,
                                int kWHalf, cbStream_t stream) {
     CB_REQUIRE(mapIn && mapOut && W > 0 && H > 0 && kHHalf >= 0 && kWHalf >= 0);

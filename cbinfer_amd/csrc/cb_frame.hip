@@ -100,6 +100,24 @@ extern "C" int cbinfer_cbconv2d_forward_fg(const float* input, float* prevInput,
                                              reluOut, C, H, W, K, kH, kW, workspace, dtype, stream);
 }
 
+// The fine-grained frame on a mask-driven contraction (row-segment kernel, blocks = 0; patch-staged kernel,
+// blocks = 1; fp32): per-value detection into the delta tensor and the SINGLE mask, then out += W * delta at
+// the mask's pixels (cbinfer_conv_accumulate_rows / _blocks).  maskCopy keeps the touched-pixel mask.
+extern "C" int cbinfer_cbconv2d_forward_fg_masked(int blocks, const float* input, float* prevInput, float* delta,
+                                                  float* prevOutput, float* reluOut, uint64_t* bits,
+                                                  int32_t* arrive, uint64_t* maskCopy, const void* weightsPrepared,
+                                                  int C, int H, int W, int K, int kH, int kW, float threshold,
+                                                  int refreshState, cbStream_t stream) {
+    CB_REQUIRE(input && prevInput && delta && prevOutput && bits && arrive && maskCopy && weightsPrepared);
+    const int st = cbinfer_change_detection_fg_bits(input, prevInput, delta, bits, W, H, C, (kH - 1) / 2,
+                                                    (kW - 1) / 2, threshold, refreshState, stream);
+    if (st != CB_OK) return st;
+    return blocks ? cbinfer_conv_accumulate_blocks(delta, bits, arrive, maskCopy, weightsPrepared, prevOutput,
+                                                   reluOut, C, H, W, K, kH, kW, stream)
+                  : cbinfer_conv_accumulate_rows(delta, bits, arrive, maskCopy, weightsPrepared, prevOutput,
+                                                 reluOut, C, H, W, K, kH, kW, stream);
+}
+
 // The frame of a layer whose contraction runs on the row-segment kernel (cbinfer_conv_changed_rows, fp32,
 // cbinfer_rowconv_supported): detection -> [state copy] -> row-segment contraction, two launches, single
 // mask.  prePool != NULL: the layer sits behind a 2x2/stride-2 max pool folded into its detection

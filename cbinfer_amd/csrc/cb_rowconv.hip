@@ -38,7 +38,9 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 struct RowParams {
     const float* state;     // [C,H,W] layer state the gather reads (conv2d.py:242)
     const float* wq;        // prepared weights (fragment order)
-    const float* bias;      // [K]
+    const float* bias;      // [K] (null in accumulate mode)
+    float* reluOut;         // accumulate mode: optional second plane set receiving relu(out)
+    int accumulate;         // fine-grained frame: out += W * delta at the mask's pixels (no bias, no ReLU on out)
     float* out;             // [K,H,W]
     unsigned long long* bits;
     int* arrive;            // per-word arrival counters (only used when gridDim.z > 1), zero between frames
@@ -188,7 +190,8 @@ __global__ __launch_bounds__(64 * CB_ROW_MAXW) void cb_rowconv_f32_kernel(RowPar
     };
     float bv[4];                   // (and the bias of this lane's four output channels)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = p.bias[min(min(mc, p.MCH - 1) * 16 + 4 * (lane >> 4) + r, p.K - 1)];
+    for (int r = 0; r < 4; ++r)
+        bv[r] = p.bias ? p.bias[min(min(mc, p.MCH - 1) * 16 + 4 * (lane >> 4) + r, p.K - 1)] : 0.f;
     loadA(qr, NB);                 // the (< CB_ROW_BS) steps beyond the last full block, taken by k-part 0
     loadA(a0, min(bBeg, bLast));
     loadA(a1, min(bBeg + 1, bLast));
@@ -338,8 +341,14 @@ __global__ __launch_bounds__(64 * CB_ROW_MAXW) void cb_rowconv_f32_kernel(RowPar
                 const int m = mc * 16 + 4 * (lane >> 4) + r;
                 if (m < p.K) {
                     float v = acc[r] + bv[r];
-                    if (p.relu) v = v <= 0.f ? 0.f : v;
-                    p.out[(long)m * HW + pix] = v;
+                    if (p.accumulate) {
+                        v += p.out[(long)m * HW + pix];
+                        p.out[(long)m * HW + pix] = v;
+                        if (p.reluOut) p.reluOut[(long)m * HW + pix] = v <= 0.f ? 0.f : v;
+                    } else {
+                        if (p.relu) v = v <= 0.f ? 0.f : v;
+                        p.out[(long)m * HW + pix] = v;
+                    }
                 }
             }
         }
@@ -430,10 +439,10 @@ int cbinfer_rowconv_prep_weights(const float* weight, void* prepared, int K, int
 
 // bits / arrive / maskCopy: cbinfer_mask_words(H,W) entries each (uint64 / int32 / uint64); bits and arrive
 // zero on first use and left zero; maskCopy receives this frame's mask.
-int cbinfer_conv_changed_rows(const float* state, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
-                              const void* prepared, const float* bias, float* output, int C, int H, int W,
-                              int K, int kH, int kW, int relu, cbStream_t stream) {
-    CB_REQUIRE(state && bits && arrive && maskCopy && prepared && bias && output && H > 0 && W > 0);
+static int cb_rows_launch(const float* state, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
+                          const void* prepared, const float* bias, float* output, int C, int H, int W,
+                          int K, int kH, int kW, int relu, int accumulate, float* reluOut, cbStream_t stream) {
+    CB_REQUIRE(state && bits && arrive && maskCopy && prepared && (bias || accumulate) && output && H > 0 && W > 0);
     if (!cbinfer_rowconv_supported(C, K, kH, kW)) return CB_ERR_UNSUPPORTED;
     if ((long)C * H * W * 4 >= (1l << 30) || H > 65535) return CB_ERR_UNSUPPORTED;
     const RowGeom g = row_geom(C, K, kH, kW);
@@ -458,6 +467,8 @@ int cbinfer_conv_changed_rows(const float* state, uint64_t* bits, int32_t* arriv
     p.G = g.G;
     p.NB = g.NB;
     p.relu = relu;
+    p.accumulate = accumulate;
+    p.reluOut = reluOut;
     p.wpr = cbinfer_mask_words_per_row(W);
     {
         static int dbg = -1;
@@ -490,6 +501,21 @@ int cbinfer_conv_changed_rows(const float* state, uint64_t* bits, int32_t* arriv
     else
         hipLaunchKernelGGL((cb_rowconv_f32_kernel<0, 0, 0>), grid, block, ldsBytes, (hipStream_t)stream, p);
     return cb_launch_status();
+}
+
+int cbinfer_conv_changed_rows(const float* state, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
+                              const void* prepared, const float* bias, float* output, int C, int H, int W,
+                              int K, int kH, int kW, int relu, cbStream_t stream) {
+    CB_REQUIRE(bias != nullptr);
+    return cb_rows_launch(state, bits, arrive, maskCopy, prepared, bias, output, C, H, W, K, kH, kW, relu, 0,
+                          nullptr, stream);
+}
+
+int cbinfer_conv_accumulate_rows(const float* delta, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
+                                 const void* prepared, float* output, float* reluOut, int C, int H, int W,
+                                 int K, int kH, int kW, cbStream_t stream) {
+    return cb_rows_launch(delta, bits, arrive, maskCopy, prepared, nullptr, output, C, H, W, K, kH, kW, 0, 1,
+                          reluOut, stream);
 }
 
 }  // extern "C"

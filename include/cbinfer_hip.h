@@ -49,7 +49,7 @@ typedef void* cbStream_t; /* hipStream_t */
 #define CB_ERR_BADARG (-1)      /* null pointer, non-positive size, unsupported dtype */
 #define CB_ERR_UNSUPPORTED (-2) /* shape outside what the kernels implement (e.g. kWHalf > 63) */
 
-#define CBINFER_ABI_VERSION 2
+#define CBINFER_ABI_VERSION 3
 
 int cbinfer_abi_version(void);
 const char* cbinfer_status_string(int status);
@@ -308,6 +308,26 @@ int cbinfer_cbconv2d_forward_fg(const float* input, float* prevInput, float* del
                                 const void* weightsPrepared, int C, int H, int W, int K, int kH, int kW,
                                 float threshold, int refreshState, void* workspace, int dtype,
                                 cbStream_t stream);
+
+/* The same frame on the mask-driven contractions (single mask + arrival counters + mask copy, as
+ * cbinfer_conv_changed_rows / _blocks; weights prepared by cbinfer_rowconv_prep_weights /
+ * cbinfer_blockconv_prep_weights): cbinfer_change_detection_fg_bits writes the delta tensor and ORs the dilated
+ * touched-pixel mask into `bits`; cbinfer_conv_accumulate_rows / _blocks add conv(weights, delta) to `output`
+ * at the mask's pixels (reluOut as above); cbinfer_cbconv2d_forward_fg_masked (blocks = 0 / 1): both. */
+int cbinfer_change_detection_fg_bits(const float* input, float* prevInput, float* delta, uint64_t* bits, int W,
+                                     int H, int C, int kHHalf, int kWHalf, float threshold, int refreshState,
+                                     cbStream_t stream);
+int cbinfer_conv_accumulate_rows(const float* delta, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
+                                 const void* prepared, float* output, float* reluOut, int C, int H, int W,
+                                 int K, int kH, int kW, cbStream_t stream);
+int cbinfer_conv_accumulate_blocks(const float* delta, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
+                                   const void* prepared, float* output, float* reluOut, int C, int H, int W,
+                                   int K, int kH, int kW, cbStream_t stream);
+int cbinfer_cbconv2d_forward_fg_masked(int blocks, const float* input, float* prevInput, float* delta,
+                                       float* prevOutput, float* reluOut, uint64_t* bits, int32_t* arrive,
+                                       uint64_t* maskCopy, const void* weightsPrepared, int C, int H, int W,
+                                       int K, int kH, int kW, float threshold, int refreshState,
+                                       cbStream_t stream);
 
 /* ---- change-based 1x1 tail: conv1x1 -> [ReLU] -> conv1x1 at the changed pixels of the producing layer,
  * one launch.  Replaces two CBConv2d fed by propagated change indexes (sceneLabeling/modelLoader.py:41-44,

@@ -770,3 +770,57 @@ def test_blockconv_vs_oracle(cb, oracle, C, K, kH, kW, H, W, frac):
                                           C, H, W, K, kH, kW, 1, None))
     torch.cuda.synchronize()
     assert torch.equal(out, before) and int(copy.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("blocks,C,K,kH,kW,H,W,frac", [
+    (0, 3, 16, 7, 7, 64, 96, 0.05), (0, 5, 12, 3, 5, 33, 70, 0.1), (1, 16, 64, 7, 7, 40, 60, 0.05),
+    (1, 33, 70, 5, 3, 21, 64, 0.05), (1, 8, 16, 3, 3, 9, 130, 0.2)])
+def test_fg_frame_on_masked_contractions(cb, oracle, blocks, C, K, kH, kW, H, W, frac):
+    """Fine-grained frame on the mask-driven contractions (cbinfer_cbconv2d_forward_fg_masked: per-value
+    detection into the delta tensor + single mask, then out += conv(W, delta) on the row-segment / patch-staged
+    kernel with the accumulating epilogue): delta and state exact against the oracle's per-value detection, the
+    output within the fp32 bar of out0 + conv(W, delta) accumulated in double, its relu'd copy consistent,
+    untouched pixels bit-identical, mask copy = the dilated touched-pixel mask, mask and counters cleared."""
+    from cbinfer_amd._lib import C as lib, check, ptr
+    assert (lib.cbinfer_blockconv_supported if blocks else lib.cbinfer_rowconv_supported)(C, K, kH, kW)
+    rng = np.random.default_rng(C * 17 + K + blocks)
+    x, st_np = rand_case(rng, C, H, W, frac, th=0.1, blocks=True)
+    w = (rng.standard_normal((K, C, kH, kW)) / np.sqrt(C * kH * kW)).astype(np.float32)
+    d = x - st_np
+    delta_o = np.where(np.abs(d) > 0.1, d, 0).astype(np.float32)
+    out0 = rng.standard_normal((1, K, H, W)).astype(np.float32)
+    want = out0.astype(np.float64) + oracle.conv2d_dense(delta_o, w, np.zeros(K, np.float32), relu=False)
+    words = lib.cbinfer_mask_words(H, W)
+    bits = torch.zeros(words, dtype=torch.int64, device="cuda")
+    arrive = torch.zeros(words, dtype=torch.int32, device="cuda")
+    copy = torch.full((words,), -1, dtype=torch.int64, device="cuda")
+    if blocks:
+        wq = torch.empty(lib.cbinfer_blockconv_prepared_bytes(C, K, kH, kW), dtype=torch.uint8, device="cuda")
+        check(lib.cbinfer_blockconv_prep_weights(ptr(dev(w)), ptr(wq), K, C, kH, kW, None))
+    else:
+        wq = torch.empty(lib.cbinfer_rowconv_prepared_bytes(C, K, kH, kW), dtype=torch.uint8, device="cuda")
+        check(lib.cbinfer_rowconv_prep_weights(ptr(dev(w)), ptr(wq), K, C, kH, kW, None))
+    dx, st = dev(x), dev(st_np)
+    delta = torch.full_like(dx, 123.0)
+    out, relu = dev(out0), torch.full((1, K, H, W), -5.0, device="cuda")
+    check(lib.cbinfer_cbconv2d_forward_fg_masked(blocks, ptr(dx), ptr(st), ptr(delta), ptr(out), ptr(relu), ptr(bits),
+                                                 ptr(arrive), ptr(copy), ptr(wq), C, H, W, K, kH, kW, 0.1, 1, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(delta.cpu().numpy(), delta_o)
+    assert np.array_equal(st.cpu().numpy(), x)                       # prev <- in wherever they differ
+    assert int(bits.abs().sum()) == 0 and int(arrive.abs().sum()) == 0
+    # touched pixels: any-channel |d| > th, dilated by the filter support
+    touched = oracle.changeDetection(x, st_np.copy(), (kH, kW), 0.1).reshape(-1).astype(bool)
+    got = out.cpu().numpy()
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(got - want).max() <= FP32_TOL * scale
+    g2 = got.reshape(K, -1)
+    assert np.array_equal(g2[:, ~touched], out0.reshape(K, -1)[:, ~touched])
+    r2 = relu.cpu().numpy().reshape(K, -1)
+    assert np.array_equal(r2[:, touched], np.maximum(g2[:, touched], 0)) and np.all(r2[:, ~touched] == -5.0)
+    # the mask copy holds exactly the touched pixels
+    idx = torch.empty(H * W, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    check(lib.cbinfer_compact_bits(ptr(copy), W, H, ptr(idx), ptr(cnt), None, None, None))
+    n = int(cnt.item())
+    assert np.array_equal(idx[:n].cpu().numpy(), np.flatnonzero(touched).astype(np.int32))

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     from cbinfer_amd import _lib
     assert declared == set(_lib.EXPORTED_SYMBOLS)
-    assert lib.cbinfer_abi_version() == 2
+    assert lib.cbinfer_abi_version() == 3
     lib.cbinfer_mask_words.restype = ctypes.c_long
     assert lib.cbinfer_mask_words_per_row(480) == 8 and lib.cbinfer_mask_words(320, 480) == 2560
     assert lib.cbinfer_weights_kpad(8) == 32 and lib.cbinfer_weights_ckkpad(147, 0) == 160

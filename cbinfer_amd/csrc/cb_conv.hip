@@ -1238,6 +1238,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
     const int HW = p.H * p.W;
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.B, 0, MODE == CB_MODE_GATHER ? p.C * HW * 2 : 0, 0x00020000);
+    // (the weights through a buffer descriptor: per-thread byte offset fixed per item, the stage as scalar offset)
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.A, 0, (int)min((long)p.KP * p.CkkP * 2, (long)0x7fffffff), 0x00020000);
     cb_half* __restrict__ out = (cb_half*)p.out;
     const cb_half* __restrict__ bias = (const cb_half*)p.bias;
 
@@ -1291,11 +1294,23 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
             }
         }
         // wave-uniform: every tap of every pixel of this wave lies inside the image -> no bounds test
+        // ... and no padded k in this slice: the tap then goes in as the load's (unsigned, unchecked) scalar
+        // offset, biased by the most negative tap, and the pixel's byte offset serves the whole item
         bool fast = false;
+        int tapBias = 0, pfast = 0;
         if (MODE == CB_MODE_GATHER) {
             const int phh = (p.kH - 1) / 2, pww = (p.kW - 1) / 2;
             fast = __all(py >= phh && py + (p.kH - 1 - phh) < p.H && px >= pww &&
-                         px + (p.kW - 1 - pww) < p.W);
+                         px + (p.kW - 1 - pww) < p.W) &&
+                   kEnd <= (p.Ckk / BK) * BK;
+            tapBias = (phh * p.W + pww) * 2;
+            pfast = pbase4 - tapBias;
+        }
+        int aoff[A_PER_T];
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) {
+            const int f = min(t + i * NT, A_V - 1);
+            aoff[i] = ((m0 + f / (BK / 8)) * p.CkkP + (f % (BK / 8)) * 8) * 2;
         }
         // taps of the NEXT stage to load, B_PER_T consecutive table entries per array: ONE scalar load
         // each (s_load_dwordx4), kept in scalar registers across the stage
@@ -1324,8 +1339,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
             for (int i = 0; i < A_PER_T; ++i) {
                 const int f = t + i * NT;
                 if (A_V % NT == 0 || f < A_V) {
-                    const int row = f / (BK / 8), c8 = f % (BK / 8);
-                    const uint4 v4 = *(const uint4*)(Ag + (long)(m0 + row) * p.CkkP + k0 + c8 * 8);
+                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i], k0 * 2, 0);
                     areg[4 * i + 0] = v4.x;
                     areg[4 * i + 1] = v4.y;
                     areg[4 * i + 2] = v4.z;
@@ -1334,9 +1349,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
             }
             if (MODE == CB_MODE_GATHER && fast) {
 #pragma unroll
-                for (int i = 0; i < B_PER_T; ++i)   // (a padded k-row has offset 2^30 -> reads 0)
+                for (int i = 0; i < B_PER_T; ++i)
                     breg[i] = __builtin_bit_cast(cb_half, __builtin_amdgcn_raw_buffer_load_b16(
-                                                              brsrc, pbase4 + pkOff[i], 0, 0));
+                                                              brsrc, pfast, pkOff[i] + tapBias, 0));
             } else
 #pragma unroll
             for (int i = 0; i < B_PER_T; ++i) {

@@ -289,6 +289,7 @@ __device__ unsigned long long cb_stage_clk[2 * 24 * 4];
 #define CB_STAGE_STAMP(pt)
 #endif
 #define CB_SKMAX 8
+#define CB_SKMAX_SEAM 32   // slices per tile when a second launch sums them
 #ifndef CB_WIDE_IL
 #define CB_WIDE_IL 0
 #endif
@@ -419,7 +420,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
     // as every slice still gets a CU of its own -- below that the slab round trip (~8 us) costs more than
     // the idle CUs, above it slices of co-resident workgroups just slow each other down.
     if (p.slabs && T > 0 && P >= 4) {
-        const int cap = min(CB_SKMAX, min(P, (int)sqrtf(3.4f * (float)P)));
+        // (summed by a second launch on all CUs the slices cost no reducer time per tile: split as far as the
+        //  work items still find a CU each -- a short list then runs few stages per workgroup)
+        const int cap = p.seam ? min(CB_SKMAX_SEAM, P) : min(CB_SKMAX, min(P, (int)sqrtf(3.4f * (float)P)));
         if (GPC == 2 && P >= 8 && T * 2 >= cus)
             SK = max(1, min(cap, (CB_SK_TARGET * cus) / T));
         else
@@ -1082,20 +1085,22 @@ __global__ __launch_bounds__(256) void cb_splitk_reduce_kernel(ConvParams p, int
         const int n = (tile / MT) * BN + nl;
         // the slab loads do not wait for the pixel index (a slot past the list holds zeros or stale sums: never stored)
         const float4* sl = slabs + (long)tile * SK * TILE4 + c;
-        float4 v[CB_SKMAX];
-#pragma unroll
-        for (int j = 0; j < CB_SKMAX; ++j)
-            if (j < SK) v[j] = sl[(long)j * TILE4];
         const int pix = n < N ? (SELFC ? p.listOut[n] : p.list[n]) : -1;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int j0 = 0; j0 < SK; j0 += CB_SKMAX) {   // eight slices in flight at a time, summed in slice order
+            float4 v[CB_SKMAX];
 #pragma unroll
-        for (int j = 0; j < CB_SKMAX; ++j)
-            if (j < SK) {
-                s0 += v[j].x;
-                s1 += v[j].y;
-                s2 += v[j].z;
-                s3 += v[j].w;
-            }
+            for (int j = 0; j < CB_SKMAX; ++j)
+                if (j0 + j < SK) v[j] = sl[(long)(j0 + j) * TILE4];
+#pragma unroll
+            for (int j = 0; j < CB_SKMAX; ++j)
+                if (j0 + j < SK) {
+                    s0 += v[j].x;
+                    s1 += v[j].y;
+                    s2 += v[j].z;
+                    s3 += v[j].w;
+                }
+        }
         if ((unsigned)pix >= (unsigned)HW) continue;
         const int m = (tile % MT) * BM + 4 * mq;
         const float sv[4] = {s0, s1, s2, s3};

@@ -232,12 +232,19 @@ class OpenPoseModel(nn.Module):
         return ['model0'] + ['model%d_%d' % (t, b) for t in range(1, self.T + 1) for b in (1, 2)]
 
 
-def convertOpenPose(model, threshold=1e-2):
+def convertOpenPose(model, threshold=1e-2, feedbackLoop=False):
     """Convert every sub-model with pycbinfer.convert(), as poseDetection/modelConverter.py:20-24 does
     (only nn.Sequential containers are traversed by convert, so the custom module is converted per
-    sub-model).  Returns the same module object with its children replaced."""
+    sub-model).  feedbackLoop=True: the reference's experiments 10/11 (modelConverter.py:84-86, "recursive
+    mode", eval03.py:31-35): every CBConv2d refreshes its state at the changed pixels only instead of copying
+    its whole input every frame.  Returns the same module object with its children replaced."""
+    from . import CBConv2d
     for name in model.submodelNames():
         setattr(model, name, convert(getattr(model, name), threshold=threshold))
+    if feedbackLoop:
+        for m in model.modules():
+            if type(m) is CBConv2d:
+                m.feedbackLoop = True
     return model
 
 

@@ -110,6 +110,12 @@ def main():
         print("concurrent branches (eager): dense %.1f f/s, CB %.1f f/s" % (
             measure(based, frames, min(args.steps, 20), 3, "eager"),
             measure(testd, frames, min(args.steps, 20), 3, "eager")))
+        # the reference's experiments 10/11: feedback ("recursive") mode, no per-frame copy of the layer inputs
+        testf = workloads.convertOpenPose(workloads.OpenPoseModel(T=2).cuda().half(), threshold=0.02,
+                                          feedbackLoop=True)
+        cbf = max(measure(testf, frames, min(args.steps, 20), 3, m) for m in ("graph", "eager"))
+        print("feedback mode (modelConverter.py:84-86): CB %.1f f/s = %.2fx dense; mean post-dilation ratio %.0f%%"
+              % (cbf, cbf / dense, 100 * sum(layer_ratios(testf)) / max(1, len(layer_ratios(testf)))))
         rs = layer_ratios(test)
         print("| dense f/s | CB f/s | speed-up | mean post-dilation ratio over 36 layers |")
         print("|---|---|---|---|")

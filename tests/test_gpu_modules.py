@@ -400,17 +400,21 @@ def test_half_network(pkg):
     assert (y.float() - r).abs().max().item() < 3e-2
 
 
-def test_openpose_half(pkg):
+@pytest.mark.parametrize("feedback", [False, True])
+def test_openpose_half(pkg, feedback):
     """BASELINE config 4 at reduced resolution: the OpenPose T=2 network (36 convs, 185-channel concat)
-    converted per sub-model as poseDetection/modelConverter.py:20-24, fp16 (cg_half path).  Frame 0 must
+    converted per sub-model as poseDetection/modelConverter.py:20-24, fp16 (cg_half path), plain and in the
+    feedback mode of the reference's pose experiments 10/11 (modelConverter.py:84-86).  Frame 0 must
     equal the dense fp16 network within fp16 accumulation noise; later frames track it up to the dropped
     sub-threshold changes."""
     from cbinfer_amd import workloads
     torch.manual_seed(0)
     base = workloads.OpenPoseModel(T=2, seed=2).cuda().half()
-    test = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, seed=2).cuda().half(), threshold=0.01)
+    test = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, seed=2).cuda().half(), threshold=0.01,
+                                     feedbackLoop=feedback)
     cbs = [m for m in test.modules() if type(m) is pkg.CBConv2d]
     assert len(cbs) == 36 and all(m.weight.dtype == torch.float16 for m in cbs)
+    assert all(m.feedbackLoop == feedback for m in cbs)
     vid = workloads.SyntheticVideo(H=64, W=96, ratio=0.125, block=16, seed=4, dtype=torch.float32)
     frames = [(f * (255.0 / 256.0) - 0.5).half() for f in vid.frames(3)]
     ref32 = workloads.OpenPoseModel(T=2, seed=2).cuda().half().float()

@@ -558,7 +558,8 @@ def main():
         reps = 1
         if min_seconds > 0:
             per_step = t_warm / max(warmup, 1)
-            reps = max(1, int(math.ceil(min_seconds / max(per_step * steps, 1e-9))))
+            # (the warm-up steps run slower than the steady state: 25 % on top, so the region does not fall short)
+            reps = max(1, int(math.ceil(1.25 * min_seconds / max(per_step * steps, 1e-9))))
             if agree is not None:
                 reps = agree(reps)
         total = steps * reps

@@ -49,6 +49,9 @@ typedef void* cbStream_t; /* hipStream_t */
 #define CB_ERR_BADARG (-1)      /* null pointer, non-positive size, unsupported dtype */
 #define CB_ERR_UNSUPPORTED (-2) /* shape outside what the kernels implement (e.g. kWHalf > 63) */
 
+/* 1: round 1.  2: CB_F32S, row-segment / patch-staged contractions, fine-grained frame, fused 1x1 tail,
+ * cbinfer_weights_ckkpad(Ckk, dtype).  3: fine-grained frame on the mask-driven contractions
+ * (cbinfer_cbconv2d_forward_fg_masked and its parts). */
 #define CBINFER_ABI_VERSION 3
 
 int cbinfer_abi_version(void);

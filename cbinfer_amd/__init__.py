@@ -215,7 +215,8 @@ def fuseTail1x1(rootModule, enabled=True):
         for i in range(len(kids) - 3):
             head, a, act, b = kids[i:i + 4]
             if (type(head) is CBConv2d and is1x1(a) and type(act) is nn.ReLU and
-                    is1x1(b) and a.out_channels <= CBTail1x1.maxHidden() and
+                    is1x1(b) and a.out_channels == b.in_channels and
+                    CBTail1x1.supported(a.in_channels, a.out_channels, b.out_channels) and
                     a.weight.dtype == torch.float32):
                 _log('fusing the 1x1 tail behind %s' % names[i])
                 head.propChangeIndexes = True

@@ -63,6 +63,7 @@ _SIGNATURES = {
     "cbinfer_cbconv2d_forward_fg_masked": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
                                                 _i, _i, _i, _f, _i, _vp]),
     "cbinfer_tail1x1_max_hidden": (_i, []),
+    "cbinfer_tail1x1_supported": (_i, [_i, _i, _i]),
     "cbinfer_tail1x1_prepared_bytes": (_l, [_i, _i]),
     "cbinfer_tail1x1_prep": (_i, [_vp, _vp, _i, _i, _vp]),
     "cbinfer_tail1x1": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

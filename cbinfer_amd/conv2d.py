@@ -429,7 +429,12 @@ class CBConv2d(nn.Module):
         self.prevOutput = po
         self.prevInput = x                                           # conv2d.py:175
         outp = F.relu(po) if self.withReLU else po
-        if self.propChangeIndexes and fused:
+        if self.propChangeIndexes and x.is_cuda:
+            if indexes is None:
+                # the atomic / deterministic / oversized-mask forms keep no list of the output pixels they
+                # touched: hand on EVERY pixel, so that a consumer fed by the tuple protocol (CBTail1x1 behind
+                # a fine-grained head) stays correct -- it then recomputes the whole map
+                indexes = torch.arange(H * W, dtype=torch.int32, device=x.device)
             return 'changeIndexes', outp, indexes
         return outp
 
@@ -517,8 +522,12 @@ class CBConv2d(nn.Module):
         if path:
             rows = self._rows_workspace(work, H, W, src.device)
             fn, wprep = self._masked_call(path)
-            # (a state that was just (re)allocated must see every pixel, whatever the producer rewrote)
-            pmask = None if fresh else lazy.producerMask()
+            # (a state that was just (re)allocated must see every pixel, whatever the producer rewrote; and the
+            #  producer-mask shortcut assumes the skipped segments compared below THIS threshold last frame: the
+            #  first frame after a change of the threshold looks at every segment again)
+            sameTh = self.__dict__.get('_pmaskThreshold') == float(self.threshold)
+            self.__dict__['_pmaskThreshold'] = float(self.threshold)
+            pmask = None if (fresh or not sameTh) else lazy.producerMask()
             args = (None, ptr(src), src.size(-2), src.size(-1), ptr(pmask), ptr(self.prevInput),
                     ptr(self.prevOutput), ptr(rows['bits']), ptr(rows['arrive']), ptr(rows['copy']), ptr(wprep),
                     ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold), 1, 0,
@@ -769,6 +778,11 @@ class CBTail1x1(nn.Module):
         return int(C.cbinfer_tail1x1_max_hidden())
 
     @staticmethod
+    def supported(C0, C1, C2):
+        """Channel counts the one-launch kernel takes (hidden width and its LDS budget)."""
+        return bool(C.cbinfer_tail1x1_supported(int(C0), int(C1), int(C2)))
+
+    @staticmethod
     def accepts(m):
         def pair(v):
             return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
@@ -778,7 +792,10 @@ class CBTail1x1(nn.Module):
     def __init__(self, conv1, conv2, relu=True):
         super(CBTail1x1, self).__init__()
         assert CBTail1x1.accepts(conv1) and CBTail1x1.accepts(conv2)
-        assert conv1.out_channels == conv2.in_channels and conv1.out_channels <= CBTail1x1.maxHidden()
+        assert conv1.out_channels == conv2.in_channels
+        if not CBTail1x1.supported(conv1.in_channels, conv1.out_channels, conv2.out_channels):
+            raise _lib.CBinferError("CBTail1x1: %d->%d->%d channels exceed the kernel's hidden width or LDS budget"
+                                    % (conv1.in_channels, conv1.out_channels, conv2.out_channels))
         self.weight1, self.bias1 = conv1.weight, conv1.bias
         self.weight2, self.bias2 = conv2.weight, conv2.bias
         self.in_channels, self.hidden_channels, self.out_channels = (

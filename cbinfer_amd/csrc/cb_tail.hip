@@ -133,6 +133,18 @@ extern "C" {
 
 int cbinfer_tail1x1_max_hidden(void) { return 16 * CB_TAIL_MAXW; }
 
+static size_t cb_tail_lds_bytes(int C0, int C1, int C2) {
+    const int C0P = (C0 + 15) / 16 * 16;
+    const int waves = (C1 + 15) / 16;
+    return ((size_t)C0P * CB_TAIL_PX + (size_t)waves * 16 * (CB_TAIL_PX + 1) + (size_t)C2 * C1 + C2) * 4;
+}
+
+// 1 if cbinfer_tail1x1 takes these channel counts (hidden width and LDS budget), so that a fusion can be refused
+// when it is set up rather than at the first frame
+int cbinfer_tail1x1_supported(int C0, int C1, int C2) {
+    return C0 > 0 && C1 > 0 && C2 > 0 && C1 <= 16 * CB_TAIL_MAXW && cb_tail_lds_bytes(C0, C1, C2) <= 60 * 1024;
+}
+
 long cbinfer_tail1x1_prepared_bytes(int C1, int C0) {
     const long C0P = (C0 + 15) / 16 * 16;
     return (long)((C1 + 15) / 16) * 16 * C0P * 4;
@@ -158,7 +170,7 @@ int cbinfer_tail1x1(const float* input, const int32_t* changeList, int numChange
     if (numChanges == 0) return CB_OK;
     const int C0P = (C0 + 15) / 16 * 16;
     const int waves = (C1 + 15) / 16;
-    const size_t lds = ((size_t)C0P * CB_TAIL_PX + (size_t)waves * 16 * (CB_TAIL_PX + 1) + (size_t)C2 * C1 + C2) * 4;
+    const size_t lds = cb_tail_lds_bytes(C0, C1, C2);
     if (lds > 60 * 1024) return CB_ERR_UNSUPPORTED;   // stays below the 64 KB that needs no opt-in
     long tiles = ((long)numChanges + CB_TAIL_PX - 1) / CB_TAIL_PX;
     if (tiles > 2048) tiles = 2048;   // grid-stride beyond: the capacity is H*W when the count is on the device

@@ -38,6 +38,18 @@ class FramePipeline(object):
             return (h[0], h[1].clone(), idx)
         return h.clone()
 
+    @staticmethod
+    def _handed(h):
+        if not isinstance(h, tuple):
+            return [h]
+        out = [h[1]]
+        idx = h[2]
+        if isinstance(idx, torch.Tensor):
+            out.append(idx)
+        else:                       # ChangeIndexes (a clone: plain buffer + count)
+            out += [idx.buffer, idx.count]
+        return out
+
     def submit(self, frame):
         """Enqueue one frame; returns the network output, valid once wait() (or a sync) has passed."""
         cur = torch.cuda.current_stream(frame.device)
@@ -50,7 +62,11 @@ class FramePipeline(object):
             h = self._private(h)
             ready = torch.cuda.Event()
             ready.record(cur)
-            for t in ([h[1]] if isinstance(h, tuple) else [h]):
+            # EVERY tensor handed over was allocated on the caller's stream and is read by stage 2 on the side
+            # stream: the boundary tensor and, with a ('changeIndexes', tensor, indexes) tuple, the cloned index
+            # buffer and its device-side count -- otherwise the next frame's stage 1 may be handed the same
+            # memory by the caching allocator while stage 2 still reads it
+            for t in self._handed(h):
                 t.record_stream(self.side)
             self.side.wait_event(ready)
             with torch.cuda.stream(self.side):

@@ -2,9 +2,48 @@
 (own module state, own replica of the read-only weights) per process, no exchange on the data path.
 The only collective is the final reduction of the timing (RCCL `nccl` backend on GPUs; `gloo` on CPU
 for tests).  The reference has no multi-GPU code."""
+import glob
 import os
+import subprocess
+import sys
 
 import torch
+
+
+def visible_gpu_count():
+    """How many GPUs a process started from here would see -- found WITHOUT a single HIP call in this process,
+    so that the caller may still start child processes that use the GPU (a process that has initialised the GPU
+    must not exec or be relied on to fork workers): the GPU nodes of the KFD topology in sysfs (simd_count > 0),
+    cut down by HIP_/CUDA_/ROCR_VISIBLE_DEVICES when set.  Where sysfs says nothing, a child python process is
+    asked for torch.cuda.device_count()."""
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        if os.environ.get(var, None) is not None and os.environ[var].strip() == '':
+            return 0                       # explicitly hidden
+    physical = None
+    props = glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties')
+    if props:
+        n = 0
+        try:
+            for f in props:
+                for line in open(f):
+                    if line.startswith('simd_count') and int(line.split()[1]) > 0:
+                        n += 1
+            physical = n
+        except (OSError, ValueError):
+            physical = None
+    if physical is None:
+        try:
+            out = subprocess.run([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'],
+                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+            return int(out.stdout.decode().strip().splitlines()[-1])    # (the child applied the env filters)
+        except Exception:
+            return 0
+    count = physical
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        if var in os.environ:
+            ids = [v for v in os.environ[var].split(',') if v.strip() != '']
+            count = min(count, len(ids))
+    return count
 
 
 class SequenceShard(object):
@@ -52,6 +91,24 @@ class SequenceShard(object):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         self.dist.all_reduce(n, op=self.dist.ReduceOp.SUM)
         return int(round(n.item())), float(t.item())
+
+    def agree_max(self, value):
+        """MAX of an integer over the ranks (CPU tensor under gloo, device tensor under RCCL)."""
+        if self.dist is None:
+            return int(value)
+        dev = "cpu" if self.backend == "gloo" else "cuda"
+        t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return int(t.item())
+
+    def broadcast_flag(self, flag, src=0):
+        """Rank src's boolean for everybody."""
+        if self.dist is None:
+            return bool(flag)
+        dev = "cpu" if self.backend == "gloo" else "cuda"
+        t = torch.tensor([1.0 if flag else 0.0], device=dev)
+        self.dist.broadcast(t, src)
+        return t.item() > 0.5
 
     def finish(self):
         if self.dist is not None:

@@ -221,7 +221,10 @@ int cbinfer_conv_changed_rows(const float* state, uint64_t* bits, int32_t* arriv
                               const void* prepared, const float* bias, float* output, int C, int H, int W,
                               int K, int kH, int kW, int relu, cbStream_t stream);
 /* producerMask (may be NULL): the change mask (cbinfer_mask_words(pH,pW) words, this frame) of the layer that
- * wrote prePool; pooled pixels none of whose window pixels it rewrote are not even read. */
+ * wrote prePool; pooled pixels none of whose window pixels it rewrote are not even read.  ASSUMPTION the
+ * caller must uphold: those pixels were compared against the SAME state with the SAME threshold on the previous
+ * call (then they compare exactly as they did, i.e. not above it).  After a change of the threshold, or against a
+ * state that was (re)allocated or written from outside, pass NULL for one frame (CBConv2d._forward_pooled does). */
 int cbinfer_change_detection_bits_pooled(const void* prePool, int pH, int pW, const uint64_t* producerMask,
                                          void* state, uint64_t* bitsOut, int W, int H, int C, int kHHalf,
                                          int kWHalf, float threshold, int dtype, cbStream_t stream);
@@ -339,6 +342,7 @@ int cbinfer_cbconv2d_forward_fg_masked(int blocks, const float* input, float* pr
  *   w1Prepared: w1 [C1,C0] re-laid out by cbinfer_tail1x1_prep (cbinfer_tail1x1_prepared_bytes bytes);
  *   C1 <= cbinfer_tail1x1_max_hidden(); w2 is the plain [C2,C1] matrix. */
 int cbinfer_tail1x1_max_hidden(void);
+int cbinfer_tail1x1_supported(int C0, int C1, int C2);   /* hidden width and LDS budget of cbinfer_tail1x1 */
 long cbinfer_tail1x1_prepared_bytes(int C1, int C0);
 int cbinfer_tail1x1_prep(const float* w1, float* w1Prepared, int C1, int C0, cbStream_t stream);
 int cbinfer_tail1x1(const float* input, const int32_t* changeList, int numChanges, const int32_t* countDev,

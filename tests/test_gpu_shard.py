@@ -1,0 +1,55 @@
+"""-m gpu rehearsal of bench.py's N > 1 control flow on the ONE GPU of the test box (verdict, round 2): two
+ranks, started by bench.py's own self-launch as a child `torch.distributed.run`, share device 0 over the gloo
+backend (RCCL refuses duplicate devices; CBINFER_ALLOW_SHARED_DEVICE=1 lifts bench.py's refusal for exactly this
+purpose).  What executes end to end: the GPU count without a HIP call, the self-launch, SequenceShard,
+the agreement on the repeat count (agree_max), the launch-form broadcast, the barriers inside timed_loop,
+aggregate() and the single JSON line of rank 0.  It is NOT a scaling measurement."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_visible_gpu_count_makes_no_hip_call():
+    # in a fresh interpreter: the count is there and torch has not initialised the GPU afterwards
+    code = ("import torch; from cbinfer_amd.shard import visible_gpu_count; n = visible_gpu_count(); "
+            "print(n, int(torch.cuda.is_initialized()))")
+    out = subprocess.run([sys.executable, "-c", code], cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    n, inited = out.stdout.decode().split()[-2:]
+    assert int(n) >= 1 and int(inited) == 0
+
+
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(CBINFER_DIST_BACKEND="gloo", CBINFER_ALLOW_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--min-seconds", "0.05", "--mode", "auto"]
+    out = subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                    # rank 0 alone prints, one line
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 0
+    assert r["steps"] % 20 == 0 and r["steps"] >= 20   # the agreed repeat count times the requested steps
+    assert r["config"]["launch"] in ("graph", "eager")
+    # whole-job value = frames of BOTH ranks over the max elapsed
+    assert abs(r["value"] - 2 * r["steps"] / r["timed_region_s"]) <= 1e-6 * r["value"]
+
+
+def test_bench_still_refuses_by_default():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK",
+                                                            "CBINFER_ALLOW_SHARED_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "7", "--steps", "1"],
+                         env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    # (a 1-GPU box; on an 8-GPU node 7 ranks would simply run -- then there is nothing to refuse)
+    from cbinfer_amd.shard import visible_gpu_count
+    if visible_gpu_count() < 7:
+        assert out.returncode != 0 and b"--gpus 7 requested but only" in out.stderr

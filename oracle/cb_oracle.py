@@ -227,15 +227,20 @@ def maxpool_dense(inp, ceil_mode=False):
 # ----------------------------------------------------------------------------------------------
 # fp16 change predicate (cbconv2d_cg_half_backend.cu:10-88), restated in numpy
 # ----------------------------------------------------------------------------------------------
-def changeDetection_half(inp, state, filtSize, threshold, updateInputState=False):
+def changeDetection_half(inp, state, filtSize, threshold, updateInputState=False, cmp=CMP_GT):
     """diff = __hsub(state, in) (one rounding to half), changed = diff > th16 | diff < -th16 with
-    th16 = __float2half(th) (cg_half.cu:24-29, :60-65); dilation and state update as in fp32."""
+    th16 = __float2half(th) (cg_half.cu:24-29, :60-65); dilation and state update as in fp32.
+    cmp=CMP_GE: the python twin's comparison on half tensors ((input-prevInput).abs().ge(th), conv2d_cg.py:126)
+    -- the two only differ on exact ties, which the reference-derived fixtures avoid."""
     assert inp.dtype == np.float16 and state.dtype == np.float16
     _, C, H, W = inp.shape
     th16 = np.float16(np.float32(threshold))
     # exact difference in float64 (11-bit significands, exponent span < 42 bits), rounded once
     diff = (state.astype(np.float64) - inp.astype(np.float64)).astype(np.float16)
-    changed = ((diff > th16) | (diff < -th16)).any(axis=1)[0]          # [H,W]
+    if cmp == CMP_GE:
+        changed = ((diff >= th16) | (diff <= -th16)).any(axis=1)[0]
+    else:
+        changed = ((diff > th16) | (diff < -th16)).any(axis=1)[0]        # [H,W]
     cm = changePropagation(changed.astype(np.int8), filtSize)
     if updateInputState:
         sel = np.broadcast_to(changed[None, None], state.shape)
@@ -498,7 +503,7 @@ class OracleCBConv2dHalf(OracleCBConv2d):
             self.prevOutput = np.full(oshape, np.inf, np.float16)
         if changeIndexes is None:
             self.changeMap = changeDetection_half(x, self.prevInput, self.kernel_size, self.threshold,
-                                                  updateInputState=self.feedbackLoop)
+                                                  updateInputState=self.feedbackLoop, cmp=self.cmp)
             changeIndexes = changeIndexesExtr(self.changeMap)
         if not self.feedbackLoop:
             self.prevInput = x.copy() if self.copyInput else x

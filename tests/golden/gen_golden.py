@@ -12,7 +12,7 @@ The reference's CPU code path (`*_python` ops, CBConv2d.forward_normal on CPU te
 pycbinfer.convert) is then executed unmodified.  The compiled reference (oracle/_ref, built by
 oracle/Makefile from the reference .cu files) supplies conv2d_fg_cpu for the fine-grained fixtures.
 
-Usage:  python tests/golden/gen_golden.py
+Usage:  python tests/golden/gen_golden.py [--only-half]
 """
 import ctypes
 import os
@@ -69,10 +69,157 @@ def np32(t):
     return t.detach().cpu().numpy().astype(np.float32)
 
 
+def np16(t):
+    assert t.dtype == torch.float16
+    return t.detach().cpu().numpy().copy()      # (a copy: the module states are updated in place by later frames)
+
+
+# ------------------------------------------------------------------------------------------------------
+# fp16 (cg_half) fixtures.  The reference's half backend (cbconv2d_cg_half_backend.cu) is unbuildable here
+# (<cuda_fp16.h>), but its Python side is dtype-agnostic: the `*_python` twins and CBConv2d.forward_normal run
+# on CPU HALF tensors of this torch build with ONE more harness-side shim -- changeDetection_python feeds a
+# float change map and a ones-filter made by `input.new(...)` (half here) to F.conv2d, which today's torch
+# refuses for mixed dtypes: F.conv2d is wrapped to cast the filter to the map's dtype (the filter is all
+# ones and the map 0/1, so the dilation is exact in any float type).  Everything else executes unmodified:
+#   predicate   (input - prevInput).abs().ge(threshold) on half tensors: ONE rounding of the difference to
+#               half, threshold converted to half -- the arithmetic of __hsub / __hgt in cg_half.cu:24-29
+#               (ties |d| == th16 excepted: the twin uses >=, the kernel >; the fixtures hold none -- the
+#               oracle tests check both comparison modes)
+#   gather      genXMatrix_python: data movement
+#   contraction matrixMult_python: torch CPU half matmul (+ in-place half bias add)
+#   scatter     updateOutput_python: clamp_(0, inf) on half
+# ------------------------------------------------------------------------------------------------------
+def gen_half(ref):
+    from pycbinfer import conv2d_cg as rcg
+    _conv2d = F.conv2d
+    refused = []
+
+    def conv2d_mixed(inp, w, *a, **k):
+        if inp.dtype != w.dtype:
+            w = w.to(inp.dtype)
+        return _conv2d(inp, w, *a, **k)
+
+    # does today's torch refuse the twin as is?  (recorded in the fixture)
+    try:
+        rcg.changeDetection_python(torch.zeros(1, 1, 4, 4).half(), torch.ones(1, 1, 4, 4).half(), (3, 3), 0.1)
+    except Exception as e:      # noqa
+        refused.append("changeDetection_python: F.conv2d(float map, half ones-filter) -> %s" % type(e).__name__)
+    F.conv2d = conv2d_mixed
+    rcg.F.conv2d = conv2d_mixed
+
+    g = torch.Generator().manual_seed(4321)
+    cases = []
+    for ci_, (C, H, W, kH, kW, K, th, nchg) in enumerate([
+            (3, 12, 17, 1, 1, 4, 0.10, 9),
+            (5, 14, 19, 3, 3, 6, 0.10, 7),
+            (4, 16, 21, 7, 7, 5, 0.25, 5),
+            (2, 9, 64, 3, 3, 3, 0.05, 11),
+            (3, 11, 65, 7, 7, 4, 0.05, 6),
+            (8, 10, 13, 3, 1, 4, 0.10, 4),
+    ]):
+        inp = torch.randn(1, C, H, W, generator=g).half()
+        prev = inp.clone()
+        ys = torch.randint(0, H, (nchg,), generator=g).tolist() + [0, H - 1, 0, H - 1]
+        xs = torch.randint(0, W, (nchg,), generator=g).tolist() + [0, W - 1, W - 1, 0]
+        cs = torch.randint(0, C, (nchg + 4,), generator=g).tolist()
+        for c, y, x in zip(cs, ys, xs):
+            prev[0, c, y, x] += (1.0 if (y + x) % 2 else -3.0)
+        for _ in range(5):      # sub-threshold perturbations that must NOT trigger
+            c = int(torch.randint(0, C, (1,), generator=g)); y = int(torch.randint(0, H, (1,), generator=g))
+            x = int(torch.randint(0, W, (1,), generator=g))
+            if prev[0, c, y, x] == inp[0, c, y, x]:
+                prev[0, c, y, x] += th * 0.5
+        # a few differences within a few half ulps of the threshold, on both sides (never exactly on it)
+        th16 = torch.tensor(th).half()
+        for side in (-3, -1, 1, 3):
+            c = int(torch.randint(0, C, (1,), generator=g)); y = int(torch.randint(0, H, (1,), generator=g))
+            x = int(torch.randint(0, W, (1,), generator=g))
+            d = torch.tensor(float(th16) * (1 + side * 2.0 ** -10)).half()
+            old = prev[0, c, y, x].clone()
+            prev[0, c, y, x] = (inp[0, c, y, x].float() + d.float()).half()
+            if (inp[0, c, y, x] - prev[0, c, y, x]).abs() == th16:      # rounded onto the threshold: not this one
+                prev[0, c, y, x] = old
+        assert not ((inp - prev).abs() == th16).any(), "tie in op case %d: change the seed" % ci_
+        weight = (torch.randn(K, C, kH, kW, generator=g) * 0.3).half()
+        bias = torch.randn(K, generator=g).half()
+        cm = rcg.changeDetection_python(inp, prev, (kH, kW), th)
+        idx = rcg.changeIndexesExtr_python(cm)
+        X = rcg.genXMatrix_python(inp, idx, (kH, kW))
+        Y = rcg.matrixMult_python(X, weight, bias)
+        assert X.dtype == torch.float16 and Y.dtype == torch.float16
+        prevOut = torch.randn(1, K, H, W, generator=g).half()
+        o_plain = rcg.updateOutput_python(Y.transpose(0, 1).clone(), idx, prevOut.clone(), withReLU=False)
+        o_relu = rcg.updateOutput_python(Y.transpose(0, 1).clone(), idx, prevOut.clone(), withReLU=True)
+        np.savez_compressed(
+            os.path.join(HERE, "ops_half_case%d.npz" % ci_), input=np16(inp), prevInput=np16(prev),
+            threshold=np.float32(th), filtSize=np.array([kH, kW]), weight=np16(weight), bias=np16(bias),
+            changeMap=cm.numpy().astype(np.int8).reshape(H, W), changeIndexes=idx.numpy().astype(np.int32),
+            X=np16(X), Y=np16(Y), prevOutput=np16(prevOut), out_plain=np16(o_plain), out_relu=np16(o_relu),
+            torch_refused=np.array(refused))
+        cases.append((C, H, W, kH, kW, int(idx.numel())))
+    print("half op cases (C,H,W,kH,kW,N):", cases, "| refused as is:", refused)
+
+    # module level: the reference's convert()-ed net in half on CPU, 4 frames
+    import contextlib
+    import io
+
+    def make_net(seed, chans=(3, 4, 6, 8, 6, 4), k=7):
+        torch.manual_seed(seed)
+        c0, c1, c2, c3, c4, c5 = chans
+        return nn.Sequential(
+            nn.Conv2d(c0, c1, k, padding=k // 2), nn.ReLU(), nn.MaxPool2d(2, 2),
+            nn.Conv2d(c1, c2, k, padding=k // 2), nn.ReLU(), nn.MaxPool2d(2, 2),
+            nn.Conv2d(c2, c3, k, padding=k // 2), nn.ReLU(),
+            nn.Conv2d(c3, c4, 1), nn.ReLU(),
+            nn.Conv2d(c4, c5, 1)).eval()
+
+    gg = torch.Generator().manual_seed(199)
+    H, W, blk = 24, 32, 6
+    f = torch.rand(1, 3, H, W, generator=gg).half()
+    frames = [f.clone()]
+    for t in range(1, 4):
+        f = f.clone()
+        for _ in range(2):
+            y0 = int(torch.randint(0, H - blk + 1, (1,), generator=gg))
+            x0 = int(torch.randint(0, W - blk + 1, (1,), generator=gg))
+            f[:, :, y0:y0 + blk, x0:x0 + blk] = torch.rand(1, 3, blk, blk, generator=gg).half()
+        frames.append(f)
+    for name, k in (("seq_half", 7), ("seq_half_k3", 3)):
+        base = make_net(0, k=k).half()
+        with contextlib.redirect_stdout(io.StringIO()):
+            cb = ref.convert(base, threshold=0.02)
+        cbmods = [m for m in cb.modules() if type(m) is ref.CBConv2d]
+        for m in cbmods:
+            m.saveChangeMap = True
+        d = dict(threshold=np.float32(0.02), childNames=np.array([n for n, _ in cb.named_children()]),
+                 k=np.int64(k), torch_refused=np.array(refused))
+        for n_, p_ in base.state_dict().items():
+            d["param_" + n_] = np16(p_)
+        ref.clearMemory(cb)
+        with torch.no_grad():
+            for t, fr in enumerate(frames):
+                y = cb(fr.clone())
+                assert y.dtype == torch.float16
+                d["frame%d" % t] = np16(fr)
+                d["out%d" % t] = np16(y)
+                for li, m in enumerate(cbmods):
+                    d["cm%d_l%d" % (t, li)] = m.changeMap.numpy().astype(np.int8).reshape(m.changeMap.shape[-2:])
+                    d["prevOutput%d_l%d" % (t, li)] = np16(m.prevOutput)
+                    d["prevInput%d_l%d" % (t, li)] = np16(m.prevInput)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        print(name, "children", d["childNames"].tolist(), "changed px per layer, last frame:",
+              [int(d["cm3_l%d" % li].sum()) for li in range(len(cbmods))])
+    F.conv2d = _conv2d
+    rcg.F.conv2d = _conv2d
+
+
 def main():
     ref = import_reference()
     from pycbinfer import conv2d_cg as rcg
     out = {}
+    if "--only-half" in sys.argv:      # (leaves the fp32 fixtures of round 1 untouched)
+        gen_half(ref)
+        return
 
     # ------------------------------------------------------------------ KAT 1: genTestData
     # conv2d_cg.py:84-97 stimulus (without .cuda()); 15 dilated indices, seed independent.
@@ -266,6 +413,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "fg_case1.npz"), input=np32(inp), prevInput=np32(prev),
                         weight=np32(w), prevOutput=np32(prevOut), output=got, threshold=np.float32(0.3))
     print("fg fixtures ok (cbconvFG_test1 err %.1e)" % err)
+    gen_half(ref)
 
 
 if __name__ == "__main__":

@@ -1159,3 +1159,50 @@ def test_bench_configuration_fullsize_parity(pkg, oracle):
     assert all(n[2] > 3000 and n[0] > 15360 for n in Ns[2:]), Ns   # steady state: 10 % input change, dilated
     # end to end the change-based network stays close to the dense one (sub-threshold changes are dropped)
     assert (y - base(walk[order[-1]])).abs().max().item() < 0.5
+
+
+@pytest.mark.parametrize("name", ["seq_half", "seq_half_k3"])
+@pytest.mark.parametrize("sync", [False, True])
+def test_golden_sequences_half(pkg, golden_dir, name, sync):
+    """cg_half at module level against the REFERENCE: 4 frames through its convert()-ed net on CPU half tensors
+    (tests/golden/gen_golden.py::gen_half; CBConv2d.forward_normal conv2d.py:178-259 over the half backend's ops,
+    cbconv2d_cg_half_backend.cu:10-237).  Every CBConv2d is fed the input the reference's own layer saw
+    (prevInput after a copyInput frame), so its change map must match bit for bit; its state within HALF_ULPS
+    fp16 ulps at the magnitude |output| + |bias| (the fixtures need <= 1: tests/test_oracle_golden.py)."""
+    from test_gpu_ops import half_tol
+    d = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    k = int(d["k"])
+    net = nn.Sequential(
+        nn.Conv2d(3, 4, k, padding=k // 2), nn.ReLU(), nn.MaxPool2d(2, 2),
+        nn.Conv2d(4, 6, k, padding=k // 2), nn.ReLU(), nn.MaxPool2d(2, 2),
+        nn.Conv2d(6, 8, k, padding=k // 2), nn.ReLU(),
+        nn.Conv2d(8, 6, 1), nn.ReLU(),
+        nn.Conv2d(6, 4, 1)).eval().half()
+    net.load_state_dict({n[len("param_"):]: torch.from_numpy(v) for n, v in d.items() if n.startswith("param_")})
+    cb = pkg.convert(net.cuda(), threshold=float(d["threshold"]))
+    assert [n for n, _ in cb.named_children()] == d["childNames"].tolist()
+    cbmods = [m for m in cb.modules() if type(m) is pkg.CBConv2d]
+    assert len(cbmods) == 5 and all(m.weight.dtype == torch.float16 for m in cbmods)
+    for m in cbmods:
+        m.saveChangeMap = True
+    pkg.setSyncIndexes(cb, sync)
+    pkg.clearMemory(cb)
+    with torch.no_grad():
+        for t in range(4):
+            for li, m in enumerate(cbmods):
+                x = torch.from_numpy(d["prevInput%d_l%d" % (t, li)]).cuda()
+                out = m(x)
+                assert out.dtype == torch.float16
+                assert np.array_equal(m.changeMap.cpu().numpy(), d["cm%d_l%d" % (t, li)]), (t, li)
+                ref = d["prevOutput%d_l%d" % (t, li)]
+                err = np.abs(out.cpu().numpy().astype(np.float64) - ref.astype(np.float64)).max()
+                tol = half_tol(ref, m.bias.detach().cpu().numpy())
+                assert err <= tol, (t, li, err, tol)
+        # and the network as a whole on the frames (free-running: later layers see this implementation's own
+        # roundings, so a pixel within an ulp of a threshold may be decided differently -- outputs are compared
+        # with the looser end-to-end bar of the reference's dense result)
+        pkg.clearMemory(cb)
+        for t in range(4):
+            y = cb(torch.from_numpy(d["frame%d" % t]).cuda())
+        ref = d["out3"]
+        assert np.abs(y.cpu().numpy().astype(np.float64) - ref.astype(np.float64)).max() <= 4 * half_tol(ref)

@@ -824,3 +824,56 @@ def test_fg_frame_on_masked_contractions(cb, oracle, blocks, C, K, kH, kW, H, W,
     check(lib.cbinfer_compact_bits(ptr(copy), W, H, ptr(idx), ptr(cnt), None, None, None))
     n = int(cnt.item())
     assert np.array_equal(idx[:n].cpu().numpy(), np.flatnonzero(touched).astype(np.int32))
+
+
+# ------------------------------------------------------------------------------------------------
+# fp16 (cg_half) against fixtures derived from the REFERENCE (its python twins on CPU half tensors,
+# tests/golden/gen_golden.py::gen_half; reference kernels: cbconv2d_cg_half_backend.cu:10-237)
+# ------------------------------------------------------------------------------------------------
+HALF_ULPS = 2.0     # bar; the fixtures need <= 1 (tests/test_oracle_golden.py explains the magnitude)
+
+
+def half_tol(ref, bias=None):
+    m = float(np.abs(ref.astype(np.float64)).max())
+    if bias is not None:
+        m += float(np.abs(bias.astype(np.float64)).max())
+    return HALF_ULPS * 2.0 ** (np.floor(np.log2(max(m, 2.0 ** -14))) - 10)
+
+
+@pytest.mark.parametrize("case", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden",
+                                                               "ops_half_case*.npz"))))
+def test_golden_ops_half(cb, case):
+    """The HIP cg_half ops on the reference-derived fp16 fixtures: mask, index list, X and scatter bit-exact
+    (incl. differences a few half ulps either side of the threshold), contraction within HALF_ULPS."""
+    _, cg, _ = cb
+    d = dict(np.load(case))
+    filt = tuple(int(v) for v in d["filtSize"])
+    th = float(d["threshold"])
+    inp, prev = dev(d["input"]), dev(d["prevInput"])
+    assert inp.dtype == torch.float16
+    cm = cg.changeDetection(inp, prev.clone(), filt, th, useHalf=True)
+    assert np.array_equal(cm.cpu().numpy(), d["changeMap"])
+    idx = cg.changeIndexesExtr(cm)
+    assert np.array_equal(idx.cpu().numpy(), d["changeIndexes"])
+    X = cg.genXMatrix(inp, idx, filt, useHalf=True)
+    assert np.array_equal(X.cpu().numpy(), d["X"])
+    w, b = dev(d["weight"]), dev(d["bias"])
+    tol = half_tol(d["Y"], d["bias"])
+    Y = cg.matrixMult(X, w, b)
+    assert Y.dtype == torch.float16
+    err = np.abs(Y.cpu().numpy().astype(np.float64) - d["Y"].astype(np.float64)).max()
+    assert err <= tol, (err, tol)
+    out = cg.updateOutput(dev(d["Y"]).t(), idx, dev(d["prevOutput"]), withReLU=False, useHalf=True)
+    assert np.array_equal(out.cpu().numpy(), d["out_plain"])
+    out = cg.updateOutput(dev(d["Y"]).t(), idx, dev(d["prevOutput"]), withReLU=True, useHalf=True)
+    assert np.array_equal(out.cpu().numpy(), d["out_relu"])
+    for relu, key in ((False, "out_plain"), (True, "out_relu")):
+        fused = cg.convChanged(inp, idx, w, b, dev(d["prevOutput"]), withReLU=relu)
+        err = np.abs(fused.cpu().numpy().astype(np.float64) - d[key].astype(np.float64)).max()
+        assert err <= tol, (key, err, tol)
+    # feedback refresh at the pre-dilation changed pixels only (cg_half.cu:68-76), against the fixture's inputs
+    st = prev.clone()
+    cg.changeDetection(inp, st, filt, th, updateInputState=True, useHalf=True)
+    cm1 = cg.changeDetection(inp, prev.clone(), (1, 1), th, useHalf=True).bool()
+    sel = cm1[None, None].expand_as(st)
+    assert torch.equal(st[sel], inp[sel]) and torch.equal(st[~sel], prev[~sel])

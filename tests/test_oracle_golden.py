@@ -173,3 +173,78 @@ def test_half_predicate(oracle):
     st[0, 0, 1, 1] = np.float16(0.0999)       # == th16 after rounding -> not strictly greater
     cm = oracle.changeDetection_half(inp, st.copy(), (1, 1), 0.1)
     assert cm[2, 3] == 1 and cm[1, 1] == 0 and cm.sum() == 1
+
+
+# ------------------------------------------------------------------------------------------------------
+# fp16 (cg_half): fixtures from the reference's python twins / CBConv2d.forward_normal on CPU HALF tensors
+# (tests/golden/gen_golden.py::gen_half).  They pin the oracle's restatement of cbconv2d_cg_half_backend.cu
+# :10-237 (oracle.changeDetection_half, genXMatrix_half, matrixMult_half, updateOutput_half,
+# OracleCBConv2dHalf): masks, lists and moved data bit-exact; the contraction within HALF_ULPS fp16 ulps of
+# the layer's largest |output| + |bias|: torch's CPU half matmul rounds the product sum (a value of up to that
+# magnitude) and then the biased sum to half, the oracle -- like the HIP kernel -- rounds once, so where bias and
+# product sum cancel the reference's own result is off by an ulp of the LARGER operand.  The fixtures need <= 1.
+# ------------------------------------------------------------------------------------------------------
+HALF_ULPS = 2.0
+
+
+def half_tol(ref, bias=None):
+    """HALF_ULPS fp16 ulps at the magnitude max|ref| + max|bias|."""
+    m = float(np.abs(ref.astype(np.float64)).max())
+    if bias is not None:
+        m += float(np.abs(bias.astype(np.float64)).max())
+    return HALF_ULPS * 2.0 ** (np.floor(np.log2(max(m, 2.0 ** -14))) - 10)
+
+
+@pytest.mark.parametrize("case", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden",
+                                                               "ops_half_case*.npz"))))
+def test_half_ops_against_reference_python(oracle, case):
+    d = dict(np.load(case))
+    assert d["input"].dtype == np.float16 and d["Y"].dtype == np.float16
+    filt = tuple(int(v) for v in d["filtSize"])
+    th = float(d["threshold"])
+    for cmp in (oracle.CMP_GT, oracle.CMP_GE):      # no exact ties in the fixtures: both modes agree
+        cm = oracle.changeDetection_half(d["input"], d["prevInput"].copy(), filt, th, cmp=cmp)
+        assert np.array_equal(cm, d["changeMap"])
+    idx = oracle.changeIndexesExtr(cm)
+    assert np.array_equal(idx, d["changeIndexes"])
+    X = oracle.genXMatrix_half(d["input"], idx, filt)
+    assert np.array_equal(X, d["X"])
+    Y = oracle.matrixMult_half(X, d["weight"], d["bias"])
+    err = np.abs(Y.astype(np.float64) - d["Y"].astype(np.float64)).max()
+    assert err <= half_tol(d["Y"], d["bias"]), (err, half_tol(d["Y"], d["bias"]))
+    Yt = np.ascontiguousarray(d["Y"].T)
+    assert np.array_equal(oracle.updateOutput_half(Yt, idx, d["prevOutput"].copy(), False), d["out_plain"])
+    assert np.array_equal(oracle.updateOutput_half(Yt, idx, d["prevOutput"].copy(), True), d["out_relu"])
+    # the feedback refresh only touches the pre-dilation changed pixels (cg_half.cu:68-76)
+    st = d["prevInput"].copy()
+    cm1 = oracle.changeDetection_half(d["input"], d["prevInput"].copy(), (1, 1), th)
+    oracle.changeDetection_half(d["input"], st, filt, th, updateInputState=True)
+    sel = np.broadcast_to(cm1.astype(bool)[None, None], st.shape)
+    assert np.array_equal(st[sel], d["input"][sel]) and np.array_equal(st[~sel], d["prevInput"][~sel])
+
+
+@pytest.mark.parametrize("name", ["seq_half", "seq_half_k3"])
+def test_half_module_sequence_against_reference(oracle, golden_dir, name):
+    """OracleCBConv2dHalf, layer by layer on the inputs the reference's own layers saw (prevInput after a
+    copyInput frame IS the layer's input), 4 frames: change maps bit-exact, states within HALF_ULPS."""
+    d = _load(golden_dir, name + ".npz")
+    k = int(d["k"])
+    convs = [0, 3, 6, 8, 10]
+    layers = []
+    for li, ci in enumerate(convs):
+        for cmp in (oracle.CMP_GT, oracle.CMP_GE):
+            layers.append((li, cmp, oracle.OracleCBConv2dHalf(d["param_%d.weight" % ci], d["param_%d.bias" % ci],
+                                                             float(d["threshold"]), withReLU=li < 4, cmp=cmp)))
+    worst = 0.0
+    for t in range(4):
+        for li, cmp, o in layers:
+            x = d["prevInput%d_l%d" % (t, li)]
+            assert x.dtype == np.float16
+            out = o.forward(x)
+            assert np.array_equal(o.changeMap, d["cm%d_l%d" % (t, li)]), (t, li, cmp)
+            ref = d["prevOutput%d_l%d" % (t, li)]
+            err = np.abs(out.astype(np.float64) - ref.astype(np.float64)).max()
+            tol = half_tol(ref, o.bias)
+            worst = max(worst, err / (tol / HALF_ULPS))
+            assert err <= tol, (t, li, err, tol)
+    assert k in (3, 7) and worst <= 1.0, worst      # what the fixtures actually need: one ulp at that magnitude

@@ -16,6 +16,15 @@ CB_F32S = 2     # f32 tensors, contraction as bf16x3 split products on the bf16 
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
+
+class SplitSeq(ctypes.Structure):
+    """cbSplitSeq of include/cbinfer_hip.h: the buffers of ONE sequence for the split-state entry points."""
+    _fields_ = [("input", _vp), ("state", _vp), ("splitState", _vp), ("frameMasks", _vp), ("producerMask", _vp),
+                ("output", _vp), ("idxOut", _vp), ("countOut", _vp), ("rangeFlag", _vp), ("maskCopy", _vp)]
+
+
+_sp = ctypes.POINTER(SplitSeq)
+
 _SIGNATURES = {
     # name: (restype, [argtypes])
     "cbinfer_abi_version": (_i, []),
@@ -80,6 +89,18 @@ _SIGNATURES = {
     "cbinfer_blockconv_prepared_bytes": (_l, [_i, _i, _i, _i]),
     "cbinfer_blockconv_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "cbinfer_conv_changed_blocks": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "cbinfer_split_supported": (_i, [_i, _i, _i, _i]),
+    "cbinfer_split_max_sequences": (_i, []),
+    "cbinfer_split_max_mask_words": (_l, [_i]),
+    "cbinfer_split_state_bytes": (_l, [_i, _i, _i, _i, _i]),
+    "cbinfer_split_prepared_bytes": (_l, [_i, _i, _i, _i]),
+    "cbinfer_split_workspace_bytes": (_l, []),
+    "cbinfer_split_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "cbinfer_split_state_init": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "cbinfer_split_state_rebuild": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "cbinfer_split_detect": (_i, [_sp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "cbinfer_split_conv": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp]),
+    "cbinfer_split_forward": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _vp]),
     "cbinfer_conv2d_fg_cpu": (None, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i]),
 }
 
@@ -97,7 +118,7 @@ def _load():
         fn = getattr(lib, name)     # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.cbinfer_abi_version() != 3:
+    if lib.cbinfer_abi_version() != 4:
         raise ImportError("cbinfer_amd: libcbinfer_hip.so ABI version mismatch")
     return lib
 

@@ -16,6 +16,8 @@ Two execution modes, chosen per module by `syncIndexes` (default False):
          and the reference-structured op sequence (changeDetection, changeIndexesExtr, genXMatrix,
          matrixMult, updateOutput) of conv2d_cg.py is what runs.
 """
+import ctypes
+import math
 import os
 
 import torch
@@ -297,6 +299,137 @@ class CBConv2d(nn.Module):
             self._wprep = (key, prepWeights(w, H, W, arith=arith))
         return self._wprep[1]
 
+    # ---------------------------------------------------------------- split-state frame (cb_split.hip)
+    def _split_ok(self, dtype, H, W):
+        """Does this layer's sync-free frame run on the split-state kernels (cbinfer_split_forward)?  fp32,
+        feedback mode (the pre-split copy of the state is refreshed at the changed pixels), 16/32/64 input
+        channels, default arithmetic (f16-pair products; exactF32 / CBINFER_ARITH=bf16x3 keep the other forms);
+        CBINFER_NO_SPLIT=1 switches it off."""
+        K, Cin, kH, kW = self.weight.size()
+        return (dtype == torch.float32 and self.feedbackLoop and not self.syncIndexes and not self.saveChangeMap
+                and not self.finegrained and self._arith_code(dtype) == _lib.CB_F32S
+                and os.environ.get('CBINFER_NO_SPLIT', '0') != '1'
+                and int(os.environ.get('CBINFER_SPLIT_MINK', '0')) <= K <= int(os.environ.get('CBINFER_SPLIT_MAXK', '100000'))
+                and os.environ.get('CBINFER_ARITH', 'f16x2') == 'f16x2'
+                and os.environ.get('CBINFER_NO_SELFCOMPACT', '0') != '1'
+                and bool(C.cbinfer_split_supported(Cin, K, kH, kW))
+                and C.cbinfer_mask_words(H, W) <= C.cbinfer_split_max_mask_words(K)
+                and H * W * W < (1 << 32))
+
+    def _split_weights(self, H, W):
+        """(prepared buffer, power-of-two weight scale): max |w| * scale in [2^13, 2^14)."""
+        w = self.weight
+        key = ('split', w.data_ptr(), w._version, w.device, H, W)
+        if self._wrows is None or self._wrows[0] != key:
+            K, Cin, kH, kW = w.size()
+            wmax = float(w.detach().abs().max())          # (one host sync when the weights change)
+            scale = 2.0 ** (13 - math.floor(math.log2(wmax))) if wmax > 0 and math.isfinite(wmax) else 1.0
+            wp = torch.empty(C.cbinfer_split_prepared_bytes(Cin, K, kH, kW), dtype=torch.uint8, device=w.device)
+            check(C.cbinfer_split_prep_weights(ptr(w.detach().contiguous()), ptr(wp), K, Cin, kH, kW, H, W,
+                                               scale, stream_ptr(w)))
+            self._wrows = (key, wp, scale)
+        return self._wrows[1], self._wrows[2]
+
+    def _split_workspace(self, work, H, W, dev):
+        sp = work.get('split')
+        if sp is None:
+            K, Cin, kH, kW = self.weight.size()
+            words = C.cbinfer_mask_words(H, W)
+            S = torch.empty(C.cbinfer_split_state_bytes(Cin, H, W, kH, kW), dtype=torch.uint8, device=dev)
+            check(C.cbinfer_split_state_init(ptr(S), Cin, H, W, kH, kW, stream_ptr(S)))
+            # (split-K slabs only for deep contractions: the kernels split along k from 48 stages on)
+            stages = kH * ((kW + 1) // 2) if Cin == 16 else kH * kW * (Cin // 32)
+            ws = torch.zeros(C.cbinfer_split_workspace_bytes(), dtype=torch.uint8, device=dev) if stages >= 48 \
+                else None
+            sp = work['split'] = dict(S=S, flag=torch.zeros(1, dtype=torch.int32, device=dev),
+                                      copy=torch.zeros(words, dtype=torch.int64, device=dev), ws=ws,
+                                      stateKey=None, seq=(_lib.SplitSeq * 1)())
+        return sp
+
+    def rangeExceeded(self):
+        """True if a state value ever left the range of the split-state arithmetic (|x| >= 2^20): the layer's
+        outputs are then not meaningful (one host sync).  Use exactF32 or CBINFER_ARITH=bf16x3 for such data."""
+        sp = self._work.get('split') if self._work else None
+        return bool(sp is not None and int(sp['flag'].item()) != 0)
+
+    def _forward_split(self, src, lazy, work):
+        """One frame on the split-state kernels: detection (+ pooling) + refresh of prevInput and of its pre-split
+        copy, then the LDS-DMA contraction.  `src` is the layer input, or the pool's input when `lazy`."""
+        K, Cin, kH, kW = self.weight.size()
+        H, W = self.prevInput.size(-2), self.prevInput.size(-1)
+        dev = src.device
+        sp = self._split_workspace(work, H, W, dev)
+        wp, scale = self._split_weights(H, W)
+        prev = self.prevInput
+        stateKey = (prev.data_ptr(), prev._version)
+        rebuilt = sp['stateKey'] != stateKey
+        if rebuilt:
+            # first frame, or prevInput was (re)allocated or written by somebody else (restored states,
+            # eval03.py:88-95): the pre-split copy is made again from it
+            check(C.cbinfer_split_state_rebuild(ptr(prev), ptr(sp['S']), Cin, H, W, kH, kW, ptr(sp['flag']),
+                                                stream_ptr(src)))
+            sp['stateKey'] = stateKey
+        pmask = None
+        if lazy is not None:
+            sameTh = self.__dict__.get('_pmaskThreshold') == float(self.threshold)
+            self.__dict__['_pmaskThreshold'] = float(self.threshold)
+            pmask = None if (rebuilt or not sameTh) else lazy.producerMask()
+        q = sp['seq'][0]
+        q.input, q.state, q.splitState = src.data_ptr(), prev.data_ptr(), sp['S'].data_ptr()
+        q.frameMasks, q.producerMask = work['bits'].data_ptr(), ptr(pmask)
+        q.output, q.idxOut, q.countOut = self.prevOutput.data_ptr(), work['idx'].data_ptr(), work['count'].data_ptr()
+        q.rangeFlag, q.maskCopy = sp['flag'].data_ptr(), sp['copy'].data_ptr()
+        args = [sp['seq'], 1, int(lazy is not None), src.size(-2) if lazy is not None else 0,
+                src.size(-1) if lazy is not None else 0, ptr(wp), ptr(self.bias.detach()), Cin, H, W, K, kH, kW,
+                float(self.threshold), float(scale), int(bool(self.withReLU)), ptr(sp['ws']), stream_ptr(src)]
+        check(C.cbinfer_split_forward(*args))
+        self._inputIsLiveState = False
+        self._lastIndexes = MaskChangeIndexes(sp['copy'], (H, W), work['idx'], work['count'], made=True)
+        w, b = self._parameters.get('weight'), self._parameters.get('bias')
+        if (w is not None and b is not None and not self.gatherComputationStats and
+                os.environ.get('CBINFER_NO_FASTPATH', '0') != '1'):
+            self._plan = dict(
+                split=True, pooled=lazy is not None, shape=tuple(src.shape), dtype=src.dtype, device=dev,
+                flags=self._flags(), w=(w.data_ptr(), w._version), b=(b.data_ptr(), b._version),
+                state=(self._buffers['prevInput'].data_ptr(), self._buffers['prevOutput'].data_ptr()),
+                stateVersion=prev._version, stream=args[-1], work=work, args=args, seq=q, pmask=ptr(pmask),
+                indexes=self._lastIndexes)
+        if self.propChangeIndexes:
+            return 'changeIndexes', self.prevOutput, self._lastIndexes
+        return self.prevOutput
+
+    def _run_split_plan(self, inp):
+        plan = self._plan
+        if plan['pooled']:
+            if type(inp) is not LazyPool:
+                return None
+            src = inp.source
+            pm = inp.producerMask()
+            if (pm.data_ptr() if pm is not None else None) != plan['pmask']:
+                return None
+        else:
+            if type(inp) is not torch.Tensor:
+                return None
+            src = inp
+        w, b, bufs = self._parameters['weight'], self._parameters['bias'], self._buffers
+        prev = bufs['prevInput']
+        if (src.shape != plan['shape'] or src.dtype != plan['dtype'] or src.device != plan['device'] or
+                not src.is_contiguous() or self._flags() != plan['flags'] or
+                (w.data_ptr(), w._version) != plan['w'] or (b.data_ptr(), b._version) != plan['b'] or
+                (prev.data_ptr(), bufs['prevOutput'].data_ptr()) != plan['state'] or
+                prev._version != plan['stateVersion'] or
+                self._work is not plan['work'] or raw_stream(src.device.index) != plan['stream']):
+            return None
+        plan['seq'].input = src.data_ptr()
+        status = C.cbinfer_split_forward(*plan['args'])
+        if status != 0:
+            check(status)
+        self._inputIsLiveState = False
+        self._lastIndexes = plan['indexes']
+        if self.propChangeIndexes:
+            return 'changeIndexes', bufs['prevOutput'], self._lastIndexes
+        return bufs['prevOutput']
+
     def _workspace(self, input, wantMap=None):
         H, W = input.size(-2), input.size(-1)
         # self-compacting frame pipeline (detection + fused kernel, no compaction launch): mask small
@@ -321,7 +454,9 @@ class CBConv2d(nn.Module):
                 count=torch.zeros(1, dtype=torch.int32, device=dev),
                 conv=conv, map=None,
                 # row-segment contraction (cbinfer_conv_changed_rows): single mask, arrival counters, mask copy
-                rows=None)
+                rows=None,
+                # split-state frame (cbinfer_split_forward): pre-split state copy, range flag, mask copy, slabs
+                split=None)
         if wantMap and self._work['map'] is None:
             self._work['map'] = torch.zeros(H, W, dtype=torch.int8, device=input.device)
         return self._work
@@ -518,6 +653,8 @@ class CBConv2d(nn.Module):
         if not work['selfc']:
             return self.forward_normal(lazy.tensor())
         K, Cin, kH, kW = self.weight.size()
+        if self._split_ok(src.dtype, H, W):
+            return self._forward_split(src, lazy, work)
         path = self._rows_path(src.dtype, H, W)
         if path:
             rows = self._rows_workspace(work, H, W, src.device)
@@ -587,6 +724,9 @@ class CBConv2d(nn.Module):
         if not prev.is_contiguous():
             prev = self.prevInput = prev.contiguous()
         mapOut = work['map'] if (self.saveChangeMap and not have) else None
+        if not have and work['selfc'] and self._split_ok(input.dtype, H, W):
+            self._forward_split(input, None, work)
+            return self._lastIndexes
         path = self._rows_path(input.dtype, H, W) if (not have and work['selfc']) else None
         if path:
             rows = self._rows_workspace(work, H, W, input.device)
@@ -691,6 +831,8 @@ class CBConv2d(nn.Module):
 
     def _run_plan(self, inp):
         plan = self._plan
+        if plan.get('split'):
+            return self._run_split_plan(inp)
         if plan['pooled']:
             if type(inp) is not LazyPool:
                 return None

@@ -65,10 +65,10 @@ class MaskChangeIndexes(ChangeIndexes):
     sync) -- a frame none of whose consumers wants the list never pays for it.  Valid until the producing
     layer's next frame."""
 
-    def __init__(self, maskCopy, size, idxBuffer, countBuffer):
+    def __init__(self, maskCopy, size, idxBuffer, countBuffer, made=False):
         self._mask, self.size = maskCopy, tuple(size)
         self._idx, self._cnt = idxBuffer, countBuffer
-        self._made = False
+        self._made = made       # (True: the frame's kernel already left list and count in the buffers)
 
     def _make(self):
         if not self._made:

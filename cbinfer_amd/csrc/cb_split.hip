@@ -1,0 +1,1072 @@
+// Split-state change-based convolution for gfx950 (round 3): the fused a1 + a5..a8 path of a feedback-mode
+// CBConv2d (conv2d.py:178-259; kernels cbconv2d_cg_backend.cu:40-81, :138-197) for layers of 16/32/64 input
+// channels, built around ONE idea: the layer state is kept a second time in exactly the form the matrix
+// cores eat.
+//
+//   state    beside prevInput [C,H,W] f32 (the module's buffer, unchanged), a pixel-major PRE-SPLIT copy
+//            S[Hp][Wp][C/16][hi|lo][16] of f16 pairs: x * 2^-4 = hi + lo * 2^-11 (22 significant bits; the
+//            detection kernel refreshes both at the changed pixels only -- feedback mode).  S has a zero
+//            border of the filter's half size, so a tap needs no bounds test, and a block of zero rows that
+//            list slots past the end point at.
+//   weights  pre-split the same way (power-of-two scale to [2^13, 2^14)), stored in MFMA fragment order per
+//            32-k stage, so a stage of an m-tile is one contiguous piece of memory.
+//   gather   both operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), 1 KB per wave
+//            instruction, no register staging, no vector ALU work and no LDS store traffic per k: a pixel's
+//            stage is 128 contiguous bytes of its record (two 16-channel groups of one tap, or -- 16 channels
+//            -- two x-adjacent taps), fetched by 8 lanes; an XOR swizzle of the 16-byte chunks makes the
+//            ds_read_b128 fragment reads of the [pixel][128 B] image conflict-free.
+//   product  v_mfma_f32_32x32x16_f16, three per 16 k: hi.hi into one accumulator, hi.lo + lo.hi into a
+//            second one (scaled 2^-11 at the end).  Error per product <= 3 * 2^-22 |a||b| -- within the
+//            bound tests/test_gpu_ops.py::test_split_contraction_accuracy holds the bf16x3 form to -- at
+//            HALF the matrix work and two thirds of the operand bytes of bf16x3.
+//   ring     four LDS stage buffers, three stages of DMA in flight, one s_barrier per stage, waits counted by
+//            hand (s_waitcnt vmcnt(N): the compiler does not track LDS-DMA against LDS reads).
+//   schedule persistent grid over (pixel tile, m-tile, k-slice) items of up to CBS_MAXSEQ independent sequences
+//            in ONE launch (blockIdx carries no meaning: each workgroup derives every sequence's list length
+//            from its change mask); a short list is split along k, slices meet in a second launch.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "cb_common.h"
+
+namespace cbs {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* cb_lds_ptr;
+typedef __attribute__((address_space(4))) const int cbs_const_int;
+
+#define CBS_MAXSEQ CBINFER_SPLIT_MAX_SEQUENCES
+#define CBS_XSCALE 0.0625f            // activations are stored as x * 2^-4 (range up to 2^20, see header)
+#define CBS_XSCALE_INV 16.f
+#define CBS_LO 2048.f                 // lo terms carry a factor 2^11
+#define CBS_F16_MINNORM 6.103515625e-05f
+#define CBS_F16_MAX 65504.f
+#define CBS_RING 4
+#define CBS_SPAD 4096                 // bytes in front of the records of a split state (see cbs_dma16: negative offsets)
+#define CBS_PRE_BIG 1536              // mask words of all sequences of a launch: 128-row tile
+#define CBS_PRE_SMALL 1280            // ... 64-row tile, two workgroups per CU
+#define CBS_PRE_MID 5120              // ... 64-row tile, one workgroup per CU
+#define CBS_SKMAX 16
+
+// ---------------------------------------------------------------------------------------------------
+// geometry of the split state / stage list (host and device)
+// ---------------------------------------------------------------------------------------------------
+struct CbsGeom {
+    int C, G, H, W, kH, kW;
+    int padY, padXL, padXR, Wp, Hp, rec;
+    int pair, kWs, nStages;
+    int dummyBase;      // byte offset of the top-left tap record of the all-zero dummy pixel
+};
+
+__host__ __device__ inline CbsGeom cbs_geom(int C, int H, int W, int kH, int kW) {
+    CbsGeom g;
+    g.C = C, g.G = C / 16, g.H = H, g.W = W, g.kH = kH, g.kW = kW;
+    g.padY = kH / 2, g.padXL = kW / 2;
+    g.pair = g.G == 1;                      // 16 channels: a stage is two x-adjacent taps
+    g.kWs = g.pair ? (kW + 1) / 2 : kW;     // stage columns per filter row
+    g.padXR = g.pair ? 2 * g.kWs - 1 - g.padXL : kW / 2;
+    g.Wp = W + g.padXL + g.padXR;
+    g.Hp = H + 4 * g.padY + 1;              // image + border, then 2 padY + 1 zero rows for the dummy pixel
+    g.rec = g.G * 64;
+    g.nStages = g.pair ? kH * g.kWs : kH * kW * (g.G / 2);
+    g.dummyBase = ((H + 2 * g.padY) * g.Wp) * g.rec;
+    return g;
+}
+
+inline bool cbs_supported(int C, int K, int kH, int kW) {
+    return (C == 16 || C == 32 || C == 64) && K >= 1 && K <= 1024 && (kH & 1) && (kW & 1) && kH <= 15 && kW <= 15 &&
+           cbs_geom(C, 64, 64, kH, kW).nStages >= 4;
+}
+inline int cbs_bm(int K) { return K <= 64 ? 64 : 128; }
+inline int cbs_kp(int K) { const int bm = cbs_bm(K); return (K + bm - 1) / bm * bm; }
+
+// x (already scaled) = hi + lo / 2^11 with f16 hi, lo.  Terms that would be f16 subnormals are dropped to zero
+// BEFORE the residual is formed, so the result does not depend on whether the matrix unit flushes them.
+__device__ __forceinline__ void cbs_split(float x, _Float16& hi, _Float16& lo) {
+    const _Float16 h = fabsf(x) < CBS_F16_MINNORM ? (_Float16)0 : (_Float16)x;
+    const float r = (x - (float)h) * CBS_LO;          // exact difference, exact scaling
+    hi = h;
+    lo = fabsf(r) < CBS_F16_MINNORM ? (_Float16)0 : (_Float16)r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weights: [stage][row tile of 32][k-step][plane][lane][8 f16] (MFMA A-fragment order) + the stage table
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cbs_prep_kernel(const float* __restrict__ w, halfx8* __restrict__ A,
+                                                      int* __restrict__ stageOff, CbsGeom g, int K, int KP,
+                                                      float wscale) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < g.nStages) {
+        const int s = (int)idx;
+        int off;
+        if (g.pair) {
+            off = ((s / g.kWs) * g.Wp + 2 * (s % g.kWs)) * g.rec;
+        } else {
+            const int tap = s / (g.G / 2), sub = s % (g.G / 2);
+            off = ((tap / g.kW) * g.Wp + tap % g.kW) * g.rec + sub * 128;
+        }
+        stageOff[s] = off;
+    }
+    const int RT = KP / 32;
+    const long total = (long)g.nStages * RT * 4 * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const long blk = idx >> 6;
+    const int plane = (int)(blk & 1), ks = (int)((blk >> 1) & 1);
+    const int rt = (int)((blk >> 2) % RT), stage = (int)((blk >> 2) / RT);
+    const int m = rt * 32 + (lane & 31);
+    halfx8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int kl = 8 * (lane >> 5) + j;
+        int ky, kx, c;
+        if (g.pair) {
+            ky = stage / g.kWs, kx = 2 * (stage % g.kWs) + ks, c = kl;
+        } else {
+            const int tap = stage / (g.G / 2), sub = stage % (g.G / 2);
+            ky = tap / g.kW, kx = tap % g.kW, c = (sub * 2 + ks) * 16 + kl;
+        }
+        float v = 0.f;
+        if (m < K && kx < g.kW) v = w[(((long)m * g.C + c) * g.kH + ky) * g.kW + kx] * wscale;
+        _Float16 hi, lo;
+        cbs_split(v, hi, lo);
+        o[j] = plane ? lo : hi;
+    }
+    A[idx] = o;
+}
+
+// split state: zero everywhere, +inf (hi plane) at the image pixels -- the f32 state starts as +inf
+// (conv2d.py:192-199), and a pixel the detection never refreshes must not contribute finite numbers either
+__global__ __launch_bounds__(256) void cbs_state_init_kernel(uint4* __restrict__ S, CbsGeom g) {
+    const long chunks = (long)g.Hp * g.Wp * (g.rec / 16);
+    if (blockIdx.x == 0) S[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);     // the CBS_SPAD bytes in front (256 x 16)
+    S += CBS_SPAD / 16;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / (g.rec / 16);
+        const int q = (int)(i % (g.rec / 16));        // chunk within the record: [group][plane][half]
+        const int py = (int)(pix / g.Wp), px = (int)(pix % g.Wp);
+        const bool inside = py >= g.padY && py < g.padY + g.H && px >= g.padXL && px < g.padXL + g.W;
+        const bool hiPlane = ((q >> 1) & 1) == 0;
+        const unsigned v = (inside && hiPlane) ? 0x7c007c00u : 0u;
+        S[i] = make_uint4(v, v, v, v);
+    }
+}
+
+// the split state made again from the f32 state (after the module's prevInput was written from outside: a restored
+// state, eval03.py:88-95): one thread per (pixel, 8-channel part); the border and the dummy rows are left alone
+__global__ __launch_bounds__(256) void cbs_state_rebuild_kernel(const float* __restrict__ state, char* __restrict__ S,
+                                                               CbsGeom g, int* rangeFlag) {
+    const long HW = (long)g.H * g.W;
+    const int parts = g.C / 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW * parts; i += (long)gridDim.x * blockDim.x) {
+        const int part = (int)(i / HW);
+        const long pix = i % HW;                       // (consecutive threads: consecutive pixels of one channel)
+        const int y = (int)(pix / g.W), x = (int)(pix % g.W);
+        const int grp = part >> 1, half = part & 1;
+        halfx8 hi, lo;
+        bool over = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = state[(long)(grp * 16 + half * 8 + j) * HW + pix] * CBS_XSCALE;
+            over |= !(fabsf(v) <= CBS_F16_MAX) && v == v && fabsf(v) != INFINITY;
+            _Float16 h, l;
+            cbs_split(v, h, l);
+            if (fabsf(v) == INFINITY) l = (_Float16)0;     // the initial +inf state: as cbs_state_init_kernel leaves it
+            hi[j] = h, lo[j] = l;
+        }
+        char* rec = S + CBS_SPAD + ((long)(y + g.padY) * g.Wp + (x + g.padXL)) * g.rec + grp * 64 + half * 16;
+        *(halfx8*)rec = hi;
+        *(halfx8*)(rec + 32) = lo;
+        if (over && rangeFlag) *rangeFlag = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// change detection (+ 2x2 max pool folded in) + dilation + feedback refresh of BOTH states
+// ---------------------------------------------------------------------------------------------------
+struct CbsDetSeq {
+    const float* in;                      // [C,H,W], or with POOL the pool's input [C,pH,pW]
+    float* state;                         // prevInput [C,H,W]
+    char* S;                              // split state
+    unsigned long long* masks;            // frame mask: [words], zeroed by the contraction (cbSplitSeq.frameMasks)
+    const unsigned long long* prodMask;   // POOL: the producing layer's change mask of this frame, or null
+    int* rangeFlag;                       // set to 1 when a refreshed value leaves the f16 pair's range
+};
+struct CbsDetArgs {
+    CbsDetSeq seq[CBS_MAXSEQ];
+    int W, H, C, kHH, kWH, wpr, pH, pW, Wp, rec, padY, padXL;
+    long words;
+    float th;
+};
+
+__device__ __forceinline__ unsigned long long cbs_valid_mask(int W, int tile) {
+    const int rem = W - tile * 64;
+    return rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+}
+
+// One workgroup = one 64-pixel row segment x all channels of one sequence (blockIdx.z); wave g owns channels
+// g, g+G, g+2G, g+3G (G = C/4 waves).  Decomposition, predicate (strict >, cbconv2d_cg_backend.cu:56), dilation
+// and producer-mask shortcut are cb_detect_kernel's (cb_detect.hip); what is new is the second state: the new
+// values of the segment go through LDS ([channel][pixel]) and come out as whole pixel records, 16 bytes per
+// lane, for the changed pixels only.
+template <bool POOL>
+__global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
+    const CbsDetSeq sq = a.seq[blockIdx.z];
+    const int W = a.W, H = a.H, C = a.C, pH = a.pH, pW = a.pW;
+    if (POOL && sq.prodMask) {
+        const int pwpr = (pW + 63) >> 6;
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int yy = 2 * (int)blockIdx.y + j, ww = 2 * (int)blockIdx.x + i;
+                if (yy < pH && ww < pwpr) any |= sq.prodMask[(long)yy * pwpr + ww];
+            }
+        if (__builtin_amdgcn_readfirstlane((int)(any != 0ull)) == 0) return;
+    }
+    unsigned long long* bits = sq.masks;      // (single mask: the contraction zeroes it once every workgroup has it)
+    const int lane = threadIdx.x & 63;
+    const int g = threadIdx.x >> 6;
+    const int G = blockDim.x >> 6;
+    const int tx = blockIdx.x, y = blockIdx.y;
+    const int x = tx * 64 + lane;
+    const bool valid = x < W;
+    const long HW = (long)H * W;
+    const long p = (long)y * W + x;
+    const float* __restrict__ in = sq.in;
+    float* state = sq.state;
+
+    const long pHW = (long)pH * pW;
+    const int py0 = 2 * y, px0 = 2 * x;
+    const bool inner = POOL && py0 + 1 < pH && px0 + 1 < pW;
+    auto ldin = [&](int c) -> float {
+        if (!POOL) return in[(long)c * HW + p];
+        const float* q = in + (long)c * pHW + (long)py0 * pW + px0;
+        if (inner) return fmaxf(fmaxf(q[0], q[1]), fmaxf(q[pW], q[pW + 1]));
+        float v = q[0];
+        if (px0 + 1 < pW) v = fmaxf(v, q[1]);
+        if (py0 + 1 < pH) {
+            v = fmaxf(v, q[pW]);
+            if (px0 + 1 < pW) v = fmaxf(v, q[pW + 1]);
+        }
+        return v;
+    };
+
+    // C == 4 G: four channels per wave, eight independent loads in flight per lane
+    bool chg = false;
+    float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f;
+    if (valid) {
+        const float s0 = state[(long)g * HW + p], x0 = ldin(g);
+        const float s1 = state[(long)(g + G) * HW + p], x1 = ldin(g + G);
+        const float s2 = state[(long)(g + 2 * G) * HW + p], x2 = ldin(g + 2 * G);
+        const float s3 = state[(long)(g + 3 * G) * HW + p], x3 = ldin(g + 3 * G);
+        chg = cb_changed(s0, x0, a.th) | cb_changed(s1, x1, a.th) | cb_changed(s2, x2, a.th) |
+              cb_changed(s3, x3, a.th);
+        k0 = x0, k1 = x1, k2 = x2, k3 = x3;
+    }
+
+    __shared__ unsigned long long sm[16];
+    __shared__ float T[64][65];
+    const unsigned long long b = __ballot(chg);
+    if (lane == 0) sm[g] = b;
+    __syncthreads();
+    unsigned long long m = 0;
+    for (int i = 0; i < G; ++i) m |= sm[i];
+    if (m == 0) return;   // uniform over the workgroup
+
+    // feedback: refresh the f32 state at the (pre-dilation) changed pixels only (.cu:74-80) ...
+    if ((m >> lane) & 1ull) {
+        state[(long)g * HW + p] = k0;
+        state[(long)(g + G) * HW + p] = k1;
+        state[(long)(g + 2 * G) * HW + p] = k2;
+        state[(long)(g + 3 * G) * HW + p] = k3;
+    }
+    // ... and the split state: [channel][pixel] through LDS, out as records
+    T[g][lane] = k0;
+    T[g + G][lane] = k1;
+    T[g + 2 * G][lane] = k2;
+    T[g + 3 * G][lane] = k3;
+    __syncthreads();
+    {
+        const int parts = C / 8;                 // 8-channel parts per pixel: (group, half)
+        const int t = threadIdx.x;
+        if (t < 64 * parts) {
+            const int pl = t / parts, part = t % parts;
+            if (((m >> pl) & 1ull) != 0ull) {
+                const int grp = part >> 1, half = part & 1;
+                halfx8 hi, lo;
+                bool over = false;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = T[grp * 16 + half * 8 + j][pl] * CBS_XSCALE;
+                    over |= !(fabsf(v) <= CBS_F16_MAX);
+                    _Float16 h, l;
+                    cbs_split(v, h, l);
+                    hi[j] = h, lo[j] = l;
+                }
+                char* rec = sq.S + CBS_SPAD + ((long)(y + a.padY) * a.Wp + (tx * 64 + pl + a.padXL)) * a.rec + grp * 64 +
+                            half * 16;
+                *(halfx8*)rec = hi;
+                *(halfx8*)(rec + 32) = lo;
+                if (over && sq.rangeFlag) *sq.rangeFlag = 1;
+            }
+        }
+    }
+
+    // dilation of the 64-pixel word (+ the parts spilling into the neighbour words), ORed into the frame mask
+    unsigned long long D = m, SR = 0, SL = 0;
+    for (int d = 1; d <= a.kWH; ++d) {
+        D |= (m << d) | (m >> d);
+        SR |= m >> (64 - d);
+        SL |= m << (64 - d);
+    }
+    D &= cbs_valid_mask(W, tx);
+    SR = (tx + 1 < a.wpr) ? (SR & cbs_valid_mask(W, tx + 1)) : 0ull;
+    if (tx == 0) SL = 0;
+    if (g == 0) {
+        const int items = 3 * (2 * a.kHH + 1);
+        for (int i = lane; i < items; i += 64) {
+            const int yy = y + i / 3 - a.kHH;
+            const int which = i % 3;
+            if (yy < 0 || yy >= H) continue;
+            const unsigned long long v = which == 0 ? D : (which == 1 ? SR : SL);
+            const int t2 = which == 0 ? tx : (which == 1 ? tx + 1 : tx - 1);
+            if (v) atomicOr(&bits[(long)yy * a.wpr + t2], v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the contraction
+// ---------------------------------------------------------------------------------------------------
+struct CbsSeq {
+    const char* S;
+    float* out;                       // prevOutput [K,H,W]
+    unsigned long long* masks;        // frame masks
+    int32_t* listOut;                 // change list (by-product), capacity H*W
+    int32_t* countOut;
+    unsigned long long* maskCopy;     // optional: this frame's change mask, at a fixed address
+};
+struct CbsParams {
+    CbsSeq seq[CBS_MAXSEQ];
+    int nSeq;
+    const char* A;                    // prepared weights
+    const int* stageOff;
+    const float* bias;
+    float* slabs;                     // split-K workspace: slabCap partial tiles of BM x BN floats
+    int* info;                        // left for the reduce launch: {SK, MT, nSeq, tilesP[q]..., N[q]...}
+    int slabCap;
+    int K, KP, H, W, Wp, rec, nStages, maskWords, wpr, relu, dummyBase;
+    long stateBytes, aBytes;
+    float outScale;
+    unsigned long long magicMW, magicWpr, magicW;   // floor(2^32 / d) + 1: x / d = (x * magic) >> 32 for x d < 2^32
+    int forceSK;                      // > 0: tuning / test aid
+    int dbg;                          // diagnostic ablations (builds with -DCBS_DBG only; CBINFER_SPLIT_DBG)
+};
+// diagnostic ablations are a build option (make EXTRA=-DCBS_DBG; tools/split_dbg_run.sh): 1 every pixel-operand
+// DMA reads the dummy pixel, 2 no fragment reads / MFMAs, 4 no DMA at all, 8 no pixel-operand fragment reads,
+// 16 no weight fragment reads, 32 no epilogue stores
+#ifdef CBS_STAMP
+// diagnostic build only (make EXTRA=-DCBS_STAMP; tools/split_stamps.py): per-workgroup phase stamps of its FIRST item,
+// 100 MHz constant clock: 0 entry, 1 list lengths known, 2 item set up, 3 ring primed, 4 stage loop done, 5 epilogue
+// done; 6 / 7: shader clock (s_memtime) at entry / after the stage loop
+__device__ unsigned long long cbs_stamp_buf[2048 * 8];
+#define CBS_STAMP_AT(i)                                                                                   \
+    do {                                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x < 2048 && cbs_first)                                           \
+            cbs_stamp_buf[blockIdx.x * 8 + (i)] = (i) >= 6 ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define CBS_STAMP_AT(i)
+#endif
+#ifdef CBS_DBG
+#define CBS_DBGBIT(b) (p.dbg & (b))
+#else
+#define CBS_DBGBIT(b) false
+#endif
+#define CBS_INFO_SK 0
+#define CBS_INFO_MT 1
+#define CBS_INFO_TP 4                  // tilesP[q] (pixel tiles of sequence q), then N[q]
+
+// One LDS-DMA instruction: every lane moves 16 bytes from (resource base + voff + soff) to lds + 16 * lane.
+// A NON-template wrapper on purpose: inside a kernel template the target builtin is a dependent call that the HOST
+// pass of the compilation cannot resolve, and clang then drops the kernel's host stub without a diagnostic.
+// OFF (immediate, < 4096) is added to the LDS address AND to the memory address.
+template <int OFF>
+__device__ __forceinline__ void cbs_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (cb_lds_ptr)lds, 16, voff, soff, OFF, 0);
+}
+
+// A fragment read the COMPILER DOES NOT SEE as an LDS access: it would otherwise put a full s_waitcnt vmcnt(0) in
+// front of every read that may alias an LDS-DMA in flight -- i.e. drain the ring every stage.  The result
+// registers are valid only behind an s_waitcnt lgkmcnt that names them (CBS_STEP's wait does).
+template <int OFF>
+__device__ __forceinline__ halfx8 cbs_lds_read16(unsigned addr) {
+    halfx8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+// x / d for x d < 2^32 by the precomputed magic = floor(2^32 / d) + 1 (a 64-bit product: d = 1 included)
+__device__ __forceinline__ int cbs_div(int x, unsigned long long magic) {
+    return (int)(((unsigned long long)(unsigned)x * magic) >> 32);
+}
+
+__device__ __forceinline__ int cbs_select_bit(unsigned long long w, int r) {
+    int pos = 0;
+#pragma unroll
+    for (int width = 32; width >= 1; width >>= 1) {
+        const unsigned long long lowmask = ((1ull << width) - 1ull) << pos;
+        const int c = __popcll(w & lowmask);
+        if (r >= c) {
+            r -= c;
+            pos += width;
+        }
+    }
+    return pos;
+}
+
+// BM x BN output tile per workgroup, WM x WN waves, each wave TN = BN/WN/32 column tiles of one 32-row tile.
+template <int BM, int BN, int WM, int WN, int PRE_CAP>
+__global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
+    constexpr int NW = WM * WN, NT = 64 * NW;
+    constexpr int TN = BN / WN / 32;
+    static_assert(BM == 32 * WM, "one 32-row tile per wave");
+    constexpr int ABLK = BM / 8, BBLK = BN / 8;          // 1-KB DMA blocks per stage
+    constexpr int APW = ABLK / NW, BPW = BBLK / NW;      // ... per wave
+    static_assert(APW * NW == ABLK && BPW * NW == BBLK && APW >= 1 && BPW >= 1, "DMA blocks must deal evenly");
+    constexpr int DPW = APW + BPW;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int TILE = BM * BN;
+    // static LDS (a workgroup may declare up to 160 KB without any opt-in): CBS_RING stages, then the mask words
+    // of ALL sequences of the launch and their popcount prefix (one scan).  PRE_CAP = capacity in words: the
+    // 64-row tile comes in two sizes, the smaller one leaves room for two workgroups per CU.
+    constexpr bool MASK_LDS = true;
+    __shared__ __attribute__((aligned(1024))) char ring[CBS_RING * STAGE];
+    __shared__ int s_pre[PRE_CAP + 1];
+    __shared__ unsigned long long s_mask[PRE_CAP];
+    __shared__ const unsigned long long* s_maskPtr[CBS_MAXSEQ];
+    __shared__ int s_wsum[NW];
+    __shared__ int s_tilePix[BN];
+    __shared__ float s_bias[BM];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int MW = p.maskWords, MT = p.KP / BM;
+#ifdef CBS_STAMP
+    bool cbs_first = true;
+#endif
+    CBS_STAMP_AT(0);
+    CBS_STAMP_AT(6);
+
+    // ---- every workgroup: change-list lengths of all sequences from their masks, ONE scan ------------
+    // (per-sequence facts live in small LDS tables, not in registers: eight sequences' worth of scalars would
+    //  crowd out the kernel's own)
+    __shared__ int s_seqN[CBS_MAXSEQ], s_seqRank[CBS_MAXSEQ], s_seqTile[CBS_MAXSEQ + 1];
+    // Mask protocol (single mask per sequence): the detection ORs into it; here every workgroup takes a copy into
+    // LDS, and the workgroup that learns -- from an arrival counter behind the mask -- that it was the LAST to do so
+    // zeroes the mask for the next frame's detection.  Nobody waits; the next launch finds it clean.
+    for (int q = t; q < p.nSeq; q += NT) s_maskPtr[q] = p.seq[q].masks;
+    __syncthreads();
+    const int E = p.nSeq * MW;
+    for (int i = t; i < E; i += NT) {
+        const int q = cbs_div(i, p.magicMW), w = i - q * MW;
+        const unsigned long long word = s_maskPtr[q][w];
+        s_pre[i] = __popcll(word);
+        s_mask[i] = word;
+    }
+    __syncthreads();      // (every load of this workgroup has returned: its values are in LDS)
+    if (t == 0) {
+        int* ctl = (int*)(p.seq[0].masks + 2 * (long)MW);
+        s_wsum[0] = __hip_atomic_fetch_add(ctl + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int q = 0; q < p.nSeq; ++q) {      // this launch also leaves a copy of the frame's masks at a fixed address
+        unsigned long long* copy = p.seq[q].maskCopy;
+        if (copy)
+            for (int i = blockIdx.x * NT + t; i < MW; i += gridDim.x * NT) copy[i] = s_mask[q * MW + i];
+    }
+    __syncthreads();
+    if (s_wsum[0] == (int)gridDim.x - 1) {      // last arriver (uniform over the workgroup)
+        for (int i = t; i < E; i += NT) {
+            const int q = cbs_div(i, p.magicMW), w = i - q * MW;
+            ((unsigned long long*)s_maskPtr[q])[w] = 0ull;
+        }
+        if (t == 0) {
+            int* ctl = (int*)(p.seq[0].masks + 2 * (long)MW);
+            __hip_atomic_store(ctl + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();      // (s_wsum is reused by the scan)
+    {
+        const int CH = (E + NT - 1) / NT, wb = t * CH;
+        int loc = 0;
+        for (int u = 0; u < CH; ++u)
+            if (wb + u < E) loc += s_pre[wb + u];
+        int incl = loc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) s_wsum[t >> 6] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (t >> 6); ++w) base += s_wsum[w];
+        int run = base + incl - loc;
+        for (int u = 0; u < CH; ++u) {
+            const int w = wb + u;
+            if (w < E) {
+                const int c = s_pre[w];
+                s_pre[w] = run;
+                run += c;
+            }
+        }
+        if (t == NT - 1) s_pre[E] = base + incl;
+        __syncthreads();
+    }
+    if (t == 0) {
+        int tiles = 0;
+        for (int q = 0; q < p.nSeq; ++q) {
+            const int rb = s_pre[q * MW], n = s_pre[(q + 1) * MW] - rb;
+            s_seqRank[q] = rb, s_seqN[q] = n, s_seqTile[q] = tiles;
+            tiles += (n + BN - 1) / BN;
+            if (blockIdx.x == 0) p.seq[q].countOut[0] = n;
+        }
+        s_seqTile[p.nSeq] = tiles;
+    }
+    __syncthreads();
+    CBS_STAMP_AT(1);
+    const int TP = __builtin_amdgcn_readfirstlane(s_seqTile[p.nSeq]);         // pixel tiles of all sequences
+    // split along k while whole CUs would idle and the k-depth pays for the slab round trip
+    int SK = 1;
+    if (p.slabs && TP > 0 && p.nStages >= 48) {
+        SK = (int)gridDim.x / (TP * MT);
+        SK = max(1, min(SK, min(CBS_SKMAX, p.nStages / 6)));
+        while (SK > 1 && TP * MT * SK > p.slabCap) --SK;
+    }
+    if (p.forceSK > 0 && p.slabs) SK = max(1, min(p.forceSK, min(CBS_SKMAX, p.nStages / 6)));
+    if (SK > 1 && TP * MT * SK > p.slabCap) SK = 1;
+    const int CMB = MT * SK, items = TP * CMB;
+    if (blockIdx.x == 0 && t == 0 && p.info) {
+        p.info[CBS_INFO_SK] = SK;
+        p.info[CBS_INFO_MT] = MT;
+        p.info[2] = p.nSeq;
+        for (int q = 0; q < CBS_MAXSEQ; ++q) {
+            p.info[CBS_INFO_TP + q] = q < p.nSeq ? s_seqTile[q + 1] - s_seqTile[q] : 0;
+            p.info[CBS_INFO_TP + CBS_MAXSEQ + q] = q < p.nSeq ? s_seqN[q] : 0;
+        }
+    }
+
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.A, 0, (int)min(p.aBytes, (long)0x7fffffff), 0x00020000);
+    cbs_const_int* stageOff = (cbs_const_int*)p.stageOff;
+    const int HW = p.H * p.W;
+    const float lo2 = 1.0f / CBS_LO;
+
+    // Stage buffer layout: every wave owns DPW = 4 consecutive KB -- its two weight blocks, then its two pixel
+    // blocks -- so that ONE value of M0 (the LDS address register of LDS-DMA) serves all four of its DMA
+    // instructions of a stage, the block being chosen by the instruction's immediate offset: one scalar write per
+    // stage instead of four.  (tools/micro/ldsdma_m0.hip: both forms -- M0 rewritten between back-to-back DMA
+    // instructions, or one M0 and immediate offsets -- place every byte correctly, also under load.)
+    //   weight block b = (row tile, k-step, plane) -> (b / APW) * 4096 + (b % APW) * 1024
+    //   pixel n: block c = n / 8                  -> (c / BPW) * 4096 + (APW + c % BPW) * 1024 + (n % 8) * 128,
+    //            chunk (k-step ks, plane pl, k-half h) at slot (ks * 4 + pl * 2 + h) ^ ((n >> 1) & 7)
+    static_assert(APW == 2 && BPW == 2, "four DMA instructions per wave and stage");
+    int aRead[4];      // this lane's A fragment of (row tile wm; e = ks * 2 + plane)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int b = wm * 4 + e;
+        aRead[e] = (b / APW) * 4096 + (b % APW) * 1024 + lane * 16;
+    }
+    int bRead[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = (wn * TN + j) * 32 + l31, c = n >> 3;
+        bRead[j] = (c / BPW) * 4096 + (APW + c % BPW) * 1024 + (n & 7) * 128 + ((h ^ ((n >> 1) & 7)) << 4);
+    }
+
+    for (int it = blockIdx.x; it < items; it += gridDim.x) {
+        const int combo = it % CMB, ptg = it / CMB;
+        const int mt = combo % MT, slice = combo / MT;
+        int q = 0;
+        for (int u = 1; u < p.nSeq; ++u)
+            if (ptg >= s_seqTile[u]) q = u;
+        q = __builtin_amdgcn_readfirstlane(q);
+        const int N = __builtin_amdgcn_readfirstlane(s_seqN[q]), rb = __builtin_amdgcn_readfirstlane(s_seqRank[q]);
+        const int n0 = (ptg - __builtin_amdgcn_readfirstlane(s_seqTile[q])) * BN, m0 = mt * BM;
+        const int sBeg = p.nStages * slice / SK, sEnd = p.nStages * (slice + 1) / SK;
+
+        // pixel of slot j of this tile = the (n0+j)-th set bit of sequence q's mask
+        __syncthreads();   // (s_tilePix and the ring of the previous item are no longer read)
+        if (t < BN) {
+            const int r = n0 + t;
+            int pos = -1;
+            if (r < N) {
+                const int R = rb + r;                       // rank in the concatenated prefix
+                int lo = q * MW, hi = lo + MW;              // largest i in [lo, hi) with s_pre[i] <= R
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_pre[mid] <= R)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                const unsigned long long word = s_mask[lo];
+                const int bit = cbs_select_bit(word, R - s_pre[lo]);
+                const int w = lo - q * MW;
+                const int row = cbs_div(w, p.magicWpr);
+                pos = row * p.W + (w - row * p.wpr) * 64 + bit;
+                if (mt == 0 && slice == 0) p.seq[q].listOut[r] = pos;
+            }
+            s_tilePix[t] = pos;
+        }
+        // (the m-tile's bias for the epilogue: requested now, put into LDS once the ring is primed)
+        const float biasv = (t < BM && p.bias && m0 + t < p.K) ? p.bias[m0 + t] : 0.f;
+        __syncthreads();
+
+        const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)p.seq[q].S, 0, (int)min(p.stateBytes + CBS_SPAD, (long)0x7fffffff), 0x00020000);
+        // DMA source offsets of this wave (the instruction's immediate offset -- i KB for its i-th DMA of a stage
+        // -- counts for the memory address too: taken off here; the pixel operand's may go negative by up to 3 KB,
+        // hence the CBS_SPAD bytes in front of the records): its APW weight blocks are contiguous in memory as in
+        // LDS, so one offset serves both; BPW pixel blocks of 8 pixels x 128 B
+        const int aVoff = wave * APW * 1024 + lane * 16;
+        int bVoff[BPW];
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const int nl = (wave * BPW + i) * 8 + (lane >> 3);
+            const int pos = s_tilePix[nl];
+            const int py = cbs_div(max(pos, 0), p.magicW);
+            const int base = (pos < 0 || CBS_DBGBIT(1)) ? p.dummyBase : (py * p.Wp + (pos - py * p.W)) * p.rec;
+            bVoff[i] = CBS_SPAD + base + (((lane & 7) ^ ((nl >> 1) & 7)) << 4) - (APW + i) * 1024;
+        }
+        const int aItem = (m0 / 32) * 4096;            // row tiles of this m-tile inside a stage
+        const int aStageBytes = (p.KP / 32) * 4096;
+
+        // (the pixel operand's stage offset comes from the table by a scalar load: requested one stage early)
+        int bNext = stageOff[sBeg];
+        auto issue = [&](int s) {      // all DMA of stage s of this wave, into ring slot s % CBS_RING
+            char* dst = ring + (s % CBS_RING) * STAGE;
+            const int aS = s * aStageBytes + aItem;
+            const int bS = bNext;
+            bNext = stageOff[min(s + 1, sEnd - 1)];
+            if (CBS_DBGBIT(4)) return;
+            char* mine = dst + wave * (DPW * 1024);      // ONE LDS base (M0) for the four
+            cbs_dma16<0>(arsrc, mine, aVoff, aS);
+            cbs_dma16<1024>(arsrc, mine, aVoff, aS);
+            cbs_dma16<2048>(brsrc, mine, bVoff[0], bS);
+            cbs_dma16<3072>(brsrc, mine, bVoff[1], bS);
+        };
+
+        floatx16 acc1[TN], acc2[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc1[j][i] = 0.f, acc2[j][i] = 0.f;
+
+        // the fragments of one stage in registers: two sets, the reads of stage s+1 run under the MFMAs of stage s
+        struct Frags {
+            halfx8 a[4];          // [ks * 2 + plane]
+            halfx8 b[TN * 4];     // [j * 4 + ks * 2 + plane]
+        };
+        const unsigned ringBase = (unsigned)(size_t)(cb_lds_ptr)ring;
+        unsigned bAddr[TN * 4];   // LDS byte address (slot 0) of this lane's B chunk [j][ks * 2 + plane]
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                bAddr[j * 4 + e] = ringBase + (bRead[j] ^ (((e >> 1) * 4 + (e & 1) * 2) << 4));
+        unsigned aAddr[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) aAddr[e] = ringBase + aRead[e];
+        auto readFrags = [&](int s, Frags& f) {
+            const unsigned slot = (s % CBS_RING) * STAGE;
+            if (CBS_DBGBIT(16)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f.a[e] = halfx8{1, 1, 1, 1, 1, 1, 1, 1};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f.a[e] = cbs_lds_read16<0>(aAddr[e] + slot);
+            }
+#pragma unroll
+            for (int e = 0; e < TN * 4; ++e) {
+                if (CBS_DBGBIT(8))
+                    f.b[e] = halfx8{1, 1, 1, 1, 1, 1, 1, 1};
+                else
+                    f.b[e] = cbs_lds_read16<0>(bAddr[e] + slot);
+            }
+        };
+        auto mma = [&](const Frags& f) {
+            if (CBS_DBGBIT(2)) return;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks * 2 + 1], f.b[j * 4 + ks * 2], acc2[j], 0, 0, 0);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks * 2], f.b[j * 4 + ks * 2 + 1], acc2[j], 0, 0, 0);
+                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks * 2], f.b[j * 4 + ks * 2], acc1[j], 0, 0, 0);
+                }
+        };
+        // s_waitcnt lgkmcnt(0) that NAMES the fragment registers it makes valid (in/out operands): nothing that
+        // consumes them can be scheduled in front of it
+        auto waitFrags = [&](Frags& f) {
+            if constexpr (TN == 2)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]),
+                               "+v"(f.b[2]), "+v"(f.b[3]), "+v"(f.b[4]), "+v"(f.b[5]), "+v"(f.b[6]), "+v"(f.b[7])
+                             :
+                             : "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]),
+                               "+v"(f.b[2]), "+v"(f.b[3])
+                             :
+                             : "memory");
+        };
+        // One step = stage s multiplied from registers while stage s+1 is read into the other set.  Before that,
+        // everything but the two youngest stages of this wave's DMA must have landed (vmcnt counts its DMA
+        // instructions, DPW per stage, issued in stage order) and -- barrier -- everybody else's: stage s+4 is then
+        // aimed at the ring slot of stage s, which nobody reads any more.  The step ENDS with the s_waitcnt that makes
+        // the freshly read set valid: the compiler takes the asm reads' results for valid at once, and any copy or
+        // spill of such a register it places before the data has arrived -- at a loop edge, a branch join -- would
+        // carry garbage (it did: wrong tiles, but only while other kernels kept the CU's LDS busy).  Inside a step
+        // there is no control flow, and the reads have the whole MFMA chain to return.
+#define CBS_STEP(WAITN, ISSUE, S, FCUR, FNEXT)                                            \
+        do {                                                                               \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");                  \
+            __builtin_amdgcn_s_barrier();                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                             \
+            if (ISSUE) issue((S) + 4);                                                     \
+            readFrags((S) + 1, FNEXT);                                                     \
+            mma(FCUR);                                                                     \
+            waitFrags(FNEXT);                                                              \
+        } while (0)
+
+        Frags F0, F1;
+        CBS_STAMP_AT(2);
+        issue(sBeg);
+        issue(sBeg + 1);
+        issue(sBeg + 2);
+        issue(sBeg + 3);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * DPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        readFrags(sBeg, F0);
+        waitFrags(F0);
+        if (t < BM) s_bias[t] = biasv;      // (read in the epilogue, many barriers later)
+        CBS_STAMP_AT(3);
+        int s = sBeg;
+        for (; s + 5 < sEnd; s += 2) {
+            CBS_STEP(2 * DPW, true, s, F0, F1);
+            CBS_STEP(2 * DPW, true, s + 1, F1, F0);
+        }
+        // four or five stages are left (a slice has at least six); the last four issue nothing, their waits count down
+        if (s + 5 == sEnd) {
+            CBS_STEP(2 * DPW, true, s, F0, F1);
+            CBS_STEP(2 * DPW, false, s + 1, F1, F0);
+            CBS_STEP(DPW, false, s + 2, F0, F1);
+            CBS_STEP(0, false, s + 3, F1, F0);
+            mma(F0);
+        } else {
+            CBS_STEP(2 * DPW, false, s, F0, F1);
+            CBS_STEP(DPW, false, s + 1, F1, F0);
+            CBS_STEP(0, false, s + 2, F0, F1);
+            mma(F1);
+        }
+#undef CBS_STEP
+        CBS_STAMP_AT(4);
+        CBS_STAMP_AT(7);
+
+        // ---- epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        float* __restrict__ out = p.seq[q].out;
+        if (CBS_DBGBIT(32)) continue;
+        if (SK > 1) {
+            // partial tile -> slab [BM/4][BN] float4 (four consecutive output channels of a pixel), plain stores:
+            // the slices meet behind the launch boundary (cbs_reduce_kernel)
+            float4* slab = (float4*)p.slabs + (long)it * (TILE / 4);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = (wn * TN + j) * 32 + l31;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int mq = wm * 8 + 2 * r4 + h;
+                    slab[mq * BN + nl] = make_float4(acc1[j][4 * r4] + acc2[j][4 * r4] * lo2,
+                                                     acc1[j][4 * r4 + 1] + acc2[j][4 * r4 + 1] * lo2,
+                                                     acc1[j][4 * r4 + 2] + acc2[j][4 * r4 + 2] * lo2,
+                                                     acc1[j][4 * r4 + 3] + acc2[j][4 * r4 + 3] * lo2);
+                }
+            }
+            CBS_STAMP_AT(5);
+#ifdef CBS_STAMP
+            cbs_first = false;
+#endif
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = (wn * TN + j) * 32 + l31;
+            const int pix = s_tilePix[nl];
+            if (pix < 0) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, m = m0 + ml;
+                if (m >= p.K) continue;
+                float v = (acc1[j][r] + acc2[j][r] * lo2) * p.outScale + s_bias[ml];
+                if (p.relu) v = v <= 0.f ? 0.f : v;
+                out[(long)m * HW + pix] = v;
+            }
+        }
+        CBS_STAMP_AT(5);
+#ifdef CBS_STAMP
+        cbs_first = false;
+#endif
+    }
+
+}
+
+// Second launch of a split contraction: sums the SK slabs of every tile in slice order, scales, adds the bias,
+// applies the ReLU and scatters (all CUs, one float4 of four output channels per thread and step).
+__global__ __launch_bounds__(256) void cbs_reduce_kernel(CbsParams p, int BM, int BN) {
+    const int SK = p.info[CBS_INFO_SK];
+    if (SK <= 1) return;
+    const int MT = p.info[CBS_INFO_MT], CMB = MT * SK, TILE4 = BM * BN / 4, HW = p.H * p.W;
+    int tilesBefore[CBS_MAXSEQ + 1];
+    tilesBefore[0] = 0;
+#pragma unroll
+    for (int q = 0; q < CBS_MAXSEQ; ++q) tilesBefore[q + 1] = tilesBefore[q] + p.info[CBS_INFO_TP + q];
+    const int TP = tilesBefore[CBS_MAXSEQ];
+    const float4* __restrict__ slabs = (const float4*)p.slabs;
+    const long total = (long)TP * MT * TILE4;
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+        const int tile = (int)(g / TILE4), c = (int)(g - (long)tile * TILE4);
+        const int ptg = tile / MT, mt = tile % MT;
+        const int nl = c % BN, mq = c / BN;
+        int q = 0;
+#pragma unroll
+        for (int u = 1; u < CBS_MAXSEQ; ++u)
+            if (u < p.nSeq && ptg >= tilesBefore[u]) q = u;
+        const int n = (ptg - tilesBefore[q]) * BN + nl;
+        const int N = p.info[CBS_INFO_TP + CBS_MAXSEQ + q];
+        const float4* sl = slabs + ((long)ptg * CMB + mt) * TILE4 + c;      // slice j: + j * MT * TILE4
+        const int pix = n < N ? p.seq[q].listOut[n] : -1;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int j0 = 0; j0 < SK; j0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j0 + j < SK) v[j] = sl[(long)(j0 + j) * MT * TILE4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j0 + j < SK) s0 += v[j].x, s1 += v[j].y, s2 += v[j].z, s3 += v[j].w;
+        }
+        if ((unsigned)pix >= (unsigned)HW) continue;
+        const int m = mt * BM + 4 * mq;
+        const float sv[4] = {s0, s1, s2, s3};
+        float* out = p.seq[q].out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (m + e >= p.K) continue;
+            float v = sv[e] * p.outScale;
+            if (p.bias) v += p.bias[m + e];
+            if (p.relu) v = v <= 0.f ? 0.f : v;
+            out[(long)(m + e) * HW + pix] = v;
+        }
+    }
+}
+
+int cbs_num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        else
+            cus = 256;
+    }
+    return cus;
+}
+
+template <int BM, int BN, int WM, int WN, int PRE_CAP>
+int cbs_launch_conv(const CbsParams& p, int perCU, hipStream_t s) {
+    if ((long)p.nSeq * p.maskWords > PRE_CAP) return CB_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)(perCU * cbs_num_cus())), block(64 * WM * WN);
+    hipLaunchKernelGGL((cbs_conv_kernel<BM, BN, WM, WN, PRE_CAP>), grid, block, 0, s, p);
+    int st = cb_launch_status();
+    if (st != CB_OK) return st;
+    if (p.slabs && (p.nStages >= 48 || p.forceSK > 0)) {
+        hipLaunchKernelGGL(cbs_reduce_kernel, dim3(4 * cbs_num_cus()), dim3(256), 0, s, p, BM, BN);
+        st = cb_launch_status();
+    }
+    return st;
+}
+
+}  // namespace cbs
+using namespace cbs;
+
+#ifdef CBS_STAMP
+extern "C" int cbinfer_debug_split_stamps(void* host, long bytes, int clear) {
+    if (clear) {
+        void* d = nullptr;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(cbs_stamp_buf)) != hipSuccess) return -1;
+        return (int)hipMemset(d, 0, sizeof(unsigned long long) * 2048 * 8);
+    }
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cbs_stamp_buf), (size_t)bytes);
+}
+#endif
+
+extern "C" {
+
+int cbinfer_split_supported(int C, int K, int kH, int kW) { return cbs_supported(C, K, kH, kW) ? 1 : 0; }
+int cbinfer_split_max_sequences(void) { return CBS_MAXSEQ; }
+// mask words (cbinfer_mask_words(H,W), summed over the sequences of a launch) the contraction of a K-channel layer takes
+long cbinfer_split_max_mask_words(int K) { return cbs_bm(K) >= 128 ? CBS_PRE_BIG : CBS_PRE_MID; }
+
+long cbinfer_split_state_bytes(int C, int H, int W, int kH, int kW) {
+    const CbsGeom g = cbs_geom(C, H, W, kH, kW);
+    return CBS_SPAD + (long)g.Hp * g.Wp * g.rec;
+}
+
+long cbinfer_split_prepared_bytes(int C, int K, int kH, int kW) {
+    const CbsGeom g = cbs_geom(C, 64, 64, kH, kW);
+    return (long)g.nStages * (cbs_kp(K) / 32) * 4096 + (long)g.nStages * 4;
+}
+
+// split-K workspace: 64 ints of launch info + one BM x BN partial tile per work item of a full grid
+long cbinfer_split_workspace_bytes(void) { return 256 + (long)2 * cbs_num_cus() * 128 * 128 * 4; }
+
+int cbinfer_split_prep_weights(const float* weight, void* prepared, int K, int C, int kH, int kW, int H, int W,
+                               float weightScale, cbStream_t stream) {
+    CB_REQUIRE(weight && prepared && H > 0 && W > 0 && weightScale > 0.f);
+    if (!cbs_supported(C, K, kH, kW)) return CB_ERR_UNSUPPORTED;
+    const CbsGeom g = cbs_geom(C, H, W, kH, kW);
+    if ((long)g.Hp * g.Wp * g.rec >= (1l << 31)) return CB_ERR_UNSUPPORTED;
+    const int KP = cbs_kp(K);
+    const long total = (long)g.nStages * (KP / 32) * 4 * 64;
+    int* stageOff = (int*)((char*)prepared + (long)g.nStages * (KP / 32) * 4096);
+    hipLaunchKernelGGL(cbs_prep_kernel, dim3(cb_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, weight,
+                       (halfx8*)prepared, stageOff, g, K, KP, weightScale);
+    return cb_launch_status();
+}
+
+int cbinfer_split_state_init(void* splitState, int C, int H, int W, int kH, int kW, cbStream_t stream) {
+    CB_REQUIRE(splitState && H > 0 && W > 0);
+    if (!cbs_supported(C, 1, kH, kW)) return CB_ERR_UNSUPPORTED;
+    const CbsGeom g = cbs_geom(C, H, W, kH, kW);
+    hipLaunchKernelGGL(cbs_state_init_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (uint4*)splitState, g);
+    return cb_launch_status();
+}
+
+// splitState <- split(state): for a state the caller wrote itself (restored states); the zero border must exist
+// already (cbinfer_split_state_init)
+int cbinfer_split_state_rebuild(const float* state, void* splitState, int C, int H, int W, int kH, int kW,
+                                int32_t* rangeFlag, cbStream_t stream) {
+    CB_REQUIRE(state && splitState && H > 0 && W > 0);
+    if (!cbs_supported(C, 1, kH, kW)) return CB_ERR_UNSUPPORTED;
+    const CbsGeom g = cbs_geom(C, H, W, kH, kW);
+    hipLaunchKernelGGL(cbs_state_rebuild_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, state,
+                       (char*)splitState, g, rangeFlag);
+    return cb_launch_status();
+}
+
+// Detection of up to CBS_MAXSEQ sequences in one launch (see cbSplitSeq in the header).  pooled != 0: `input` is
+// the tensor in front of a 2x2/stride-2 max pool, [C,pH,pW].
+int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, int C, int H, int W,
+                         int kH, int kW, float threshold, cbStream_t stream) {
+    CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && H > 0 && W > 0);
+    if (!cbs_supported(C, 1, kH, kW) || H > 65535) return CB_ERR_UNSUPPORTED;
+    if (pooled) CB_REQUIRE((H == pH / 2 || H == (pH + 1) / 2) && (W == pW / 2 || W == (pW + 1) / 2));
+    const CbsGeom g = cbs_geom(C, H, W, kH, kW);
+    CbsDetArgs a;
+    for (int q = 0; q < nSeq; ++q) {
+        CB_REQUIRE(seqs[q].input && seqs[q].state && seqs[q].splitState && seqs[q].frameMasks);
+        a.seq[q].in = seqs[q].input;
+        a.seq[q].state = seqs[q].state;
+        a.seq[q].S = (char*)seqs[q].splitState;
+        a.seq[q].masks = (unsigned long long*)seqs[q].frameMasks;
+        a.seq[q].prodMask = pooled ? (const unsigned long long*)seqs[q].producerMask : nullptr;
+        a.seq[q].rangeFlag = seqs[q].rangeFlag;
+    }
+    a.W = W, a.H = H, a.C = C, a.kHH = (kH - 1) / 2, a.kWH = (kW - 1) / 2;
+    a.wpr = cbinfer_mask_words_per_row(W), a.pH = pH, a.pW = pW;
+    a.Wp = g.Wp, a.rec = g.rec, a.padY = g.padY, a.padXL = g.padXL;
+    a.words = cbinfer_mask_words(H, W);
+    a.th = threshold;
+    dim3 grid(a.wpr, H, nSeq), block(64 * (C / 4));
+    if (pooled)
+        hipLaunchKernelGGL(cbs_detect_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(cbs_detect_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+    return cb_launch_status();
+}
+
+// The contraction of up to CBS_MAXSEQ sequences in one launch (+ the reduce launch of a split contraction).
+// outScale = 1 / (weightScale * 2^-4).  forceSplit > 0 overrides the k-split decision (tests, tuning).
+int cbinfer_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
+                       int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
+                       cbStream_t stream) {
+    CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && prepared && H > 0 && W > 0 && weightScale > 0.f);
+    if (!cbs_supported(C, K, kH, kW)) return CB_ERR_UNSUPPORTED;
+    const CbsGeom g = cbs_geom(C, H, W, kH, kW);
+    const int KP = cbs_kp(K), BM = cbs_bm(K);
+    const long MW = cbinfer_mask_words(H, W);
+    if ((long)nSeq * MW > (BM >= 128 ? CBS_PRE_BIG : CBS_PRE_MID) || (long)g.Hp * g.Wp * g.rec >= (1l << 31) ||
+        (long)H * W * W >= (1l << 32))
+        return CB_ERR_UNSUPPORTED;
+    CbsParams p;
+    for (int q = 0; q < nSeq; ++q) {
+        CB_REQUIRE(seqs[q].splitState && seqs[q].output && seqs[q].frameMasks && seqs[q].idxOut && seqs[q].countOut);
+        p.seq[q].S = (const char*)seqs[q].splitState;
+        p.seq[q].out = seqs[q].output;
+        p.seq[q].masks = (unsigned long long*)seqs[q].frameMasks;
+        p.seq[q].listOut = seqs[q].idxOut;
+        p.seq[q].countOut = seqs[q].countOut;
+        p.seq[q].maskCopy = (unsigned long long*)seqs[q].maskCopy;
+    }
+    p.nSeq = nSeq;
+    p.aBytes = (long)g.nStages * (KP / 32) * 4096;
+    p.A = (const char*)prepared;
+    p.stageOff = (const int*)((const char*)prepared + p.aBytes);
+    p.bias = bias;
+    p.info = workspace ? (int*)workspace : nullptr;
+    p.slabs = workspace ? (float*)((char*)workspace + 256) : nullptr;
+    p.K = K, p.KP = KP, p.H = H, p.W = W, p.Wp = g.Wp, p.rec = g.rec, p.nStages = g.nStages;
+    p.maskWords = (int)MW, p.wpr = cbinfer_mask_words_per_row(W), p.relu = relu, p.dummyBase = g.dummyBase;
+    p.stateBytes = (long)g.Hp * g.Wp * g.rec;
+    p.outScale = 1.0f / (weightScale * CBS_XSCALE);
+    p.magicMW = (1ull << 32) / (unsigned long long)MW + 1ull;
+    p.magicWpr = (1ull << 32) / (unsigned long long)p.wpr + 1ull;
+    p.magicW = (1ull << 32) / (unsigned long long)W + 1ull;
+    p.forceSK = forceSplit;
+    p.dbg = 0;
+#ifdef CBS_DBG
+    if (const char* e = getenv("CBINFER_SPLIT_DBG")) p.dbg = atoi(e);
+#endif
+    hipStream_t s = (hipStream_t)stream;
+    if (BM == 128) {
+        p.slabCap = workspace ? (int)((cbinfer_split_workspace_bytes() - 256) / (128 * 128 * 4)) : 0;
+        return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG>(p, 1, s);
+    }
+    p.slabCap = workspace ? (int)((cbinfer_split_workspace_bytes() - 256) / (64 * 64 * 4)) : 0;
+    // (the mask words and their prefix live in LDS: the small capacity leaves room for two workgroups per CU)
+    if ((long)nSeq * MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL>(p, 2, s);
+    return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID>(p, 1, s);
+}
+
+// One frame of a feedback-mode CBConv2d (conv2d.py:178-259) of every sequence: detection (+ pooling) + refresh of
+// both states, then the contraction.
+int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared,
+                          const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
+                          float weightScale, int relu, void* workspace, cbStream_t stream) {
+    const int st = cbinfer_split_detect(seqs, nSeq, pooled, pH, pW, C, H, W, kH, kW, threshold, stream);
+    if (st != CB_OK) return st;
+    return cbinfer_split_conv(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace, 0,
+                              stream);
+}
+
+}  // extern "C"

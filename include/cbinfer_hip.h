@@ -51,8 +51,9 @@ typedef void* cbStream_t; /* hipStream_t */
 
 /* 1: round 1.  2: CB_F32S, row-segment / patch-staged contractions, fine-grained frame, fused 1x1 tail,
  * cbinfer_weights_ckkpad(Ckk, dtype).  3: fine-grained frame on the mask-driven contractions
- * (cbinfer_cbconv2d_forward_fg_masked and its parts). */
-#define CBINFER_ABI_VERSION 3
+ * (cbinfer_cbconv2d_forward_fg_masked and its parts).  4: split-state frame (cbinfer_split_*, several sequences
+ * per launch), cbinfer_tail1x1_supported. */
+#define CBINFER_ABI_VERSION 4
 
 int cbinfer_abi_version(void);
 const char* cbinfer_status_string(int status);
@@ -349,6 +350,58 @@ int cbinfer_tail1x1(const float* input, const int32_t* changeList, int numChange
                     const float* w1Prepared, const float* b1, const float* w2, const float* b2,
                     float* output, int C0, int C1, int C2, int H, int W, int relu1, int relu2,
                     cbStream_t stream);
+
+/* ---- a1 + a5..a8 fused, SPLIT-STATE form (round 3; fp32 tensors, feedback mode, 16 / 32 / 64 input channels).
+ * Replaces, per frame and layer, the launcher sequence changeDetection (cbconv2d_cg_backend.cu:83-100, with
+ * updateInputState) -> torch.nonzero (conv2d_cg.py:200-209) -> genXMatrix (:138-173) -> matmul (conv2d_cg.py:
+ * 342-349) -> updateOutput (:175-197) of CBConv2d.forward_normal (conv2d.py:220-251) -- for up to
+ * CBINFER_SPLIT_MAX_SEQUENCES independent sequences (own state each, shared weights) in ONE launch per step.
+ * The layer state is kept twice: prevInput [C,H,W] f32 (the module's buffer, refreshed at the changed pixels
+ * as .cu:74-80 does) and a pixel-major pre-split f16-pair copy with a zero border (cbinfer_split_state_bytes;
+ * cbinfer_split_state_init once, then maintained by cbinfer_split_detect), from which the contraction gathers
+ * by LDS-DMA.  Arithmetic: x * 2^-4 = hi + lo * 2^-11 with f16 hi, lo (weights likewise, scaled by the power of
+ * two weightScale that brings max|w| into [2^13, 2^14)); products hi.hi + (hi.lo + lo.hi) 2^-11 on the f16 MFMA,
+ * f32 accumulation: |error| <= 3 * 2^-22 |a||b| per product.  Range of the state values: |x| < 2^20; a refreshed
+ * value beyond it sets *rangeFlag (the result is then not meaningful).
+ *   frameMasks : cbinfer_frame_mask_bytes(H,W) bytes, zero on first use: ONE mask (cbinfer_mask_words words) the
+ *                detection ORs into and the contraction zeroes again, + an arrival counter behind it
+ *   idxOut     : change list of the frame (H*W ints), countOut its length -- by-products, ascending order
+ *   workspace  : cbinfer_split_workspace_bytes() bytes, zero on first use; may be NULL (no split along k)
+ * pooled != 0: `input` is the tensor in FRONT of a 2x2/stride-2 max pool [C,pH,pW] (CBPoolMax2d folded into the
+ * detection, see cbinfer_cbconv2d_forward_pooled); producerMask as for cbinfer_change_detection_bits_pooled. */
+#define CBINFER_SPLIT_MAX_SEQUENCES 8
+typedef struct {
+    const float* input;           /* this frame's layer input (or the pool's input) */
+    float* state;                 /* prevInput [C,H,W] */
+    void* splitState;             /* cbinfer_split_state_bytes(C,H,W,kH,kW) */
+    uint64_t* frameMasks;
+    const uint64_t* producerMask; /* pooled only; may be NULL */
+    float* output;                /* prevOutput [K,H,W] */
+    int32_t* idxOut;
+    int32_t* countOut;
+    int32_t* rangeFlag;           /* may be NULL */
+    uint64_t* maskCopy;           /* may be NULL: receives this frame's change mask (cbinfer_mask_words words) at a
+                                     fixed address -- the producerMask of the next layer's pooled detection */
+} cbSplitSeq;
+int cbinfer_split_supported(int C, int K, int kH, int kW);
+int cbinfer_split_max_sequences(void);
+long cbinfer_split_max_mask_words(int K);   /* cbinfer_mask_words(H,W) x sequences a launch of a K-channel layer takes */
+long cbinfer_split_state_bytes(int C, int H, int W, int kH, int kW);
+long cbinfer_split_prepared_bytes(int C, int K, int kH, int kW);
+long cbinfer_split_workspace_bytes(void);
+int cbinfer_split_prep_weights(const float* weight, void* prepared, int K, int C, int kH, int kW, int H, int W,
+                               float weightScale, cbStream_t stream);
+int cbinfer_split_state_init(void* splitState, int C, int H, int W, int kH, int kW, cbStream_t stream);
+int cbinfer_split_state_rebuild(const float* state, void* splitState, int C, int H, int W, int kH, int kW,
+                                int32_t* rangeFlag, cbStream_t stream);
+int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, int C, int H, int W,
+                         int kH, int kW, float threshold, cbStream_t stream);
+int cbinfer_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
+                       int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
+                       cbStream_t stream);
+int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared,
+                          const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
+                          float weightScale, int relu, void* workspace, cbStream_t stream);
 
 /* replaces conv2d_fg_cpu, cbconv2d_fg_backend.cu:81-112: HOST pointers, host code, race-free. */
 void cbinfer_conv2d_fg_cpu(const float* input, const float* prevInput, float* output,

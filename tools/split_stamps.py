@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-workgroup phase stamps of the split-state contraction (needs the -DCBS_STAMP build:
+tools/split_stamp_run.sh).  usage: split_stamps.py [nSeq] [forceSplit]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cbinfer_amd import _lib  # noqa: E402
+import tools.bench_split as bs  # noqa: E402
+
+raw = ctypes.CDLL(_lib.LIB_PATH)
+NAMES = ['entry', 'list lengths known', 'item set up', 'ring primed', 'stage loop done', 'epilogue done']
+
+
+def report():
+    torch.cuda.synchronize()
+    buf = np.zeros(2048 * 8, dtype=np.uint64)
+    raw.cbinfer_debug_split_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(buf.nbytes), 0)
+    st = buf.reshape(2048, 8).astype(np.int64)
+    st = st[st[:, 0] > 0]
+    if len(st) == 0:
+        return
+    t0 = st[:, 0].min()
+    print("  %d workgroups stamped" % len(st))
+    for i, n in enumerate(NAMES):
+        v = st[:, i] >= t0
+        if v.sum() == 0:
+            continue
+        us = (st[v, i] - t0) / 100.0
+        print("  %-20s min %7.2f  mean %7.2f  max %7.2f us (%d wgs)" % (n, us.min(), us.mean(), us.max(), v.sum()))
+    ok = (st[:, 4] > st[:, 3]) & (st[:, 3] >= t0)
+    if ok.sum():
+        d = (st[ok, 4] - st[ok, 3]) / 100.0
+        cyc = (st[ok, 7] - st[ok, 6]).astype(np.float64)
+        tot = (st[ok, 4] - st[ok, 0]) / 100.0
+        print("  stage loop of the first item: min %.2f mean %.2f max %.2f us over %d wgs; shader clock ~%.0f MHz"
+              % (d.min(), d.mean(), d.max(), ok.sum(), np.median(cyc / np.maximum(tot, 0.01))))
+    raw.cbinfer_debug_split_stamps(None, 0, 1)
+
+
+_ev = bs.ev
+
+
+def ev_once(fn, reps=3):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    raw.cbinfer_debug_split_stamps(None, 0, 1)
+    fn()
+    report()
+    return 1.0
+
+
+bs.ev = ev_once
+if __name__ == "__main__":
+    bs.main()

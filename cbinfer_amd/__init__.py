@@ -15,6 +15,7 @@ from .conv2d import CBPoolMax2d
 from .conv2d import CBTail1x1
 from .conv2d_cg import ChangeIndexes
 from .pipeline import FramePipeline
+from .batch import SequenceBatch
 
 __version__ = "0.1.0"
 
@@ -273,7 +274,7 @@ def tuneThresholdParameters(vidSeqReader, evalSequences, numFramesPerSeq, target
         anchor = measure()
 
 
-__all__ = ['CBConv2d', 'CBPoolMax2d', 'CBTail1x1', 'ChangeIndexes', 'FramePipeline', 'convert', 'convertRecur', 'subsitute',
+__all__ = ['CBConv2d', 'CBPoolMax2d', 'CBTail1x1', 'ChangeIndexes', 'FramePipeline', 'SequenceBatch', 'convert', 'convertRecur', 'subsitute',
            'mergeReLURecur', 'propChangeIndexesOf1x1', 'insertCBPooling', 'fusePoolingIntoDetection', 'fuseTail1x1',
            'clearMemory', 'getStateTensors',
            'setSyncIndexes', 'tuneThresholdParameters']

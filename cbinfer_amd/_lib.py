@@ -25,6 +25,15 @@ class SplitSeq(ctypes.Structure):
 
 _sp = ctypes.POINTER(SplitSeq)
 
+
+class TailSeq(ctypes.Structure):
+    """cbTailSeq of include/cbinfer_hip.h."""
+    _fields_ = [("input", _vp), ("changeList", _vp), ("countDev", _vp), ("output", _vp)]
+
+
+_tp = ctypes.POINTER(TailSeq)
+_vpp = ctypes.POINTER(ctypes.c_void_p)
+
 _SIGNATURES = {
     # name: (restype, [argtypes])
     "cbinfer_abi_version": (_i, []),
@@ -89,12 +98,16 @@ _SIGNATURES = {
     "cbinfer_blockconv_prepared_bytes": (_l, [_i, _i, _i, _i]),
     "cbinfer_blockconv_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "cbinfer_conv_changed_blocks": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "cbinfer_change_detection_bits_batched": (_i, [_vpp, _vpp, _vpp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "cbinfer_conv_changed_rows_batched": (_i, [_vpp, _vpp, _vpp, _vpp, _vpp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i,
+                                               _vp]),
+    "cbinfer_tail1x1_batched": (_i, [_tp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cbinfer_split_supported": (_i, [_i, _i, _i, _i]),
     "cbinfer_split_max_sequences": (_i, []),
     "cbinfer_split_max_mask_words": (_l, [_i]),
     "cbinfer_split_state_bytes": (_l, [_i, _i, _i, _i, _i]),
     "cbinfer_split_prepared_bytes": (_l, [_i, _i, _i, _i]),
-    "cbinfer_split_workspace_bytes": (_l, []),
+    "cbinfer_split_workspace_bytes": (_l, [_i, _i, _i, _i, _i, _i, _i]),
     "cbinfer_split_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "cbinfer_split_state_init": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "cbinfer_split_state_rebuild": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -337,10 +337,9 @@ class CBConv2d(nn.Module):
             words = C.cbinfer_mask_words(H, W)
             S = torch.empty(C.cbinfer_split_state_bytes(Cin, H, W, kH, kW), dtype=torch.uint8, device=dev)
             check(C.cbinfer_split_state_init(ptr(S), Cin, H, W, kH, kW, stream_ptr(S)))
-            # (split-K slabs only for deep contractions: the kernels split along k from 48 stages on)
-            stages = kH * ((kW + 1) // 2) if Cin == 16 else kH * kW * (Cin // 32)
-            ws = torch.zeros(C.cbinfer_split_workspace_bytes(), dtype=torch.uint8, device=dev) if stages >= 48 \
-                else None
+            # (slabs only for deep contractions -- 48 k-stages and more: 0 bytes otherwise)
+            wsBytes = C.cbinfer_split_workspace_bytes(1, Cin, H, W, K, kH, kW)
+            ws = torch.zeros(wsBytes, dtype=torch.uint8, device=dev) if wsBytes > 0 else None
             sp = work['split'] = dict(S=S, flag=torch.zeros(1, dtype=torch.int32, device=dev),
                                       copy=torch.zeros(words, dtype=torch.int64, device=dev), ws=ws,
                                       stateKey=None, seq=(_lib.SplitSeq * 1)())

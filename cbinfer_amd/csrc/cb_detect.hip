@@ -22,6 +22,17 @@ __device__ __forceinline__ unsigned long long cb_valid_mask(int W, int tile) {
 // state at (c, y, x) is the pooled one, computed on the fly (windows clipped at the border as the pool
 // kernel clips them).  The pooled map itself is never written: a feedback-mode layer only needs it in
 // its state, which this kernel refreshes at the changed pixels.
+// (several sequences in one launch -- batch.nSeq > 1: blockIdx.y = sequence * H + row, input / state / mask from
+//  the table)
+struct DetBatch {
+    int nSeq;
+    struct {
+        const void* in;
+        void* state;
+        unsigned long long* bits;
+    } seq[CBINFER_SPLIT_MAX_SEQUENCES];
+};
+
 template <typename T, bool BITS, bool POOL = false>
 __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ in, T* state,
                                                         int8_t* __restrict__ map,
@@ -29,8 +40,15 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
                                                         int H, int C, int kHH, int kWH, float thf,
                                                         int update, int wpr,
                                                         const int* __restrict__ parity, long altWords,
-                                                        int pH = 0, int pW = 0,
-                                                        const unsigned long long* __restrict__ prodMask = nullptr) {
+                                                        int pH, int pW,
+                                                        const unsigned long long* __restrict__ prodMask,
+                                                        DetBatch batch) {
+    int yb = blockIdx.y;
+    if (batch.nSeq > 1) {
+        const int q = (int)blockIdx.y / H;
+        yb -= q * H;
+        in = (const T*)batch.seq[q].in, state = (T*)batch.seq[q].state, bits = batch.seq[q].bits;
+    }
     // POOL with the producer's change mask (pre-pool resolution, this frame): a pooled pixel none of whose
     // window pixels was rewritten by the producing layer compares exactly as it did last frame, i.e. not
     // above the threshold -- the 64 pooled pixels of this workgroup lie under four words of that mask
@@ -41,7 +59,7 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int yy = 2 * (int)blockIdx.y + j, ww = 2 * (int)blockIdx.x + i;
+                const int yy = 2 * yb + j, ww = 2 * (int)blockIdx.x + i;
                 if (yy < pH && ww < pwpr) any |= prodMask[(long)yy * pwpr + ww];
             }
         if (__builtin_amdgcn_readfirstlane((int)(any != 0ull)) == 0) return;
@@ -52,7 +70,7 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
     const int g = threadIdx.x >> 6;
     const int G = blockDim.x >> 6;
     const int tx = blockIdx.x;
-    const int y = blockIdx.y;
+    const int y = yb;
     const int x = tx * 64 + lane;
     const bool valid = x < W;
     const long HW = (long)H * W;
@@ -352,13 +370,18 @@ int detect_groups(int C) {
 template <typename T, bool BITS, bool POOL = false>
 int launch_detect(const void* input, void* state, int8_t* map, uint64_t* bits, int W, int H, int C,
                   int kHH, int kWH, float th, int update, hipStream_t s, const int* parity = nullptr,
-                  long altWords = 0, int pH = 0, int pW = 0, const uint64_t* prodMask = nullptr) {
+                  long altWords = 0, int pH = 0, int pW = 0, const uint64_t* prodMask = nullptr,
+                  const DetBatch* batch = nullptr) {
     const int wpr = cbinfer_mask_words_per_row(W);
     const int G = detect_groups(C);
-    dim3 grid(wpr, H), block(64 * G);
+    DetBatch b;
+    b.nSeq = 1;
+    if (batch) b = *batch;
+    if ((long)H * b.nSeq > 65535) return CB_ERR_UNSUPPORTED;
+    dim3 grid(wpr, H * b.nSeq), block(64 * G);
     hipLaunchKernelGGL((cb_detect_kernel<T, BITS, POOL>), grid, block, 0, s, (const T*)input, (T*)state,
                        map, (unsigned long long*)bits, W, H, C, kHH, kWH, th, update, wpr, parity, altWords,
-                       pH, pW, (const unsigned long long*)prodMask);
+                       pH, pW, (const unsigned long long*)prodMask, b);
     return cb_launch_status();
 }
 
@@ -399,6 +422,23 @@ int cbinfer_change_detection_bits(const void* input, void* state, uint64_t* bits
         return launch_detect<cb_half, true>(input, state, nullptr, bitsOut, W, H, C, kHHalf, kWHalf,
                                             threshold, updateInputState, s);
     return CB_ERR_BADARG;
+}
+
+// cbinfer_change_detection_bits (fp32) for nSeq sequences in one launch: inputs[q] / states[q] / bitsOut[q]
+int cbinfer_change_detection_bits_batched(const float* const* inputs, float* const* states, uint64_t* const* bitsOut,
+                                          int nSeq, int W, int H, int C, int kHHalf, int kWHalf, float threshold,
+                                          int updateInputState, cbStream_t stream) {
+    CB_REQUIRE(inputs && states && bitsOut && nSeq >= 1 && nSeq <= CBINFER_SPLIT_MAX_SEQUENCES && W > 0 && H > 0 &&
+               C > 0 && kHHalf >= 0 && kWHalf >= 0);
+    if (kWHalf > 63) return CB_ERR_UNSUPPORTED;
+    DetBatch b;
+    b.nSeq = nSeq;
+    for (int q = 0; q < nSeq; ++q) {
+        CB_REQUIRE(inputs[q] && states[q] && bitsOut[q]);
+        b.seq[q].in = inputs[q], b.seq[q].state = states[q], b.seq[q].bits = (unsigned long long*)bitsOut[q];
+    }
+    return launch_detect<float, true>(inputs[0], states[0], nullptr, bitsOut[0], W, H, C, kHHalf, kWHalf, threshold,
+                                      updateInputState, (hipStream_t)stream, nullptr, 0, 0, 0, nullptr, &b);
 }
 
 // Single-mask form of the pooled detection (see cbinfer_change_detection_frame_pooled): ORs into bitsOut.

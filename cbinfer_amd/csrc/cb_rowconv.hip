@@ -52,6 +52,16 @@ struct RowParams {
     int MCH, MCW;           // 16-row output-channel chunks in all / per workgroup (4 waves each)
     int halves;             // 1: one workgroup per word; 2: words with more than 32 pixels are shared by two
     int dbg;                // diagnostic ablations (CBINFER_ROW_DBG): 1 no staging loads, 2 no k-loop, 4 no stores
+    // several sequences in one launch (nSeq > 1): blockIdx.y = sequence * H + row, the per-sequence tensors
+    // come from this table instead of the fields above
+    int nSeq;
+    struct {
+        const float* state;
+        float* out;
+        unsigned long long* bits;
+        int* arrive;
+        unsigned long long* maskCopy;
+    } seq[CBINFER_SPLIT_MAX_SEQUENCES];
 };
 
 // r-th (0-based) set bit of w, r < popcount(w)
@@ -133,11 +143,19 @@ struct cb_row_blocks<KH, KW, Q, NBLK, NBLK> {
 
 // KH, KW, Q (= padded channels / 4) > 0: shape known at compile time (the hot layers); 0, 0, 0: any shape
 template <int KH, int KW, int Q>
-__global__ __launch_bounds__(64 * CB_ROW_MAXW) void cb_rowconv_f32_kernel(RowParams p) {
+__global__ __launch_bounds__(64 * CB_ROW_MAXW) void cb_rowconv_f32_kernel(RowParams pin) {
     extern __shared__ float lds[];   // patch [CP][CS] | red [waves][64][4]
     constexpr bool CT = KH > 0;
     CB_RSTAMP(0);
-    const int tx = blockIdx.x, y = blockIdx.y;
+    RowParams p = pin;
+    int y = blockIdx.y;
+    if (pin.nSeq > 1) {
+        const int q = (int)blockIdx.y / pin.H;
+        y -= q * pin.H;
+        p.state = pin.seq[q].state, p.out = pin.seq[q].out, p.bits = pin.seq[q].bits;
+        p.arrive = pin.seq[q].arrive, p.maskCopy = pin.seq[q].maskCopy;
+    }
+    const int tx = blockIdx.x;
     // pixel half (tiles 2nh, 2nh+1; with halves == 1 one workgroup takes all four tiles), chunk group
     const int nh = p.halves == 2 ? (blockIdx.z & 1) : 0, msc = p.halves == 2 ? (blockIdx.z >> 1) : blockIdx.z;
     const int widx = y * p.wpr + tx;
@@ -439,9 +457,20 @@ int cbinfer_rowconv_prep_weights(const float* weight, void* prepared, int K, int
 
 // bits / arrive / maskCopy: cbinfer_mask_words(H,W) entries each (uint64 / int32 / uint64); bits and arrive
 // zero on first use and left zero; maskCopy receives this frame's mask.
+struct RowBatch {
+    int nSeq;
+    struct {
+        const float* state;
+        float* out;
+        unsigned long long* bits;
+        int* arrive;
+        unsigned long long* maskCopy;
+    } seq[CBINFER_SPLIT_MAX_SEQUENCES];
+};
 static int cb_rows_launch(const float* state, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,
                           const void* prepared, const float* bias, float* output, int C, int H, int W,
-                          int K, int kH, int kW, int relu, int accumulate, float* reluOut, cbStream_t stream) {
+                          int K, int kH, int kW, int relu, int accumulate, float* reluOut, cbStream_t stream,
+                          const RowBatch* batch = nullptr) {
     CB_REQUIRE(state && bits && arrive && maskCopy && prepared && (bias || accumulate) && output && H > 0 && W > 0);
     if (!cbinfer_rowconv_supported(C, K, kH, kW)) return CB_ERR_UNSUPPORTED;
     if ((long)C * H * W * 4 >= (1l << 30) || H > 65535) return CB_ERR_UNSUPPORTED;
@@ -469,6 +498,13 @@ static int cb_rows_launch(const float* state, uint64_t* bits, int32_t* arrive, u
     p.relu = relu;
     p.accumulate = accumulate;
     p.reluOut = reluOut;
+    p.nSeq = batch ? batch->nSeq : 1;
+    if (batch)
+        for (int q = 0; q < batch->nSeq; ++q) {
+            p.seq[q].state = batch->seq[q].state, p.seq[q].out = batch->seq[q].out;
+            p.seq[q].bits = batch->seq[q].bits, p.seq[q].arrive = batch->seq[q].arrive;
+            p.seq[q].maskCopy = batch->seq[q].maskCopy;
+        }
     p.wpr = cbinfer_mask_words_per_row(W);
     {
         static int dbg = -1;
@@ -492,7 +528,8 @@ static int cb_rows_launch(const float* state, uint64_t* bits, int32_t* arrive, u
     // a word with all 64 pixels changed costs 4 tiles x MCW chunks x S MFMA steps on one CU: share heavy
     // words between two workgroups
     p.halves = (long)p.MCW * g.S >= 256 ? 2 : 1;
-    dim3 grid(p.wpr, H, p.halves * ((g.MCH + p.MCW - 1) / p.MCW)), block(256 * p.MCW);
+    if ((long)H * p.nSeq > 65535) return CB_ERR_UNSUPPORTED;
+    dim3 grid(p.wpr, H * p.nSeq, p.halves * ((g.MCH + p.MCW - 1) / p.MCW)), block(256 * p.MCW);
     // the hot shapes of the scene-labeling network get their tap offsets as immediates
     if (kH == 7 && kW == 7 && g.CP == 4)
         hipLaunchKernelGGL((cb_rowconv_f32_kernel<7, 7, 1>), grid, block, ldsBytes, (hipStream_t)stream, p);
@@ -509,6 +546,24 @@ int cbinfer_conv_changed_rows(const float* state, uint64_t* bits, int32_t* arriv
     CB_REQUIRE(bias != nullptr);
     return cb_rows_launch(state, bits, arrive, maskCopy, prepared, bias, output, C, H, W, K, kH, kW, relu, 0,
                           nullptr, stream);
+}
+
+// nSeq sequences in one launch: states[q] / outputs[q] / bits[q] / arrive[q] / maskCopies[q] as above, shared weights
+int cbinfer_conv_changed_rows_batched(const float* const* states, uint64_t* const* bits, int32_t* const* arrive,
+                                      uint64_t* const* maskCopies, float* const* outputs, int nSeq,
+                                      const void* prepared, const float* bias, int C, int H, int W, int K, int kH,
+                                      int kW, int relu, cbStream_t stream) {
+    CB_REQUIRE(states && bits && arrive && maskCopies && outputs && bias && nSeq >= 1 &&
+               nSeq <= CBINFER_SPLIT_MAX_SEQUENCES);
+    RowBatch b;
+    b.nSeq = nSeq;
+    for (int q = 0; q < nSeq; ++q) {
+        CB_REQUIRE(states[q] && bits[q] && arrive[q] && maskCopies[q] && outputs[q]);
+        b.seq[q].state = states[q], b.seq[q].out = outputs[q], b.seq[q].bits = (unsigned long long*)bits[q];
+        b.seq[q].arrive = arrive[q], b.seq[q].maskCopy = (unsigned long long*)maskCopies[q];
+    }
+    return cb_rows_launch(states[0], bits[0], arrive[0], maskCopies[0], prepared, bias, outputs[0], C, H, W, K, kH,
+                          kW, relu, 0, nullptr, stream, &b);
 }
 
 int cbinfer_conv_accumulate_rows(const float* delta, uint64_t* bits, int32_t* arrive, uint64_t* maskCopy,

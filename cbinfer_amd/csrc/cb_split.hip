@@ -48,7 +48,7 @@ typedef __attribute__((address_space(4))) const int cbs_const_int;
 #define CBS_PRE_BIG 1536              // mask words of all sequences of a launch: 128-row tile
 #define CBS_PRE_SMALL 1280            // ... 64-row tile, two workgroups per CU
 #define CBS_PRE_MID 5120              // ... 64-row tile, one workgroup per CU
-#define CBS_SKMAX 16
+#define CBS_CHUNKS 4                  // canonical k-chunks of a deep contraction (see cbs_conv_kernel)
 
 // ---------------------------------------------------------------------------------------------------
 // geometry of the split state / stage list (host and device)
@@ -358,7 +358,7 @@ struct CbsParams {
     const float* bias;
     float* slabs;                     // split-K workspace: slabCap partial tiles of BM x BN floats
     int* info;                        // left for the reduce launch: {SK, MT, nSeq, tilesP[q]..., N[q]...}
-    int slabCap;
+    int slabCap;                      // (unused)
     int K, KP, H, W, Wp, rec, nStages, maskWords, wpr, relu, dummyBase;
     long stateBytes, aBytes;
     float outScale;
@@ -373,11 +373,12 @@ struct CbsParams {
 // diagnostic build only (make EXTRA=-DCBS_STAMP; tools/split_stamps.py): per-workgroup phase stamps of its FIRST item,
 // 100 MHz constant clock: 0 entry, 1 list lengths known, 2 item set up, 3 ring primed, 4 stage loop done, 5 epilogue
 // done; 6 / 7: shader clock (s_memtime) at entry / after the stage loop
-__device__ unsigned long long cbs_stamp_buf[2048 * 8];
+__device__ unsigned long long cbs_stamp_buf[2 * 2048 * 8];      // [64-row tile | 128-row tile]
 #define CBS_STAMP_AT(i)                                                                                   \
     do {                                                                                                  \
         if (threadIdx.x == 0 && blockIdx.x < 2048 && cbs_first)                                           \
-            cbs_stamp_buf[blockIdx.x * 8 + (i)] = (i) >= 6 ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime(); \
+            cbs_stamp_buf[(BM >= 128 ? 2048 * 8 : 0) + blockIdx.x * 8 + (i)] =                            \
+                (i) >= 6 ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();               \
     } while (0)
 #else
 #define CBS_STAMP_AT(i)
@@ -469,8 +470,9 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     //  crowd out the kernel's own)
     __shared__ int s_seqN[CBS_MAXSEQ], s_seqRank[CBS_MAXSEQ], s_seqTile[CBS_MAXSEQ + 1];
     // Mask protocol (single mask per sequence): the detection ORs into it; here every workgroup takes a copy into
-    // LDS, and the workgroup that learns -- from an arrival counter behind the mask -- that it was the LAST to do so
-    // zeroes the mask for the next frame's detection.  Nobody waits; the next launch finds it clean.
+    // LDS and never looks at the mask again.  On its way OUT of the kernel each workgroup counts itself on an
+    // arrival counter behind the mask, and the one that learns it was the last zeroes the masks for the next
+    // frame's detection.  Nobody waits for anybody; the next launch finds them clean.
     for (int q = t; q < p.nSeq; q += NT) s_maskPtr[q] = p.seq[q].masks;
     __syncthreads();
     const int E = p.nSeq * MW;
@@ -480,28 +482,12 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         s_pre[i] = __popcll(word);
         s_mask[i] = word;
     }
-    __syncthreads();      // (every load of this workgroup has returned: its values are in LDS)
-    if (t == 0) {
-        int* ctl = (int*)(p.seq[0].masks + 2 * (long)MW);
-        s_wsum[0] = __hip_atomic_fetch_add(ctl + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     for (int q = 0; q < p.nSeq; ++q) {      // this launch also leaves a copy of the frame's masks at a fixed address
         unsigned long long* copy = p.seq[q].maskCopy;
         if (copy)
-            for (int i = blockIdx.x * NT + t; i < MW; i += gridDim.x * NT) copy[i] = s_mask[q * MW + i];
+            for (int i = blockIdx.x * NT + t; i < MW; i += gridDim.x * NT) copy[i] = s_maskPtr[q][i];
     }
-    __syncthreads();
-    if (s_wsum[0] == (int)gridDim.x - 1) {      // last arriver (uniform over the workgroup)
-        for (int i = t; i < E; i += NT) {
-            const int q = cbs_div(i, p.magicMW), w = i - q * MW;
-            ((unsigned long long*)s_maskPtr[q])[w] = 0ull;
-        }
-        if (t == 0) {
-            int* ctl = (int*)(p.seq[0].masks + 2 * (long)MW);
-            __hip_atomic_store(ctl + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();      // (s_wsum is reused by the scan)
+    __syncthreads();      // (every load of this workgroup has returned: its values are in LDS)
     {
         const int CH = (E + NT - 1) / NT, wb = t * CH;
         int loc = 0;
@@ -542,15 +528,16 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     __syncthreads();
     CBS_STAMP_AT(1);
     const int TP = __builtin_amdgcn_readfirstlane(s_seqTile[p.nSeq]);         // pixel tiles of all sequences
-    // split along k while whole CUs would idle and the k-depth pays for the slab round trip
+    // Split along k while whole CUs would idle and the k-depth pays for the slab round trip -- WITHOUT letting the
+    // partitioning into the arithmetic: a deep contraction (>= 48 stages) is always the sum, left to right, of
+    // CBS_CHUNKS partial sums over fixed stage ranges, each accumulated from zero.  Split, every chunk is a work
+    // item of its own and the reduce launch adds the slabs in chunk order; unsplit, one workgroup walks the whole
+    // depth and folds its accumulators into a running sum at the chunk boundaries: the same additions in the
+    // same order, so a sequence gets the same bits whether it runs alone (split) or beside others (unsplit).
+    const int CH = (p.nStages >= 48 && p.slabs) ? CBS_CHUNKS : 1;      // (the host refuses a deep layer without slabs)
     int SK = 1;
-    if (p.slabs && TP > 0 && p.nStages >= 48) {
-        SK = (int)gridDim.x / (TP * MT);
-        SK = max(1, min(SK, min(CBS_SKMAX, p.nStages / 6)));
-        while (SK > 1 && TP * MT * SK > p.slabCap) --SK;
-    }
-    if (p.forceSK > 0 && p.slabs) SK = max(1, min(p.forceSK, min(CBS_SKMAX, p.nStages / 6)));
-    if (SK > 1 && TP * MT * SK > p.slabCap) SK = 1;
+    if (TP > 0 && CH > 1 && TP * MT * CH <= (int)gridDim.x) SK = CH;
+    if (p.forceSK > 0 && CH > 1) SK = p.forceSK >= CH ? CH : 1;         // (tests: 1 = unsplit, >= 4 = split)
     const int CMB = MT * SK, items = TP * CMB;
     if (blockIdx.x == 0 && t == 0 && p.info) {
         p.info[CBS_INFO_SK] = SK;
@@ -599,7 +586,14 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         q = __builtin_amdgcn_readfirstlane(q);
         const int N = __builtin_amdgcn_readfirstlane(s_seqN[q]), rb = __builtin_amdgcn_readfirstlane(s_seqRank[q]);
         const int n0 = (ptg - __builtin_amdgcn_readfirstlane(s_seqTile[q])) * BN, m0 = mt * BM;
-        const int sBeg = p.nStages * slice / SK, sEnd = p.nStages * (slice + 1) / SK;
+        // Stages of this item: one chunk (split) or all of them (then the accumulators are folded into the running
+        // sum at the chunk boundaries).  Chunk c = stage pairs [P c / CH, P (c+1) / CH) of the P = nStages / 2 pairs
+        // (+ the odd last stage in the last chunk): every boundary lies an even number of stages behind the start,
+        // which keeps the two fragment register sets in step with the loop below.
+        const int P2 = p.nStages >> 1;
+        auto chunkBeg = [&](int c) { return c >= CH ? p.nStages : 2 * (P2 * c / CH); };
+        const int c0 = SK == 1 ? 0 : slice, c1 = SK == 1 ? CH : slice + 1;
+        const int sBeg = chunkBeg(c0), sEnd = chunkBeg(c1);
 
         // pixel of slot j of this tile = the (n0+j)-th set bit of sequence q's mask
         __syncthreads();   // (s_tilePix and the ring of the previous item are no longer read)
@@ -668,6 +662,34 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc1[j][i] = 0.f, acc2[j][i] = 0.f;
+        // Chunk boundary of an unsplit deep item: running sum = (first ? 0 : running sum) + (acc1 + acc2 / 2^11),
+        // accumulators from zero again.  The running sum lives in this item's (otherwise idle) slab -- every lane
+        // reads back what it wrote itself -- not in 32 more registers: the stage loop has none to spare, and a
+        // spill placed between an asm fragment read and its wait would carry garbage.
+        int folds = 0;
+        float4* const mySlab = p.slabs ? (float4*)p.slabs + (long)it * (TILE / 4) : nullptr;
+        auto fold = [&]() {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = (wn * TN + j) * 32 + l31;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    float4* sp = mySlab + (wm * 8 + 2 * r4 + h) * BN + nl;
+                    float4 c = make_float4(acc1[j][4 * r4] + acc2[j][4 * r4] * lo2,
+                                           acc1[j][4 * r4 + 1] + acc2[j][4 * r4 + 1] * lo2,
+                                           acc1[j][4 * r4 + 2] + acc2[j][4 * r4 + 2] * lo2,
+                                           acc1[j][4 * r4 + 3] + acc2[j][4 * r4 + 3] * lo2);
+                    if (folds > 0) {
+                        const float4 o = *sp;
+                        c = make_float4(o.x + c.x, o.y + c.y, o.z + c.z, o.w + c.w);
+                    }
+                    *sp = c;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc1[j][i] = 0.f, acc2[j][i] = 0.f;
+            }
+            ++folds;
+        };
 
         // the fragments of one stage in registers: two sets, the reads of stage s+1 run under the MFMAs of stage s
         struct Frags {
@@ -761,6 +783,16 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         if (t < BM) s_bias[t] = biasv;      // (read in the epilogue, many barriers later)
         CBS_STAMP_AT(3);
         int s = sBeg;
+        // (an unsplit deep item: the chunks before the last one are whole pairs of full steps -- at least six stages
+        //  follow each of them -- and end in a fold)
+        for (int c = c0; c + 1 < c1; ++c) {
+            const int cEnd = chunkBeg(c + 1);
+            for (; s < cEnd; s += 2) {
+                CBS_STEP(2 * DPW, true, s, F0, F1);
+                CBS_STEP(2 * DPW, true, s + 1, F1, F0);
+            }
+            fold();
+        }
         for (; s + 5 < sEnd; s += 2) {
             CBS_STEP(2 * DPW, true, s, F0, F1);
             CBS_STEP(2 * DPW, true, s + 1, F1, F0);
@@ -816,7 +848,10 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, m = m0 + ml;
                 if (m >= p.K) continue;
-                float v = (acc1[j][r] + acc2[j][r] * lo2) * p.outScale + s_bias[ml];
+                float v = acc1[j][r] + acc2[j][r] * lo2;
+                if (folds > 0)                          // (the last chunk joins the running sum)
+                    v = ((const float*)(mySlab + (wm * 8 + 2 * (r >> 2) + h) * BN + nl))[r & 3] + v;
+                v = v * p.outScale + s_bias[ml];
                 if (p.relu) v = v <= 0.f ? 0.f : v;
                 out[(long)m * HW + pix] = v;
             }
@@ -827,6 +862,23 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
 #endif
     }
 
+    // last workgroup out zeroes the masks (every workgroup copied them into its LDS before its first barrier)
+    __syncthreads();
+    if (t == 0) {
+        int* ctl = (int*)(p.seq[0].masks + 2 * (long)MW);
+        s_wsum[0] = __hip_atomic_fetch_add(ctl + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_wsum[0] == (int)gridDim.x - 1) {
+        for (int i = t; i < E; i += NT) {
+            const int q = cbs_div(i, p.magicMW), w = i - q * MW;
+            ((unsigned long long*)s_maskPtr[q])[w] = 0ull;
+        }
+        if (t == 0) {
+            int* ctl = (int*)(p.seq[0].masks + 2 * (long)MW);
+            __hip_atomic_store(ctl + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // Second launch of a split contraction: sums the SK slabs of every tile in slice order, scales, adds the bias,
@@ -914,7 +966,7 @@ extern "C" int cbinfer_debug_split_stamps(void* host, long bytes, int clear) {
     if (clear) {
         void* d = nullptr;
         if (hipGetSymbolAddress(&d, HIP_SYMBOL(cbs_stamp_buf)) != hipSuccess) return -1;
-        return (int)hipMemset(d, 0, sizeof(unsigned long long) * 2048 * 8);
+        return (int)hipMemset(d, 0, sizeof(unsigned long long) * 2 * 2048 * 8);
     }
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cbs_stamp_buf), (size_t)bytes);
 }
@@ -937,8 +989,17 @@ long cbinfer_split_prepared_bytes(int C, int K, int kH, int kW) {
     return (long)g.nStages * (cbs_kp(K) / 32) * 4096 + (long)g.nStages * 4;
 }
 
-// split-K workspace: 64 ints of launch info + one BM x BN partial tile per work item of a full grid
-long cbinfer_split_workspace_bytes(void) { return 256 + (long)2 * cbs_num_cus() * 128 * 128 * 4; }
+// Workspace of a deep contraction (>= 48 stages; 0 bytes otherwise): 64 ints of launch info + one BM x BN partial
+// tile per work item -- split, at most a grid of them; unsplit, one per tile of every sequence (the running sums)
+long cbinfer_split_workspace_bytes(int nSeq, int C, int H, int W, int K, int kH, int kW) {
+    if (!cbs_supported(C, K, kH, kW)) return 0;
+    const CbsGeom g = cbs_geom(C, H, W, kH, kW);
+    if (g.nStages < 48) return 0;
+    const int bm = cbs_bm(K), bn = bm >= 128 ? 128 : 64;
+    const long tiles = (long)nSeq * (((long)H * W + bn - 1) / bn) * (cbs_kp(K) / bm);
+    const long items = tiles > 2l * cbs_num_cus() ? tiles : 2l * cbs_num_cus();
+    return 256 + items * bm * bn * 4;
+}
 
 int cbinfer_split_prep_weights(const float* weight, void* prepared, int K, int C, int kH, int kW, int H, int W,
                                float weightScale, cbStream_t stream) {
@@ -1010,6 +1071,8 @@ int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, i
 int cbinfer_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
                        int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
                        cbStream_t stream) {
+    if (workspace == nullptr && cbs_supported(C, K, kH, kW) && cbs_geom(C, H, W, kH, kW).nStages >= 48)
+        return CB_ERR_BADARG;      // a deep contraction needs its workspace (cbinfer_split_workspace_bytes)
     CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && prepared && H > 0 && W > 0 && weightScale > 0.f);
     if (!cbs_supported(C, K, kH, kW)) return CB_ERR_UNSUPPORTED;
     const CbsGeom g = cbs_geom(C, H, W, kH, kW);
@@ -1048,11 +1111,8 @@ int cbinfer_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, c
     if (const char* e = getenv("CBINFER_SPLIT_DBG")) p.dbg = atoi(e);
 #endif
     hipStream_t s = (hipStream_t)stream;
-    if (BM == 128) {
-        p.slabCap = workspace ? (int)((cbinfer_split_workspace_bytes() - 256) / (128 * 128 * 4)) : 0;
-        return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG>(p, 1, s);
-    }
-    p.slabCap = workspace ? (int)((cbinfer_split_workspace_bytes() - 256) / (64 * 64 * 4)) : 0;
+    p.slabCap = 0;      // (sized by cbinfer_split_workspace_bytes for this very geometry: never exceeded)
+    if (BM == 128) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG>(p, 1, s);
     // (the mask words and their prefix live in LDS: the small capacity leaves room for two workgroups per CU)
     if ((long)nSeq * MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL>(p, 2, s);
     return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID>(p, 1, s);

@@ -33,12 +33,25 @@ __global__ __launch_bounds__(256) void cb_tail_prep_kernel(const float* __restri
     w1p[e] = (m < C1 && k < C0) ? w1[(long)m * C0 + k] : 0.f;
 }
 
+// (several sequences in one launch: blockIdx.y names the sequence, its tensors come from the table)
+struct TailSeqs {
+    struct {
+        const float* x;
+        const int32_t* list;
+        const int32_t* countDev;
+        float* out;
+    } seq[CBINFER_SPLIT_MAX_SEQUENCES];
+};
+
 __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cb_tail1x1_kernel(
-    const float* __restrict__ x, const int32_t* __restrict__ list, int nHost,
-    const int32_t* __restrict__ countDev, const float* __restrict__ w1p, const float* __restrict__ b1,
-    const float* __restrict__ w2, const float* __restrict__ b2, float* out, int C0, int C0P, int C1, int C2,
+    TailSeqs tab, int nHost, const float* __restrict__ w1p, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, int C0, int C0P, int C1, int C2,
     int HW, int relu1, int relu2) {
     extern __shared__ float sm[];   // Xs[C0P][16] | Hs[C1P][17] | W2s[C2][C1] | b2s[C2]
+    const float* __restrict__ x = tab.seq[blockIdx.y].x;
+    const int32_t* __restrict__ list = tab.seq[blockIdx.y].list;
+    const int32_t* __restrict__ countDev = tab.seq[blockIdx.y].countDev;
+    float* out = tab.seq[blockIdx.y].out;
     const int N = countDev ? min(*countDev, nHost) : nHost;
     const int t = threadIdx.x, NT = blockDim.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -160,6 +173,33 @@ int cbinfer_tail1x1_prep(const float* w1, float* w1Prepared, int C1, int C0, cbS
     return cb_launch_status();
 }
 
+// The same for nSeq sequences in one launch (own input, change list, count and output each; shared weights).
+int cbinfer_tail1x1_batched(const cbTailSeq* seqs, int nSeq, int numChanges, const float* w1Prepared,
+                            const float* b1, const float* w2, const float* b2, int C0, int C1, int C2, int H, int W,
+                            int relu1, int relu2, cbStream_t stream) {
+    CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBINFER_SPLIT_MAX_SEQUENCES && w1Prepared && b1 && w2 && b2 && C0 > 0 &&
+               C1 > 0 && C2 > 0 && H > 0 && W > 0 && numChanges >= 0);
+    if (C1 > 16 * CB_TAIL_MAXW) return CB_ERR_UNSUPPORTED;
+    if (numChanges == 0) return CB_OK;
+    TailSeqs tab;
+    for (int q = 0; q < nSeq; ++q) {
+        CB_REQUIRE(seqs[q].input && seqs[q].changeList && seqs[q].output);
+        tab.seq[q].x = seqs[q].input;
+        tab.seq[q].list = seqs[q].changeList;
+        tab.seq[q].countDev = seqs[q].countDev;
+        tab.seq[q].out = seqs[q].output;
+    }
+    const int C0P = (C0 + 15) / 16 * 16;
+    const int waves = (C1 + 15) / 16;
+    const size_t lds = cb_tail_lds_bytes(C0, C1, C2);
+    if (lds > 60 * 1024) return CB_ERR_UNSUPPORTED;
+    long tiles = ((long)numChanges + CB_TAIL_PX - 1) / CB_TAIL_PX;
+    if (tiles > 2048) tiles = 2048;
+    hipLaunchKernelGGL(cb_tail1x1_kernel, dim3((unsigned)tiles, nSeq), dim3(64 * waves), lds, (hipStream_t)stream,
+                       tab, numChanges, w1Prepared, b1, w2, b2, C0, C0P, C1, C2, H * W, relu1, relu2);
+    return cb_launch_status();
+}
+
 int cbinfer_tail1x1(const float* input, const int32_t* changeList, int numChanges, const int32_t* countDev,
                     const float* w1Prepared, const float* b1, const float* w2, const float* b2,
                     float* output, int C0, int C1, int C2, int H, int W, int relu1, int relu2,
@@ -168,6 +208,8 @@ int cbinfer_tail1x1(const float* input, const int32_t* changeList, int numChange
                C2 > 0 && H > 0 && W > 0 && numChanges >= 0);
     if (C1 > 16 * CB_TAIL_MAXW) return CB_ERR_UNSUPPORTED;
     if (numChanges == 0) return CB_OK;
+    TailSeqs tab;
+    tab.seq[0].x = input, tab.seq[0].list = changeList, tab.seq[0].countDev = countDev, tab.seq[0].out = output;
     const int C0P = (C0 + 15) / 16 * 16;
     const int waves = (C1 + 15) / 16;
     const size_t lds = cb_tail_lds_bytes(C0, C1, C2);
@@ -175,8 +217,7 @@ int cbinfer_tail1x1(const float* input, const int32_t* changeList, int numChange
     long tiles = ((long)numChanges + CB_TAIL_PX - 1) / CB_TAIL_PX;
     if (tiles > 2048) tiles = 2048;   // grid-stride beyond: the capacity is H*W when the count is on the device
     hipLaunchKernelGGL(cb_tail1x1_kernel, dim3((unsigned)tiles), dim3(64 * waves), lds, (hipStream_t)stream,
-                       input, changeList, numChanges, countDev, w1Prepared, b1, w2, b2, output, C0, C0P, C1,
-                       C2, H * W, relu1, relu2);
+                       tab, numChanges, w1Prepared, b1, w2, b2, C0, C0P, C1, C2, H * W, relu1, relu2);
     return cb_launch_status();
 }
 

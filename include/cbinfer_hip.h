@@ -366,7 +366,11 @@ int cbinfer_tail1x1(const float* input, const int32_t* changeList, int numChange
  *   frameMasks : cbinfer_frame_mask_bytes(H,W) bytes, zero on first use: ONE mask (cbinfer_mask_words words) the
  *                detection ORs into and the contraction zeroes again, + an arrival counter behind it
  *   idxOut     : change list of the frame (H*W ints), countOut its length -- by-products, ascending order
- *   workspace  : cbinfer_split_workspace_bytes() bytes, zero on first use; may be NULL (no split along k)
+ *   workspace  : cbinfer_split_workspace_bytes(nSeq, ...) bytes, zero on first use (0 bytes / NULL for layers of
+ *                fewer than 48 k-stages).  A deep contraction is ALWAYS the left-to-right sum of four partial sums
+ *                over fixed k-ranges, whether these are computed by four workgroups (few tiles: slabs + a reduce
+ *                launch) or one after the other by the same one (many tiles): a sequence gets the same bits alone
+ *                and inside a batch.
  * pooled != 0: `input` is the tensor in FRONT of a 2x2/stride-2 max pool [C,pH,pW] (CBPoolMax2d folded into the
  * detection, see cbinfer_cbconv2d_forward_pooled); producerMask as for cbinfer_change_detection_bits_pooled. */
 #define CBINFER_SPLIT_MAX_SEQUENCES 8
@@ -388,7 +392,7 @@ int cbinfer_split_max_sequences(void);
 long cbinfer_split_max_mask_words(int K);   /* cbinfer_mask_words(H,W) x sequences a launch of a K-channel layer takes */
 long cbinfer_split_state_bytes(int C, int H, int W, int kH, int kW);
 long cbinfer_split_prepared_bytes(int C, int K, int kH, int kW);
-long cbinfer_split_workspace_bytes(void);
+long cbinfer_split_workspace_bytes(int nSeq, int C, int H, int W, int K, int kH, int kW);
 int cbinfer_split_prep_weights(const float* weight, void* prepared, int K, int C, int kH, int kW, int H, int W,
                                float weightScale, cbStream_t stream);
 int cbinfer_split_state_init(void* splitState, int C, int H, int W, int kH, int kW, cbStream_t stream);
@@ -399,6 +403,24 @@ int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, i
 int cbinfer_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
                        int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
                        cbStream_t stream);
+/* the other launches of a frame for several sequences at once (own tensors per sequence, shared weights):
+ * cbinfer_change_detection_bits, cbinfer_conv_changed_rows and cbinfer_tail1x1 with arrays of nSeq pointers */
+int cbinfer_change_detection_bits_batched(const float* const* inputs, float* const* states, uint64_t* const* bitsOut,
+                                          int nSeq, int W, int H, int C, int kHHalf, int kWHalf, float threshold,
+                                          int updateInputState, cbStream_t stream);
+int cbinfer_conv_changed_rows_batched(const float* const* states, uint64_t* const* bits, int32_t* const* arrive,
+                                      uint64_t* const* maskCopies, float* const* outputs, int nSeq,
+                                      const void* prepared, const float* bias, int C, int H, int W, int K, int kH,
+                                      int kW, int relu, cbStream_t stream);
+typedef struct {
+    const float* input;
+    const int32_t* changeList;
+    const int32_t* countDev; /* may be NULL: numChanges entries */
+    float* output;
+} cbTailSeq;
+int cbinfer_tail1x1_batched(const cbTailSeq* seqs, int nSeq, int numChanges, const float* w1Prepared,
+                            const float* b1, const float* w2, const float* b2, int C0, int C1, int C2, int H, int W,
+                            int relu1, int relu2, cbStream_t stream);
 int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared,
                           const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
                           float weightScale, int relu, void* workspace, cbStream_t stream);

@@ -199,3 +199,15 @@ def test_oracle_pool_change_indexes():
     idx7 = np.array([6, 13, 48], dtype=np.int32)                     # 7x7 input, floor pool 3x3
     assert orc.poolChangeIndexes(idx7, (7, 7), (3, 3)).tolist() == []
     assert orc.poolChangeIndexes(idx7, (7, 7), (4, 4)).tolist() == [3, 15]        # ceil-mode pool
+
+
+def test_split_kernel_fragment_reads_are_not_touched_in_flight():
+    """cb_split.hip reads its MFMA fragments with inline-asm ds_read_b128 (so that the compiler does not drain the
+    LDS-DMA ring in front of every read); the results only arrive behind the next s_waitcnt lgkmcnt(0).  The
+    generated code must not move, spill or read such a register in between (tools/lint_split_isa.py)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "lint_split_isa.py")], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=600)
+    assert out.returncode == 0, out.stdout.decode()[-3000:]
+    assert b"3 cbs_conv_kernel instance(s), 0 finding(s)" in out.stdout

@@ -61,7 +61,7 @@ def main():
             s.output, s.idxOut, s.countOut, s.rangeFlag, s.maskCopy = ptr(out), ptr(lst), ptr(cnt), ptr(flag), ptr(cp)
             keep.append((x, S, flag, fm, both, out, lst, cnt, cp))
             fills.append((fm, both, 2 * words))
-        ws = torch.zeros(lib.cbinfer_split_workspace_bytes(), dtype=torch.uint8, device="cuda")
+        ws = torch.zeros(max(lib.cbinfer_split_workspace_bytes(nseq, C, H, W, K, k, k), 8), dtype=torch.uint8, device="cuda")
 
         def fill():
             for fm, both, n in fills:

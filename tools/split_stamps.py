@@ -16,12 +16,21 @@ raw = ctypes.CDLL(_lib.LIB_PATH)
 NAMES = ['entry', 'list lengths known', 'item set up', 'ring primed', 'stage loop done', 'epilogue done']
 
 
-def report():
+def report(clear=True):
     torch.cuda.synchronize()
-    buf = np.zeros(2048 * 8, dtype=np.uint64)
+    buf = np.zeros(2 * 2048 * 8, dtype=np.uint64)
     raw.cbinfer_debug_split_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(buf.nbytes), 0)
-    st = buf.reshape(2048, 8).astype(np.int64)
-    st = st[st[:, 0] > 0]
+    for cfg, name in ((0, "64-row tile"), (1, "128-row tile")):
+        st = buf.reshape(2, 2048, 8)[cfg].astype(np.int64)
+        st = st[st[:, 0] > 0]
+        if len(st):
+            print(" ", name)
+            report_one(st)
+    if clear:
+        raw.cbinfer_debug_split_stamps(None, 0, 1)
+
+
+def report_one(st):
     if len(st) == 0:
         return
     t0 = st[:, 0].min()
@@ -39,7 +48,6 @@ def report():
         tot = (st[ok, 4] - st[ok, 0]) / 100.0
         print("  stage loop of the first item: min %.2f mean %.2f max %.2f us over %d wgs; shader clock ~%.0f MHz"
               % (d.min(), d.mean(), d.max(), ok.sum(), np.median(cyc / np.maximum(tot, 0.01))))
-    raw.cbinfer_debug_split_stamps(None, 0, 1)
 
 
 _ev = bs.ev
@@ -57,4 +65,18 @@ def ev_once(fn, reps=3):
 
 bs.ev = ev_once
 if __name__ == "__main__":
-    bs.main()
+    if len(sys.argv) > 1 and sys.argv[1] == "frame":
+        # the stamps of the LAST frame of a bench-like eager run: the kernels as they run inside the frame
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        base, test = bench.build_bench_model()
+        frames = bench.bench_video(1234).frames(24)
+        with torch.no_grad():
+            for f in frames[:-1]:
+                test(f)
+            torch.cuda.synchronize()
+            raw.cbinfer_debug_split_stamps(None, 0, 1)
+            test(frames[-1])
+        report()
+    else:
+        bs.main()

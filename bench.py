@@ -224,202 +224,170 @@ def event_time_ms(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-def kernel_breakdown(test, frame, reps=50):
-    """Per-layer, per-kernel time of the change-based layers on the state left by the timed sequence,
-    by re-launching each kernel stand-alone through the C ABI (idempotent: same inputs, same outputs).
-    Returns a list of dicts with the algorithmic bytes / flops of SURVEY 8d."""
-    import pycbinfer
-    from cbinfer_amd import conv2d_cg as cg
-    from cbinfer_amd.conv2d import LazyPool
-    from cbinfer_amd._lib import C as lib, check, stream_ptr, ptr
-    rows = []
-    # feed one more frame layer by layer, keeping each CB layer's input
-    x = frame
-    with torch.no_grad():
-        for m in test.children():
-            xin = x
-            x = m(x)
-            if type(m) is pycbinfer.CBConv2d and not m.finegrained:
-                lazy = xin if isinstance(xin, LazyPool) else None     # pool folded into this detection
-                inp = lazy.tensor() if lazy is not None else (xin[1] if isinstance(xin, tuple) else xin)
-                K, C, kH, kW = m.weight.shape
-                Hh, Ww = inp.shape[-2:]
-                s = 4 if inp.dtype == torch.float32 else 2
-                ci = m.lastChangeIndexes()
-                N = ci.numel()
-                mpath = m._rows_path(inp.dtype, Hh, Ww)
-                rowsws = m._work.get('rows') if mpath else None
-                bits = torch.zeros_like(m._work['bits'])
-                cnt = torch.zeros(1, dtype=torch.int32, device=inp.device)
-                idx = torch.empty_like(m._work['idx'])
-                dt = 0 if s == 4 else 1
-                if lazy is not None:
-                    src, st = lazy.source.contiguous(), m.prevInput.clone()
-                    t_det = event_time_ms(lambda: (bits.zero_(), check(lib.cbinfer_change_detection_frame_pooled(
-                        ptr(src), src.shape[-2], src.shape[-1], ptr(st), ptr(bits), Ww, Hh, C, (kH - 1) // 2,
-                        (kW - 1) // 2, float(m.threshold), dt, stream_ptr()))), reps)
-                else:
-                    t_det = event_time_ms(lambda: (bits.zero_(), check(lib.cbinfer_change_detection_bits(
-                        ptr(inp), ptr(m.prevInput), ptr(bits), Ww, Hh, C, (kH - 1) // 2, (kW - 1) // 2,
-                        float(m.threshold), 0, dt, stream_ptr()))), reps)
-                t_zero = event_time_ms(lambda: bits.zero_(), reps)
-                mask_now = rowsws['copy'] if rowsws is not None else m._work['bits']
-                t_cmp = event_time_ms(lambda: check(lib.cbinfer_compact_bits(
-                    ptr(mask_now), Ww, Hh, ptr(idx), ptr(cnt), None, None, stream_ptr())), reps)
-                ar = m._arith(inp)
-                wp = m._prepared_weights(Hh, Ww, ar)
-                ws = m._work['conv']
-                if rowsws is not None:      # row-segment kernel: it consumes its mask, so refill it per launch
-                    saved, rb = rowsws['copy'].clone(), torch.zeros_like(rowsws['bits'])
-                    sink = torch.empty_like(saved)
-                    rw = m._masked_call(mpath)[1]
-                    kern = lib.cbinfer_conv_changed_rows if mpath == 'rows' else lib.cbinfer_conv_changed_blocks
-                    t_fill = event_time_ms(lambda: rb.copy_(saved), reps)
-                    t_conv = max(0.0, event_time_ms(lambda: (rb.copy_(saved), check(kern(
-                        ptr(m.prevInput), ptr(rb), ptr(rowsws['arrive']), ptr(sink), ptr(rw), ptr(m.bias.detach()),
-                        ptr(m.prevOutput), C, Hh, Ww, K, kH, kW, int(m.withReLU), stream_ptr()))), reps) - t_fill)
-                else:
-                    t_conv = event_time_ms(lambda: check(lib.cbinfer_conv_changed(
-                        ptr(m.prevInput), ptr(ci.buffer), Hh * Ww, ptr(ci.count), ptr(wp), ptr(m.bias.detach()),
-                        ptr(m.prevOutput), C, Hh, Ww, K, kH, kW, int(m.withReLU), 0, None, 0, ptr(ws), ar,
-                        stream_ptr())), reps)
-                HW = Hh * Ww
-                rows.append(dict(layer="conv %d->%d k%d @%dx%d" % (C, K, kH, Hh, Ww), N=N,
-                                 conv_kernel=("cb_rowconv_f32_kernel" if mpath == 'rows' else "cb_blockconv_kernel")
-                                 if rowsws is not None else
-                                 ("cb_mfma_f32_kernel<X3: bf16x3 split>" if ar == 2 else "cb_mfma_f32_kernel"),
-                                 ratio=N / float(HW),
-                                 detect_ms=max(t_det - t_zero, 0.0),
-                                 detect_bytes=(5 if lazy is not None else 2) * C * HW * s + HW // 8,
-                                 detect_pooled=lazy is not None,
-                                 compact_ms=t_cmp, compact_bytes=HW // 8 + 4 * N,
-                                 conv_ms=t_conv, conv_flops=2.0 * N * C * kH * kW * K,
-                                 conv_bytes=(N * C * kH * kW + K * C * kH * kW + N * K) * s))
-            elif type(m) is pycbinfer.CBTail1x1:
-                inp, ci = xin[1], xin[2]
-                N = ci.numel()
-                t_tail = event_time_ms(lambda: m(xin), reps)
-                rows.append(dict(layer="tail 1x1 %d->%d->%d @%dx%d" % (m.in_channels, m.hidden_channels,
-                                                                       m.out_channels, inp.shape[-2], inp.shape[-1]),
-                                 N=N, tail_ms=t_tail,
-                                 tail_flops=2.0 * N * (m.in_channels * m.hidden_channels +
-                                                       m.hidden_channels * m.out_channels)))
-            elif type(m) is pycbinfer.CBPoolMax2d:
-                inp, ci = xin[1], xin[2]
-                N = ci.numel()
-                C = inp.shape[1]
-                s = 4 if inp.dtype == torch.float32 else 2
-                if getattr(m, 'lazy', False):   # no launch: folded into the next layer's detection
-                    rows.append(dict(layer="pool C%d @%dx%d (folded into the next detection)"
-                                     % (C, inp.shape[-2], inp.shape[-1]), N=N, pool_ms=0.0, pool_bytes=0))
-                    continue
-                t_pool = event_time_ms(lambda: cg.maxPool2d(inp, m.outputState, ci, (2, 2), (2, 2)), reps)
-                rows.append(dict(layer="pool C%d @%dx%d" % (C, inp.shape[-2], inp.shape[-1]), N=N,
-                                 pool_ms=t_pool, pool_bytes=N * C * 5 * s + 4 * N))
-    return rows
-
-
-def inframe_conv_times(test, frames, start, reps=40):
-    """Duration of every CBConv2d's fused contraction INSIDE the frame: the frame is enqueued eagerly module by
-    module as the network would, except that each change-based layer is issued as its two library calls
-    (detection, then the contraction launch(es)) so that HIP events can be recorded around the second on the
+def inframe_layer_times(test, frames, start, reps=40):
+    """Duration of every launch group of the frame INSIDE the frame: the frame is enqueued eagerly module by
+    module as the network would, except that each change-based layer is issued as its separate library calls
+    (detection, then the contraction launch(es)) so that HIP events can be recorded around ONE of them on the
     launch stream.  The kernel then runs on what the preceding layers just left in the caches, next to the same
-    neighbours as in the timed loop (stand-alone re-launches run warm and came out up to 35 % shorter).
-    ONE layer is bracketed per pass -- every other layer of the frame runs undisturbed (round 2 bracketed all
-    layers in every frame, and its per-layer times summed to more than the frame) -- and each layer gets a
-    second pass with the two events recorded back to back at the same place (nothing between them): that
-    empty-pair time (the cost of the event packets themselves, ~5 us) is reported beside the measurement as
-    its upper error bound, not subtracted.
-    The walk over `frames` continues at step `start`.  Returns {layer label: (mean microseconds, mean changed
-    pixels per launch, empty-pair microseconds)} or None if a layer is not in the sync-free form."""
+    neighbours as in the timed loop (stand-alone re-launches run warm and came out up to 35 % shorter).  One
+    call is bracketed per pass -- every other launch of the frame runs undisturbed -- and one more pass records
+    the two events back to back (nothing between them): that empty-pair time (the cost of the event packets
+    themselves, ~5 us) is reported beside the measurements as their upper error bound, not subtracted.
+    The walk over `frames` continues at step `start`.  Returns (rows, next step) or None if a layer is not in a
+    sync-free feedback-mode form.  rows: one dict per module with the algorithmic work of SURVEY 8d."""
     import pycbinfer
     from cbinfer_amd.conv2d import LazyPool
     from cbinfer_amd._lib import C as lib, check, ptr, stream_ptr, dtype_code
     from cbinfer_amd.conv2d_cg import ChangeIndexes, MaskChangeIndexes
     mods = list(test.children())
-    targets = [i for i, m in enumerate(mods) if type(m) is pycbinfer.CBConv2d and not m.finegrained]
-    out = {}
     step = start
+    # the calls of a frame, in order: (module index, 'detect' | 'conv' | 'tail')
+    calls = []
+    for i, m in enumerate(mods):
+        if type(m) is pycbinfer.CBConv2d and not m.finegrained:
+            calls += [(i, 'detect'), (i, 'conv')]
+        elif type(m) is pycbinfer.CBTail1x1:
+            calls += [(i, 'tail')]
+    info = {}
+
+    def bracket(which, key, empty, sink, fn):
+        mine = which == key
+        if mine:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if empty:
+                e1.record()
+        fn()
+        if mine:
+            if not empty:
+                e1.record()
+            sink.append((e0, e1))
 
     def run_frame(x, which, empty, sink):
         for mi, m in enumerate(mods):
+            if type(m) is pycbinfer.CBTail1x1:
+                xin = x
+                out = []
+                bracket(which, (mi, 'tail'), empty, sink, lambda: out.append(m(xin)))
+                x = out[0]
+                info[mi] = dict(layer="tail 1x1 %d->%d->%d @%dx%d" % (m.in_channels, m.hidden_channels,
+                                                                       m.out_channels, xin[1].shape[-2],
+                                                                       xin[1].shape[-1]),
+                                count=xin[2].count, flops_per_px=2.0 * (m.in_channels * m.hidden_channels +
+                                                                         m.hidden_channels * m.out_channels))
+                continue
             if type(m) is not pycbinfer.CBConv2d or m.finegrained:
                 x = m(x)
                 continue
             work = m._work
-            if (work is None or not work['selfc'] or not m.feedbackLoop or m.syncIndexes or
-                    isinstance(x, tuple)):
+            if (work is None or not work['selfc'] or not m.feedbackLoop or m.syncIndexes or isinstance(x, tuple)):
                 return None
             K, C, kH, kW = m.weight.shape
             lazy = x if isinstance(x, LazyPool) else None
             src = (lazy.source if lazy is not None else x).contiguous()
             Hh, Ww = (lazy.outSize[-2:] if lazy is not None else src.shape[-2:])
             dt, st = dtype_code(src), stream_ptr(src)
-            mpath = m._rows_path(src.dtype, Hh, Ww)
-            rows = work.get('rows') if mpath else None
-            bits = rows['bits'] if rows is not None else work['bits']
-            if lazy is not None:
-                if rows is not None:
-                    check(lib.cbinfer_change_detection_bits_pooled(
-                        ptr(src), src.shape[-2], src.shape[-1], ptr(lazy.producerMask()), ptr(m.prevInput),
-                        ptr(bits), Ww, Hh, C, (kH - 1) // 2, (kW - 1) // 2, float(m.threshold), dt, st))
+            s_el = 4 if src.dtype == torch.float32 else 2
+            if m._split_ok(src.dtype, Hh, Ww):
+                sp = work['split']
+                if sp is None:
+                    return None
+                wp, scale = m._split_weights(Hh, Ww)
+                q = sp['seq'][0]
+                pm = lazy.producerMask() if lazy is not None else None
+                q.input, q.producerMask = src.data_ptr(), ptr(pm)
+                pooled = int(lazy is not None)
+                pH, pW = (src.size(-2), src.size(-1)) if lazy is not None else (0, 0)
+                bracket(which, (mi, 'detect'), empty, sink, lambda: check(lib.cbinfer_split_detect(
+                    sp['seq'], 1, pooled, pH, pW, C, Hh, Ww, kH, kW, float(m.threshold), st)))
+                bracket(which, (mi, 'conv'), empty, sink, lambda: check(lib.cbinfer_split_conv(
+                    sp['seq'], 1, ptr(wp), ptr(m.bias.detach()), C, Hh, Ww, K, kH, kW, float(scale),
+                    int(bool(m.withReLU)), ptr(sp['ws']), 0, st)))
+                ci = MaskChangeIndexes(sp['copy'], (Hh, Ww), work['idx'], work['count'], made=True)
+                kern = "cbs_conv_kernel (split-state, LDS-DMA, f16-pair products)" + \
+                    (" + cbs_reduce_kernel" if sp['ws'] is not None else "")
+            else:
+                mpath = m._rows_path(src.dtype, Hh, Ww)
+                rows = m._rows_workspace(work, Hh, Ww, src.device) if mpath else None
+                bits = rows['bits'] if rows is not None else work['bits']
+                if lazy is not None:
+                    if rows is not None:
+                        det = lambda: check(lib.cbinfer_change_detection_bits_pooled(
+                            ptr(src), src.shape[-2], src.shape[-1], ptr(lazy.producerMask()), ptr(m.prevInput),
+                            ptr(bits), Ww, Hh, C, (kH - 1) // 2, (kW - 1) // 2, float(m.threshold), dt, st))
+                    else:
+                        det = lambda: check(lib.cbinfer_change_detection_frame_pooled(
+                            ptr(src), src.shape[-2], src.shape[-1], ptr(m.prevInput), ptr(bits), Ww, Hh, C,
+                            (kH - 1) // 2, (kW - 1) // 2, float(m.threshold), dt, st))
                 else:
-                    check(lib.cbinfer_change_detection_frame_pooled(
-                        ptr(src), src.shape[-2], src.shape[-1], ptr(m.prevInput), ptr(bits), Ww, Hh, C,
-                        (kH - 1) // 2, (kW - 1) // 2, float(m.threshold), dt, st))
-            else:
-                det = lib.cbinfer_change_detection_bits if rows is not None else \
-                    lib.cbinfer_change_detection_frame
-                check(det(ptr(src), ptr(m.prevInput), ptr(bits), Ww, Hh, C, (kH - 1) // 2, (kW - 1) // 2,
-                          float(m.threshold), 1, dt, st))
-            mine = mi == which
-            if mine:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                if empty:
-                    e1.record()
-            if rows is not None:
-                kern = lib.cbinfer_conv_changed_rows if mpath == 'rows' else lib.cbinfer_conv_changed_blocks
-                check(kern(ptr(m.prevInput), ptr(rows['bits']), ptr(rows['arrive']), ptr(rows['copy']),
-                           ptr(m._masked_call(mpath)[1]), ptr(m.bias.detach()), ptr(m.prevOutput), C, Hh, Ww, K,
-                           kH, kW, int(m.withReLU), st))
-            else:
-                check(lib.cbinfer_conv_changed_from_mask(
-                    ptr(m.prevInput), ptr(work['bits']), ptr(work['idx']), ptr(work['count']),
-                    ptr(m._prepared_weights(Hh, Ww, m._arith(src))), ptr(m.bias.detach()), ptr(m.prevOutput), C,
-                    Hh, Ww, K, kH, kW, int(m.withReLU), ptr(work['conv']), m._arith(src), st))
-            if mine and not empty:
-                e1.record()
-            ci = (MaskChangeIndexes(rows['copy'], (Hh, Ww), work['idx'], work['count']) if rows is not None
-                  else ChangeIndexes(work['idx'], work['count'], (Hh, Ww)))
-            if mine:
-                sink.append((e0, e1, ci if not empty else None,
-                             "conv %d->%d k%d @%dx%d" % (C, K, kH, Hh, Ww)))
+                    dfn = lib.cbinfer_change_detection_bits if rows is not None else \
+                        lib.cbinfer_change_detection_frame
+                    det = lambda: check(dfn(ptr(src), ptr(m.prevInput), ptr(bits), Ww, Hh, C, (kH - 1) // 2,
+                                            (kW - 1) // 2, float(m.threshold), 1, dt, st))
+                bracket(which, (mi, 'detect'), empty, sink, det)
+                if rows is not None:
+                    kfn = lib.cbinfer_conv_changed_rows if mpath == 'rows' else lib.cbinfer_conv_changed_blocks
+                    conv = lambda: check(kfn(ptr(m.prevInput), ptr(rows['bits']), ptr(rows['arrive']),
+                                             ptr(rows['copy']), ptr(m._masked_call(mpath)[1]), ptr(m.bias.detach()),
+                                             ptr(m.prevOutput), C, Hh, Ww, K, kH, kW, int(m.withReLU), st))
+                    kern = "cb_rowconv_f32_kernel" if mpath == 'rows' else "cb_blockconv_kernel"
+                else:
+                    ar = m._arith(src)
+                    conv = lambda: check(lib.cbinfer_conv_changed_from_mask(
+                        ptr(m.prevInput), ptr(work['bits']), ptr(work['idx']), ptr(work['count']),
+                        ptr(m._prepared_weights(Hh, Ww, ar)), ptr(m.bias.detach()), ptr(m.prevOutput), C, Hh, Ww, K,
+                        kH, kW, int(m.withReLU), ptr(work['conv']), ar, st))
+                    kern = "cb_mfma_f32_kernel<X3: bf16x3 split>" if ar == 2 else "cb_mfma_f32_kernel"
+                bracket(which, (mi, 'conv'), empty, sink, conv)
+                ci = (MaskChangeIndexes(rows['copy'], (Hh, Ww), work['idx'], work['count']) if rows is not None
+                      else ChangeIndexes(work['idx'], work['count'], (Hh, Ww)))
+            info[mi] = dict(layer="conv %d->%d k%d @%dx%d" % (C, K, kH, Hh, Ww), conv_kernel=kern, count=ci,
+                            HW=Hh * Ww, C=C, K=K, k=kH * kW, s=s_el, pooled=lazy is not None)
             x = ('changeIndexes', m.prevOutput, ci) if m.propChangeIndexes else m.prevOutput
         return x
 
+    times, counts = {}, {}
     with torch.no_grad():
-        for which in targets:
-            res = {}
-            for empty in (True, False):
-                sink, cnt = [], torch.zeros(1, dtype=torch.int64, device=frames[0].device)
-                for it in range(reps + 3):
-                    got = []
-                    if run_frame(frames[pingpong(step, len(frames))], which, empty, got) is None:
-                        return None
-                    step += 1
-                    if it >= 3:
-                        sink += got
-                        if not empty:
-                            cnt += got[0][2].count     # (after the timed kernel; a mask-driven frame compacts here)
-                torch.cuda.synchronize()
-                res[empty] = (1e3 * sum(a.elapsed_time(b) for a, b, _, _ in sink) / len(sink),
-                              cnt.item() / float(len(sink)), sink[0][3])
-            # (the bracketed time is reported as measured: an empty pair costs ~5.5 us, but around a kernel most of
-            #  that hides under the kernel -- subtracting it gave 44.6 us where rocprofv3 sees 42.1 + 6.6 us of
-            #  kernels plus their gap; unsubtracted, 50.3.  The empty-pair time is reported beside it.)
-            out[res[False][2]] = (res[False][0], res[False][1], res[True][0])
-    return out, step
+        for key in [None] + calls:          # None: the empty-pair pass (bracket at the first call's place)
+            sink = []
+            cnt = {}
+            for it in range(reps + 3):
+                got = []
+                if run_frame(frames[pingpong(step, len(frames))], calls[0] if key is None else key, key is None,
+                             got) is None:
+                    return None
+                step += 1
+                if it >= 3:
+                    sink += got
+                    if key is not None and key[1] != 'detect':
+                        c = info[key[0]]['count']
+                        c = c.count if hasattr(c, 'count') and not isinstance(c, torch.Tensor) else c
+                        cnt.setdefault(key[0], torch.zeros(1, dtype=torch.int64, device=frames[0].device))
+                        cnt[key[0]] += c
+            torch.cuda.synchronize()
+            times[key] = 1e3 * sum(a.elapsed_time(b) for a, b in sink) / len(sink)      # microseconds
+            for k, v in cnt.items():
+                counts[k] = v.item() / float(len(sink))
+    rows = []
+    for mi, m in enumerate(mods):
+        if mi not in info:
+            if type(m) is pycbinfer.CBPoolMax2d:
+                rows.append(dict(layer="pool (folded into the next detection)" if getattr(m, 'lazy', False)
+                                 else "pool (own launch: timed with its consumer)"))
+            continue
+        d = info[mi]
+        if 'flops_per_px' in d:
+            n = counts.get(mi, 0.0)
+            rows.append(dict(layer=d['layer'], N=n, tail_ms=times[(mi, 'tail')] * 1e-3,
+                             tail_flops=d['flops_per_px'] * n))
+            continue
+        n = counts.get(mi, 0.0)
+        rows.append(dict(layer=d['layer'], N=n, ratio=n / float(d['HW']), conv_kernel=d['conv_kernel'],
+                         detect_ms=times[(mi, 'detect')] * 1e-3, detect_pooled=d['pooled'],
+                         detect_bytes=(5 if d['pooled'] else 2) * d['C'] * d['HW'] * d['s'] + d['HW'] // 8,
+                         conv_ms=times[(mi, 'conv')] * 1e-3, conv_flops=2.0 * n * d['C'] * d['k'] * d['K'],
+                         conv_bytes=(n * d['C'] * d['k'] + d['K'] * d['C'] * d['k'] + n * d['K']) * d['s']))
+    return rows, step, times[None]
 
 
 def kernel_source_hash():
@@ -447,7 +415,7 @@ def measured_traffic(kname, layer):
     if pmc.get("kernel_source_sha256") != kernel_source_hash():
         return None, "%s was collected on other kernel sources (%s, now %s)" % (
             name, pmc.get("kernel_source_sha256"), kernel_source_hash())
-    key = ("cb_mfma_f32_kernel " if kname == "conv" else "cb_%s_kernel " % kname) + layer
+    key = ("conv " if kname == "conv" else "cb_%s_kernel " % kname) + layer
     if key not in pmc:
         return None, "%s has no entry %r" % (name, key)
     return pmc[key].get("bytes_per_launch"), "%s (commit %s)" % (name, pmc.get("commit", "?"))
@@ -699,6 +667,60 @@ def main():
             del drunner, dfr
         del mseqs
         torch.cuda.synchronize()
+        multi_result["streams_value"] = multi_result["value"]
+        multi_result["how"] = ("streams: one model copy, HIP stream and captured graph per sequence; batched: "
+                               "pycbinfer.SequenceBatch -- ONE launch per step of the frame for all sequences "
+                               "(own state each, shared weights; per sequence bit-identical to a run alone, "
+                               "tests/test_gpu_batch.py).  value = the batched form")
+        # the same S sequences through pycbinfer.SequenceBatch (experiment 5/6 networks with both fusions)
+        if args.experiment in (5, 6) and not args.no_fuse_tail and not args.no_fuse_pool:
+            import pycbinfer as _pk
+            _, bnet = build_bench_model(args.experiment, args.threshold, True, True, args.pool_clone)
+            sb = _pk.SequenceBatch(bnet, args.multi)
+            nfr = max(8, min(max(args.steps, args.warmup), 256))
+            bvids = [bench_video(shard.sequence_seed(1234) + 7919 * (1 + q), args.ratio, args.block, args.pattern)
+                     for q in range(args.multi)]
+            bfr = [v.frames(2 + nfr) for v in bvids]
+            best = None
+            with torch.no_grad():
+                for i in range(2):
+                    sb([f[i] for f in bfr])
+                walk = [f[2:] for f in bfr]
+                for bmode in ("eager", "graph"):
+                    static = [w[0].clone() for w in walk]
+                    g = None
+                    if bmode == "graph":
+                        side = torch.cuda.Stream()
+                        side.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(side):
+                            sb(static)
+                        torch.cuda.current_stream().wait_stream(side)
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=side):
+                            sb(static)
+
+                    def bstep(i):
+                        fr = [w[pingpong(i, len(w))] for w in walk]
+                        if g is None:
+                            sb(fr)
+                        else:
+                            for q in range(args.multi):
+                                static[q].copy_(fr[q])
+                            g.replay()
+                    for i in range(max(args.warmup, 1)):
+                        bstep(i)
+                    torch.cuda.synchronize()
+                    n = max(args.steps, int(math.ceil(args.min_seconds * multi_result["streams_value"] / args.multi)))
+                    t0 = time.perf_counter()
+                    for i in range(n):
+                        bstep(max(args.warmup, 1) + i)
+                    torch.cuda.synchronize()
+                    fps_b = args.multi * n / (time.perf_counter() - t0)
+                    if best is None or fps_b > best[0]:
+                        best = (fps_b, bmode, n)
+            multi_result.update(value=best[0], batched_value=best[0], batched_launch=best[1], steps=best[2])
+            del sb, bnet, bfr, bvids
+            torch.cuda.synchronize()
 
     mode, calibration = args.mode, None
     if mode == "graph" and not capturable:
@@ -833,68 +855,48 @@ def main():
 
     # per-kernel measurement (HIP events on the launch stream) -> roofline of the dominant kernel
     if world == 1:
-        pos = seqs[0]['pos']
-        got = inframe_conv_times(test, frames, pos)     # contraction kernels as they run in the frame
-        inframe, pos = got if got is not None else (None, pos)
-        # every kernel stand-alone (warm re-launches) on the next frame of the walk
-        test_rows = kernel_breakdown(test, frames[pingpong(pos, len(frames))])
-        for r in test_rows:
-            if inframe and r.get("layer") in inframe:
-                us, n, empty_us = inframe[r["layer"]]
-                r["conv_ms_standalone"], r["N_standalone"] = r["conv_ms"], r["N"]
-                r["conv_ms"], r["N"] = us * 1e-3, n
-                r["event_pair_ms"] = empty_us * 1e-3
-                r["conv_flops"] = r["conv_flops"] * n / max(r["N_standalone"], 1)
-                r["conv_timing"] = ("in-frame: HIP events around the contraction launch(es) inside the eager "
-                                    "frame, one layer bracketed per pass (event_pair_ms = an empty event pair at "
-                                    "the same place: upper bound of what the bracket itself adds); mean N")
-        result["layers"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()}
-                            for r in test_rows]
-        if inframe:
-            # the contractions are part of the frame: their in-frame durations must fit into one step
-            tot = sum(r["conv_ms"] for r in test_rows if "conv_timing" in r)
-            result["layers_check"] = {"sum_conv_ms_in_frame": round(tot, 5),
+        got = inframe_layer_times(test, frames, seqs[0]['pos'])
+        if got is not None:
+            test_rows, _, pair_us = got
+            timing = ("in-frame: HIP events around the library call (one or two launches) inside the eager frame, "
+                      "one call bracketed per pass; event_pair_ms = an empty event pair at the same place -- the "
+                      "upper bound of what the bracket itself adds (not subtracted); mean N")
+            result["layers"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()}
+                                for r in test_rows]
+            result["layers_timing"] = timing
+            result["event_pair_ms"] = round(pair_us * 1e-3, 5)
+            # the launches are parts of the frame: their in-frame durations -- each of which carries up to one
+            # event pair of bracket overhead -- must fit into one step plus those overheads
+            n_meas = sum(("conv_ms" in r) * 2 + ("tail_ms" in r) for r in test_rows)
+            tot = sum(r.get("conv_ms", 0.0) + r.get("detect_ms", 0.0) + r.get("tail_ms", 0.0) for r in test_rows)
+            result["layers_check"] = {"sum_ms_in_frame": round(tot, 5), "measurements": n_meas,
                                       "ms_per_step": round(result["ms_per_step"], 5),
-                                      "consistent": bool(tot <= result["ms_per_step"])}
-            if tot > result["ms_per_step"]:
-                log("bench: WARNING in-frame contraction times sum to %.4f ms > %.4f ms per step"
-                    % (tot, result["ms_per_step"]))
-        best = None
-        for r in test_rows:
-            for kname in ("detect", "compact", "conv", "pool"):
-                if kname + "_ms" in r and (best is None or r[kname + "_ms"] > best[2]):
-                    best = (r, kname, r[kname + "_ms"])
-        if best is None:     # (fine-grained experiment: no coarse-grained kernel to break down)
-            best = (None, None, 0.0)
-        r, kname, ms = best
-        if kname is not None:
-            traffic, traffic_src = measured_traffic(kname, r["layer"])
-            timing = r.get("conv_timing", "stand-alone re-launches") if kname == "conv" else "stand-alone re-launches"
-            if kname == "conv":
-                ach = r["conv_flops"] / (ms * 1e-3) / 1e12
-                result["roofline"] = {"kernel": r.get("conv_kernel", "cb_mfma_f32_kernel") +
-                                      " (fused gather->MFMA->scatter), " + r["layer"],
-                                      "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                                      "peak_note": "dense f32 MFMA peak (the dtype's); the bf16x3 arithmetic's own "
-                                                   "ceiling is 2500/6 = 416.7 TFLOP/s of f32-equivalent work",
-                                      "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                                      "traffic_source": traffic_src, "avg_duration_us": ms * 1e3,
-                                      "duration_timing": timing, "units_per_launch": r["N"]}
-                if "cb_mfma" in r.get("conv_kernel", ""):
-                    result["roofline"]["launches"] = (
-                        "the contraction is two launches when its k-range is split over workgroups (16-wave forms): "
-                        "cb_mfma_f32_kernel and cb_splitk_reduce_kernel, which sums the slices; avg_duration_us and "
-                        "traffic cover both")
-            else:
-                ach = r[kname + "_bytes"] / (ms * 1e-3) / 1e9
-                result["roofline"] = {"kernel": kname + ", " + r["layer"], "bound": "hbm", "achieved": ach,
-                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                      "traffic": traffic, "traffic_source": traffic_src,
-                                      "avg_duration_us": ms * 1e3, "duration_timing": timing,
-                                      "units_per_launch": r["N"]}
-        if args.breakdown:
-            for r in test_rows:
-                log(json.dumps(r))
+                                      "consistent": bool(tot - n_meas * pair_us * 1e-3 <= result["ms_per_step"])}
+            best = max((r for r in test_rows if "conv_ms" in r), key=lambda r: r["conv_ms"], default=None)
+            if best is not None:
+                r = best
+                ach = r["conv_flops"] / (r["conv_ms"] * 1e-3) / 1e12
+                split = "split-state" in r["conv_kernel"]
+                ceiling = 2500.0 / 3 if split else 2500.0 / 6
+                traffic, traffic_src = measured_traffic("conv", r["layer"])
+                result["roofline"] = {
+                    "kernel": r["conv_kernel"] + " (fused gather->MFMA->scatter), " + r["layer"],
+                    "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+                    "peak_note": "dense f32 MFMA peak (the tensors' dtype).  The contraction runs as %s on the "
+                                 "16-bit MFMA (2.5 PFLOP/s dense): its own ceiling is %.1f TFLOP/s of f32-equivalent "
+                                 "work" % ("f16-pair products (3 per multiply)" if split else
+                                           "bf16x3 split products (6 per multiply)", ceiling),
+                    "arith_ceiling": ceiling, "frac_of_arith_ceiling": ach / ceiling,
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "avg_duration_us": r["conv_ms"] * 1e3, "duration_timing": timing,
+                    "units_per_launch": r["N"],
+                    "launches": "the contraction is two launches when its k-range is split over workgroups (short "
+                                "change lists): the partial tiles are summed by a reduce launch; avg_duration_us "
+                                "and traffic cover both"}
+            if args.breakdown:
+                for r in test_rows:
+                    log(json.dumps(r))
 
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(args)

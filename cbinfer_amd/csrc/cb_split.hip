@@ -476,7 +476,8 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     for (int q = t; q < p.nSeq; q += NT) s_maskPtr[q] = p.seq[q].masks;
     __syncthreads();
     const int E = p.nSeq * MW;
-    for (int i = t; i < E; i += NT) {
+#pragma unroll 4
+    for (int i = t; i < E; i += NT) {      // (independent loads: several in flight per thread)
         const int q = cbs_div(i, p.magicMW), w = i - q * MW;
         const unsigned long long word = s_maskPtr[q][w];
         s_pre[i] = __popcll(word);
@@ -839,21 +840,31 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
 #endif
             continue;
         }
+        // (an unsplit deep item: the running sum of the earlier chunks comes back from the slab, 16 bytes per load,
+        //  all loads requested before the first is used)
+        float4 rs[TN][4];
+        if (folds > 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                    rs[j][r4] = mySlab[(wm * 8 + 2 * r4 + h) * BN + (wn * TN + j) * 32 + l31];
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nl = (wn * TN + j) * 32 + l31;
             const int pix = s_tilePix[nl];
-            if (pix < 0) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, m = m0 + ml;
-                if (m >= p.K) continue;
                 float v = acc1[j][r] + acc2[j][r] * lo2;
-                if (folds > 0)                          // (the last chunk joins the running sum)
-                    v = ((const float*)(mySlab + (wm * 8 + 2 * (r >> 2) + h) * BN + nl))[r & 3] + v;
+                if (folds > 0) {                         // (the last chunk joins the running sum)
+                    const float4 o = rs[j][r >> 2];
+                    v = ((r & 3) == 0 ? o.x : (r & 3) == 1 ? o.y : (r & 3) == 2 ? o.z : o.w) + v;
+                }
                 v = v * p.outScale + s_bias[ml];
                 if (p.relu) v = v <= 0.f ? 0.f : v;
-                out[(long)m * HW + pix] = v;
+                if (pix >= 0 && m < p.K) out[(long)m * HW + pix] = v;
             }
         }
         CBS_STAMP_AT(5);

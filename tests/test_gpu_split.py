@@ -1,0 +1,282 @@
+"""-m gpu tests of the split-state kernels (cb_split.hip) through the C ABI: detection + refresh of both states,
+the LDS-DMA contraction in f16-pair arithmetic, the k-split and its invariance, several sequences per launch.
+Reference behaviour: cbconv2d_cg_backend.cu:40-81 (detection, feedback refresh), :138-197 + conv2d_cg.py:342-349
+(gather, contraction, scatter) as restated by the oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from cbinfer_amd import _lib
+    assert torch.cuda.is_available()
+    return _lib
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+class Layer(object):
+    """Buffers of one layer for nSeq sequences + the calls, as CBConv2d._forward_split makes them."""
+
+    def __init__(self, lib, w, b, H, W, nSeq=1, pooled=None):
+        C_ = lib.C
+        self.lib, self.nSeq, self.H, self.W = lib, nSeq, H, W
+        self.K, self.C, self.kH, self.kW = w.shape
+        self.w, self.b = dev(w), dev(b)
+        wmax = float(np.abs(w).max())
+        self.scale = 2.0 ** (13 - math.floor(math.log2(wmax)))
+        K, Cc, kH, kW = w.shape
+        self.wp = torch.empty(C_.cbinfer_split_prepared_bytes(Cc, K, kH, kW), dtype=torch.uint8, device="cuda")
+        lib.check(C_.cbinfer_split_prep_weights(self.w.data_ptr(), self.wp.data_ptr(), K, Cc, kH, kW, H, W,
+                                                 self.scale, None))
+        words = C_.cbinfer_mask_words(H, W)
+        wsb = C_.cbinfer_split_workspace_bytes(nSeq, Cc, H, W, K, kH, kW)
+        self.ws = torch.zeros(wsb, dtype=torch.uint8, device="cuda") if wsb else None
+        self.seqs = (lib.SplitSeq * nSeq)()
+        self.state, self.S, self.masks, self.out, self.idx, self.cnt, self.copy = [], [], [], [], [], [], []
+        self.flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        self.pooled = pooled
+        for q in range(nSeq):
+            self.state.append(torch.full((1, Cc, H, W), float("inf"), device="cuda"))
+            S = torch.empty(C_.cbinfer_split_state_bytes(Cc, H, W, kH, kW), dtype=torch.uint8, device="cuda")
+            lib.check(C_.cbinfer_split_state_init(S.data_ptr(), Cc, H, W, kH, kW, None))
+            lib.check(C_.cbinfer_split_state_rebuild(self.state[q].data_ptr(), S.data_ptr(), Cc, H, W, kH, kW,
+                                                     self.flag.data_ptr(), None))
+            self.S.append(S)
+            self.masks.append(torch.zeros(C_.cbinfer_frame_mask_bytes(H, W) // 8, dtype=torch.int64, device="cuda"))
+            self.out.append(torch.full((1, K, H, W), float("inf"), device="cuda"))
+            self.idx.append(torch.zeros(H * W, dtype=torch.int32, device="cuda"))
+            self.cnt.append(torch.zeros(1, dtype=torch.int32, device="cuda"))
+            self.copy.append(torch.zeros(words, dtype=torch.int64, device="cuda"))
+            s = self.seqs[q]
+            s.state, s.splitState, s.frameMasks = self.state[q].data_ptr(), S.data_ptr(), self.masks[q].data_ptr()
+            s.output, s.idxOut, s.countOut = self.out[q].data_ptr(), self.idx[q].data_ptr(), self.cnt[q].data_ptr()
+            s.rangeFlag, s.maskCopy = self.flag.data_ptr(), self.copy[q].data_ptr()
+
+    def frame(self, inputs, th, relu=False, force=0, prodMasks=None):
+        C_ = self.lib.C
+        for q, x in enumerate(inputs):
+            self.seqs[q].input = x.data_ptr()
+            self.seqs[q].producerMask = prodMasks[q].data_ptr() if prodMasks else None
+        pH, pW = (inputs[0].shape[-2], inputs[0].shape[-1]) if self.pooled else (0, 0)
+        self.lib.check(C_.cbinfer_split_detect(self.seqs, self.nSeq, int(bool(self.pooled)), pH, pW, self.C, self.H,
+                                               self.W, self.kH, self.kW, th, None))
+        self.lib.check(C_.cbinfer_split_conv(self.seqs, self.nSeq, self.wp.data_ptr(), self.b.data_ptr(), self.C,
+                                             self.H, self.W, self.K, self.kH, self.kW, self.scale, int(relu),
+                                             self.ws.data_ptr() if self.ws is not None else None, force, None))
+        torch.cuda.synchronize()
+
+    def list(self, q=0):
+        return self.idx[q][:int(self.cnt[q].item())].cpu().numpy()
+
+
+def block_video(rng, C, H, W, frames, frac, blk=8):
+    x = rng.standard_normal((1, C, H, W)).astype(np.float32)
+    out = [x.copy()]
+    for _ in range(frames - 1):
+        x = x.copy()
+        for _ in range(max(1, int(frac * H * W / blk / blk))):
+            y0, x0 = rng.integers(0, max(1, H - blk)), rng.integers(0, max(1, W - blk))
+            bh, bw = min(blk, H - y0), min(blk, W - x0)
+            x[0, :, y0:y0 + bh, x0:x0 + bw] = rng.standard_normal((C, bh, bw))
+        out.append(x)
+    return out
+
+
+@pytest.mark.parametrize("C,K,kH,kW,H,W,frac", [
+    (16, 64, 7, 7, 160, 240, 0.1), (64, 256, 7, 7, 80, 120, 0.1), (64, 256, 7, 7, 80, 120, 0.6),
+    (16, 16, 3, 3, 37, 70, 0.3), (32, 40, 3, 5, 45, 67, 0.2), (64, 130, 5, 5, 33, 64, 0.15),
+    (16, 64, 7, 7, 7, 9, 0.5), (32, 200, 7, 7, 21, 130, 0.05)])
+def test_split_frames_vs_oracle(lib, oracle, C, K, kH, kW, H, W, frac):
+    """Feedback-mode frames of one layer against the oracle's state machine (CBConv2d.forward_normal,
+    conv2d.py:178-259): change list bit-exact incl. order, refreshed state bit-exact, outputs <= 1e-4, the mask
+    copy equal to the dilated map; odd sizes, non-square filters, output channels off the tile grid."""
+    rng = np.random.default_rng(C * 1000 + K + H)
+    w = (rng.standard_normal((K, C, kH, kW)) / np.sqrt(C * kH * kW)).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    L = Layer(lib, w, b, H, W)
+    o = oracle.OracleCBConv2d(w, b, 0.1, withReLU=True, feedbackLoop=True, propChangeIndexes=True)
+    for t, x in enumerate(block_video(rng, C, H, W, 5, frac)):
+        # sub-threshold noise everywhere: must never trigger, and must not leak into the state either
+        xn = (x + rng.uniform(-0.03, 0.03, x.shape)).astype(np.float32)
+        L.frame([dev(xn)], 0.1, relu=True)
+        got = o.forward(xn)
+        assert np.array_equal(L.list(), got[2]), t
+        assert np.array_equal(L.state[0].cpu().numpy(), o.prevInput), t
+        err = np.abs(L.out[0].cpu().numpy() - o.prevOutput).max()
+        assert err <= FP32_TOL, (t, err)
+        words = L.copy[0].cpu().numpy().view(np.uint64)
+        wpr = (W + 63) // 64
+        bits = np.unpackbits(words.view(np.uint8), bitorder="little").reshape(H, wpr * 64)[:, :W]
+        assert np.array_equal(bits.astype(np.int8), o.changeMap), t
+    assert int(L.flag.item()) == 0
+    # a repeated frame changes nothing and leaves an empty list
+    L.frame([dev(xn)], 0.1, relu=True)
+    assert L.list().size == 0
+
+
+@pytest.mark.parametrize("C,K,H,W", [(64, 256, 40, 60), (16, 64, 80, 120), (32, 128, 33, 47)])
+def test_split_arithmetic_accuracy(lib, oracle, C, K, H, W):
+    """The f16-pair arithmetic (x 2^-4 = hi + lo 2^-11, three MFMA products per multiply, f32 accumulation)
+    against the double-accumulated oracle on operands spanning many binades: every element within
+    64 * 2^-24 * sum|a||b| -- the bound tests/test_gpu_ops.py::test_split_contraction_accuracy holds the bf16x3 form
+    to -- and the worst relative error reported (per product the analysis gives <= 3 * 2^-22)."""
+    rng = np.random.default_rng(C + K)
+    x = (rng.standard_normal((1, C, H, W)) * np.exp(rng.uniform(-6, 3, (1, C, 1, 1)))).astype(np.float32)
+    x[0, 0, :4] *= 1e-6                                     # values deep in the f16 subnormal range of hi AND lo
+    w = (rng.standard_normal((K, C, 7, 7)) / np.sqrt(C * 49) * np.exp(rng.uniform(-4, 2, (K, 1, 1, 1)))).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    L = Layer(lib, w, b, H, W)
+    L.frame([dev(x)], 0.1)                                   # first frame: every pixel
+    idx = np.arange(H * W, dtype=np.int32)
+    assert np.array_equal(L.list(), idx)
+    X = oracle.genXMatrix(x, idx, (7, 7))
+    Y = oracle.matrixMult(X, w, b).T.reshape(1, K, H, W)
+    mag = (np.abs(X).astype(np.float64) @ np.abs(w.reshape(K, -1)).astype(np.float64).T).T.reshape(1, K, H, W)
+    err = np.abs(L.out[0].cpu().numpy().astype(np.float64) - Y)
+    rel = (err / (mag + 1e-30)).max()
+    print("C%d K%d: max |err| %.3g, relative to sum|a||b| %.3g (2^%.1f)" % (C, K, err.max(), rel, np.log2(rel)))
+    assert np.all(err <= 64 * 2.0 ** -24 * mag + 1e-30)
+    assert rel <= 8 * 2.0 ** -22
+
+
+def test_split_is_invariant_under_the_k_split(lib, oracle):
+    """A deep contraction is the left-to-right sum of four partial sums over fixed k-ranges whether four workgroups
+    compute them (slabs + reduce launch) or one does, one after the other: bit-identical outputs."""
+    rng = np.random.default_rng(5)
+    C, K, H, W = 64, 256, 40, 60
+    w = (rng.standard_normal((K, C, 7, 7)) / np.sqrt(C * 49)).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    vid = block_video(rng, C, H, W, 4, 0.2)
+    outs = {}
+    for force in (1, 4):
+        L = Layer(lib, w, b, H, W)
+        for x in vid:
+            L.frame([dev(x)], 0.05, relu=True, force=force)
+        outs[force] = L.out[0].clone()
+    assert torch.equal(outs[1], outs[4])
+    Ld = Layer(lib, w, b, H, W)              # (the kernel's own choice: split while the tiles are few)
+    for x in vid:
+        Ld.frame([dev(x)], 0.05, relu=True)
+    assert torch.equal(Ld.out[0], outs[1])
+
+
+@pytest.mark.parametrize("C,K,H,W", [(16, 64, 64, 96), (64, 256, 40, 60)])
+def test_split_sequences_in_one_launch(lib, oracle, C, K, H, W):
+    """nSeq sequences per launch: each one bit-identical to its own single-sequence run, whatever the others do
+    (an unchanged one, a fully changing one)."""
+    rng = np.random.default_rng(9)
+    w = (rng.standard_normal((K, C, 7, 7)) / np.sqrt(C * 49)).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    S = 5
+    vids = [block_video(rng, C, H, W, 4, f) for f in (0.1, 0.0, 1.0, 0.3, 0.02)]
+    vids[1] = [vids[1][0]] * 4                               # a static sequence
+    Lb = Layer(lib, w, b, H, W, nSeq=S)
+    singles = [Layer(lib, w, b, H, W) for _ in range(S)]
+    for t in range(4):
+        Lb.frame([dev(v[t]) for v in vids], 0.05, relu=True)
+        for q in range(S):
+            singles[q].frame([dev(vids[q][t])], 0.05, relu=True)
+            assert np.array_equal(Lb.list(q), singles[q].list()), (t, q)
+            assert torch.equal(Lb.out[q], singles[q].out[0]), (t, q)
+            assert torch.equal(Lb.state[q], singles[q].state[0]), (t, q)
+            assert torch.equal(Lb.copy[q], singles[q].copy[0]), (t, q)
+    assert Lb.list(1).size == 0
+
+
+def test_split_pooled_detection_and_producer_mask(lib, oracle):
+    """The 2x2 pool folded into the detection (odd sizes, floor mode), with and without the producer-mask
+    shortcut: same list, same states as detection on the densely pooled tensor."""
+    rng = np.random.default_rng(11)
+    C, K, pH, pW = 16, 32, 45, 67
+    H, W = pH // 2, pW // 2
+    w = (rng.standard_normal((K, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    La, Lb, Lc = Layer(lib, w, b, H, W, pooled=True), Layer(lib, w, b, H, W), Layer(lib, w, b, H, W, pooled=True)
+    vid = block_video(rng, C, pH, pW, 4, 0.1, blk=6)
+    prev = None
+    for t, x in enumerate(vid):
+        xd = dev(x)
+        pooled = torch.nn.functional.max_pool2d(xd, 2, 2)
+        La.frame([xd], 0.1)
+        Lb.frame([pooled.contiguous()], 0.1)
+        # producer mask: the pre-pool pixels that differ from the previous frame (a superset is allowed)
+        if prev is None:
+            Lc.frame([xd], 0.1)
+        else:
+            ch = (x != prev).any(axis=1)[0]
+            wpr = (pW + 63) // 64
+            bits = np.zeros((pH, wpr * 64), np.uint8)
+            bits[:, :pW] = ch
+            pm = dev(np.packbits(bits, axis=1, bitorder="little").view(np.int64).reshape(-1))
+            Lc.frame([xd], 0.1, prodMasks=[pm])
+        prev = x
+        for L in (La, Lc):
+            assert np.array_equal(L.list(), Lb.list()), t
+            assert torch.equal(L.state[0], Lb.state[0]) and torch.equal(L.out[0], Lb.out[0]), t
+
+
+def test_split_state_rebuild_and_range_flag(lib, oracle):
+    """A state written from outside (restored states, eval03.py:88-95) is re-split by cbinfer_split_state_rebuild;
+    values beyond the arithmetic's range (|x| >= 2^20) raise the flag."""
+    rng = np.random.default_rng(13)
+    C, K, H, W = 16, 64, 24, 40
+    w = (rng.standard_normal((K, C, 7, 7)) / np.sqrt(C * 49)).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    L = Layer(lib, w, b, H, W)
+    x0, x1 = [dev(v) for v in block_video(rng, C, H, W, 2, 0.2)]
+    L.frame([x0], 0.1)
+    # overwrite the state with another frame, re-split, and present a frame that differs in a few pixels only
+    y = dev(rng.standard_normal((1, C, H, W)).astype(np.float32))
+    L.state[0].copy_(y)
+    lib.check(lib.C.cbinfer_split_state_rebuild(L.state[0].data_ptr(), L.S[0].data_ptr(), C, H, W, 7, 7,
+                                                L.flag.data_ptr(), None))
+    y2 = y.clone()
+    y2[0, :, 5:9, 7:12] += 1.0
+    L.frame([y2], 0.1)
+    o = oracle.OracleCBConv2d(w, b, 0.1, feedbackLoop=True, propChangeIndexes=True)
+    o.forward(x0.cpu().numpy())
+    o.prevInput = y.cpu().numpy().copy()
+    got = o.forward(y2.cpu().numpy())
+    assert np.array_equal(L.list(), got[2])
+    n = L.list()
+    out = L.out[0].cpu().numpy().reshape(K, -1)[:, n]
+    assert np.abs(out - o.prevOutput.reshape(K, -1)[:, n]).max() <= FP32_TOL
+    assert int(L.flag.item()) == 0
+    y3 = y2.clone()
+    y3[0, 3, 0, 0] = 3e6
+    L.frame([y3], 0.1)
+    assert int(L.flag.item()) == 1
+
+
+def test_split_module_reports_range_and_survives_state_restore(lib):
+    import pycbinfer
+    from cbinfer_amd import workloads
+    import bench
+    _, net = bench.build_bench_model()
+    _, ref = bench.build_bench_model()
+    vid = workloads.SyntheticVideo(H=96, W=160, ratio=0.1, block=16, seed=3)
+    frames = vid.frames(6)
+    with torch.no_grad():
+        for f in frames[:3]:
+            net(f), ref(f)
+        # save / restore the state tensors as the reference's eval03.py:88-95 does
+        saved = [t.clone() for t in pycbinfer.getStateTensors(net)]
+        for f in frames[3:]:
+            net(f)
+        for t, s_ in zip(pycbinfer.getStateTensors(net), saved):
+            t.copy_(s_)
+        for f in frames[3:]:
+            a, b_ = net(f), ref(f)
+            assert torch.equal(a, b_)
+    convs = [m for m in net.children() if type(m) is pycbinfer.CBConv2d]
+    assert not convs[1].rangeExceeded() and not convs[2].rangeExceeded()

@@ -47,6 +47,7 @@ typedef __attribute__((address_space(4))) const int cbs_const_int;
 #define CBS_SPAD 4096                 // bytes in front of the records of a split state (see cbs_dma16: negative offsets)
 #define CBS_PRE_BIG 1536              // mask words of all sequences of a launch: 128-row tile
 #define CBS_PRE_SMALL 1280            // ... 64-row tile, two workgroups per CU
+#define CBS_PRE_MID2 2600             // ... 64-row tile, two workgroups per CU, mask words not kept in LDS
 #define CBS_PRE_MID 5120              // ... 64-row tile, one workgroup per CU
 #define CBS_CHUNKS 4                  // canonical k-chunks of a deep contraction (see cbs_conv_kernel)
 
@@ -431,7 +432,7 @@ __device__ __forceinline__ int cbs_select_bit(unsigned long long w, int r) {
 }
 
 // BM x BN output tile per workgroup, WM x WN waves, each wave TN = BN/WN/32 column tiles of one 32-row tile.
-template <int BM, int BN, int WM, int WN, int PRE_CAP>
+template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS>
 __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TN = BN / WN / 32;
@@ -442,13 +443,13 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     constexpr int DPW = APW + BPW;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int TILE = BM * BN;
-    // static LDS (a workgroup may declare up to 160 KB without any opt-in): CBS_RING stages, then the mask words
-    // of ALL sequences of the launch and their popcount prefix (one scan).  PRE_CAP = capacity in words: the
-    // 64-row tile comes in two sizes, the smaller one leaves room for two workgroups per CU.
-    constexpr bool MASK_LDS = true;
+    // static LDS (a workgroup may declare up to 160 KB without any opt-in): CBS_RING stages, then the popcount
+    // prefix over the mask words of ALL sequences of the launch (one scan) and -- MASK_LDS -- the words themselves.
+    // PRE_CAP = capacity in words.  The 64-row tile comes in three sizes: the two smaller ones leave room for two
+    // workgroups per CU, the middle one by fetching the one word a pixel lookup needs from memory.
     __shared__ __attribute__((aligned(1024))) char ring[CBS_RING * STAGE];
     __shared__ int s_pre[PRE_CAP + 1];
-    __shared__ unsigned long long s_mask[PRE_CAP];
+    __shared__ unsigned long long s_mask[MASK_LDS ? PRE_CAP : 1];
     __shared__ const unsigned long long* s_maskPtr[CBS_MAXSEQ];
     __shared__ int s_wsum[NW];
     __shared__ int s_tilePix[BN];
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         const int q = cbs_div(i, p.magicMW), w = i - q * MW;
         const unsigned long long word = s_maskPtr[q][w];
         s_pre[i] = __popcll(word);
-        s_mask[i] = word;
+        if (MASK_LDS) s_mask[i] = word;
     }
     for (int q = 0; q < p.nSeq; ++q) {      // this launch also leaves a copy of the frame's masks at a fixed address
         unsigned long long* copy = p.seq[q].maskCopy;
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
                     else
                         hi = mid;
                 }
-                const unsigned long long word = s_mask[lo];
+                const unsigned long long word = MASK_LDS ? s_mask[lo] : s_maskPtr[q][lo - q * MW];
                 const int bit = cbs_select_bit(word, R - s_pre[lo]);
                 const int w = lo - q * MW;
                 const int row = cbs_div(w, p.magicWpr);
@@ -955,11 +956,11 @@ int cbs_num_cus() {
     return cus;
 }
 
-template <int BM, int BN, int WM, int WN, int PRE_CAP>
+template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS>
 int cbs_launch_conv(const CbsParams& p, int perCU, hipStream_t s) {
     if ((long)p.nSeq * p.maskWords > PRE_CAP) return CB_ERR_UNSUPPORTED;
     dim3 grid((unsigned)(perCU * cbs_num_cus())), block(64 * WM * WN);
-    hipLaunchKernelGGL((cbs_conv_kernel<BM, BN, WM, WN, PRE_CAP>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((cbs_conv_kernel<BM, BN, WM, WN, PRE_CAP, MASK_LDS>), grid, block, 0, s, p);
     int st = cb_launch_status();
     if (st != CB_OK) return st;
     if (p.slabs && (p.nStages >= 48 || p.forceSK > 0)) {
@@ -1123,10 +1124,11 @@ int cbinfer_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, c
 #endif
     hipStream_t s = (hipStream_t)stream;
     p.slabCap = 0;      // (sized by cbinfer_split_workspace_bytes for this very geometry: never exceeded)
-    if (BM == 128) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG>(p, 1, s);
+    if (BM == 128) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG, true>(p, 1, s);
     // (the mask words and their prefix live in LDS: the small capacity leaves room for two workgroups per CU)
-    if ((long)nSeq * MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL>(p, 2, s);
-    return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID>(p, 1, s);
+    if ((long)nSeq * MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true>(p, 2, s);
+    if ((long)nSeq * MW <= CBS_PRE_MID2) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID2, false>(p, 2, s);
+    return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false>(p, 1, s);
 }
 
 // One frame of a feedback-mode CBConv2d (conv2d.py:178-259) of every sequence: detection (+ pooling) + refresh of

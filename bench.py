@@ -415,7 +415,7 @@ def measured_traffic(kname, layer):
     if pmc.get("kernel_source_sha256") != kernel_source_hash():
         return None, "%s was collected on other kernel sources (%s, now %s)" % (
             name, pmc.get("kernel_source_sha256"), kernel_source_hash())
-    key = ("conv " if kname == "conv" else "cb_%s_kernel " % kname) + layer
+    key = layer
     if key not in pmc:
         return None, "%s has no entry %r" % (name, key)
     return pmc[key].get("bytes_per_launch"), "%s (commit %s)" % (name, pmc.get("commit", "?"))
@@ -764,10 +764,12 @@ def main():
         "ms_per_step": 1e3 * elapsed / steps_timed, "timed_region_s": elapsed,
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "arithmetic": "f32 tensors and accumulation; 7x7 contractions of the wide layers as bf16x3 split products "
-                      "(three bf16 terms per operand, six cross products) on the bf16 MFMA -- error <= that of the "
-                      "f32 fma chain (tests/test_gpu_ops.py::test_split_contraction_accuracy); 3->16 layer and the "
-                      "1x1 tail on the exact f32 MFMA",
+        "arithmetic": "f32 tensors and accumulation; the 7x7 contractions of the 16- and 64-channel layers as "
+                      "f16-pair products (each operand = hi + lo * 2^-11 in f16, 22 significant bits; three cross "
+                      "products per multiply) on the 16-bit MFMA with f32 accumulation -- error bound 3 * 2^-22 |a||b| "
+                      "per product, inside the bound the tests hold it to "
+                      "(tests/test_gpu_split.py::test_split_arithmetic_accuracy); 3->16 layer and the 1x1 tail on the "
+                      "exact f32 MFMA",
         "config": {"workload": "sceneLabeling CBConv2d coarse-grained fp32, synthetic 480x320 seq @%g%% "
                                "change (%s), experiment %d, %s per GPU"
                                % (100 * vid.ratio, ("%dx%d re-drawn blocks" % (args.block, args.block))

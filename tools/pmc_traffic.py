@@ -3,8 +3,8 @@
 passes of tools/collect_profiles.sh.  Prints a text summary and, with --json OUT, writes the file bench.py reads
 for `roofline.traffic` (keyed by the bench's layer labels, stamped with the hash of the kernel sources the
 passes ran on).  In the bench workload every layer has a contraction kernel of its own: cb_rowconv (3->16),
-cb_blockconv (16->64), cb_mfma_f32_kernel (64->256: the 128 x 128 self-compacting form), so no clustering by
-value is needed."""
+cbs_conv_kernel<64,64,...> (16->64), cbs_conv_kernel<128,128,...> + its reduce launch (64->256), so no clustering
+by value is needed."""
 import csv
 import glob
 import json
@@ -29,21 +29,22 @@ def load(sub, counter):
 
 
 fetch, write = load("pmc_fetch", "FETCH_SIZE"), load("pmc_write", "WRITE_SIZE")
-LAYER = [("cb_rowconv_f32_kernel", "cb_mfma_f32_kernel conv 3->16 k7 @320x480"),
-         ("cb_blockconv_kernel", "cb_mfma_f32_kernel conv 16->64 k7 @160x240"),
-         # in-frame forms of the 64->256 contraction (the first that occurs), plus its split-K reduce launch
-         ("cb_mfma_f32_kernel<4, 2, 2, 1, 2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),
-         ("cb_mfma_f32_kernel<2, 4, 2, 1, 2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),
-         ("cb_mfma_f32_kernel<2, 2, 2, 1, 2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),
-         ("cb_tail1x1_kernel", "cb_tail1x1_kernel 256->64->8 @80x120")]
-ADDS = [("cb_splitk_reduce_kernel<float, 2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120"),
-        ("cb_splitk_reduce_kernel<2, true", "cb_mfma_f32_kernel conv 64->256 k7 @80x120")]
+L1, L2, L3, TAIL = ("conv 3->16 k7 @320x480", "conv 16->64 k7 @160x240", "conv 64->256 k7 @80x120",
+                    "tail 1x1 256->64->8 @80x120")
+# the kernel of every layer in the bench workload (first pattern that matches), by the bench's layer label
+LAYER = [("cb_rowconv_f32_kernel", L1),
+         ("cbs_conv_kernel<64, 64", L2), ("cb_blockconv_kernel", L2),
+         ("cbs_conv_kernel<128, 128", L3), ("cb_mfma_f32_kernel<4, 2, 2, 1, 2, true", L3),
+         ("cb_mfma_f32_kernel<2, 4, 2, 1, 2, true", L3), ("cb_mfma_f32_kernel<2, 2, 2, 1, 2, true", L3),
+         ("cb_tail1x1_kernel", TAIL)]
+# second launch of the same contraction (summed into the layer's entry)
+ADDS = [("cbs_reduce_kernel", L3), ("cbs_reduce_tail_kernel", L3), ("cb_splitk_reduce_kernel<2, true", L3)]
 table = {}
 extra = {}
 for name in sorted(set(fetch) | set(write)):
-    if "cb_" not in name:
+    if "cb_" not in name and "cbs" not in name:
         continue
-    short = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:90]
+    short = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void cbs::", "cbs::")[:90]
     # steady state: drop the first dispatches (100 %-change first frame, priming)
     f = fetch.get(name, [])[3:] or fetch.get(name, [])
     w = write.get(name, [])[3:] or write.get(name, [])

@@ -78,5 +78,21 @@ if __name__ == "__main__":
             raw.cbinfer_debug_split_stamps(None, 0, 1)
             test(frames[-1])
         report()
+    elif len(sys.argv) > 1 and sys.argv[1] == "batch":
+        # the same for a SequenceBatch step of S sequences
+        import bench
+        import pycbinfer
+        S = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+        _, net = bench.build_bench_model()
+        sb = pycbinfer.SequenceBatch(net, S)
+        vids = [bench.bench_video(1234 + 7919 * q) for q in range(S)]
+        walk = [[v.frame] + [v.next() for _ in range(23)] for v in vids]
+        with torch.no_grad():
+            for i in range(23):
+                sb([w[i] for w in walk])
+            torch.cuda.synchronize()
+            raw.cbinfer_debug_split_stamps(None, 0, 1)
+            sb([w[23] for w in walk])
+        report()
     else:
         bs.main()

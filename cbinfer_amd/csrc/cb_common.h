@@ -55,3 +55,17 @@ __device__ __forceinline__ float cb_max(float a, float b) { return fmaxf(a, b); 
 __device__ __forceinline__ cb_half cb_max(cb_half a, cb_half b) { return a < b ? b : a; }
 __device__ __forceinline__ float cb_threshold(float th, float*) { return th; }
 __device__ __forceinline__ cb_half cb_threshold(float th, cb_half*) { return (cb_half)th; }  // RNE
+
+// A kernel whose arguments are a struct of several hundred bytes reads them where it needs them: a handful of
+// scalar loads at a time, each group a round trip to the kernel-argument memory (which misses the scalar cache
+// the first time a 64-byte line is touched), one after the other along the kernel's critical path.  This touches
+// every line of the first BYTES argument bytes in ONE burst at kernel entry, so that all later reads hit.
+template <int BYTES>
+__device__ __forceinline__ void cb_touch_kernarg() {
+    typedef __attribute__((address_space(4))) const int cb_kint;
+    cb_kint* ka = (cb_kint*)__builtin_amdgcn_kernarg_segment_ptr();
+    int acc = 0;
+#pragma unroll
+    for (int o = 0; o < BYTES; o += 64) acc |= ka[o / 4];
+    asm volatile("" ::"s"(acc));
+}

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
                                                         int pH, int pW,
                                                         const unsigned long long* __restrict__ prodMask,
                                                         DetBatch batch) {
+    cb_touch_kernarg<104 + sizeof(DetBatch)>();
     int yb = blockIdx.y;
     if (batch.nSeq > 1) {
         const int q = (int)blockIdx.y / H;

@@ -144,6 +144,7 @@ struct cb_row_blocks<KH, KW, Q, NBLK, NBLK> {
 // KH, KW, Q (= padded channels / 4) > 0: shape known at compile time (the hot layers); 0, 0, 0: any shape
 template <int KH, int KW, int Q>
 __global__ __launch_bounds__(64 * CB_ROW_MAXW) void cb_rowconv_f32_kernel(RowParams pin) {
+    cb_touch_kernarg<sizeof(RowParams)>();
     extern __shared__ float lds[];   // patch [CP][CS] | red [waves][64][4]
     constexpr bool CT = KH > 0;
     CB_RSTAMP(0);

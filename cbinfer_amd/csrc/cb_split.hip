@@ -19,7 +19,7 @@
 //            second one (scaled 2^-11 at the end).  Error per product <= 3 * 2^-22 |a||b| -- within the
 //            bound tests/test_gpu_ops.py::test_split_contraction_accuracy holds the bf16x3 form to -- at
 //            HALF the matrix work and two thirds of the operand bytes of bf16x3.
-//   ring     four LDS stage buffers, three stages of DMA in flight, one s_barrier per stage, waits counted by
+//   ring     four (eight: the small tile alone on a CU) LDS stage buffers, all but one in flight, one s_barrier per stage, waits counted by
 //            hand (s_waitcnt vmcnt(N): the compiler does not track LDS-DMA against LDS reads).
 //   schedule persistent grid over (pixel tile, m-tile, k-slice) items of up to CBS_MAXSEQ independent sequences
 //            in ONE launch (blockIdx carries no meaning: each workgroup derives every sequence's list length
@@ -43,7 +43,6 @@ typedef __attribute__((address_space(4))) const int cbs_const_int;
 #define CBS_LO 2048.f                 // lo terms carry a factor 2^11
 #define CBS_F16_MINNORM 6.103515625e-05f
 #define CBS_F16_MAX 65504.f
-#define CBS_RING 4
 #define CBS_SPAD 4096                 // bytes in front of the records of a split state (see cbs_dma16: negative offsets)
 #define CBS_PRE_BIG 1536              // mask words of all sequences of a launch: 128-row tile
 #define CBS_PRE_SMALL 1280            // ... 64-row tile, two workgroups per CU
@@ -214,6 +213,7 @@ __device__ __forceinline__ unsigned long long cbs_valid_mask(int W, int tile) {
 // lane, for the changed pixels only.
 template <bool POOL>
 __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
+    cb_touch_kernarg<sizeof(CbsDetArgs)>();
     const CbsDetSeq sq = a.seq[blockIdx.z];
     const int W = a.W, H = a.H, C = a.C, pH = a.pH, pW = a.pW;
     if (POOL && sq.prodMask) {
@@ -363,7 +363,7 @@ struct CbsParams {
     int K, KP, H, W, Wp, rec, nStages, maskWords, wpr, relu, dummyBase;
     long stateBytes, aBytes;
     float outScale;
-    unsigned long long magicMW, magicWpr, magicW;   // floor(2^32 / d) + 1: x / d = (x * magic) >> 32 for x d < 2^32
+    unsigned long long magicMW, magicWpr, magicW, magicMT;   // floor(2^32 / d) + 1: x / d = (x * magic) >> 32 for x d < 2^32
     int forceSK;                      // > 0: tuning / test aid
     int dbg;                          // diagnostic ablations (builds with -DCBS_DBG only; CBINFER_SPLIT_DBG)
 };
@@ -373,13 +373,13 @@ struct CbsParams {
 #ifdef CBS_STAMP
 // diagnostic build only (make EXTRA=-DCBS_STAMP; tools/split_stamps.py): per-workgroup phase stamps of its FIRST item,
 // 100 MHz constant clock: 0 entry, 1 list lengths known, 2 item set up, 3 ring primed, 4 stage loop done, 5 epilogue
-// done; 6 / 7: shader clock (s_memtime) at entry / after the stage loop
-__device__ unsigned long long cbs_stamp_buf[2 * 2048 * 8];      // [64-row tile | 128-row tile]
+// done; 6 / 7: shader clock (s_memtime) at entry / after the stage loop; 8.. finer prologue marks (see tools/split_stamps.py)
+__device__ unsigned long long cbs_stamp_buf[2 * 2048 * 16];      // [64-row tile | 128-row tile]
 #define CBS_STAMP_AT(i)                                                                                   \
     do {                                                                                                  \
         if (threadIdx.x == 0 && blockIdx.x < 2048 && cbs_first)                                           \
-            cbs_stamp_buf[(BM >= 128 ? 2048 * 8 : 0) + blockIdx.x * 8 + (i)] =                            \
-                (i) >= 6 ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();               \
+            cbs_stamp_buf[(BM >= 128 ? 2048 * 16 : 0) + blockIdx.x * 16 + (i)] =                            \
+                ((i) == 6 || (i) == 7) ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();               \
     } while (0)
 #else
 #define CBS_STAMP_AT(i)
@@ -417,23 +417,10 @@ __device__ __forceinline__ int cbs_div(int x, unsigned long long magic) {
     return (int)(((unsigned long long)(unsigned)x * magic) >> 32);
 }
 
-__device__ __forceinline__ int cbs_select_bit(unsigned long long w, int r) {
-    int pos = 0;
-#pragma unroll
-    for (int width = 32; width >= 1; width >>= 1) {
-        const unsigned long long lowmask = ((1ull << width) - 1ull) << pos;
-        const int c = __popcll(w & lowmask);
-        if (r >= c) {
-            r -= c;
-            pos += width;
-        }
-    }
-    return pos;
-}
-
 // BM x BN output tile per workgroup, WM x WN waves, each wave TN = BN/WN/32 column tiles of one 32-row tile.
-template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS>
+template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING>
 __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
+    cb_touch_kernarg<sizeof(CbsParams)>();
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TN = BN / WN / 32;
     static_assert(BM == 32 * WM, "one 32-row tile per wave");
@@ -443,11 +430,11 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     constexpr int DPW = APW + BPW;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int TILE = BM * BN;
-    // static LDS (a workgroup may declare up to 160 KB without any opt-in): CBS_RING stages, then the popcount
+    // static LDS (a workgroup may declare up to 160 KB without any opt-in): RING stages, then the popcount
     // prefix over the mask words of ALL sequences of the launch (one scan) and -- MASK_LDS -- the words themselves.
     // PRE_CAP = capacity in words.  The 64-row tile comes in three sizes: the two smaller ones leave room for two
     // workgroups per CU, the middle one by fetching the one word a pixel lookup needs from memory.
-    __shared__ __attribute__((aligned(1024))) char ring[CBS_RING * STAGE];
+    __shared__ __attribute__((aligned(1024))) char ring[RING * STAGE];
     __shared__ int s_pre[PRE_CAP + 1];
     __shared__ unsigned long long s_mask[MASK_LDS ? PRE_CAP : 1];
     __shared__ const unsigned long long* s_maskPtr[CBS_MAXSEQ];
@@ -477,24 +464,32 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     for (int q = t; q < p.nSeq; q += NT) s_maskPtr[q] = p.seq[q].masks;
     __syncthreads();
     const int E = p.nSeq * MW;
-#pragma unroll 4
-    for (int i = t; i < E; i += NT) {      // (independent loads: several in flight per thread)
-        const int q = cbs_div(i, p.magicMW), w = i - q * MW;
-        const unsigned long long word = s_maskPtr[q][w];
-        s_pre[i] = __popcll(word);
-        if (MASK_LDS) s_mask[i] = word;
+    // Thread t owns the CH consecutive words [t CH, (t+1) CH) of the concatenated masks: their popcounts stay in
+    // registers, one wave scan + one exchange of the wave totals gives every thread its base, and the exclusive
+    // prefix goes to LDS once -- two barriers, no serial section for a single sequence.
+    constexpr int CHMAX = (PRE_CAP + NT - 1) / NT;
+    const int CHW = (E + NT - 1) / NT, wb = t * CHW;
+    int cnt[CHMAX];
+    unsigned long long wordReg[MASK_LDS ? CHMAX : 1];
+    int loc = 0, totAll = 0;
+#pragma unroll
+    for (int u = 0; u < CHMAX; ++u) {
+        const int i = wb + u;
+        cnt[u] = 0;
+        if (u < CHW && i < E) {
+            const int q = cbs_div(i, p.magicMW), w = i - q * MW;
+            const unsigned long long word = s_maskPtr[q][w];
+            cnt[u] = __popcll(word);
+            if (MASK_LDS) wordReg[u] = word;
+        }
+        loc += cnt[u];
     }
     for (int q = 0; q < p.nSeq; ++q) {      // this launch also leaves a copy of the frame's masks at a fixed address
         unsigned long long* copy = p.seq[q].maskCopy;
         if (copy)
             for (int i = blockIdx.x * NT + t; i < MW; i += gridDim.x * NT) copy[i] = s_maskPtr[q][i];
     }
-    __syncthreads();      // (every load of this workgroup has returned: its values are in LDS)
     {
-        const int CH = (E + NT - 1) / NT, wb = t * CH;
-        int loc = 0;
-        for (int u = 0; u < CH; ++u)
-            if (wb + u < E) loc += s_pre[wb + u];
         int incl = loc;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -503,33 +498,50 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         }
         if (lane == 63) s_wsum[t >> 6] = incl;
         __syncthreads();
-        int base = 0;
-        for (int w = 0; w < (t >> 6); ++w) base += s_wsum[w];
+        CBS_STAMP_AT(8);
+        int base = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int v = s_wsum[w];
+            base += w < (t >> 6) ? v : 0;
+            tot += v;
+        }
+        totAll = __builtin_amdgcn_readfirstlane(tot);
         int run = base + incl - loc;
-        for (int u = 0; u < CH; ++u) {
-            const int w = wb + u;
-            if (w < E) {
-                const int c = s_pre[w];
-                s_pre[w] = run;
-                run += c;
+#pragma unroll
+        for (int u = 0; u < CHMAX; ++u) {
+            const int i = wb + u;
+            if (u < CHW && i < E) {
+                s_pre[i] = run;
+                if (MASK_LDS) s_mask[i] = wordReg[u];
+                run += cnt[u];
             }
         }
-        if (t == NT - 1) s_pre[E] = base + incl;
+        if (t == 0) {
+            s_pre[E] = tot;
+            if (p.nSeq == 1) {      // (one sequence: its tables need nothing from LDS)
+                s_seqRank[0] = 0, s_seqN[0] = tot, s_seqTile[0] = 0, s_seqTile[1] = (tot + BN - 1) / BN;
+                if (blockIdx.x == 0) p.seq[0].countOut[0] = tot;
+            }
+        }
         __syncthreads();
     }
-    if (t == 0) {
-        int tiles = 0;
-        for (int q = 0; q < p.nSeq; ++q) {
-            const int rb = s_pre[q * MW], n = s_pre[(q + 1) * MW] - rb;
-            s_seqRank[q] = rb, s_seqN[q] = n, s_seqTile[q] = tiles;
-            tiles += (n + BN - 1) / BN;
-            if (blockIdx.x == 0) p.seq[q].countOut[0] = n;
+    if (p.nSeq > 1) {
+        if (t == 0) {
+            int tiles = 0;
+            for (int q = 0; q < p.nSeq; ++q) {
+                const int rb = s_pre[q * MW], n = s_pre[(q + 1) * MW] - rb;
+                s_seqRank[q] = rb, s_seqN[q] = n, s_seqTile[q] = tiles;
+                tiles += (n + BN - 1) / BN;
+                if (blockIdx.x == 0) p.seq[q].countOut[0] = n;
+            }
+            s_seqTile[p.nSeq] = tiles;
         }
-        s_seqTile[p.nSeq] = tiles;
+        __syncthreads();
     }
-    __syncthreads();
     CBS_STAMP_AT(1);
-    const int TP = __builtin_amdgcn_readfirstlane(s_seqTile[p.nSeq]);         // pixel tiles of all sequences
+    const int TP = p.nSeq == 1 ? (totAll + BN - 1) / BN                       // pixel tiles of all sequences
+                               : __builtin_amdgcn_readfirstlane(s_seqTile[p.nSeq]);
     // Split along k while whole CUs would idle and the k-depth pays for the slab round trip -- WITHOUT letting the
     // partitioning into the arithmetic: a deep contraction (>= 48 stages) is always the sum, left to right, of
     // CBS_CHUNKS partial sums over fixed stage ranges, each accumulated from zero.  Split, every chunk is a work
@@ -551,8 +563,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         }
     }
 
-    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.A, 0, (int)min(p.aBytes, (long)0x7fffffff), 0x00020000);
+    const int aRecords = (int)min(p.aBytes, (long)0x7fffffff);
     cbs_const_int* stageOff = (cbs_const_int*)p.stageOff;
     const int HW = p.H * p.W;
     const float lo2 = 1.0f / CBS_LO;
@@ -580,53 +591,69 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     }
 
     for (int it = blockIdx.x; it < items; it += gridDim.x) {
-        const int combo = it % CMB, ptg = it / CMB;
-        const int mt = combo % MT, slice = combo / MT;
-        int q = 0;
-        for (int u = 1; u < p.nSeq; ++u)
-            if (ptg >= s_seqTile[u]) q = u;
-        q = __builtin_amdgcn_readfirstlane(q);
-        const int N = __builtin_amdgcn_readfirstlane(s_seqN[q]), rb = __builtin_amdgcn_readfirstlane(s_seqRank[q]);
-        const int n0 = (ptg - __builtin_amdgcn_readfirstlane(s_seqTile[q])) * BN, m0 = mt * BM;
+        // it = (ptg * SK + slice) * MT + mt -- MT by its magic, SK (1 or CBS_CHUNKS, powers of two) by shifts: no
+        // integer division by a run-time value on the way to the first DMA
+        const int d = cbs_div(it, p.magicMT), mt = it - d * MT;
+        const int slice = d & (SK - 1), ptg = SK == 1 ? d : d / CBS_CHUNKS;
+        int q = 0, N = totAll, rb = 0, tile0 = 0;
+        if (p.nSeq > 1) {      // (one sequence: all of it known without LDS)
+            for (int u = 1; u < p.nSeq; ++u)
+                if (ptg >= s_seqTile[u]) q = u;
+            q = __builtin_amdgcn_readfirstlane(q);
+            N = __builtin_amdgcn_readfirstlane(s_seqN[q]), rb = __builtin_amdgcn_readfirstlane(s_seqRank[q]);
+            tile0 = __builtin_amdgcn_readfirstlane(s_seqTile[q]);
+        }
+        const int n0 = (ptg - tile0) * BN, m0 = mt * BM;
         // Stages of this item: one chunk (split) or all of them (then the accumulators are folded into the running
         // sum at the chunk boundaries).  Chunk c = stage pairs [P c / CH, P (c+1) / CH) of the P = nStages / 2 pairs
         // (+ the odd last stage in the last chunk): every boundary lies an even number of stages behind the start,
         // which keeps the two fragment register sets in step with the loop below.
         const int P2 = p.nStages >> 1;
-        auto chunkBeg = [&](int c) { return c >= CH ? p.nStages : 2 * (P2 * c / CH); };
+        static_assert(CBS_CHUNKS == 4, "chunk boundaries by shifts");
+        auto chunkBeg = [&](int c) { return c >= CH ? p.nStages : (CH == 1 ? 0 : 2 * ((P2 * c) >> 2)); };
         const int c0 = SK == 1 ? 0 : slice, c1 = SK == 1 ? CH : slice + 1;
         const int sBeg = chunkBeg(c0), sEnd = chunkBeg(c1);
 
-        // pixel of slot j of this tile = the (n0+j)-th set bit of sequence q's mask
+        // Pixel of slot j of this tile = the (n0+j)-th set bit of sequence q's mask.  Two cooperative steps instead
+        // of a binary search and a bit select per pixel: every thread tests a few words for holding the tile's first
+        // / last rank; then the waves expand the words in between, one word per wave and step, one bit per lane.
+        __shared__ int s_wRange[2];
         __syncthreads();   // (s_tilePix and the ring of the previous item are no longer read)
-        if (t < BN) {
-            const int r = n0 + t;
-            int pos = -1;
-            if (r < N) {
-                const int R = rb + r;                       // rank in the concatenated prefix
-                int lo = q * MW, hi = lo + MW;              // largest i in [lo, hi) with s_pre[i] <= R
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_pre[mid] <= R)
-                        lo = mid;
-                    else
-                        hi = mid;
-                }
-                const unsigned long long word = MASK_LDS ? s_mask[lo] : s_maskPtr[q][lo - q * MW];
-                const int bit = cbs_select_bit(word, R - s_pre[lo]);
-                const int w = lo - q * MW;
-                const int row = cbs_div(w, p.magicWpr);
-                pos = row * p.W + (w - row * p.wpr) * 64 + bit;
-                if (mt == 0 && slice == 0) p.seq[q].listOut[r] = pos;
+        {
+            const int R0 = rb + n0, R1 = rb + min(n0 + BN, N) - 1;
+            for (int i = q * MW + t; i < (q + 1) * MW; i += NT) {
+                const int a = s_pre[i], b = s_pre[i + 1];
+                if (a <= R0 && R0 < b) s_wRange[0] = i;
+                if (a <= R1 && R1 < b) s_wRange[1] = i;
             }
-            s_tilePix[t] = pos;
+            if (t < BN) s_tilePix[t] = -1;
+            __syncthreads();
+            const int w0 = __builtin_amdgcn_readfirstlane(s_wRange[0]), w1 = __builtin_amdgcn_readfirstlane(s_wRange[1]);
+            const bool first = mt == 0 && slice == 0;
+            int32_t* listOut = p.seq[q].listOut;
+            for (int i = w0 + wave; i <= w1; i += NW) {
+                const unsigned long long word = MASK_LDS ? s_mask[i] : s_maskPtr[q][i - q * MW];
+                if (word == 0ull) continue;
+                if ((word >> lane) & 1ull) {
+                    const int r = s_pre[i] + __popcll(word & ((1ull << lane) - 1ull)) - R0;
+                    if (r >= 0 && r < BN) {
+                        const int w = i - q * MW;
+                        const int row = cbs_div(w, p.magicWpr);
+                        const int pos = row * p.W + (w - row * p.wpr) * 64 + lane;
+                        s_tilePix[r] = pos;
+                        if (first) listOut[n0 + r] = pos;
+                    }
+                }
+            }
         }
+        CBS_STAMP_AT(9);
         // (the m-tile's bias for the epilogue: requested now, put into LDS once the ring is primed)
         const float biasv = (t < BM && p.bias && m0 + t < p.K) ? p.bias[m0 + t] : 0.f;
         __syncthreads();
+        CBS_STAMP_AT(10);
 
-        const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)p.seq[q].S, 0, (int)min(p.stateBytes + CBS_SPAD, (long)0x7fffffff), 0x00020000);
+        const char* Sq = p.seq[q].S;
+        const int bRecords = (int)min(p.stateBytes + CBS_SPAD, (long)0x7fffffff);
         // DMA source offsets of this wave (the instruction's immediate offset -- i KB for its i-th DMA of a stage
         // -- counts for the memory address too: taken off here; the pixel operand's may go negative by up to 3 KB,
         // hence the CBS_SPAD bytes in front of the records): its APW weight blocks are contiguous in memory as in
@@ -645,18 +672,27 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         const int aStageBytes = (p.KP / 32) * 4096;
 
         // (the pixel operand's stage offset comes from the table by a scalar load: requested one stage early)
+        CBS_STAMP_AT(11);
         int bNext = stageOff[sBeg];
-        auto issue = [&](int s) {      // all DMA of stage s of this wave, into ring slot s % CBS_RING
-            char* dst = ring + (s % CBS_RING) * STAGE;
-            const int aS = s * aStageBytes + aItem;
+        // All DMA of stage s of this wave, into ring slot s % RING.  Past the item's last stage the same four
+        // instructions are issued DEAD -- through a resource of zero records, so that every access is out of range:
+        // no memory traffic, zeros into a ring slot nobody reads any more (tools/micro/ldsdma_oob.hip) -- which keeps
+        // the number of DMA instructions in flight, and with it the s_waitcnt vmcnt(N) of a step, the same in every
+        // step: one step body, no peeled tail.
+        auto issue = [&](int s) {
+            char* dst = ring + (s % RING) * STAGE;
+            const bool live = s < sEnd;
+            const int aS = live ? s * aStageBytes + aItem : 0;
             const int bS = bNext;
             bNext = stageOff[min(s + 1, sEnd - 1)];
             if (CBS_DBGBIT(4)) return;
+            const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, live ? aRecords : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)Sq, 0, live ? bRecords : 0, 0x00020000);
             char* mine = dst + wave * (DPW * 1024);      // ONE LDS base (M0) for the four
-            cbs_dma16<0>(arsrc, mine, aVoff, aS);
-            cbs_dma16<1024>(arsrc, mine, aVoff, aS);
-            cbs_dma16<2048>(brsrc, mine, bVoff[0], bS);
-            cbs_dma16<3072>(brsrc, mine, bVoff[1], bS);
+            cbs_dma16<0>(ar, mine, aVoff, aS);
+            cbs_dma16<1024>(ar, mine, aVoff, aS);
+            cbs_dma16<2048>(br, mine, bVoff[0], bS);
+            cbs_dma16<3072>(br, mine, bVoff[1], bS);
         };
 
         floatx16 acc1[TN], acc2[TN];
@@ -708,33 +744,45 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         unsigned aAddr[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) aAddr[e] = ringBase + aRead[e];
-        auto readFrags = [&](int s, Frags& f) {
-            const unsigned slot = (s % CBS_RING) * STAGE;
-            if (CBS_DBGBIT(16)) {
+        auto readA = [&](int s, Frags& f) {
+            const unsigned slot = (s % RING) * STAGE;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) f.a[e] = halfx8{1, 1, 1, 1, 1, 1, 1, 1};
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) f.a[e] = cbs_lds_read16<0>(aAddr[e] + slot);
+            for (int e = 0; e < 4; ++e) {
+                if (CBS_DBGBIT(16))
+                    f.a[e] = halfx8{1, 1, 1, 1, 1, 1, 1, 1};
+                else
+                    f.a[e] = cbs_lds_read16<0>(aAddr[e] + slot);
             }
+        };
+        auto readB = [&](int s, Frags& f, int j) {
+            const unsigned slot = (s % RING) * STAGE;
 #pragma unroll
-            for (int e = 0; e < TN * 4; ++e) {
+            for (int e = 4 * j; e < 4 * j + 4; ++e) {
                 if (CBS_DBGBIT(8))
                     f.b[e] = halfx8{1, 1, 1, 1, 1, 1, 1, 1};
                 else
                     f.b[e] = cbs_lds_read16<0>(bAddr[e] + slot);
             }
         };
-        auto mma = [&](const Frags& f) {
+        auto readFrags = [&](int s, Frags& f) {
+            readA(s, f);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) readB(s, f, j);
+        };
+        // the 6 TN matrix instructions of a stage, numbered i = (ks * TN + j) * 3 + term
+        constexpr int NM = 6 * TN;
+        auto mmaRange = [&](const Frags& f, int i0, int i1) {
             if (CBS_DBGBIT(2)) return;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
+            for (int i = i0; i < i1; ++i) {
+                const int ks = i / (3 * TN), j = (i / 3) % TN, term = i % 3;
+                if (term == 0)
                     acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks * 2 + 1], f.b[j * 4 + ks * 2], acc2[j], 0, 0, 0);
+                else if (term == 1)
                     acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks * 2], f.b[j * 4 + ks * 2 + 1], acc2[j], 0, 0, 0);
+                else
                     acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks * 2], f.b[j * 4 + ks * 2], acc1[j], 0, 0, 0);
-                }
+            }
         };
         // s_waitcnt lgkmcnt(0) that NAMES the fragment registers it makes valid (in/out operands): nothing that
         // consumes them can be scheduled in front of it
@@ -753,31 +801,49 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
                              : "memory");
         };
         // One step = stage s multiplied from registers while stage s+1 is read into the other set.  Before that,
-        // everything but the two youngest stages of this wave's DMA must have landed (vmcnt counts its DMA
-        // instructions, DPW per stage, issued in stage order) and -- barrier -- everybody else's: stage s+4 is then
+        // everything but the RING-2 youngest stages of this wave's DMA must have landed (vmcnt counts its DMA
+        // instructions, DPW per stage, issued in stage order) and -- barrier -- everybody else's: stage s+RING is then
         // aimed at the ring slot of stage s, which nobody reads any more.  The step ENDS with the s_waitcnt that makes
         // the freshly read set valid: the compiler takes the asm reads' results for valid at once, and any copy or
         // spill of such a register it places before the data has arrived -- at a loop edge, a branch join -- would
         // carry garbage (it did: wrong tiles, but only while other kernels kept the CU's LDS busy).  Inside a step
         // there is no control flow, and the reads have the whole MFMA chain to return.
+        // The instruction order inside a step is fixed by hand (sched_barrier between the groups): the matrix
+        // pipe is fed from the first cycle behind the barrier, and the DMA issue, the address arithmetic and the
+        // fragment reads of the next stage sit in the shadows of matrix instructions that are already queued.  Left
+        // to itself the compiler puts most reads behind the first matrix instructions and the wait for them right
+        // behind the reads -- with most of the stage's matrix work still to be issued.
+#define CBS_SB() __builtin_amdgcn_sched_barrier(0)
 #define CBS_STEP(WAITN, ISSUE, S, FCUR, FNEXT)                                            \
         do {                                                                               \
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");                  \
             __builtin_amdgcn_s_barrier();                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                             \
-            if (ISSUE) issue((S) + 4);                                                     \
-            readFrags((S) + 1, FNEXT);                                                     \
-            mma(FCUR);                                                                     \
+            CBS_SB();                                                                      \
+            mmaRange(FCUR, 0, 2);                                                          \
+            CBS_SB();                                                                      \
+            if (ISSUE) issue((S) + RING);                                                    \
+            CBS_SB();                                                                      \
+            mmaRange(FCUR, 2, 3);                                                          \
+            CBS_SB();                                                                      \
+            readA((S) + 1, FNEXT);                                                         \
+            CBS_SB();                                                                      \
+            mmaRange(FCUR, 3, 4);                                                          \
+            CBS_SB();                                                                      \
+            readB((S) + 1, FNEXT, 0);                                                      \
+            CBS_SB();                                                                      \
+            mmaRange(FCUR, 4, 5);                                                          \
+            CBS_SB();                                                                      \
+            if (TN > 1) readB((S) + 1, FNEXT, TN - 1);                                     \
+            CBS_SB();                                                                      \
+            mmaRange(FCUR, 5, NM);                                                         \
             waitFrags(FNEXT);                                                              \
         } while (0)
 
         Frags F0, F1;
         CBS_STAMP_AT(2);
-        issue(sBeg);
-        issue(sBeg + 1);
-        issue(sBeg + 2);
-        issue(sBeg + 3);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * DPW) : "memory");
+#pragma unroll
+        for (int i = 0; i < RING; ++i) issue(sBeg + i);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 1) * DPW) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         readFrags(sBeg, F0);
@@ -785,34 +851,22 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         if (t < BM) s_bias[t] = biasv;      // (read in the epilogue, many barriers later)
         CBS_STAMP_AT(3);
         int s = sBeg;
-        // (an unsplit deep item: the chunks before the last one are whole pairs of full steps -- at least six stages
-        //  follow each of them -- and end in a fold)
-        for (int c = c0; c + 1 < c1; ++c) {
+        // Chunks before the last one (an unsplit deep item) are whole pairs of steps and end in a fold; the last
+        // chunk may end in a single step.  The last steps of the item issue dead DMAs and read a stage that does
+        // not exist (a ring slot with old bytes) into the fragment set nobody multiplies.
+        for (int c = c0; c < c1; ++c) {
             const int cEnd = chunkBeg(c + 1);
-            for (; s < cEnd; s += 2) {
-                CBS_STEP(2 * DPW, true, s, F0, F1);
-                CBS_STEP(2 * DPW, true, s + 1, F1, F0);
+            for (; s + 1 < cEnd; s += 2) {
+                CBS_STEP((RING - 2) * DPW, true, s, F0, F1);
+                CBS_STEP((RING - 2) * DPW, true, s + 1, F1, F0);
             }
-            fold();
+            if (c + 1 < c1) fold();
         }
-        for (; s + 5 < sEnd; s += 2) {
-            CBS_STEP(2 * DPW, true, s, F0, F1);
-            CBS_STEP(2 * DPW, true, s + 1, F1, F0);
-        }
-        // four or five stages are left (a slice has at least six); the last four issue nothing, their waits count down
-        if (s + 5 == sEnd) {
-            CBS_STEP(2 * DPW, true, s, F0, F1);
-            CBS_STEP(2 * DPW, false, s + 1, F1, F0);
-            CBS_STEP(DPW, false, s + 2, F0, F1);
-            CBS_STEP(0, false, s + 3, F1, F0);
-            mma(F0);
-        } else {
-            CBS_STEP(2 * DPW, false, s, F0, F1);
-            CBS_STEP(DPW, false, s + 1, F1, F0);
-            CBS_STEP(0, false, s + 2, F0, F1);
-            mma(F1);
-        }
+        if (s < sEnd) CBS_STEP((RING - 2) * DPW, true, s, F0, F1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (no dead DMA lands in the ring of the next item)
 #undef CBS_STEP
+#undef CBS_SB
+        __builtin_amdgcn_sched_barrier(0);      // (nothing of the epilogue -- its loads, its addresses -- up into the steps)
         CBS_STAMP_AT(4);
         CBS_STAMP_AT(7);
 
@@ -896,6 +950,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
 // Second launch of a split contraction: sums the SK slabs of every tile in slice order, scales, adds the bias,
 // applies the ReLU and scatters (all CUs, one float4 of four output channels per thread and step).
 __global__ __launch_bounds__(256) void cbs_reduce_kernel(CbsParams p, int BM, int BN) {
+    cb_touch_kernarg<sizeof(CbsParams) + 8>();
     const int SK = p.info[CBS_INFO_SK];
     if (SK <= 1) return;
     const int MT = p.info[CBS_INFO_MT], CMB = MT * SK, TILE4 = BM * BN / 4, HW = p.H * p.W;
@@ -956,11 +1011,11 @@ int cbs_num_cus() {
     return cus;
 }
 
-template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS>
+template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING>
 int cbs_launch_conv(const CbsParams& p, int perCU, hipStream_t s) {
     if ((long)p.nSeq * p.maskWords > PRE_CAP) return CB_ERR_UNSUPPORTED;
     dim3 grid((unsigned)(perCU * cbs_num_cus())), block(64 * WM * WN);
-    hipLaunchKernelGGL((cbs_conv_kernel<BM, BN, WM, WN, PRE_CAP, MASK_LDS>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((cbs_conv_kernel<BM, BN, WM, WN, PRE_CAP, MASK_LDS, RING>), grid, block, 0, s, p);
     int st = cb_launch_status();
     if (st != CB_OK) return st;
     if (p.slabs && (p.nStages >= 48 || p.forceSK > 0)) {
@@ -978,7 +1033,7 @@ extern "C" int cbinfer_debug_split_stamps(void* host, long bytes, int clear) {
     if (clear) {
         void* d = nullptr;
         if (hipGetSymbolAddress(&d, HIP_SYMBOL(cbs_stamp_buf)) != hipSuccess) return -1;
-        return (int)hipMemset(d, 0, sizeof(unsigned long long) * 2 * 2048 * 8);
+        return (int)hipMemset(d, 0, sizeof(unsigned long long) * 2 * 2048 * 16);
     }
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cbs_stamp_buf), (size_t)bytes);
 }
@@ -1117,6 +1172,7 @@ int cbinfer_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, c
     p.magicMW = (1ull << 32) / (unsigned long long)MW + 1ull;
     p.magicWpr = (1ull << 32) / (unsigned long long)p.wpr + 1ull;
     p.magicW = (1ull << 32) / (unsigned long long)W + 1ull;
+    p.magicMT = (1ull << 32) / (unsigned long long)(KP / BM) + 1ull;
     p.forceSK = forceSplit;
     p.dbg = 0;
 #ifdef CBS_DBG
@@ -1124,11 +1180,15 @@ int cbinfer_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, c
 #endif
     hipStream_t s = (hipStream_t)stream;
     p.slabCap = 0;      // (sized by cbinfer_split_workspace_bytes for this very geometry: never exceeded)
-    if (BM == 128) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG, true>(p, 1, s);
-    // (the mask words and their prefix live in LDS: the small capacity leaves room for two workgroups per CU)
-    if ((long)nSeq * MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true>(p, 2, s);
-    if ((long)nSeq * MW <= CBS_PRE_MID2) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID2, false>(p, 2, s);
-    return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false>(p, 1, s);
+    if (BM == 128) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG, true, 4>(p, 1, s);
+    // The 64-row tile moves 16 KB per stage, and what bounds its stage rate is the DMA in flight on the CU (bytes in
+    // flight / latency): one sequence rarely has more tiles than there are CUs, so it runs one workgroup per CU with
+    // a ring of eight stages (seven in flight, 112 KB); several sequences run two workgroups per CU with four-stage
+    // rings (96 KB in flight between them) while the mask words and their prefix fit beside two rings.
+    if (nSeq == 1 && MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 8>(p, 1, s);
+    if ((long)nSeq * MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 4>(p, 2, s);
+    if ((long)nSeq * MW <= CBS_PRE_MID2) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID2, false, 4>(p, 2, s);
+    return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 8>(p, 1, s);
 }
 
 // One frame of a feedback-mode CBConv2d (conv2d.py:178-259) of every sequence: detection (+ pooling) + refresh of

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cb_tail1x1_kernel(
     const float* __restrict__ w2, const float* __restrict__ b2, int C0, int C0P, int C1, int C2,
     int HW, int relu1, int relu2) {
     extern __shared__ float sm[];   // Xs[C0P][16] | Hs[C1P][17] | W2s[C2][C1] | b2s[C2]
+    cb_touch_kernarg<sizeof(TailSeqs) + 72>();
     const float* __restrict__ x = tab.seq[blockIdx.y].x;
     const int32_t* __restrict__ list = tab.seq[blockIdx.y].list;
     const int32_t* __restrict__ countDev = tab.seq[blockIdx.y].countDev;

@@ -15,8 +15,8 @@ for f in files:
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 rows = rows[len(rows) // 2:]          # second half: the timed region / in-frame measurement
-key = "cb_detect_kernel<float, true, false>"
-starts = [i for i, r in enumerate(rows) if key in r["Kernel_Name"]]
+# a frame starts with the detection in front of the first layer's row-segment contraction
+starts = [i - 1 for i, r in enumerate(rows) if "cb_rowconv_f32_kernel" in r["Kernel_Name"] and i > 0]
 frames = []
 for a, b in zip(starts[:-1], starts[1:]):
     fr = rows[a:b]
@@ -29,7 +29,7 @@ tot = []
 for k in range(lens):
     dur = [(int(f[k]["End_Timestamp"]) - int(f[k]["Start_Timestamp"])) / 1e3 for f in frames]
     gap = [(int(f[k]["Start_Timestamp"]) - int(f[k - 1]["End_Timestamp"])) / 1e3 for f in frames] if k else [0.0]
-    name = frames[0][k]["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    name = frames[0][k]["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void cbs::", "cbs::")
     print("  gap %6.2f us | %7.2f us  %s" % (statistics.median(gap), statistics.median(dur), name[:80]))
     tot.append(statistics.median(dur) + statistics.median(gap))
 period = [(int(b[0]["Start_Timestamp"]) - int(a[0]["Start_Timestamp"])) / 1e3 for a, b in zip(frames[:-1], frames[1:])]

@@ -14,14 +14,15 @@ import tools.bench_split as bs  # noqa: E402
 
 raw = ctypes.CDLL(_lib.LIB_PATH)
 NAMES = ['entry', 'list lengths known', 'item set up', 'ring primed', 'stage loop done', 'epilogue done']
+FINE = {8: 'mask words in LDS', 9: 'pixel lookup done (thread 0)', 10: 'lookup barrier passed', 11: 'DMA offsets ready'}
 
 
 def report(clear=True):
     torch.cuda.synchronize()
-    buf = np.zeros(2 * 2048 * 8, dtype=np.uint64)
+    buf = np.zeros(2 * 2048 * 16, dtype=np.uint64)
     raw.cbinfer_debug_split_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(buf.nbytes), 0)
     for cfg, name in ((0, "64-row tile"), (1, "128-row tile")):
-        st = buf.reshape(2, 2048, 8)[cfg].astype(np.int64)
+        st = buf.reshape(2, 2048, 16)[cfg].astype(np.int64)
         st = st[st[:, 0] > 0]
         if len(st):
             print(" ", name)
@@ -41,6 +42,11 @@ def report_one(st):
             continue
         us = (st[v, i] - t0) / 100.0
         print("  %-20s min %7.2f  mean %7.2f  max %7.2f us (%d wgs)" % (n, us.min(), us.mean(), us.max(), v.sum()))
+    for i, n in sorted(FINE.items()):
+        v = st[:, i] >= t0
+        if v.sum():
+            us = (st[v, i] - t0) / 100.0
+            print("    %-28s min %7.2f  mean %7.2f  max %7.2f us (%d wgs)" % (n, us.min(), us.mean(), us.max(), v.sum()))
     ok = (st[:, 4] > st[:, 3]) & (st[:, 3] >= t0)
     if ok.sum():
         d = (st[ok, 4] - st[ok, 3]) / 100.0

@@ -221,7 +221,9 @@ def fuseTail1x1(rootModule, enabled=True):
                     a.weight.dtype == torch.float32):
                 _log('fusing the 1x1 tail behind %s' % names[i])
                 head.propChangeIndexes = True
-                seq._modules[names[i + 1]] = CBTail1x1(a, b, relu=True)
+                tail = CBTail1x1(a, b, relu=True)
+                seq._modules[names[i + 1]] = tail
+                head.__dict__['_fusedTail'] = tail      # (a plain reference, not a child: see CBConv2d._folded_tail)
                 del seq._modules[names[i + 2]]
                 del seq._modules[names[i + 3]]
                 break

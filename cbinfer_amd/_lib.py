@@ -32,6 +32,16 @@ class TailSeq(ctypes.Structure):
 
 
 _tp = ctypes.POINTER(TailSeq)
+
+
+class SplitTail(ctypes.Structure):
+    """cbSplitTail of include/cbinfer_hip.h: the fused 1x1 tail behind a split-state layer."""
+    _fields_ = [("w1Prepared", ctypes.c_void_p), ("b1", ctypes.c_void_p), ("w2", ctypes.c_void_p),
+                ("b2", ctypes.c_void_p), ("C1", ctypes.c_int), ("C2", ctypes.c_int), ("relu1", ctypes.c_int),
+                ("relu2", ctypes.c_int), ("output", ctypes.c_void_p * 8)]
+
+
+_stp = ctypes.POINTER(SplitTail)
 _vpp = ctypes.POINTER(ctypes.c_void_p)
 
 _SIGNATURES = {
@@ -114,6 +124,9 @@ _SIGNATURES = {
     "cbinfer_split_detect": (_i, [_sp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "cbinfer_split_conv": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp]),
     "cbinfer_split_forward": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _vp]),
+    "cbinfer_split_forward_tail": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _i,
+                                        _stp, _vp]),
+    "cbinfer_split_tail_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "cbinfer_conv2d_fg_cpu": (None, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i]),
 }
 
@@ -131,7 +144,7 @@ def _load():
         fn = getattr(lib, name)     # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.cbinfer_abi_version() != 4:
+    if lib.cbinfer_abi_version() != 5:
         raise ImportError("cbinfer_amd: libcbinfer_hip.so ABI version mismatch")
     return lib
 

@@ -18,6 +18,7 @@ CBPoolMax2d between them, an optional CBTail1x1 at the end.  Anything else raise
 sequence per stream instead.
 """
 import ctypes
+import os
 
 import torch
 
@@ -83,6 +84,21 @@ class SequenceBatch(object):
                     seqs[q].input, seqs[q].changeList = prod['prevOutput'][q].data_ptr(), prod['idx'][q].data_ptr()
                     seqs[q].countDev, seqs[q].output = prod['count'][q].data_ptr(), L['prevOutput'][q].data_ptr()
                 L['seqs'] = seqs
+                # ... or rides in the producing layer's second launch (cbinfer_split_forward_tail)
+                pm = prod['m']
+                pK, pC, pkH, pkW = pm.weight.size()
+                L['folded'] = bool(prod['ws'] is not None and m.in_channels == pK and
+                                   os.environ.get('CBINFER_NO_TAILFOLD', '0') != '1' and
+                                   C.cbinfer_split_tail_supported(pC, pK, pkH, pkW, m.hidden_channels, m.out_channels))
+                if L['folded']:
+                    st = _lib.SplitTail()
+                    L['keep'] = (m._prepared(), m.bias1.detach(), m.weight2.detach().contiguous(), m.bias2.detach())
+                    st.w1Prepared, st.b1, st.w2, st.b2 = [x.data_ptr() for x in L['keep']]
+                    st.C1, st.C2, st.relu1, st.relu2 = (m.hidden_channels, m.out_channels, int(m.relu),
+                                                        int(bool(m.withReLU)))
+                    for q in range(S):
+                        st.output[q] = L['prevOutput'][q].data_ptr()
+                    prod['tail'] = st
                 layers.append(L)
                 shape = (1, m.out_channels, h, w)
                 continue
@@ -195,10 +211,15 @@ class SequenceBatch(object):
                         for q in range(S):
                             seqs[q].producerMask = prod['copy'][q].data_ptr() if use else None
                 L['th'] = float(m.threshold)
-                check(C.cbinfer_split_forward(seqs, S, int(pooled is not None), pooled[1] if pooled else 0,
-                                              pooled[2] if pooled else 0, ptr(L['wp']), ptr(m.bias.detach()), L['C'],
-                                              L['H'], L['W'], L['K'], L['kH'], L['kW'], float(m.threshold),
-                                              float(L['scale']), int(bool(m.withReLU)), ptr(L['ws']), st))
+                args = [seqs, S, int(pooled is not None), pooled[1] if pooled else 0, pooled[2] if pooled else 0,
+                        ptr(L['wp']), ptr(m.bias.detach()), L['C'], L['H'], L['W'], L['K'], L['kH'], L['kW'],
+                        float(m.threshold), float(L['scale']), int(bool(m.withReLU)), ptr(L['ws'])]
+                if L.get('tail') is not None:
+                    check(C.cbinfer_split_forward_tail(*(args + [0, ctypes.pointer(L['tail']), st])))
+                else:
+                    check(C.cbinfer_split_forward(*(args + [st])))
+            elif L.get('folded'):
+                pass          # (evaluated by the producing layer's second launch)
             else:
                 check(C.cbinfer_tail1x1_batched(L['seqs'], S, L['H'] * L['W'], ptr(m._prepared()),
                                                 ptr(m.bias1.detach()), ptr(m.weight2.detach().contiguous()),

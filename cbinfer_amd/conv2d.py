@@ -345,6 +345,27 @@ class CBConv2d(nn.Module):
                                       stateKey=None, seq=(_lib.SplitSeq * 1)())
         return sp
 
+    def _folded_tail(self, sp, H, W, dev):
+        """The CBTail1x1 behind this layer if its evaluation can ride in this layer's second launch
+        (cbinfer_split_forward_tail), with sp['tail'] (cbSplitTail) filled in -- else None: the tail module then
+        runs its own launch.  CBINFER_NO_TAILFOLD=1 switches the folding off."""
+        t = self.__dict__.get('_fusedTail')
+        K, Cin, kH, kW = self.weight.size()
+        if (t is None or sp['ws'] is None or not self.propChangeIndexes or t.in_channels != K or
+                t.weight1.dtype != torch.float32 or t.weight1.device != dev or
+                os.environ.get('CBINFER_NO_TAILFOLD', '0') == '1' or
+                not C.cbinfer_split_tail_supported(Cin, K, kH, kW, t.hidden_channels, t.out_channels)):
+            return None
+        out = t._output_for(H, W, dev, torch.float32)
+        st = sp.get('tail')
+        if st is None:
+            st = sp['tail'] = _lib.SplitTail()
+        sp['tailKeep'] = (t._prepared(), t.bias1.detach(), t.weight2.detach().contiguous(), t.bias2.detach())
+        st.w1Prepared, st.b1, st.w2, st.b2 = [x.data_ptr() for x in sp['tailKeep']]
+        st.C1, st.C2, st.relu1, st.relu2 = t.hidden_channels, t.out_channels, int(t.relu), int(bool(t.withReLU))
+        st.output[0] = out.data_ptr()
+        return t
+
     def rangeExceeded(self):
         """True if a state value ever left the range of the split-state arithmetic (|x| >= 2^20): the layer's
         outputs are then not meaningful (one host sync).  Use exactF32 or CBINFER_ARITH=bf16x3 for such data."""
@@ -380,10 +401,19 @@ class CBConv2d(nn.Module):
         q.rangeFlag, q.maskCopy = sp['flag'].data_ptr(), sp['copy'].data_ptr()
         args = [sp['seq'], 1, int(lazy is not None), src.size(-2) if lazy is not None else 0,
                 src.size(-1) if lazy is not None else 0, ptr(wp), ptr(self.bias.detach()), Cin, H, W, K, kH, kW,
-                float(self.threshold), float(scale), int(bool(self.withReLU)), ptr(sp['ws']), stream_ptr(src)]
-        check(C.cbinfer_split_forward(*args))
+                float(self.threshold), float(scale), int(bool(self.withReLU)), ptr(sp['ws'])]
+        # the fused 1x1 tail behind this layer (pycbinfer.fuseTail1x1) rides in the contraction's second launch
+        tail = self._folded_tail(sp, H, W, dev)
+        if tail is not None:
+            fn = C.cbinfer_split_forward_tail
+            args += [0, ctypes.pointer(sp['tail']), stream_ptr(src)]
+        else:
+            fn = C.cbinfer_split_forward
+            args += [stream_ptr(src)]
+        check(fn(*args))
         self._inputIsLiveState = False
         self._lastIndexes = MaskChangeIndexes(sp['copy'], (H, W), work['idx'], work['count'], made=True)
+        self._lastIndexes.tailDone = tail
         w, b = self._parameters.get('weight'), self._parameters.get('bias')
         if (w is not None and b is not None and not self.gatherComputationStats and
                 os.environ.get('CBINFER_NO_FASTPATH', '0') != '1'):
@@ -392,7 +422,7 @@ class CBConv2d(nn.Module):
                 flags=self._flags(), w=(w.data_ptr(), w._version), b=(b.data_ptr(), b._version),
                 state=(self._buffers['prevInput'].data_ptr(), self._buffers['prevOutput'].data_ptr()),
                 stateVersion=prev._version, stream=args[-1], work=work, args=args, seq=q, pmask=ptr(pmask),
-                indexes=self._lastIndexes)
+                indexes=self._lastIndexes, fn=fn, tail=tail, tailKey=tail._fold_key() if tail is not None else None)
         if self.propChangeIndexes:
             return 'changeIndexes', self.prevOutput, self._lastIndexes
         return self.prevOutput
@@ -419,8 +449,11 @@ class CBConv2d(nn.Module):
                 prev._version != plan['stateVersion'] or
                 self._work is not plan['work'] or raw_stream(src.device.index) != plan['stream']):
             return None
+        if plan['tail'] is not None and (self.__dict__.get('_fusedTail') is not plan['tail'] or
+                                         plan['tail']._fold_key() != plan['tailKey']):
+            return None
         plan['seq'].input = src.data_ptr()
-        status = C.cbinfer_split_forward(*plan['args'])
+        status = plan['fn'](*plan['args'])
         if status != 0:
             check(status)
         self._inputIsLiveState = False
@@ -969,18 +1002,33 @@ class CBTail1x1(nn.Module):
             self._w1prep = (key, wp)
         return self._w1prep[1]
 
+    def _output_for(self, H, W, device, dtype):
+        size = (1, self.out_channels, H, W)
+        if not _same_shape(self.prevOutput, size) or self.prevOutput.device != device:
+            self.prevOutput = torch.full(size, float('inf'), dtype=dtype, device=device)
+        return self.prevOutput
+
+    def _fold_key(self):
+        """What a producing layer's call plan that folds this tail into its own launch depends on."""
+        ts = (self.weight1, self.bias1, self.weight2, self.bias2)
+        return (tuple((t.data_ptr(), t._version) for t in ts), self._buffers['prevOutput'].data_ptr(), self.relu,
+                bool(self.withReLU))
+
     def forward(self, inp):
         assert type(inp) == tuple and inp[0] == 'changeIndexes', \
             "CBTail1x1 needs the ('changeIndexes', tensor, indexes) tuple of a CBConv2d with propChangeIndexes"
+        if getattr(inp[2], 'tailDone', None) is self:
+            # the producing layer evaluated this tail in its own second launch (cbinfer_split_forward_tail)
+            if self.propChangeIndexes:
+                return 'changeIndexes', self.prevOutput, inp[2]
+            return self.prevOutput
         x, indexes = inp[1].detach().contiguous(), inp[2]
         require_device(x)
         assert x.dim() == 4 and x.size(0) == 1 and x.size(1) == self.in_channels
         if x.dtype != torch.float32:
             raise _lib.CBinferError("CBTail1x1 is fp32 only")
         H, W = x.size(-2), x.size(-1)
-        size = (1, self.out_channels, H, W)
-        if not _same_shape(self.prevOutput, size) or self.prevOutput.device != x.device:
-            self.prevOutput = torch.full(size, float('inf'), dtype=x.dtype, device=x.device)
+        self._output_for(H, W, x.device, x.dtype)
         if isinstance(indexes, ChangeIndexes):
             idx, count, cap = indexes.buffer, indexes.count, min(indexes.buffer.numel(), H * W)
         else:

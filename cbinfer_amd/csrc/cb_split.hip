@@ -30,6 +30,18 @@
 
 #include "cb_common.h"
 
+#ifdef CBS_STAMP
+// diagnostic build only (make EXTRA=-DCBS_STAMP; tools/split_stamps.py): per-workgroup phase stamps, 100 MHz constant
+// clock: [64-row tile | 128-row tile | reduce+tail launch] x 2048 workgroups x 16 marks
+__device__ unsigned long long cbs_stamp_buf[3 * 2048 * 16];
+#define CB_TAIL_STAMP(i)                                                                 \
+    do {                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 2048)                                       \
+            cbs_stamp_buf[(2 * 2048 + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#endif
+#include "cb_tail_core.h"
+
 namespace cbs {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -374,7 +386,6 @@ struct CbsParams {
 // diagnostic build only (make EXTRA=-DCBS_STAMP; tools/split_stamps.py): per-workgroup phase stamps of its FIRST item,
 // 100 MHz constant clock: 0 entry, 1 list lengths known, 2 item set up, 3 ring primed, 4 stage loop done, 5 epilogue
 // done; 6 / 7: shader clock (s_memtime) at entry / after the stage loop; 8.. finer prologue marks (see tools/split_stamps.py)
-__device__ unsigned long long cbs_stamp_buf[2 * 2048 * 16];      // [64-row tile | 128-row tile]
 #define CBS_STAMP_AT(i)                                                                                   \
     do {                                                                                                  \
         if (threadIdx.x == 0 && blockIdx.x < 2048 && cbs_first)                                           \
@@ -917,8 +928,8 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
                     const float4 o = rs[j][r >> 2];
                     v = ((r & 3) == 0 ? o.x : (r & 3) == 1 ? o.y : (r & 3) == 2 ? o.z : o.w) + v;
                 }
-                v = v * p.outScale + s_bias[ml];
-                if (p.relu) v = v <= 0.f ? 0.f : v;
+                v = fmaf(v, p.outScale, s_bias[ml]);      // (an explicit fma here, in the reduce launch and in the
+                if (p.relu) v = v <= 0.f ? 0.f : v;        //  fused tail: one rounding at all three sites)
                 if (pix >= 0 && m < p.K) out[(long)m * HW + pix] = v;
             }
         }
@@ -990,11 +1001,137 @@ __global__ __launch_bounds__(256) void cbs_reduce_kernel(CbsParams p, int BM, in
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (m + e >= p.K) continue;
-            float v = sv[e] * p.outScale;
-            if (p.bias) v += p.bias[m + e];
+            float v = fmaf(sv[e], p.outScale, p.bias ? p.bias[m + e] : 0.f);
             if (p.relu) v = v <= 0.f ? 0.f : v;
             out[(long)(m + e) * HW + pix] = v;
         }
+    }
+}
+
+// The second launch of a deep contraction when a fused 1x1 tail (cb_tail.hip) follows the layer: per group of
+// CB_TAIL_PX changed pixels it finishes the layer's outputs -- split contraction: the sum of the tile's slabs in
+// chunk order, scale, bias, ReLU, scattered to prevOutput; unsplit: already there, gathered -- into an LDS tile
+// and evaluates conv1x1 -> [ReLU] -> conv1x1 on it (cb_tail_tile: the tail kernel's own arithmetic).  The tail's
+// gather pass over prevOutput and a launch boundary go away.
+struct CbsTailArgs {
+    const float* w1p;
+    const float* b1;
+    const float* w2;
+    const float* b2;
+    float* out[CBS_MAXSEQ];
+    int C1, C2, relu1, relu2;
+};
+template <int BM, int BN>
+__global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cbs_reduce_tail_kernel(CbsParams p, CbsTailArgs ta) {
+    extern __shared__ float cbs_tail_sm[];
+    cb_touch_kernarg<sizeof(CbsParams) + sizeof(CbsTailArgs)>();
+    const int C0 = p.K, C0P = (C0 + 15) / 16 * 16, C1 = ta.C1, C2 = ta.C2, HW = p.H * p.W;
+    const int t = threadIdx.x, NT = blockDim.x;
+    // Round trips to memory are what this launch consists of.  First: the launch info of the contraction, the
+    // layer's biases, the second layer's matrix.  Second (per group): the slabs of the group's 16 pixel columns --
+    // their address needs no pixel index -- and the 16 pixel indices.  Third: this wave's rows of W1.
+    CB_TAIL_STAMP(0);
+    const int SK = p.info[CBS_INFO_SK], MT = p.info[CBS_INFO_MT], CMB = MT * SK, TILE4 = BM * BN / 4;
+    int tilesBefore[CBS_MAXSEQ + 1];
+    tilesBefore[0] = 0;
+#pragma unroll
+    for (int q = 0; q < CBS_MAXSEQ; ++q) tilesBefore[q + 1] = tilesBefore[q] + p.info[CBS_INFO_TP + q];
+    const int GP = BN / CB_TAIL_PX, groups = tilesBefore[CBS_MAXSEQ] * GP;
+    if ((int)blockIdx.x >= groups) return;
+    CB_TAIL_STAMP(1);
+    const CbTailLds L = cb_tail_lds(cbs_tail_sm, C0P, C1, C2, NT);
+    __shared__ int s_pix[CB_TAIL_PX];
+    for (int i = t; i < C2 * C1; i += NT) L.W2s[i] = ta.w2[i];
+    for (int i = t; i < C2; i += NT) L.b2s[i] = ta.b2[i];
+    const float4* __restrict__ slabs = (const float4*)p.slabs;
+    const bool hasBias = p.bias != nullptr;
+    const float* biasp = hasBias ? p.bias : ta.b1;      // (no bias: any readable address, the values are not used)
+    const int px = t & 15, cstep = NT >> 4;
+    for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+        const int ptg = g / GP, gi = g - ptg * GP;
+        int q = 0;
+#pragma unroll
+        for (int u = 1; u < CBS_MAXSEQ; ++u)
+            if (u < p.nSeq && ptg >= tilesBefore[u]) q = u;
+        const int nl0 = gi * CB_TAIL_PX, n0 = (ptg - tilesBefore[q]) * BN + nl0;
+        const int N = p.info[CBS_INFO_TP + CBS_MAXSEQ + q];
+        if (n0 >= N) continue;      // (uniform: a tile's last groups may be empty)
+        float* outq = p.seq[q].out;
+        int pixMine = -1;           // (thread px of every 16: the same 16 indices, no LDS hop before the scatter)
+        if (n0 + px < N) pixMine = p.seq[q].listOut[n0 + px];
+        // (everything below that depends only on the thread index is the same in every round of this loop, and the
+        //  compiler would keep it all -- some eighty registers of addresses -- alive across the loop: an opaque copy
+        //  of the index makes it recompute them, a few integer instructions per use)
+        int tq = t >> 4;
+        asm volatile("" : "+v"(tq));
+        if ((unsigned)pixMine >= (unsigned)HW) pixMine = -1;
+        const int pixLd = max(pixMine, 0);      // (loads are never predicated -- a predicated load is a branch, and
+                                                //  sixteen branches in a row are sixteen round trips: clamped addresses,
+                                                //  predicated USES)
+        if (SK > 1) {
+            // X[c][px] from the slabs (SK = CBS_CHUNKS of them): thread -> (px, channel quads t/16 + i NT/16); all loads
+            // of a thread in flight.  The same number of rounds for every thread, so that all reach the barrier.
+            const float4* sl0 = slabs + (long)ptg * CMB * TILE4 + nl0 + px;
+            const int QN = C0P / 4, rounds = (QN + 4 * cstep - 1) / (4 * cstep);
+            for (int rd = 0; rd < rounds; ++rd) {
+                const int cq0 = tq + rd * 4 * cstep;
+                float4 v[4][CBS_CHUNKS], bq[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cq = min(cq0 + u * cstep, QN - 1), mt = cq / (BM / 4), mq = cq - mt * (BM / 4);
+#pragma unroll
+                    for (int j = 0; j < CBS_CHUNKS; ++j) v[u][j] = sl0[((long)j * MT + mt) * TILE4 + mq * BN];
+                    bq[u] = *(const float4*)(biasp + min(4 * cq, p.K - 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);      // (all loads requested before anything of the second half)
+                if (rd == 0) {
+                    __syncthreads();   // previous group's Hs / s_pix / Xs reads are done
+                    if (t < CB_TAIL_PX) s_pix[t] = pixMine;
+                    CB_TAIL_STAMP(2);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cq = cq0 + u * cstep;
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < CBS_CHUNKS; ++j) s0 += v[u][j].x, s1 += v[u][j].y, s2 += v[u][j].z, s3 += v[u][j].w;
+                    const float sv[4] = {s0, s1, s2, s3}, bv[4] = {bq[u].x, bq[u].y, bq[u].z, bq[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = 4 * cq + e;
+                        float r = fmaf(sv[e], p.outScale, hasBias ? bv[e] : 0.f);
+                        if (p.relu) r = r <= 0.f ? 0.f : r;
+                        if (cq < QN) {
+                            if (pixMine >= 0 && m < p.K) outq[(long)m * HW + pixMine] = r;
+                            L.Xs[m * CB_TAIL_PX + px] = m < p.K ? r : 0.f;
+                        }
+                    }
+                }
+            }
+        } else {
+            // unsplit: the contraction's epilogue has written prevOutput; gather as the tail kernel does
+            __syncthreads();
+            if (t < CB_TAIL_PX) s_pix[t] = pixMine;
+            for (int c0 = tq; c0 < C0P; c0 += 16 * cstep) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = outq[(long)min(c0 + u * cstep, C0 - 1) * HW + pixLd];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int c = c0 + u * cstep;
+                    if (c < C0P) L.Xs[c * CB_TAIL_PX + px] = (pixMine >= 0 && c < C0) ? v[u] : 0.f;
+                }
+            }
+        }
+        // this wave's rows of W1: requested once the slab registers are free (requested earlier -- beside the slabs,
+        // or behind their barrier -- the launch came out longer: the barrier waits for them too, and the stores of the
+        // sums queue behind them), per group -- few workgroups see a second one -- rather than kept across the loop
+        asm volatile("" ::: "memory");
+        CbTailPre P;
+        cb_tail_preload(P, ta.w1p, ta.b1, C0P, C1);
+        CB_TAIL_STAMP(3);
+        cb_tail_tile(L, s_pix, P, ta.w1p, ta.out[q], C0P, C1, C2, HW, ta.relu1, ta.relu2);
+        CB_TAIL_STAMP(7);
     }
 }
 
@@ -1012,13 +1149,20 @@ int cbs_num_cus() {
 }
 
 template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING>
-int cbs_launch_conv(const CbsParams& p, int perCU, hipStream_t s) {
+int cbs_launch_conv(const CbsParams& p, int perCU, const CbsTailArgs* tail, hipStream_t s) {
     if ((long)p.nSeq * p.maskWords > PRE_CAP) return CB_ERR_UNSUPPORTED;
+    const bool second = p.slabs && (p.nStages >= 48 || p.forceSK > 0);
+    if (tail && !second) return CB_ERR_UNSUPPORTED;      // (the fused tail reads the launch info of a deep contraction)
     dim3 grid((unsigned)(perCU * cbs_num_cus())), block(64 * WM * WN);
     hipLaunchKernelGGL((cbs_conv_kernel<BM, BN, WM, WN, PRE_CAP, MASK_LDS, RING>), grid, block, 0, s, p);
     int st = cb_launch_status();
     if (st != CB_OK) return st;
-    if (p.slabs && (p.nStages >= 48 || p.forceSK > 0)) {
+    if (tail) {
+        const int waves = (tail->C1 + 15) / 16;
+        hipLaunchKernelGGL((cbs_reduce_tail_kernel<BM, BN>), dim3(2 * cbs_num_cus()), dim3(64 * waves),
+                           cb_tail_lds_bytes(p.K, tail->C1, tail->C2), s, p, *tail);
+        st = cb_launch_status();
+    } else if (second) {
         hipLaunchKernelGGL(cbs_reduce_kernel, dim3(4 * cbs_num_cus()), dim3(256), 0, s, p, BM, BN);
         st = cb_launch_status();
     }
@@ -1033,7 +1177,7 @@ extern "C" int cbinfer_debug_split_stamps(void* host, long bytes, int clear) {
     if (clear) {
         void* d = nullptr;
         if (hipGetSymbolAddress(&d, HIP_SYMBOL(cbs_stamp_buf)) != hipSuccess) return -1;
-        return (int)hipMemset(d, 0, sizeof(unsigned long long) * 2 * 2048 * 16);
+        return (int)hipMemset(d, 0, sizeof(unsigned long long) * 3 * 2048 * 16);
     }
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cbs_stamp_buf), (size_t)bytes);
 }
@@ -1135,9 +1279,9 @@ int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, i
 
 // The contraction of up to CBS_MAXSEQ sequences in one launch (+ the reduce launch of a split contraction).
 // outScale = 1 / (weightScale * 2^-4).  forceSplit > 0 overrides the k-split decision (tests, tuning).
-int cbinfer_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
-                       int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
-                       cbStream_t stream) {
+static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
+                          int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
+                          const CbsTailArgs* tail, cbStream_t stream) {
     if (workspace == nullptr && cbs_supported(C, K, kH, kW) && cbs_geom(C, H, W, kH, kW).nStages >= 48)
         return CB_ERR_BADARG;      // a deep contraction needs its workspace (cbinfer_split_workspace_bytes)
     CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && prepared && H > 0 && W > 0 && weightScale > 0.f);
@@ -1180,15 +1324,51 @@ int cbinfer_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, c
 #endif
     hipStream_t s = (hipStream_t)stream;
     p.slabCap = 0;      // (sized by cbinfer_split_workspace_bytes for this very geometry: never exceeded)
-    if (BM == 128) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG, true, 4>(p, 1, s);
+    if (BM == 128) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG, true, 4>(p, 1, tail, s);
     // The 64-row tile moves 16 KB per stage, and what bounds its stage rate is the DMA in flight on the CU (bytes in
     // flight / latency): one sequence rarely has more tiles than there are CUs, so it runs one workgroup per CU with
     // a ring of eight stages (seven in flight, 112 KB); several sequences run two workgroups per CU with four-stage
     // rings (96 KB in flight between them) while the mask words and their prefix fit beside two rings.
-    if (nSeq == 1 && MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 8>(p, 1, s);
-    if ((long)nSeq * MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 4>(p, 2, s);
-    if ((long)nSeq * MW <= CBS_PRE_MID2) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID2, false, 4>(p, 2, s);
-    return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 8>(p, 1, s);
+    if (nSeq == 1 && MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 8>(p, 1, tail, s);
+    if ((long)nSeq * MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 4>(p, 2, tail, s);
+    if ((long)nSeq * MW <= CBS_PRE_MID2) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID2, false, 4>(p, 2, tail, s);
+    return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 8>(p, 1, tail, s);
+}
+
+int cbinfer_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
+                       int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
+                       cbStream_t stream) {
+    return cbs_split_conv(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace, forceSplit,
+                          nullptr, stream);
+}
+
+// 1 if cbinfer_split_forward_tail takes this layer + tail: a deep contraction (its second launch exists anyway) and
+// a tail the one-launch tail kernel would take
+int cbinfer_split_tail_supported(int C, int K, int kH, int kW, int C1, int C2) {
+    return cbs_supported(C, K, kH, kW) && cbs_geom(C, 64, 64, kH, kW).nStages >= 48 && K % 16 == 0 && C1 >= 4 && C2 >= 1 &&
+           C1 <= 16 * CB_TAIL_MAXW && cb_tail_lds_bytes(K, C1, C2) <= 60 * 1024;
+}
+
+// cbinfer_split_forward + the fused 1x1 tail behind the layer (cbinfer_tail1x1's arithmetic and weight layout) in
+// the contraction's second launch: conv1x1 (K -> C1) -> [relu1] -> conv1x1 (C1 -> C2) -> [relu2] at the changed pixels,
+// into tail->output[sequence] [C2,H,W].  forceSplit as for cbinfer_split_conv.
+int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared,
+                               const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
+                               float weightScale, int relu, void* workspace, int forceSplit, const cbSplitTail* tail,
+                               cbStream_t stream) {
+    CB_REQUIRE(tail && tail->w1Prepared && tail->b1 && tail->w2 && tail->b2 && nSeq >= 1 && nSeq <= CBS_MAXSEQ);
+    if (!cbinfer_split_tail_supported(C, K, kH, kW, tail->C1, tail->C2)) return CB_ERR_UNSUPPORTED;
+    CbsTailArgs ta;
+    ta.w1p = tail->w1Prepared, ta.b1 = tail->b1, ta.w2 = tail->w2, ta.b2 = tail->b2;
+    ta.C1 = tail->C1, ta.C2 = tail->C2, ta.relu1 = tail->relu1, ta.relu2 = tail->relu2;
+    for (int q = 0; q < CBS_MAXSEQ; ++q) {
+        if (q < nSeq) CB_REQUIRE(tail->output[q]);
+        ta.out[q] = q < nSeq ? tail->output[q] : nullptr;
+    }
+    const int st = cbinfer_split_detect(seqs, nSeq, pooled, pH, pW, C, H, W, kH, kW, threshold, stream);
+    if (st != CB_OK) return st;
+    return cbs_split_conv(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace, forceSplit, &ta,
+                          stream);
 }
 
 // One frame of a feedback-mode CBConv2d (conv2d.py:178-259) of every sequence: detection (+ pooling) + refresh of
@@ -1198,8 +1378,8 @@ int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, 
                           float weightScale, int relu, void* workspace, cbStream_t stream) {
     const int st = cbinfer_split_detect(seqs, nSeq, pooled, pH, pW, C, H, W, kH, kW, threshold, stream);
     if (st != CB_OK) return st;
-    return cbinfer_split_conv(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace, 0,
-                              stream);
+    return cbs_split_conv(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace, 0, nullptr,
+                          stream);
 }
 
 }  // extern "C"

@@ -12,13 +12,10 @@
 // the gathered X tile staged once through LDS.  relu(H + b1) goes to LDS, and the C2 x 16 outputs of the
 // second (tiny) layer are plain f32 dot products over it.
 #include "cb_common.h"
+#include "cb_tail_core.h"
 
 namespace {
 
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-#define CB_TAIL_PX 16
-#define CB_TAIL_MAXW 8          // waves per workgroup = ceil(C1/16) <= 8  -> C1 <= 128
 
 // W1 [C1, C0] -> fragment order [mt][s4][lane][4]: element (mt, s4, lane, j) = W1[16 mt + lane%16][16 s4 + 4 j + lane/16]
 __global__ __launch_bounds__(256) void cb_tail_prep_kernel(const float* __restrict__ w1, float* __restrict__ w1p,
@@ -53,14 +50,15 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cb_tail1x1_kernel(
     const int32_t* __restrict__ list = tab.seq[blockIdx.y].list;
     const int32_t* __restrict__ countDev = tab.seq[blockIdx.y].countDev;
     float* out = tab.seq[blockIdx.y].out;
-    const int N = countDev ? min(*countDev, nHost) : nHost;
     const int t = threadIdx.x, NT = blockDim.x;
-    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    float* Xs = sm;
-    float* Hs = sm + (long)C0P * CB_TAIL_PX;
-    float* W2s = Hs + (NT >> 6) * 16 * (CB_TAIL_PX + 1);
-    float* b2s = W2s + C2 * C1;
+    const CbTailLds L = cb_tail_lds(sm, C0P, C1, C2, NT);
+    float* Xs = L.Xs;
+    float* W2s = L.W2s;
+    float* b2s = L.b2s;
     __shared__ int s_pix[CB_TAIL_PX];
+    CbTailPre P;
+    cb_tail_preload(P, w1p, b1, C0P, C1);      // (requested beside the change count: one round trip, not two)
+    const int N = countDev ? min(*countDev, nHost) : nHost;
     if ((int)blockIdx.x * CB_TAIL_PX >= N) return;
     // the second layer's (small) matrix and bias live in LDS for the life of the workgroup
     for (int i = t; i < C2 * C1; i += NT) W2s[i] = w2[i];
@@ -78,66 +76,22 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cb_tail1x1_kernel(
         // gather X[c][px]: thread -> (px = t % 16, c = t / 16 + i * NT/16); 16 neighbouring lanes read the
         // 16 pixels of one channel plane (contiguous where the changed pixels are)
         const int px = t & 15;
-        const int mypix = s_pix[px];
+        const int mypix = s_pix[px], pixLd = max(mypix, 0);
         const int cstep = NT >> 4;
         for (int c0 = t >> 4; c0 < C0P; c0 += 16 * cstep) {   // sixteen loads in flight per lane
+            // (never predicated -- a predicated load is a branch of its own, sixteen of them sixteen round trips:
+            //  clamped addresses, predicated uses)
             float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int c = c0 + u * cstep;
-                v[u] = (mypix >= 0 && c < C0) ? x[(long)c * HW + mypix] : 0.f;
-            }
+            for (int u = 0; u < 16; ++u) v[u] = x[(long)min(c0 + u * cstep, C0 - 1) * HW + pixLd];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int c = c0 + u * cstep;
-                if (c < C0P) Xs[c * CB_TAIL_PX + px] = v[u];
+                if (c < C0P) Xs[c * CB_TAIL_PX + px] = (mypix >= 0 && c < C0) ? v[u] : 0.f;
             }
         }
 
-        // H tile of this wave: rows 16 wave .. +15, cols = 16 px.  A: lane holds W1[16w + l%16][4s + l/16],
-        // B: lane holds X[4s + l/16][l%16].  The weight fragments of up to 256 input channels are requested in
-        // one go (16 x 16 B per lane), before the gathered tile is even waited for: fetched one by one in the
-        // MFMA loop they cost sixteen L2 round trips per tile (15.8 us per launch in the frame, round 2).
-        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-        const floatx4* ap = (const floatx4*)w1p + ((long)wave * (C0P / 16)) * 64 + lane;
-        const float* bp = Xs + (lane >> 4) * CB_TAIL_PX + (lane & 15);
-        const int groups = C0P / 16;
-        for (int g0 = 0; g0 < groups; g0 += 16) {
-            floatx4 a[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) a[i] = ap[(long)min(g0 + i, groups - 1) * 64];
-            if (g0 == 0) __syncthreads();   // the X tile is complete
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (g0 + i < groups) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], bp[(16 * (g0 + i) + 4 * j) * CB_TAIL_PX], acc,
-                                                                   0, 0, 0);
-                }
-            }
-        }
-        // C/D map of the 16x16 tile: col = lane%16, row = 4*(lane/16) + r
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = 16 * wave + 4 * (lane >> 4) + r;
-            float v = acc[r] + (m < C1 ? b1[m] : 0.f);
-            if (relu1) v = v <= 0.f ? 0.f : v;
-            Hs[m * (CB_TAIL_PX + 1) + (lane & 15)] = v;
-        }
-        __syncthreads();
-        // second layer: out[c2][px] = b2[c2] + sum_j W2[c2][j] * H[j][px]
-        for (int o = t; o < C2 * CB_TAIL_PX; o += NT) {
-            const int c2 = o >> 4, p2 = o & 15;
-            const int pix = s_pix[p2];
-            if (pix < 0) continue;
-            float v = b2s[c2];
-            const float* wr = W2s + c2 * C1;
-#pragma unroll 8
-            for (int j = 0; j < C1; ++j) v = fmaf(wr[j], Hs[j * (CB_TAIL_PX + 1) + p2], v);
-            if (relu2) v = v <= 0.f ? 0.f : v;
-            out[(long)c2 * HW + pix] = v;
-        }
+        cb_tail_tile(L, s_pix, P, w1p, out, C0P, C1, C2, HW, relu1, relu2);
     }
 }
 
@@ -146,12 +100,6 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cb_tail1x1_kernel(
 extern "C" {
 
 int cbinfer_tail1x1_max_hidden(void) { return 16 * CB_TAIL_MAXW; }
-
-static size_t cb_tail_lds_bytes(int C0, int C1, int C2) {
-    const int C0P = (C0 + 15) / 16 * 16;
-    const int waves = (C1 + 15) / 16;
-    return ((size_t)C0P * CB_TAIL_PX + (size_t)waves * 16 * (CB_TAIL_PX + 1) + (size_t)C2 * C1 + C2) * 4;
-}
 
 // 1 if cbinfer_tail1x1 takes these channel counts (hidden width and LDS budget), so that a fusion can be refused
 // when it is set up rather than at the first frame

@@ -52,8 +52,9 @@ typedef void* cbStream_t; /* hipStream_t */
 /* 1: round 1.  2: CB_F32S, row-segment / patch-staged contractions, fine-grained frame, fused 1x1 tail,
  * cbinfer_weights_ckkpad(Ckk, dtype).  3: fine-grained frame on the mask-driven contractions
  * (cbinfer_cbconv2d_forward_fg_masked and its parts).  4: split-state frame (cbinfer_split_*, several sequences
- * per launch), cbinfer_tail1x1_supported. */
-#define CBINFER_ABI_VERSION 4
+ * per launch), cbinfer_tail1x1_supported.  5: cbinfer_split_forward_tail (the 1x1 tail in the contraction's second
+ * launch), cbinfer_split_tail_supported. */
+#define CBINFER_ABI_VERSION 5
 
 int cbinfer_abi_version(void);
 const char* cbinfer_status_string(int status);
@@ -424,6 +425,26 @@ int cbinfer_tail1x1_batched(const cbTailSeq* seqs, int nSeq, int numChanges, con
 int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared,
                           const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
                           float weightScale, int relu, void* workspace, cbStream_t stream);
+/* The layer + the fused 1x1 tail behind it (sceneLabeling/modelLoader.py:45-47: the dense conv1x1 -> ReLU -> conv1x1
+ * the experiments keep; cbinfer_tail1x1 evaluates it at the changed pixels) with the tail folded into the second
+ * launch of a deep contraction: the launch that finishes the layer's outputs -- summing the partial tiles of a split
+ * contraction -- keeps each group of 16 finished pixel columns in LDS and runs the tail on them.  Same arithmetic
+ * as cbinfer_split_forward followed by cbinfer_tail1x1 (bit-identical outputs), one launch and the tail's gather
+ * pass over prevOutput less.  cbinfer_split_tail_supported: deep contraction (>= 48 k-stages) and a tail
+ * cbinfer_tail1x1_supported(K, C1, C2) takes. */
+typedef struct {
+    const float* w1Prepared;      /* cbinfer_tail1x1_prep */
+    const float* b1;
+    const float* w2;              /* [C2, C1] */
+    const float* b2;
+    int C1, C2, relu1, relu2;
+    float* output[CBINFER_SPLIT_MAX_SEQUENCES];   /* [C2,H,W] per sequence */
+} cbSplitTail;
+int cbinfer_split_tail_supported(int C, int K, int kH, int kW, int C1, int C2);
+int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared,
+                               const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
+                               float weightScale, int relu, void* workspace, int forceSplit, const cbSplitTail* tail,
+                               cbStream_t stream);
 
 /* replaces conv2d_fg_cpu, cbconv2d_fg_backend.cu:81-112: HOST pointers, host code, race-free. */
 void cbinfer_conv2d_fg_cpu(const float* input, const float* prevInput, float* output,

@@ -280,3 +280,58 @@ def test_split_module_reports_range_and_survives_state_restore(lib):
             assert torch.equal(a, b_)
     convs = [m for m in net.children() if type(m) is pycbinfer.CBConv2d]
     assert not convs[1].rangeExceeded() and not convs[2].rangeExceeded()
+
+
+@pytest.mark.parametrize("nSeq,force", [(1, 0), (1, 1), (1, 4), (3, 0), (3, 4)])
+def test_split_tail_in_the_second_launch(lib, oracle, nSeq, force):
+    """cbinfer_split_forward_tail = cbinfer_split_forward followed by cbinfer_tail1x1, bit for bit (layer outputs,
+    change lists, tail outputs), whether the contraction is split along k (the tail's columns come out of the slabs)
+    or not (gathered from prevOutput), for one and for several sequences; and the tail agrees with a dense
+    conv1x1 -> ReLU -> conv1x1 of the layer output (sceneLabeling/modelLoader.py:45-47) within the fp32 bar."""
+    C_ = lib.C
+    rng = np.random.default_rng(21 + nSeq + force)
+    C, K, H, W, C1, C2 = 64, 256, 40, 60, 64, 8
+    assert C_.cbinfer_split_tail_supported(C, K, 7, 7, C1, C2) == 1
+    assert C_.cbinfer_split_tail_supported(16, 64, 7, 7, C1, C2) == 0       # (not a deep contraction)
+    w = (rng.standard_normal((K, C, 7, 7)) / np.sqrt(C * 49)).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    w1 = (rng.standard_normal((C1, K)) / np.sqrt(K)).astype(np.float32)
+    b1 = rng.standard_normal(C1).astype(np.float32)
+    w2 = (rng.standard_normal((C2, C1)) / np.sqrt(C1)).astype(np.float32)
+    b2 = rng.standard_normal(C2).astype(np.float32)
+    dw1, db1, dw2, db2 = dev(w1), dev(b1), dev(w2), dev(b2)
+    w1p = torch.empty(C_.cbinfer_tail1x1_prepared_bytes(C1, K) // 4, device="cuda")
+    lib.check(C_.cbinfer_tail1x1_prep(dw1.data_ptr(), w1p.data_ptr(), C1, K, None))
+    vids = [block_video(rng, C, H, W, 4, f) for f in (0.15, 0.6, 0.02)[:nSeq]]
+    ref, fused = Layer(lib, w, b, H, W, nSeq=nSeq), Layer(lib, w, b, H, W, nSeq=nSeq)
+    tref = [torch.full((1, C2, H, W), float("inf"), device="cuda") for _ in range(nSeq)]
+    tfus = [torch.full((1, C2, H, W), float("inf"), device="cuda") for _ in range(nSeq)]
+    st = lib.SplitTail()
+    st.w1Prepared, st.b1, st.w2, st.b2 = w1p.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr()
+    st.C1, st.C2, st.relu1, st.relu2 = C1, C2, 1, 0
+    for q in range(nSeq):
+        st.output[q] = tfus[q].data_ptr()
+    import ctypes
+    for t in range(4):
+        xs = [dev(v[t]) for v in vids]
+        ref.frame(xs, 0.05, relu=True, force=force)
+        for q in range(nSeq):
+            lib.check(C_.cbinfer_tail1x1(ref.out[q].data_ptr(), ref.idx[q].data_ptr(), H * W, ref.cnt[q].data_ptr(),
+                                         w1p.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
+                                         tref[q].data_ptr(), K, C1, C2, H, W, 1, 0, None))
+        for q, x in enumerate(xs):
+            fused.seqs[q].input = x.data_ptr()
+            fused.seqs[q].producerMask = None
+        lib.check(C_.cbinfer_split_forward_tail(fused.seqs, nSeq, 0, 0, 0, fused.wp.data_ptr(), fused.b.data_ptr(), C,
+                                                H, W, K, 7, 7, 0.05, fused.scale, 1, fused.ws.data_ptr(), force,
+                                                ctypes.pointer(st), None))
+        torch.cuda.synchronize()
+        for q in range(nSeq):
+            assert np.array_equal(ref.list(q), fused.list(q)), (t, q)
+            assert torch.equal(ref.out[q], fused.out[q]), (t, q)
+            assert torch.equal(tref[q], tfus[q]), (t, q)
+    for q in range(nSeq):
+        y = fused.out[q]
+        dense = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(
+            y.double(), dw1.double().view(C1, K, 1, 1), db1.double())), dw2.double().view(C2, C1, 1, 1), db2.double())
+        assert float((dense - tfus[q].double()).abs().max()) <= FP32_TOL

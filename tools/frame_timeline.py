@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
-"""One steady-state frame from a rocprofv3 --kernel-trace CSV of the bench (eager): start offsets, durations
-and the idle gaps between consecutive kernels, medians over many frames.
+"""Steady-state frames from a rocprofv3 --kernel-trace CSV of the bench: the dispatches are cut into frames (a
+frame starts with the detection in front of the first layer's row-segment contraction), frames are grouped by
+their sequence of kernel names -- the timed loop and the in-frame measurement passes issue different sequences --
+and for every common sequence the medians of durations and of the idle gaps between consecutive kernels are
+printed.  Under the profiler an eager run is host-bound (the gaps are the host's), so the durations are the
+figures to read.
 usage: frame_timeline.py <dir-or-csv>"""
+import collections
 import csv
 import glob
 import os
@@ -14,23 +19,29 @@ rows = []
 for f in files:
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-rows = rows[len(rows) // 2:]          # second half: the timed region / in-frame measurement
-# a frame starts with the detection in front of the first layer's row-segment contraction
+
+
+def short(n):
+    return n.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace(
+        "void cbs::", "cbs::")
+
+
 starts = [i - 1 for i, r in enumerate(rows) if "cb_rowconv_f32_kernel" in r["Kernel_Name"] and i > 0]
-frames = []
+groups = collections.defaultdict(list)
 for a, b in zip(starts[:-1], starts[1:]):
     fr = rows[a:b]
     if 5 <= len(fr) <= 12:
-        frames.append(fr)
-lens = statistics.mode([len(f) for f in frames])
-frames = [f for f in frames if len(f) == lens]
-print("%d frames of %d kernels" % (len(frames), lens))
-tot = []
-for k in range(lens):
-    dur = [(int(f[k]["End_Timestamp"]) - int(f[k]["Start_Timestamp"])) / 1e3 for f in frames]
-    gap = [(int(f[k]["Start_Timestamp"]) - int(f[k - 1]["End_Timestamp"])) / 1e3 for f in frames] if k else [0.0]
-    name = frames[0][k]["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void cbs::", "cbs::")
-    print("  gap %6.2f us | %7.2f us  %s" % (statistics.median(gap), statistics.median(dur), name[:80]))
-    tot.append(statistics.median(dur) + statistics.median(gap))
-period = [(int(b[0]["Start_Timestamp"]) - int(a[0]["Start_Timestamp"])) / 1e3 for a, b in zip(frames[:-1], frames[1:])]
-print("sum of kernels+gaps %.1f us; frame period median %.1f us" % (sum(tot), statistics.median(period)))
+        groups[tuple(short(r["Kernel_Name"]).split("(")[0] for r in fr)].append(fr)
+for sig, frames in sorted(groups.items(), key=lambda kv: -len(kv[1]))[:3]:
+    if len(frames) < 20:
+        continue
+    frames = frames[len(frames) // 5:]      # (drop the warm-up fifth)
+    print("%d frames of %d kernels" % (len(frames), len(sig)))
+    tot = []
+    for k in range(len(sig)):
+        dur = [(int(f[k]["End_Timestamp"]) - int(f[k]["Start_Timestamp"])) / 1e3 for f in frames]
+        gap = [(int(f[k]["Start_Timestamp"]) - int(f[k - 1]["End_Timestamp"])) / 1e3 for f in frames] if k else [0.0]
+        print("  gap %6.2f us | %7.2f us  %s" % (statistics.median(gap), statistics.median(dur),
+                                               short(frames[0][k]["Kernel_Name"])[:80]))
+        tot.append(statistics.median(dur))
+    print("  sum of kernel durations %.1f us" % sum(tot))

@@ -19,14 +19,26 @@ FINE = {8: 'mask words in LDS', 9: 'pixel lookup done (thread 0)', 10: 'lookup b
 
 def report(clear=True):
     torch.cuda.synchronize()
-    buf = np.zeros(2 * 2048 * 16, dtype=np.uint64)
+    buf = np.zeros(3 * 2048 * 16, dtype=np.uint64)
     raw.cbinfer_debug_split_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(buf.nbytes), 0)
     for cfg, name in ((0, "64-row tile"), (1, "128-row tile")):
-        st = buf.reshape(2, 2048, 16)[cfg].astype(np.int64)
+        st = buf.reshape(3, 2048, 16)[cfg].astype(np.int64)
         st = st[st[:, 0] > 0]
         if len(st):
             print(" ", name)
             report_one(st)
+    st = buf.reshape(3, 2048, 16)[2].astype(np.int64)
+    st = st[st[:, 0] > 0]
+    if len(st):
+        print("  reduce + tail launch: %d workgroups stamped" % len(st))
+        t0 = st[:, 0].min()
+        names = ['entry', 'launch info known', 'slab columns arrived', 'X tile written', 'X tile complete (barrier)',
+                 'first layer done', 'hidden tile complete (barrier)', 'group done']
+        for i, n in enumerate(names):
+            v = st[:, i] >= t0
+            if v.sum():
+                us = (st[v, i] - t0) / 100.0
+                print("    %-32s min %7.2f  mean %7.2f  max %7.2f us (%d wgs)" % (n, us.min(), us.mean(), us.max(), v.sum()))
     if clear:
         raw.cbinfer_debug_split_stamps(None, 0, 1)
 

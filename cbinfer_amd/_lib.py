@@ -127,6 +127,7 @@ _SIGNATURES = {
     "cbinfer_split_forward_tail": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _i,
                                         _stp, _vp]),
     "cbinfer_split_tail_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "cbinfer_split_conv_tail": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _stp, _vp]),
     "cbinfer_conv2d_fg_cpu": (None, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i]),
 }
 

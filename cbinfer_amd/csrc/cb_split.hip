@@ -1349,13 +1349,11 @@ int cbinfer_split_tail_supported(int C, int K, int kH, int kW, int C1, int C2) {
            C1 <= 16 * CB_TAIL_MAXW && cb_tail_lds_bytes(K, C1, C2) <= 60 * 1024;
 }
 
-// cbinfer_split_forward + the fused 1x1 tail behind the layer (cbinfer_tail1x1's arithmetic and weight layout) in
-// the contraction's second launch: conv1x1 (K -> C1) -> [relu1] -> conv1x1 (C1 -> C2) -> [relu2] at the changed pixels,
-// into tail->output[sequence] [C2,H,W].  forceSplit as for cbinfer_split_conv.
-int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared,
-                               const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
-                               float weightScale, int relu, void* workspace, int forceSplit, const cbSplitTail* tail,
-                               cbStream_t stream) {
+// cbinfer_split_conv with the fused 1x1 tail in the second launch (the two launches of cbinfer_split_forward_tail behind
+// its detection)
+int cbinfer_split_conv_tail(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
+                            int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
+                            const cbSplitTail* tail, cbStream_t stream) {
     CB_REQUIRE(tail && tail->w1Prepared && tail->b1 && tail->w2 && tail->b2 && nSeq >= 1 && nSeq <= CBS_MAXSEQ);
     if (!cbinfer_split_tail_supported(C, K, kH, kW, tail->C1, tail->C2)) return CB_ERR_UNSUPPORTED;
     CbsTailArgs ta;
@@ -1365,10 +1363,23 @@ int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int pooled, int
         if (q < nSeq) CB_REQUIRE(tail->output[q]);
         ta.out[q] = q < nSeq ? tail->output[q] : nullptr;
     }
-    const int st = cbinfer_split_detect(seqs, nSeq, pooled, pH, pW, C, H, W, kH, kW, threshold, stream);
-    if (st != CB_OK) return st;
     return cbs_split_conv(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace, forceSplit, &ta,
                           stream);
+}
+
+// cbinfer_split_forward + the fused 1x1 tail behind the layer (cbinfer_tail1x1's arithmetic and weight layout) in
+// the contraction's second launch: conv1x1 (K -> C1) -> [relu1] -> conv1x1 (C1 -> C2) -> [relu2] at the changed pixels,
+// into tail->output[sequence] [C2,H,W].  forceSplit as for cbinfer_split_conv.
+int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared,
+                               const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
+                               float weightScale, int relu, void* workspace, int forceSplit, const cbSplitTail* tail,
+                               cbStream_t stream) {
+    CB_REQUIRE(tail);
+    if (!cbinfer_split_tail_supported(C, K, kH, kW, tail->C1, tail->C2)) return CB_ERR_UNSUPPORTED;
+    const int st = cbinfer_split_detect(seqs, nSeq, pooled, pH, pW, C, H, W, kH, kW, threshold, stream);
+    if (st != CB_OK) return st;
+    return cbinfer_split_conv_tail(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace,
+                                   forceSplit, tail, stream);
 }
 
 // One frame of a feedback-mode CBConv2d (conv2d.py:178-259) of every sequence: detection (+ pooling) + refresh of

@@ -441,6 +441,9 @@ typedef struct {
     float* output[CBINFER_SPLIT_MAX_SEQUENCES];   /* [C2,H,W] per sequence */
 } cbSplitTail;
 int cbinfer_split_tail_supported(int C, int K, int kH, int kW, int C1, int C2);
+int cbinfer_split_conv_tail(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
+                            int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
+                            const cbSplitTail* tail, cbStream_t stream);
 int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared,
                                const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
                                float weightScale, int relu, void* workspace, int forceSplit, const cbSplitTail* tail,

@@ -12,7 +12,7 @@ _, net = bench.build_bench_model()
 sb = pycbinfer.SequenceBatch(net, S)
 vids = [bench.bench_video(1234 + 7919 * q) for q in range(S)]
 walk = [[v.frame] + [v.next() for _ in range(39)] for v in vids]
-names = ["cbinfer_change_detection_bits_batched", "cbinfer_conv_changed_rows_batched", "cbinfer_split_forward",
+names = ["cbinfer_change_detection_bits_batched", "cbinfer_conv_changed_rows_batched", "cbinfer_split_forward", "cbinfer_split_forward_tail",
          "cbinfer_tail1x1_batched"]
 orig = {n: getattr(B.C, n) for n in names}
 state = dict(which=-1, idx=0, pairs=[])

@@ -21,7 +21,7 @@ echo "stats done"
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$O/pmc_$(echo $c | tr A-Z a-z | sed 's/_size//')
   run timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d $d -o p --output-format csv -- \
-      python3 $R/bench.py --mode eager --steps 40 --warmup 5 --min-seconds 0 --no-cpu-baseline --no-dense --multi 0 \
+      python3 $R/bench.py --mode eager --steps 40 --warmup 5 --min-seconds 0 --no-cpu-baseline --no-dense --multi 0 --no-variants --no-last-frame --no-pipelined \
       > $d.json 2> $d.err || exit 1
   echo "$c done"
 done

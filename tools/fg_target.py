@@ -36,7 +36,10 @@ def main():
     print("fine-grained experiment 7, in-place form, %.0f %% change: %.0f frames/s" % (100 * vid.ratio, steps / dt))
     for m in cbs:
         K, C, kH, kW = m.weight.shape
-        n = int(m._work['count'].item())
+        # (a mask-driven fine-grained frame leaves the mask of touched output pixels; its list and count are made
+        #  when somebody asks -- lastChangeIndexes().count does)
+        ci = m.lastChangeIndexes()
+        n = int(ci.count.item()) if ci is not None else int(m._work['count'].item())
         H, W = m.prevOutput.shape[-2:]
         print("  conv %d->%d k%d @%dx%d: %d touched output pixels (%.0f %%), algorithmic %.1f MFLOP (2*N*C*k*k*K)"
               % (C, K, kH, H, W, n, 100.0 * n / (H * W), 2e-6 * n * C * kH * kW * K))

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collect SQ/TA/TCP counters for the contraction kernel, one small counter group per rocprofv3 pass
 # (counters only: --pmc is never combined with a trace domain).  usage: pmc_passes.sh OUTDIR [target args]
+# PMC_TARGET=bench_split.py: the split-state contraction on the 16->64 and 64->256 shapes instead (round 3)
 # (TA_*/TCP_* derived sums are left out: that pass did not finish within 180 s on this pool.)
 # Stops at the first pass that times out or is killed.
 out=$1; shift
@@ -11,7 +12,7 @@ while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
   timeout -k 10 180 rocprofv3 --kernel-trace --pmc $group -d "$out/p$i" -o p --output-format csv -- \
-      python3 "$GRAFT_REPO_ROOT/tools/pmc_target.py" "$@" > "$out/p$i.log" 2>&1
+      python3 "$GRAFT_REPO_ROOT/tools/${PMC_TARGET:-pmc_target.py}" "$@" > "$out/p$i.log" 2>&1
   rc=$?
   echo "pass $i [$group] rc=$rc"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "stopping: pass killed"; exit 1; fi

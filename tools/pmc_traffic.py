@@ -38,7 +38,7 @@ LAYER = [("cb_rowconv_f32_kernel", L1),
          ("cb_mfma_f32_kernel<2, 4, 2, 1, 2, true", L3), ("cb_mfma_f32_kernel<2, 2, 2, 1, 2, true", L3),
          ("cb_tail1x1_kernel", TAIL)]
 # second launch of the same contraction (summed into the layer's entry)
-ADDS = [("cbs_reduce_kernel", L3), ("cbs_reduce_tail_kernel", L3), ("cb_splitk_reduce_kernel<2, true", L3)]
+ADDS = [("cbs_reduce_tail_kernel", L3), ("cbs_reduce_kernel", L3), ("cb_splitk_reduce_kernel<2, true", L3)]
 table = {}
 extra = {}
 for name in sorted(set(fetch) | set(write)):
@@ -56,10 +56,10 @@ for name in sorted(set(fetch) | set(write)):
             table[label] = {"kernel": short, "fetch_kb": fm, "write_kb": wm,
                             "bytes_per_launch": int((fm + wm) * 1024),
                             "bytes_per_launch_fetch_x2": int((2 * fm + wm) * 1024)}
-    for pat, label in ADDS:
-        if pat in name:
-            extra.setdefault(label, (short, fm, wm))
-for label, (short, fm, wm) in extra.items():      # second launch of the same contraction: add its bytes
+    for prio, (pat, label) in enumerate(ADDS):      # (the first pattern of ADDS that occurs wins)
+        if pat in name and (label not in extra or prio < extra[label][0]):
+            extra[label] = (prio, short, fm, wm)
+for label, (_, short, fm, wm) in extra.items():      # second launch of the same contraction: add its bytes
     if label in table:
         t = table[label]
         t["kernel"] += " + " + short

@@ -43,7 +43,7 @@ with torch.no_grad():
     for i in range(4):
         sb([w[i] for w in walk])
     torch.cuda.synchronize()
-    ncalls = 5
+    ncalls = 4
     tot = 0.0
     for which in list(range(ncalls)) + [-2]:
         state['which'], state['pairs'] = which, []

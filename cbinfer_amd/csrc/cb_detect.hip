@@ -61,7 +61,8 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int yy = 2 * yb + j, ww = 2 * (int)blockIdx.x + i;
-                if (yy < pH && ww < pwpr) any |= prodMask[(long)yy * pwpr + ww];
+                const unsigned long long v = prodMask[(long)min(yy, pH - 1) * pwpr + min(ww, pwpr - 1)];
+                any |= (yy < pH && ww < pwpr) ? v : 0ull;      // (clamped, not predicated: one round trip for the four)
             }
         if (__builtin_amdgcn_readfirstlane((int)(any != 0ull)) == 0) return;
     }
@@ -81,18 +82,14 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
     // input value of channel c at this lane's pixel
     const long pHW = (long)pH * pW;
     const int py0 = 2 * y, px0 = 2 * x;
-    const bool inner = POOL && py0 + 1 < pH && px0 + 1 < pW;   // whole window inside the pre-pool map
+    // (four unconditional loads with clamped coordinates -- a window cut off by the map's edge reads a pixel twice,
+    //  max(a, a) = a: a per-lane branch around the loads makes the compiler wait for one channel's window before it
+    //  requests the next)
+    const int px1 = min(px0 + 1, pW - 1) - px0, py1 = (min(py0 + 1, pH - 1) - py0) * pW;
     auto ldin = [&](int c) -> T {
         if (!POOL) return in[(long)c * HW + p];
         const T* q = in + (long)c * pHW + (long)py0 * pW + px0;
-        if (inner) return cb_max(cb_max(q[0], q[1]), cb_max(q[pW], q[pW + 1]));
-        T v = q[0];                                            // (py0 < pH and px0 < pW by construction)
-        if (px0 + 1 < pW) v = cb_max(v, q[1]);
-        if (py0 + 1 < pH) {
-            v = cb_max(v, q[pW]);
-            if (px0 + 1 < pW) v = cb_max(v, q[pW + 1]);
-        }
-        return v;
+        return cb_max(cb_max(q[0], q[px1]), cb_max(q[py1], q[py1 + px1]));
     };
 
     bool chg = false;

@@ -32,13 +32,21 @@
 
 #ifdef CBS_STAMP
 // diagnostic build only (make EXTRA=-DCBS_STAMP; tools/split_stamps.py): per-workgroup phase stamps, 100 MHz constant
-// clock: [64-row tile | 128-row tile | reduce+tail launch] x 2048 workgroups x 16 marks
-__device__ unsigned long long cbs_stamp_buf[3 * 2048 * 16];
+// clock: [64-row tile | 128-row tile | reduce+tail launch | pooled detection] x 2048 workgroups x 16 marks
+__device__ unsigned long long cbs_stamp_buf[4 * 2048 * 16];
 #define CB_TAIL_STAMP(i)                                                                 \
     do {                                                                                 \
         if (threadIdx.x == 0 && blockIdx.x < 2048)                                       \
             cbs_stamp_buf[(2 * 2048 + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+#define CBS_DET_STAMP(i)                                                                                            \
+    do {                                                                                                            \
+        const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;                                                    \
+        if (POOL && threadIdx.x == 0 && blockIdx.z == 0 && wg < 2048)                                               \
+            cbs_stamp_buf[(3 * 2048 + wg) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();                            \
+    } while (0)
+#else
+#define CBS_DET_STAMP(i)
 #endif
 #include "cb_tail_core.h"
 
@@ -228,18 +236,21 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
     cb_touch_kernarg<sizeof(CbsDetArgs)>();
     const CbsDetSeq sq = a.seq[blockIdx.z];
     const int W = a.W, H = a.H, C = a.C, pH = a.pH, pW = a.pW;
+    CBS_DET_STAMP(0);
     if (POOL && sq.prodMask) {
         const int pwpr = (pW + 63) >> 6;
         unsigned long long any = 0ull;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 2; ++i) {      // (clamped, not predicated: four loads in one round trip)
                 const int yy = 2 * (int)blockIdx.y + j, ww = 2 * (int)blockIdx.x + i;
-                if (yy < pH && ww < pwpr) any |= sq.prodMask[(long)yy * pwpr + ww];
+                const unsigned long long v = sq.prodMask[(long)min(yy, pH - 1) * pwpr + min(ww, pwpr - 1)];
+                any |= (yy < pH && ww < pwpr) ? v : 0ull;
             }
         if (__builtin_amdgcn_readfirstlane((int)(any != 0ull)) == 0) return;
     }
+    CBS_DET_STAMP(1);
     unsigned long long* bits = sq.masks;      // (single mask: the contraction zeroes it once every workgroup has it)
     const int lane = threadIdx.x & 63;
     const int g = threadIdx.x >> 6;
@@ -254,18 +265,15 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
 
     const long pHW = (long)pH * pW;
     const int py0 = 2 * y, px0 = 2 * x;
-    const bool inner = POOL && py0 + 1 < pH && px0 + 1 < pW;
+    // The 2x2 window by four UNCONDITIONAL loads with clamped coordinates (a window cut off by the map's edge reads a
+    // pixel twice: max(a, a) = a).  A per-lane `if (inside) ... else ...` around the loads is a branch region of its
+    // own for every channel, and the compiler then waits for one channel's loads before it requests the next: four
+    // round trips instead of one (2.6 of the 4.5 us of this kernel's per-workgroup chain, round 3 stamps).
+    const int px1 = min(px0 + 1, pW - 1) - px0, py1 = (min(py0 + 1, pH - 1) - py0) * pW;
     auto ldin = [&](int c) -> float {
         if (!POOL) return in[(long)c * HW + p];
         const float* q = in + (long)c * pHW + (long)py0 * pW + px0;
-        if (inner) return fmaxf(fmaxf(q[0], q[1]), fmaxf(q[pW], q[pW + 1]));
-        float v = q[0];
-        if (px0 + 1 < pW) v = fmaxf(v, q[1]);
-        if (py0 + 1 < pH) {
-            v = fmaxf(v, q[pW]);
-            if (px0 + 1 < pW) v = fmaxf(v, q[pW + 1]);
-        }
-        return v;
+        return fmaxf(fmaxf(q[0], q[px1]), fmaxf(q[py1], q[py1 + px1]));
     };
 
     // C == 4 G: four channels per wave, eight independent loads in flight per lane
@@ -288,6 +296,7 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
     __syncthreads();
     unsigned long long m = 0;
     for (int i = 0; i < G; ++i) m |= sm[i];
+    CBS_DET_STAMP(2);
     if (m == 0) return;   // uniform over the workgroup
 
     // feedback: refresh the f32 state at the (pre-dilation) changed pixels only (.cu:74-80) ...
@@ -303,6 +312,7 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
     T[g + 2 * G][lane] = k2;
     T[g + 3 * G][lane] = k3;
     __syncthreads();
+    CBS_DET_STAMP(3);
     {
         const int parts = C / 8;                 // 8-channel parts per pixel: (group, half)
         const int t = threadIdx.x;
@@ -329,6 +339,7 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
         }
     }
 
+    CBS_DET_STAMP(4);
     // dilation of the 64-pixel word (+ the parts spilling into the neighbour words), ORed into the frame mask
     unsigned long long D = m, SR = 0, SL = 0;
     for (int d = 1; d <= a.kWH; ++d) {
@@ -350,6 +361,7 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
             if (v) atomicOr(&bits[(long)yy * a.wpr + t2], v);
         }
     }
+    CBS_DET_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1177,7 +1189,7 @@ extern "C" int cbinfer_debug_split_stamps(void* host, long bytes, int clear) {
     if (clear) {
         void* d = nullptr;
         if (hipGetSymbolAddress(&d, HIP_SYMBOL(cbs_stamp_buf)) != hipSuccess) return -1;
-        return (int)hipMemset(d, 0, sizeof(unsigned long long) * 3 * 2048 * 16);
+        return (int)hipMemset(d, 0, sizeof(unsigned long long) * 4 * 2048 * 16);
     }
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cbs_stamp_buf), (size_t)bytes);
 }

@@ -19,15 +19,15 @@ FINE = {8: 'mask words in LDS', 9: 'pixel lookup done (thread 0)', 10: 'lookup b
 
 def report(clear=True):
     torch.cuda.synchronize()
-    buf = np.zeros(3 * 2048 * 16, dtype=np.uint64)
+    buf = np.zeros(4 * 2048 * 16, dtype=np.uint64)
     raw.cbinfer_debug_split_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(buf.nbytes), 0)
     for cfg, name in ((0, "64-row tile"), (1, "128-row tile")):
-        st = buf.reshape(3, 2048, 16)[cfg].astype(np.int64)
+        st = buf.reshape(4, 2048, 16)[cfg].astype(np.int64)
         st = st[st[:, 0] > 0]
         if len(st):
             print(" ", name)
             report_one(st)
-    st = buf.reshape(3, 2048, 16)[2].astype(np.int64)
+    st = buf.reshape(4, 2048, 16)[2].astype(np.int64)
     st = st[st[:, 0] > 0]
     if len(st):
         print("  reduce + tail launch: %d workgroups stamped" % len(st))
@@ -39,6 +39,25 @@ def report(clear=True):
             if v.sum():
                 us = (st[v, i] - t0) / 100.0
                 print("    %-32s min %7.2f  mean %7.2f  max %7.2f us (%d wgs)" % (n, us.min(), us.mean(), us.max(), v.sum()))
+    st = buf.reshape(4, 2048, 16)[3].astype(np.int64)
+    st = st[st[:, 0] > 0]
+    if len(st):
+        print("  pooled detection (the LAST one of the frame): %d workgroups stamped" % len(st))
+        t0 = st[:, 0].min()
+        names = ['entry', 'producer mask says changed', 'values loaded, ballots merged', 'states refreshed, tile in LDS',
+                 'records written', 'mask words ORed (end)']
+        # (two launches of the frame write here, the second over the first's first entries: per workgroup, from its
+        #  own entry; the launch span from the entries of the last launch = the largest cluster of entry times)
+        for i, n in enumerate(names):
+            v = st[:, i] >= st[:, 0]
+            v &= st[:, i] > 0
+            if v.sum() and i:
+                us = (st[v, i] - st[v, 0]) / 100.0
+                print("    %-32s min %7.2f  mean %7.2f  max %7.2f us after the workgroup's own entry (%d wgs)"
+                      % (n, us.min(), us.mean(), us.max(), v.sum()))
+        ent = np.sort(st[:, 0])
+        late = ent[ent > ent[-1] - 1500]
+        print("    entries of the last launch: %d workgroups over %.2f us" % (len(late), (late[-1] - late[0]) / 100.0))
     if clear:
         raw.cbinfer_debug_split_stamps(None, 0, 1)
 

@@ -404,6 +404,10 @@ def inframe_layer_times(test, frames, start, reps=40):
     return rows, step, times[None]
 
 
+DEFAULT_BUILD_FLAGS = (b" -O3 --offload-arch=gfx950 -fPIC -fopenmp -std=c++17 -Wall -Wno-unused-function "
+                       b"-Wno-bitwise-instead-of-logical\n")
+
+
 def kernel_source_hash():
     """sha256 over the kernel sources: profiles/rNN_pmc_traffic.json records it at collection time, so a
     bench line only carries `traffic` figures that were measured on the kernels it ran."""
@@ -412,9 +416,10 @@ def kernel_source_hash():
         h.update(open(f, "rb").read())
     # the compile flags the library was built with (a diagnostic build -- make EXTRA=-DCB_STAMP ... -- is another
     # library from the same sources): cbinfer_amd/csrc/Makefile keeps them in build/.flags
+    # (where the build directory did not travel -- the GPU box gets the built library only -- the library is the
+    #  plain build: the Makefile's default flags, tests/test_host_logic.py keeps the two in step)
     flags = os.path.join(REPO, "cbinfer_amd", "csrc", "build", ".flags")
-    if os.path.exists(flags):
-        h.update(open(flags, "rb").read())
+    h.update(open(flags, "rb").read() if os.path.exists(flags) else DEFAULT_BUILD_FLAGS)
     return h.hexdigest()[:16]
 
 

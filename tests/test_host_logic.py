@@ -211,3 +211,19 @@ def test_split_kernel_fragment_reads_are_not_touched_in_flight():
                          stderr=subprocess.STDOUT, timeout=600)
     assert out.returncode == 0, out.stdout.decode()[-3000:]
     assert b"5 cbs_conv_kernel instance(s), 0 finding(s)" in out.stdout
+
+
+def test_bench_default_build_flags_match_the_makefile():
+    """bench.kernel_source_hash() folds the build flags into the hash that ties a bench line to the PMC passes it may
+    quote; where the build directory did not travel it uses bench.DEFAULT_BUILD_FLAGS, which must be what a plain
+    `make` records in build/.flags."""
+    import subprocess
+    import bench
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cbinfer_amd", "csrc")
+    # (the Makefile's CFLAGS starts with $(EXTRA), empty in a plain build: the leading blank stays)
+    rec = subprocess.run(["make", "-s", "-C", csrc, "--eval", "show: ; @echo '$(CFLAGS)'", "show"],
+                         capture_output=True, text=True).stdout
+    assert rec.encode() == bench.DEFAULT_BUILD_FLAGS, (rec, bench.DEFAULT_BUILD_FLAGS)
+    flags = os.path.join(csrc, "build", ".flags")
+    if os.path.exists(flags):
+        assert open(flags, "rb").read() == bench.DEFAULT_BUILD_FLAGS

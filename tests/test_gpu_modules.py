@@ -1209,3 +1209,45 @@ def test_golden_sequences_half(pkg, golden_dir, name, sync):
             y = cb(torch.from_numpy(d["frame%d" % t]).cuda())
         ref = d["out3"]
         assert np.abs(y.cpu().numpy().astype(np.float64) - ref.astype(np.float64)).max() <= float(d["threshold"])
+
+
+def test_tail_folded_into_the_contraction_matches_its_own_launch(pkg, monkeypatch):
+    """The fused 1x1 tail evaluated by the 64->256 layer's second launch (cbinfer_split_forward_tail, the default)
+    against the same network with the tail in its own launch (CBINFER_NO_TAILFOLD=1): bit-identical network outputs
+    and layer states over a walk of frames, through the per-layer call plans, across a change of the tail's weights
+    in mid-sequence (the plan must notice) and across clearMemory()."""
+    import copy
+    import bench
+    _, folded = bench.build_bench_model()
+    own = copy.deepcopy(folded)
+    kids = list(folded.children())
+    head = [m for m in kids if type(m) is pkg.CBConv2d][-1]
+    tail = kids[-1]
+    assert type(tail) is pkg.CBTail1x1 and head.__dict__["_fusedTail"] is tail
+    okids = list(own.children())
+    assert [m for m in okids if type(m) is pkg.CBConv2d][-1].__dict__["_fusedTail"] is okids[-1]
+    frames = bench.bench_video(77).frames(10)
+    seen = []
+
+    def run(net, f, fold):
+        monkeypatch.setenv("CBINFER_NO_TAILFOLD", "0" if fold else "1")
+        with torch.no_grad():
+            y = net(f)
+        ci = [m for m in net.children() if type(m) is pkg.CBConv2d][-1].lastChangeIndexes()
+        seen.append((fold, getattr(ci, "tailDone", None) is not None))
+        return y
+
+    for t, f in enumerate(frames):
+        if t == 5:
+            with torch.no_grad():          # (bumps the version counters: the call plans must be rebuilt)
+                tail.weight2.mul_(1.25)
+                okids[-1].weight2.mul_(1.25)
+        if t == 8:
+            pkg.clearMemory(folded)
+            pkg.clearMemory(own)
+        ya, yb = run(folded, f, True), run(own, f, False)
+        assert torch.equal(ya, yb), t
+        for ma, mb in zip(folded.children(), own.children()):
+            if type(ma) is pkg.CBConv2d:
+                assert torch.equal(ma.prevOutput, mb.prevOutput) and torch.equal(ma.prevInput, mb.prevInput), t
+    assert all(done == fold for fold, done in seen)      # the folded form really ran, the other really did not

@@ -227,3 +227,21 @@ def test_bench_default_build_flags_match_the_makefile():
     flags = os.path.join(csrc, "build", ".flags")
     if os.path.exists(flags):
         assert open(flags, "rb").read() == bench.DEFAULT_BUILD_FLAGS
+
+
+def test_fused_tail_link_survives_pickle_and_deepcopy():
+    """pycbinfer.fuseTail1x1 leaves the producing layer a plain reference to the CBTail1x1 (not a child module: the
+    network's module names stay the reference's); copies of the network keep it pointing at THEIR tail."""
+    import copy
+    import pickle
+    import pycbinfer
+    from cbinfer_amd import workloads
+    _, net = workloads.sceneLabelingModels(experimentIdx=6, threshold=0.05, device="cpu")
+    names = [n for n, _ in net.named_modules()]
+    pycbinfer.fuseTail1x1(net)
+    for clone in (net, pickle.loads(pickle.dumps(net)), copy.deepcopy(net)):
+        kids = list(clone.children())
+        head = [m for m in kids if type(m) is pycbinfer.CBConv2d][-1]
+        assert type(kids[-1]) is pycbinfer.CBTail1x1 and head.__dict__["_fusedTail"] is kids[-1]
+        assert not any(type(m) is pycbinfer.CBTail1x1 for m in head.modules())
+    assert [n for n, _ in net.named_modules()] == names[:len(names) - 2]

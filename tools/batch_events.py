@@ -12,6 +12,8 @@ _, net = bench.build_bench_model()
 sb = pycbinfer.SequenceBatch(net, S)
 vids = [bench.bench_video(1234 + 7919 * q) for q in range(S)]
 walk = [[v.frame] + [v.next() for _ in range(39)] for v in vids]
+if os.environ.get('STATIC') == '1':      # no change at all: what the launches cost when nothing is to be done
+    walk = [[w[0]] * 40 for w in walk]
 names = ["cbinfer_change_detection_bits_batched", "cbinfer_conv_changed_rows_batched", "cbinfer_split_forward", "cbinfer_split_forward_tail",
          "cbinfer_tail1x1_batched"]
 orig = {n: getattr(B.C, n) for n in names}

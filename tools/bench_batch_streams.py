@@ -32,3 +32,28 @@ with torch.no_grad():
     torch.cuda.synchronize()
     fps = G * B * n / (time.perf_counter() - t0)
 print("%d groups x %d sequences: %.0f frames/s (%.1f us per step of all)" % (G, B, fps, 1e6 * G * B / fps))
+# the same with every group's step captured as a hipGraph (static input buffers, replay on the group's stream)
+with torch.no_grad():
+    for gr in groups:
+        gr['static'] = [w[4].clone() for w in gr['walk']]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(gr['stream']):
+            gr['batch'](gr['static'])
+        torch.cuda.synchronize()
+        gr['graph'] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr['graph'], stream=gr['stream']):
+            gr['batch'](gr['static'])
+    torch.cuda.synchronize()
+    n = 0
+    t0 = time.perf_counter()
+    for rep in range(40):
+        for i in list(range(4, 16)) + list(range(14, 4, -1)):
+            for gr in groups:
+                with torch.cuda.stream(gr['stream']):
+                    for q in range(B):
+                        gr['static'][q].copy_(gr['walk'][q][i])
+                    gr['graph'].replay()
+            n += 1
+    torch.cuda.synchronize()
+    fps = G * B * n / (time.perf_counter() - t0)
+print("   ... as graphs: %.0f frames/s" % fps)

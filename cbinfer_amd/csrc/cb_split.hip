@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cbs_reduce_tail_kernel(CbsP
                     const int cq = min(cq0 + u * cstep, QN - 1), mt = cq / (BM / 4), mq = cq - mt * (BM / 4);
 #pragma unroll
                     for (int j = 0; j < CBS_CHUNKS; ++j) v[u][j] = sl0[((long)j * MT + mt) * TILE4 + mq * BN];
-                    bq[u] = *(const float4*)(biasp + min(4 * cq, p.K - 4));
+                    bq[u] = *(const float4*)(biasp + (hasBias ? min(4 * cq, p.K - 4) : 0));
                 }
                 __builtin_amdgcn_sched_barrier(0);      // (all loads requested before anything of the second half)
                 if (rd == 0) {
@@ -1367,6 +1367,8 @@ int cbinfer_split_conv_tail(const cbSplitSeq* seqs, int nSeq, const void* prepar
                             int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
                             const cbSplitTail* tail, cbStream_t stream) {
     CB_REQUIRE(tail && tail->w1Prepared && tail->b1 && tail->w2 && tail->b2 && nSeq >= 1 && nSeq <= CBS_MAXSEQ);
+    // (the second launch reads the layer's bias -- and, without one, the tail's first -- four values at a time)
+    CB_REQUIRE((((size_t)bias | (size_t)tail->b1) & 15) == 0);
     if (!cbinfer_split_tail_supported(C, K, kH, kW, tail->C1, tail->C2)) return CB_ERR_UNSUPPORTED;
     CbsTailArgs ta;
     ta.w1p = tail->w1Prepared, ta.b1 = tail->b1, ta.w2 = tail->w2, ta.b2 = tail->b2;

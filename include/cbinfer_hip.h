@@ -430,8 +430,8 @@ int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, 
  * launch of a deep contraction: the launch that finishes the layer's outputs -- summing the partial tiles of a split
  * contraction -- keeps each group of 16 finished pixel columns in LDS and runs the tail on them.  Same arithmetic
  * as cbinfer_split_forward followed by cbinfer_tail1x1 (bit-identical outputs), one launch and the tail's gather
- * pass over prevOutput less.  cbinfer_split_tail_supported: deep contraction (>= 48 k-stages) and a tail
- * cbinfer_tail1x1_supported(K, C1, C2) takes. */
+ * pass over prevOutput less.  cbinfer_split_tail_supported: deep contraction (>= 48 k-stages), K a multiple of 16
+ * and a tail cbinfer_tail1x1_supported(K, C1, C2) takes with C1 >= 4; `bias` and `b1` 16-byte aligned. */
 typedef struct {
     const float* w1Prepared;      /* cbinfer_tail1x1_prep */
     const float* b1;

@@ -282,8 +282,9 @@ def test_split_module_reports_range_and_survives_state_restore(lib):
     assert not convs[1].rangeExceeded() and not convs[2].rangeExceeded()
 
 
-@pytest.mark.parametrize("nSeq,force", [(1, 0), (1, 1), (1, 4), (3, 0), (3, 4)])
-def test_split_tail_in_the_second_launch(lib, oracle, nSeq, force):
+@pytest.mark.parametrize("nSeq,force,bias", [(1, 0, True), (1, 1, True), (1, 4, True), (3, 0, True), (3, 4, True),
+                                             (1, 4, False), (2, 1, False)])
+def test_split_tail_in_the_second_launch(lib, oracle, nSeq, force, bias):
     """cbinfer_split_forward_tail = cbinfer_split_forward followed by cbinfer_tail1x1, bit for bit (layer outputs,
     change lists, tail outputs), whether the contraction is split along k (the tail's columns come out of the slabs)
     or not (gathered from prevOutput), for one and for several sequences; and the tail agrees with a dense
@@ -304,6 +305,12 @@ def test_split_tail_in_the_second_launch(lib, oracle, nSeq, force):
     lib.check(C_.cbinfer_tail1x1_prep(dw1.data_ptr(), w1p.data_ptr(), C1, K, None))
     vids = [block_video(rng, C, H, W, 4, f) for f in (0.15, 0.6, 0.02)[:nSeq]]
     ref, fused = Layer(lib, w, b, H, W, nSeq=nSeq), Layer(lib, w, b, H, W, nSeq=nSeq)
+    if not bias:            # (a layer without bias: the C ABI takes a null pointer)
+        class NoBias(object):
+            @staticmethod
+            def data_ptr():
+                return None
+        ref.b = fused.b = NoBias()
     tref = [torch.full((1, C2, H, W), float("inf"), device="cuda") for _ in range(nSeq)]
     tfus = [torch.full((1, C2, H, W), float("inf"), device="cuda") for _ in range(nSeq)]
     st = lib.SplitTail()

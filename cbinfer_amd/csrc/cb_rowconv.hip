@@ -199,21 +199,21 @@ __global__ __launch_bounds__(64 * CB_ROW_MAXW) void cb_rowconv_f32_kernel(RowPar
     const int base = (lane >> 4) * CS + xl;   // + tap offset (ky*RS + kx + 4 g CS) = LDS float index
     const int bBeg = NB * kp / kparts, bEnd = NB * (kp + 1) / kparts, bLast = max(bEnd - 1, bBeg);
 
-    // ---- the weights of this wave's first blocks are requested before anything else: their latency
-    //      overlaps the staging of the patch ---------------------------------------------------------------
-    const floatx4* Aw = (const floatx4*)p.wq + (long)min(mc, p.MCH - 1) * G * 64 + lane;   // group g: Aw[g * 64]
+    // ---- the weights: buffer loads with ONE per-lane offset and a scalar offset per 16-byte group, so that no load
+    //      needs an address register of its own (with 64-bit per-load addresses the compiler recycled the registers
+    //      of a load in flight for the next load's address and waited for it: a round trip to memory before the
+    //      patch was even requested; round 3) --------------------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.wq, 0, (int)min((long)p.MCH * G * 1024, (long)0x7fffffff), 0x00020000);
+    const int wBase = min(mc, p.MCH - 1) * G * 1024, wLane = lane * 16;      // group g: + g * 1024
     cb_ablock a0, a1, a2, qr;
     auto loadA = [&](cb_ablock& dst, int b) {
 #pragma unroll
-        for (int i = 0; i < CB_ROW_BG; ++i) dst[i] = Aw[(long)min(b * CB_ROW_BG + i, G - 1) * 64];
+        for (int i = 0; i < CB_ROW_BG; ++i)
+            dst[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                     wrsrc, wLane, wBase + min(b * CB_ROW_BG + i, G - 1) * 1024, 0));
     };
     float bv[4];                   // (and the bias of this lane's four output channels)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        bv[r] = p.bias ? p.bias[min(min(mc, p.MCH - 1) * 16 + 4 * (lane >> 4) + r, p.K - 1)] : 0.f;
-    loadA(qr, NB);                 // the (< CB_ROW_BS) steps beyond the last full block, taken by k-part 0
-    loadA(a0, min(bBeg, bLast));
-    loadA(a1, min(bBeg + 1, bLast));
 
     // ---- stage the input rows under the segment: patch[c][ky][j] = state[c][y+ky-ph][64 tx - pw + j] -----
     const int ph = (kH - 1) / 2, pw = (kW - 1) / 2;
@@ -230,7 +230,11 @@ __global__ __launch_bounds__(64 * CB_ROW_MAXW) void cb_rowconv_f32_kernel(RowPar
         s_rowsrc[t] = (c < p.C && yy >= 0 && yy < p.H) ? (c * p.H + yy) * p.W : -1;
         s_rowdst[t] = c * CS + ky * RS;
     }
-    __syncthreads();
+    // (an LDS-only barrier: __syncthreads() is also a fence and would wait here for the weight and bias loads just
+    //  requested -- a whole round trip to memory in front of the staging loads' round trip; round 3 stamps: 1.2 us of
+    //  a 6 us workgroup)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     CB_RSTAMP(2);
     if (!(p.dbg & 1)) {
         // the kW-1 columns beyond the 64: TW (power of two >= kW-1) slots per row, flattened over the threads
@@ -240,8 +244,7 @@ __global__ __launch_bounds__(64 * CB_ROW_MAXW) void cb_rowconv_f32_kernel(RowPar
         // columns 0..63 of every row: one row per wave and pass, eight passes' loads in flight
         const int xa = x0 + lane;
         const bool oka = xa >= 0 && xa < p.W;
-        for (int r0 = wave, e0 = t; r0 < rows || e0 < total; r0 += 8 * NW, e0 += 2 * NTH) {
-            float v[8], tv[2];
+        auto request = [&](int r0, int e0, float (&v)[8], float (&tv)[2]) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = min(e0 + NTH * u, max(total - 1, 0));
@@ -258,6 +261,8 @@ __global__ __launch_bounds__(64 * CB_ROW_MAXW) void cb_rowconv_f32_kernel(RowPar
                 v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                      rsrc, (src >= 0 && oka) ? (src + xa) * 4 : (1 << 30), 0, 0));
             }
+        };
+        auto deposit = [&](int r0, int e0, const float (&v)[8], const float (&tv)[2]) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = e0 + NTH * u;
@@ -269,7 +274,33 @@ __global__ __launch_bounds__(64 * CB_ROW_MAXW) void cb_rowconv_f32_kernel(RowPar
                 const int r = r0 + NW * u;
                 if (r < rows) lds[s_rowdst[r] + lane] = v[u];
             }
+        };
+        // The first pass (the only one for 7x7 over 3 or 4 channels) in straight-line code: the patch is requested
+        // FIRST, the weights of this wave's first blocks and the bias right behind it -- all of it one round trip,
+        // and the patch, the older request, can be consumed while the weights are still on their way.
+        {
+            float v[8], tv[2];
+            request(wave, t, v, tv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                bv[r] = p.bias ? p.bias[min(min(mc, p.MCH - 1) * 16 + 4 * (lane >> 4) + r, p.K - 1)] : 0.f;
+            loadA(qr, NB);                 // the (< CB_ROW_BS) steps beyond the last full block, taken by k-part 0
+            loadA(a0, min(bBeg, bLast));
+            loadA(a1, min(bBeg + 1, bLast));
+            deposit(wave, t, v, tv);
         }
+        for (int r0 = wave + 8 * NW, e0 = t + 2 * NTH; r0 < rows || e0 < total; r0 += 8 * NW, e0 += 2 * NTH) {
+            float v[8], tv[2];
+            request(r0, e0, v, tv);
+            deposit(r0, e0, v, tv);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            bv[r] = p.bias ? p.bias[min(min(mc, p.MCH - 1) * 16 + 4 * (lane >> 4) + r, p.K - 1)] : 0.f;
+        loadA(qr, NB);
+        loadA(a0, min(bBeg, bLast));
+        loadA(a1, min(bBeg + 1, bLast));
     }
     floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();   // patch complete

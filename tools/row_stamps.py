@@ -75,5 +75,47 @@ def main():
             print("   (half-exits with stamp 1: %d, mask wait median %.2f)" % (len(d), np.median(d) if len(d) else 0))
 
 
+def batch(S):
+    """the row-segment launch of a SequenceBatch step of S sequences of the bench workload"""
+    import bench
+    import pycbinfer
+    _, net = bench.build_bench_model()
+    sb = pycbinfer.SequenceBatch(net, S)
+    vids = [bench.bench_video(1234 + 7919 * q) for q in range(S)]
+    walk = [[v.frame] + [v.next() for _ in range(11)] for v in vids]
+    with torch.no_grad():
+        for i in range(11):
+            sb([w[i] for w in walk])
+        torch.cuda.synchronize()
+        raw.cbinfer_debug_row_stamps(None, 0, 1)
+        torch.cuda.synchronize()
+        sb([w[11] for w in walk])
+        torch.cuda.synchronize()
+    buf = np.zeros(8192 * 8, dtype=np.uint64)
+    raw.cbinfer_debug_row_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(buf.nbytes), 0)
+    st = buf.reshape(8192, 8).astype(np.int64)
+    ran = st[:, 0] > 0
+    act = ran & (st[:, 6] > 0)
+    t0 = st[ran, 0].min()
+    print("S=%d: %d workgroups stamped (of %d), %d active; first start -> last start %.2f us, span to the last store %.2f us"
+          % (S, ran.sum(), 2560 * S, act.sum(), (st[ran, 0].max() - t0) / 100.0, (st[act, 6].max() - t0) / 100.0))
+    a = st[act]
+    for i, nm in enumerate(["mask word", "row table", "staging", "k-loop", "reduce", "store"]):
+        d = (a[:, i + 1] - a[:, i]) / 100.0
+        print("   %-10s median %.2f us   p90 %.2f   max %.2f" % (nm, np.median(d), np.percentile(d, 90), d.max()))
+    life = (a[:, 6] - a[:, 0]) / 100.0
+    print("   lifetime   median %.2f us   p90 %.2f   max %.2f" % (np.median(life), np.percentile(life, 90), life.max()))
+    # start times by workgroup index: how fast does the dispatcher walk the grid?
+    idx = np.nonzero(ran)[0]
+    for lo in range(0, 8192, 1024):
+        sel = ran[lo:lo + 1024]
+        if sel.any():
+            ts = (st[lo:lo + 1024][sel, 0] - t0) / 100.0
+            print("   workgroups %4d..%4d start at %.2f .. %.2f us" % (lo, lo + 1023, ts.min(), ts.max()))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[1] == "batch":
+        batch(int(sys.argv[2]))
+    else:
+        main()

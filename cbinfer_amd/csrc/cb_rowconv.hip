@@ -608,6 +608,13 @@ int cbinfer_conv_accumulate_rows(const float* delta, uint64_t* bits, int32_t* ar
 }  // extern "C"
 
 #ifdef CB_ROW_STAMP
+// (diagnostic build) resident workgroups per CU of the 7x7 form at `threads` threads and `ldsBytes` of dynamic LDS
+extern "C" int cbinfer_debug_row_occupancy(int threads, long ldsBytes) {
+    int n = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cb_rowconv_f32_kernel<7, 7, 1>, threads, (size_t)ldsBytes) != hipSuccess)
+        return -1;
+    return n;
+}
 extern "C" int cbinfer_debug_row_stamps(void* host, long bytes, int clear) {
     if (clear) {
         void* d = nullptr;

@@ -75,6 +75,13 @@ def main():
             print("   (half-exits with stamp 1: %d, mask wait median %.2f)" % (len(d), np.median(d) if len(d) else 0))
 
 
+def occupancy():
+    raw.cbinfer_debug_row_occupancy.restype = ctypes.c_int
+    for lds in (0, 12032, 16384, 32768):
+        print("resident workgroups per CU (256 threads, %5d B dynamic LDS): %d"
+              % (lds, raw.cbinfer_debug_row_occupancy(256, ctypes.c_long(lds))))
+
+
 def batch(S):
     """the row-segment launch of a SequenceBatch step of S sequences of the bench workload"""
     import bench
@@ -116,6 +123,7 @@ def batch(S):
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "batch":
+        occupancy()
         batch(int(sys.argv[2]))
     else:
         main()

@@ -947,6 +947,11 @@ def main():
                     "arith_ceiling": ceiling, "frac_of_arith_ceiling": ach / ceiling,
                     "traffic": traffic, "traffic_source": traffic_src,
                     "avg_duration_us": r["conv_ms"] * 1e3, "duration_timing": timing,
+                    # the same with the empty event pair's time taken off (what rocprofv3 reports for the kernels
+                    # themselves lies at or below this; `achieved` / `frac` above keep the un-corrected duration)
+                    "avg_duration_us_net_of_event_pair": max(r["conv_ms"] * 1e3 - pair_us, 0.0),
+                    "achieved_net_of_event_pair": r["conv_flops"] / max(r["conv_ms"] * 1e-3 - pair_us * 1e-6, 1e-9)
+                    / 1e12,
                     "units_per_launch": r["N"],
                     "launches": "a deep contraction is two launches: the partial tiles of a k-range split over "
                                 "workgroups (short change lists) are summed by the second one, which -- when the fused "

@@ -352,6 +352,7 @@ class CBConv2d(nn.Module):
         t = self.__dict__.get('_fusedTail')
         K, Cin, kH, kW = self.weight.size()
         if (t is None or sp['ws'] is None or not self.propChangeIndexes or t.in_channels != K or
+                self.__dict__.get('_noTailFold') or
                 t.weight1.dtype != torch.float32 or t.weight1.device != dev or
                 os.environ.get('CBINFER_NO_TAILFOLD', '0') == '1' or
                 not C.cbinfer_split_tail_supported(Cin, K, kH, kW, t.hidden_channels, t.out_channels)):

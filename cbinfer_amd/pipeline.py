@@ -26,6 +26,12 @@ class FramePipeline(object):
         mods = list(net.children())
         assert 0 < cut < len(mods), "cut must leave at least one module on each side"
         self.stage1, self.stage2 = mods[:cut], mods[cut:]
+        # a 1x1 tail that rides in its producer's second launch (CBConv2d._folded_tail) would be evaluated by stage 1
+        # into a stage-2 module's state: where the cut separates the two, the tail keeps its own launch
+        for m in self.stage1:
+            tail = m.__dict__.get('_fusedTail')
+            if tail is not None and any(tail is k for k in self.stage2):
+                m.__dict__['_noTailFold'] = True
         self.side = side_stream
         self._done = None       # event: stage 2 of the most recently submitted frame
 

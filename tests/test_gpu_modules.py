@@ -1016,6 +1016,9 @@ def test_frame_pipeline_cut_behind_change_indexes(pkg):
     kids = list(piped.children())
     assert type(kids[4]) is pkg.CBConv2d and kids[4].propChangeIndexes and type(kids[5]) is pkg.CBTail1x1
     pipe = pkg.FramePipeline(piped, cut=5)
+    # (the tail would otherwise ride in its producer's second launch -- stage 1 writing a stage-2 module's state while
+    #  stage 2 of the frame before still hands that state out: the pipeline keeps the tail's own launch here)
+    assert kids[4].__dict__.get('_noTailFold') and kids[4].__dict__['_fusedTail'] is kids[5]
     frames = workloads.SyntheticVideo(H=96, W=160, ratio=0.1, block=16, seed=32).frames(16)
     got, want = [], []
     with torch.no_grad():
@@ -1031,6 +1034,8 @@ def test_frame_pipeline_cut_behind_change_indexes(pkg):
         torch.cuda.synchronize()
         for f in frames:
             want.append(serial(f).clone())
+    assert getattr(kids[4].lastChangeIndexes(), 'tailDone', None) is None
+    assert getattr([m for m in serial.children()][4].lastChangeIndexes(), 'tailDone', None) is not None
     for t, (a, b) in enumerate(zip(got, want)):
         assert torch.equal(a, b), t
     for ms, mp_ in zip([m for m in serial.modules() if type(m) in (pkg.CBConv2d, pkg.CBTail1x1)],

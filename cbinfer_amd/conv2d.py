@@ -451,6 +451,8 @@ class CBConv2d(nn.Module):
                 self._work is not plan['work'] or raw_stream(src.device.index) != plan['stream']):
             return None
         if plan['tail'] is not None and (self.__dict__.get('_fusedTail') is not plan['tail'] or
+                                         self.__dict__.get('_noTailFold') or
+                                         os.environ.get('CBINFER_NO_TAILFOLD', '0') == '1' or
                                          plan['tail']._fold_key() != plan['tailKey']):
             return None
         plan['seq'].input = src.data_ptr()

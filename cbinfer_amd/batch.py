@@ -162,8 +162,32 @@ class SequenceBatch(object):
             shape = (1, K, h, w)
         if pooledFrom is not None:
             raise CBinferError("SequenceBatch: a lazy pool needs a consuming CBConv2d")
+        for L in layers:
+            L['wkey'] = self._weight_key(L['m'])
         self.layers = layers
         self._first = True
+
+    @staticmethod
+    def _weight_key(m):
+        ts = (m.weight1, m.bias1, m.weight2, m.bias2) if type(m) is CBTail1x1 else (m.weight, m.bias)
+        return tuple((t.data_ptr(), t._version) for t in ts)
+
+    def _refresh_weights(self, li):
+        """The prepared copies of a layer's weights after the module's parameters were written (the states stay)."""
+        L = self.layers[li]
+        m = L['m']
+        if L['kind'] == 'split':
+            L['wp'], L['scale'] = m._split_weights(L['H'], L['W'])
+        elif L['kind'] == 'rows':
+            L['wp'] = m._masked_call('rows')[1]
+        if L['kind'] == 'tail' or L.get('tail') is not None:
+            t = m if L['kind'] == 'tail' else self.layers[li + 1]['m']
+            owner = L if L['kind'] == 'tail' else self.layers[li + 1]
+            owner['keep'] = (t._prepared(), t.bias1.detach(), t.weight2.detach().contiguous(), t.bias2.detach())
+            st = (self.layers[li - 1] if L['kind'] == 'tail' else L).get('tail')
+            if st is not None:
+                st.w1Prepared, st.b1, st.w2, st.b2 = [x.data_ptr() for x in owner['keep']]
+        L['wkey'] = self._weight_key(m)
 
     # ------------------------------------------------------------------------------------------
     def __call__(self, frames):
@@ -183,6 +207,9 @@ class SequenceBatch(object):
         st = stream_ptr(f0)
         S = self.S
         first = self._first
+        for li, L in enumerate(self.layers):      # (before any launch: a folded tail's weights are used by its producer)
+            if self._weight_key(L['m']) != L['wkey']:
+                self._refresh_weights(li)
         for li, L in enumerate(self.layers):
             m = L['m']
             if L['kind'] == 'rows':

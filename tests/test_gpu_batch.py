@@ -116,3 +116,37 @@ def test_batch_refuses_what_it_cannot_run(pkg):
     b = pkg.SequenceBatch(net, 2)
     with pytest.raises(CBinferError):
         b([torch.rand(1, 3, 64, 96, device="cuda")])                               # one frame for two sequences
+
+
+def test_batch_notices_written_weights(pkg):
+    """Parameters written between steps (every layer kind: row-segment, split-state, the folded tail): the batch
+    re-prepares its copies and keeps the sequences' states -- still bit-identical to independent networks whose
+    parameters were written the same way."""
+    from cbinfer_amd import workloads
+    S, H, W = 2, 96, 160
+    nets = _nets(pkg, S, (H, W))
+    bnet = _nets(pkg, 1, (H, W))[0]
+    batch = pkg.SequenceBatch(bnet, S)
+    vids = [workloads.SyntheticVideo(H=H, W=W, ratio=0.15, block=16, seed=70 + q) for q in range(S)]
+
+    def params(net):
+        out = []
+        for m in net.children():
+            if type(m) is pkg.CBConv2d:
+                out += [m.weight, m.bias]
+            elif type(m) is pkg.CBTail1x1:
+                out += [m.weight1, m.bias1, m.weight2, m.bias2]
+        return out
+
+    with torch.no_grad():
+        for t in range(8):
+            if t in (3, 5):
+                for net in nets + [bnet]:
+                    for k, p in enumerate(params(net)):
+                        p.mul_(1.0 + 0.01 * (k + t))
+            frames = [v.frame if t == 0 else v.next() for v in vids]
+            outs = batch([f.contiguous() for f in frames])
+            for q in range(S):
+                assert torch.equal(outs[q], nets[q](frames[q])), (t, q)
+                for (pi, po), (bi, bo) in zip(_states(pkg, nets[q]), batch.states(q)):
+                    assert torch.equal(po, bo), (t, q)

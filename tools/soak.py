@@ -23,6 +23,7 @@ def main():
         for m in test.modules():
             if type(m) is pycbinfer.CBPoolMax2d:
                 m.cloneOutput = False
+        pycbinfer.fuseTail1x1(test)              # (the tail in the contraction's second launch, as the bench runs it)
         pycbinfer.fusePoolingIntoDetection(test)
         seqs.append((base, test, workloads.SyntheticVideo(H=320, W=480, ratio=0.05 + 0.05 * q, block=32,
                                                           seed=100 + q), torch.cuda.Stream()))
@@ -44,6 +45,24 @@ def main():
     torch.cuda.synchronize()
     print("worst %.3e over %d frames x %d sequences" % (worst, T, S))
     assert worst <= 1e-4
+    # the same through ONE SequenceBatch (one launch per step for all sequences) at the bench's threshold against
+    # independent networks, bit for bit
+    import bench
+    nets = [bench.build_bench_model()[1] for _ in range(S)]
+    batch = pycbinfer.SequenceBatch(bench.build_bench_model()[1], S)
+    vids = [bench.bench_video(500 + q, ratio=0.05 + 0.05 * q) for q in range(S)]
+    bad = 0
+    with torch.no_grad():
+        for t in range(T // 4):
+            frames = [v.frame if t == 0 else v.next() for v in vids]
+            outs = batch(frames)
+            for q in range(S):
+                y = nets[q](frames[q])
+                if t % 25 == 0 or t == T // 4 - 1:
+                    bad += int(not torch.equal(outs[q], y))
+    torch.cuda.synchronize()
+    print("SequenceBatch vs independent networks over %d steps: %d mismatching outputs" % (T // 4, bad))
+    assert bad == 0
 
 
 if __name__ == "__main__":

@@ -724,31 +724,26 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc1[j][i] = 0.f, acc2[j][i] = 0.f;
         // Chunk boundary of an unsplit deep item: running sum = (first ? 0 : running sum) + (acc1 + acc2 / 2^11),
-        // accumulators from zero again.  The running sum lives in this item's (otherwise idle) slab -- every lane
-        // reads back what it wrote itself -- not in 32 more registers: the stage loop has none to spare, and a
-        // spill placed between an asm fragment read and its wait would carry garbage.
+        // accumulators from zero again.  The running sum is kept in REGISTERS (16 TN per lane): with one step body the
+        // stage loop has them to spare (round 3's first form, with its peeled loop tails, did not -- it kept the sum
+        // in the item's slab, 6 x 64 KB of memory traffic per item).
         int folds = 0;
-        float4* const mySlab = p.slabs ? (float4*)p.slabs + (long)it * (TILE / 4) : nullptr;
+        floatx16 run[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) run[j][i] = 0.f;
         auto fold = [&]() {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nl = (wn * TN + j) * 32 + l31;
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    float4* sp = mySlab + (wm * 8 + 2 * r4 + h) * BN + nl;
-                    float4 c = make_float4(acc1[j][4 * r4] + acc2[j][4 * r4] * lo2,
-                                           acc1[j][4 * r4 + 1] + acc2[j][4 * r4 + 1] * lo2,
-                                           acc1[j][4 * r4 + 2] + acc2[j][4 * r4 + 2] * lo2,
-                                           acc1[j][4 * r4 + 3] + acc2[j][4 * r4 + 3] * lo2);
-                    if (folds > 0) {
-                        const float4 o = *sp;
-                        c = make_float4(o.x + c.x, o.y + c.y, o.z + c.z, o.w + c.w);
-                    }
-                    *sp = c;
+                for (int i = 0; i < 16; ++i) {
+                    // (the first chunk's sum is taken as it is: 0 + x would turn a -0 into +0 where the split form,
+                    //  which adds the second slab to the first, keeps it)
+                    const float c = acc1[j][i] + acc2[j][i] * lo2;
+                    run[j][i] = folds > 0 ? run[j][i] + c : c;
+                    acc1[j][i] = 0.f, acc2[j][i] = 0.f;
                 }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc1[j][i] = 0.f, acc2[j][i] = 0.f;
-            }
             ++folds;
         };
 
@@ -918,16 +913,6 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
 #endif
             continue;
         }
-        // (an unsplit deep item: the running sum of the earlier chunks comes back from the slab, 16 bytes per load,
-        //  all loads requested before the first is used)
-        float4 rs[TN][4];
-        if (folds > 0) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4)
-                    rs[j][r4] = mySlab[(wm * 8 + 2 * r4 + h) * BN + (wn * TN + j) * 32 + l31];
-        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nl = (wn * TN + j) * 32 + l31;
@@ -936,10 +921,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, m = m0 + ml;
                 float v = acc1[j][r] + acc2[j][r] * lo2;
-                if (folds > 0) {                         // (the last chunk joins the running sum)
-                    const float4 o = rs[j][r >> 2];
-                    v = ((r & 3) == 0 ? o.x : (r & 3) == 1 ? o.y : (r & 3) == 2 ? o.z : o.w) + v;
-                }
+                if (folds > 0) v = run[j][r] + v;        // (the last chunk joins the running sum)
                 v = fmaf(v, p.outScale, s_bias[ml]);      // (an explicit fma here, in the reduce launch and in the
                 if (p.relu) v = v <= 0.f ? 0.f : v;        //  fused tail: one rounding at all three sites)
                 if (pix >= 0 && m < p.K) out[(long)m * HW + pix] = v;
@@ -1213,7 +1195,8 @@ long cbinfer_split_prepared_bytes(int C, int K, int kH, int kW) {
 }
 
 // Workspace of a deep contraction (>= 48 stages; 0 bytes otherwise): 64 ints of launch info + one BM x BN partial
-// tile per work item -- split, at most a grid of them; unsplit, one per tile of every sequence (the running sums)
+// tile per work item of a split contraction (at most a grid of them; sized for one per tile of every sequence, which
+// an earlier form of the unsplit case used for its running sums)
 long cbinfer_split_workspace_bytes(int nSeq, int C, int H, int W, int K, int kH, int kW) {
     if (!cbs_supported(C, K, kH, kW)) return 0;
     const CbsGeom g = cbs_geom(C, H, W, kH, kW);

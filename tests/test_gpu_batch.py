@@ -150,3 +150,28 @@ def test_batch_notices_written_weights(pkg):
                 assert torch.equal(outs[q], nets[q](frames[q])), (t, q)
                 for (pi, po), (bi, bo) in zip(_states(pkg, nets[q]), batch.states(q)):
                     assert torch.equal(po, bo), (t, q)
+
+
+def test_two_batches_on_two_streams(pkg):
+    """What bench.py's `grouped_value` runs: two SequenceBatch groups of two sequences, each on its own stream, their
+    steps enqueued back to back without any sync in between -- every sequence bit-identical to its own network."""
+    from cbinfer_amd import workloads
+    H, W, T = 160, 240, 8
+    nets = _nets(pkg, 4, (H, W))
+    groups = [(pkg.SequenceBatch(_nets(pkg, 1, (H, W))[0], 2), torch.cuda.Stream()) for _ in range(2)]
+    vids = [workloads.SyntheticVideo(H=H, W=W, ratio=r, block=16, seed=90 + q)
+            for q, r in enumerate((0.1, 0.3, 0.05, 0.2))]
+    frames = [[v.frame] + [v.next() for _ in range(T - 1)] for v in vids]
+    torch.cuda.synchronize()
+    got = [[None] * T for _ in range(4)]
+    with torch.no_grad():
+        for t in range(T):
+            for gi, (sb, st) in enumerate(groups):
+                with torch.cuda.stream(st):
+                    outs = sb([frames[2 * gi][t], frames[2 * gi + 1][t]])
+                    for k in range(2):
+                        got[2 * gi + k][t] = outs[k].clone()
+        torch.cuda.synchronize()
+        for q in range(4):
+            for t in range(T):
+                assert torch.equal(got[q][t], nets[q](frames[q][t])), (q, t)

@@ -61,8 +61,12 @@ class SequenceBatch(object):
         shape = tuple(frame.shape)          # (1, C, H, W) of what the next layer sees
         pooledFrom = None                   # set behind a lazy pool: the producing layer's index
         kids = list(self.net.children())
-        for m in kids:
+        if len(_lib.SplitTail().output) != C.cbinfer_split_max_sequences():
+            raise CBinferError("SequenceBatch: cbSplitTail.output[] and cbinfer_split_max_sequences() disagree")
+        for pos, m in enumerate(kids):
             if type(m) is CBPoolMax2d:
+                if not layers:
+                    raise CBinferError("SequenceBatch: a CBPoolMax2d needs a producing CBConv2d in front of it")
                 if not getattr(m, 'lazy', False) or m.propChangeIndexes:
                     raise CBinferError("SequenceBatch: CBPoolMax2d must be folded into the next detection "
                                        "(pycbinfer.fusePoolingIntoDetection)")
@@ -72,9 +76,11 @@ class SequenceBatch(object):
                 shape = (1, c, oh, ow)
                 continue
             if type(m) is CBTail1x1:
-                prod = layers[-1]
-                if prod['kind'] != 'split' or pooledFrom is not None:
+                if not layers or layers[-1]['kind'] != 'split' or pooledFrom is not None:
                     raise CBinferError("SequenceBatch: CBTail1x1 must follow a split-state CBConv2d")
+                if pos != len(kids) - 1:
+                    raise CBinferError("SequenceBatch: a CBTail1x1 must be the network's last module")
+                prod = layers[-1]
                 _, c, h, w = shape
                 L = dict(kind='tail', m=m, H=h, W=w,
                          prevOutput=[torch.full((1, m.out_channels, h, w), float('inf'), device=dev)

@@ -187,6 +187,7 @@ class CBConv2d(nn.Module):
                 self.register_buffer(name, tmp)
         self.prevInput = self.weight.detach().new_zeros(0)
         self.prevOutput = self.weight.detach().new_zeros(0)
+        self.__dict__['_rangeFallback'] = False
         if hasattr(self, 'compStats'):
             self.compStats = None
         # device work buffers (not part of the module state)
@@ -286,9 +287,11 @@ class CBConv2d(nn.Module):
         return _lib.CB_F32
 
     def _arith(self, t):
-        """Arithmetic of the fused contraction: fp16 as is; fp32 as bf16x3 split products on the bf16 MFMA
-        (CB_F32S: every operand as three bf16 terms, the six cross products above 2^-24, f32 accumulation
-        -- f32-level accuracy at 2.7x the f32 MFMA's rate) unless exactF32 asks for the exact f32 fma chain."""
+        """Arithmetic code of the fused contraction for the library's list / patch-staged kernels: fp16 as is; fp32 as
+        split products on the 16-bit MFMA (CB_F32S: bf16x3 there -- three bf16 terms per operand, the six cross
+        products above 2^-24, f32 accumulation; the split-state kernels, which this code also admits (_split_ok), use
+        f16 pairs instead: 22-23 significant bits per operand, three products) unless exactF32 asks for the exact f32
+        fma chain on the f32 MFMA (CB_F32)."""
         dtype_code(t)     # (rejects anything but fp32 / fp16)
         return self._arith_code(t.dtype)
 
@@ -308,6 +311,7 @@ class CBConv2d(nn.Module):
         K, Cin, kH, kW = self.weight.size()
         return (dtype == torch.float32 and self.feedbackLoop and not self.syncIndexes and not self.saveChangeMap
                 and not self.finegrained and self._arith_code(dtype) == _lib.CB_F32S
+                and not self.__dict__.get('_rangeFallback')
                 and os.environ.get('CBINFER_NO_SPLIT', '0') != '1'
                 and int(os.environ.get('CBINFER_SPLIT_MINK', '0')) <= K <= int(os.environ.get('CBINFER_SPLIT_MAXK', '100000'))
                 and os.environ.get('CBINFER_ARITH', 'f16x2') == 'f16x2'
@@ -340,7 +344,12 @@ class CBConv2d(nn.Module):
             # (slabs only for deep contractions -- 48 k-stages and more: 0 bytes otherwise)
             wsBytes = C.cbinfer_split_workspace_bytes(1, Cin, H, W, K, kH, kW)
             ws = torch.zeros(wsBytes, dtype=torch.uint8, device=dev) if wsBytes > 0 else None
+            # (a frame mask of its own: the list kernels' protocol -- two masks alternating by a device-side parity --
+            #  and the split-state kernels' -- one mask, an arrival counter behind it -- must never meet in one
+            #  buffer when a module changes paths in mid-sequence)
             sp = work['split'] = dict(S=S, flag=torch.zeros(1, dtype=torch.int32, device=dev),
+                                      bits=torch.zeros(C.cbinfer_frame_mask_bytes(H, W) // 8, dtype=torch.int64,
+                                                       device=dev),
                                       copy=torch.zeros(words, dtype=torch.int64, device=dev), ws=ws,
                                       stateKey=None, seq=(_lib.SplitSeq * 1)())
         return sp
@@ -354,6 +363,8 @@ class CBConv2d(nn.Module):
         if (t is None or sp['ws'] is None or not self.propChangeIndexes or t.in_channels != K or
                 self.__dict__.get('_noTailFold') or
                 t.weight1.dtype != torch.float32 or t.weight1.device != dev or
+                # (the second launch reads the layer's bias and the tail's first four values at a time)
+                (self.bias.data_ptr() | t.bias1.data_ptr()) & 15 or
                 os.environ.get('CBINFER_NO_TAILFOLD', '0') == '1' or
                 not C.cbinfer_split_tail_supported(Cin, K, kH, kW, t.hidden_channels, t.out_channels)):
             return None
@@ -368,10 +379,34 @@ class CBConv2d(nn.Module):
         return t
 
     def rangeExceeded(self):
-        """True if a state value ever left the range of the split-state arithmetic (|x| >= 2^20): the layer's
-        outputs are then not meaningful (one host sync).  Use exactF32 or CBINFER_ARITH=bf16x3 for such data."""
+        """True if a state value of this layer ever left the range of the f16-pair arithmetic (|x| >= 2^20, or a
+        non-finite input) since the state was cleared (one host sync unless the module has noticed already).  The
+        outputs are right either way: from the frame that trips the flag on, the contraction kernel itself computes
+        the layer from prevInput with plain f32 arithmetic (cb_split.hip: cbs_exact_tile) -- slowly -- until the module
+        notices (`_poll_range`, no sync) and moves the layer to the bf16x3 kernels, which have f32's range."""
+        if self.__dict__.get('_rangeFallback'):
+            return True
         sp = self._work.get('split') if self._work else None
         return bool(sp is not None and int(sp['flag'].item()) != 0)
+
+    def _poll_range(self, sp):
+        """Every 64th split-state frame: an asynchronous copy of the layer's range flag into pinned memory, and a look
+        at what the previous copy brought (no sync, no wait).  A tripped flag moves the layer to the bf16x3 kernels for
+        good (`_rangeFallback`; clearMemory resets it): the in-kernel exact path that kept the frames since the trip
+        right is orders of magnitude slower than either."""
+        n = sp['poll'] = sp.get('poll', 0) + 1
+        if n & 63 or torch.cuda.is_current_stream_capturing():
+            return
+        host, ev = sp.get('flagHost'), sp.get('flagEvent')
+        if host is None:
+            host = sp['flagHost'] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        elif ev is not None and ev.query() and int(host[0]) != 0:
+            self.__dict__['_rangeFallback'] = True
+            self._plan = None
+            return
+        host.copy_(sp['flag'], non_blocking=True)
+        ev = sp['flagEvent'] = torch.cuda.Event()
+        ev.record()
 
     def _forward_split(self, src, lazy, work):
         """One frame on the split-state kernels: detection (+ pooling) + refresh of prevInput and of its pre-split
@@ -397,7 +432,7 @@ class CBConv2d(nn.Module):
             pmask = None if (rebuilt or not sameTh) else lazy.producerMask()
         q = sp['seq'][0]
         q.input, q.state, q.splitState = src.data_ptr(), prev.data_ptr(), sp['S'].data_ptr()
-        q.frameMasks, q.producerMask = work['bits'].data_ptr(), ptr(pmask)
+        q.frameMasks, q.producerMask = sp['bits'].data_ptr(), ptr(pmask)
         q.output, q.idxOut, q.countOut = self.prevOutput.data_ptr(), work['idx'].data_ptr(), work['count'].data_ptr()
         q.rangeFlag, q.maskCopy = sp['flag'].data_ptr(), sp['copy'].data_ptr()
         args = [sp['seq'], 1, int(lazy is not None), src.size(-2) if lazy is not None else 0,
@@ -412,6 +447,8 @@ class CBConv2d(nn.Module):
             fn = C.cbinfer_split_forward
             args += [stream_ptr(src)]
         check(fn(*args))
+        self._poll_range(sp)
+        self.__dict__['_ranSplit'] = True
         self._inputIsLiveState = False
         self._lastIndexes = MaskChangeIndexes(sp['copy'], (H, W), work['idx'], work['count'], made=True)
         self._lastIndexes.tailDone = tail
@@ -459,6 +496,7 @@ class CBConv2d(nn.Module):
         status = plan['fn'](*plan['args'])
         if status != 0:
             check(status)
+        self._poll_range(plan['work']['split'])
         self._inputIsLiveState = False
         self._lastIndexes = plan['indexes']
         if self.propChangeIndexes:
@@ -919,10 +957,20 @@ class CBConv2d(nn.Module):
                 return out
             self._plan = None
         self._setDefaultValues()
+        self.__dict__['_ranSplit'] = False
         if self.finegrained:
             assert self.feedbackLoop == False
-            return self.forward_fg(inp)
-        return self.forward_normal(inp)
+            out = self.forward_fg(inp)
+        else:
+            out = self.forward_normal(inp)
+        if not self.__dict__['_ranSplit']:
+            # A frame on any other path refreshes prevInput through raw pointers (neither its address nor its
+            # version counter moves): the pre-split copy of the state is stale from here on and is made again from
+            # prevInput when the module returns to the split-state kernels
+            sp = self._work.get('split') if self._work else None
+            if sp is not None:
+                sp['stateKey'] = None
+        return out
 
     def __repr__(self):
         """One line in the reference's format (conv2d.py:271-290): fixed head, then the conv attributes

@@ -115,9 +115,12 @@ __device__ __forceinline__ void cbs_split(float x, _Float16& hi, _Float16& lo) {
 // weights: [stage][row tile of 32][k-step][plane][lane][8 f16] (MFMA A-fragment order) + the stage table
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cbs_prep_kernel(const float* __restrict__ w, halfx8* __restrict__ A,
-                                                      int* __restrict__ stageOff, CbsGeom g, int K, int KP,
-                                                      float wscale) {
+                                                      int* __restrict__ stageOff, float* __restrict__ wPlain,
+                                                      CbsGeom g, int K, int KP, float wscale) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // (the plain f32 filter bank, as it came, behind the stage table: what the exact path of a layer whose state left
+    //  the f16 pair's range multiplies with -- cbs_exact_tile)
+    for (long i = idx; i < (long)K * g.C * g.kH * g.kW; i += (long)gridDim.x * blockDim.x) wPlain[i] = w[i];
     if (idx < g.nStages) {
         const int s = (int)idx;
         int off;
@@ -369,6 +372,8 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
 // ---------------------------------------------------------------------------------------------------
 struct CbsSeq {
     const char* S;
+    const float* state;               // prevInput [C,H,W] f32 (read by the exact path only)
+    const int* rangeFlag;             // != 0: the split state is not usable (a value left the f16 pair's range)
     float* out;                       // prevOutput [K,H,W]
     unsigned long long* masks;        // frame masks
     int32_t* listOut;                 // change list (by-product), capacity H*W
@@ -380,11 +385,12 @@ struct CbsParams {
     int nSeq;
     const char* A;                    // prepared weights
     const int* stageOff;
+    const float* wPlain;              // the f32 filter bank [K,C,kH,kW] (exact path)
     const float* bias;
     float* slabs;                     // split-K workspace: slabCap partial tiles of BM x BN floats
     int* info;                        // left for the reduce launch: {SK, MT, nSeq, tilesP[q]..., N[q]...}
-    int slabCap;                      // (unused)
-    int K, KP, H, W, Wp, rec, nStages, maskWords, wpr, relu, dummyBase;
+    int slabCap;                      // partial tiles the workspace holds (cbs_slab_capacity)
+    int K, KP, H, W, Wp, rec, nStages, maskWords, wpr, relu, dummyBase, kH, kW;
     long stateBytes, aBytes;
     float outScale;
     unsigned long long magicMW, magicWpr, magicW, magicMT;   // floor(2^32 / d) + 1: x / d = (x * magic) >> 32 for x d < 2^32
@@ -479,12 +485,20 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     // ---- every workgroup: change-list lengths of all sequences from their masks, ONE scan ------------
     // (per-sequence facts live in small LDS tables, not in registers: eight sequences' worth of scalars would
     //  crowd out the kernel's own)
-    __shared__ int s_seqN[CBS_MAXSEQ], s_seqRank[CBS_MAXSEQ], s_seqTile[CBS_MAXSEQ + 1];
+    __shared__ int s_seqN[CBS_MAXSEQ], s_seqRank[CBS_MAXSEQ], s_seqTile[CBS_MAXSEQ + 1], s_exact[CBS_MAXSEQ];
     // Mask protocol (single mask per sequence): the detection ORs into it; here every workgroup takes a copy into
     // LDS and never looks at the mask again.  On its way OUT of the kernel each workgroup counts itself on an
     // arrival counter behind the mask, and the one that learns it was the last zeroes the masks for the next
     // frame's detection.  Nobody waits for anybody; the next launch finds them clean.
     for (int q = t; q < p.nSeq; q += NT) s_maskPtr[q] = p.seq[q].masks;
+    // the layer's range flag (set by the detection when a state value left the f16 pair's range, sticky): requested
+    // here, looked at behind the scan -- such a sequence's tiles are then computed by plain f32 arithmetic from the
+    // f32 state (cbs_exact_tile below): slow, right, in this very frame
+    int flagv = 0;
+    if (t < p.nSeq) {
+        const int* rf = p.seq[t].rangeFlag;
+        if (rf) flagv = *rf;
+    }
     __syncthreads();
     const int E = p.nSeq * MW;
     // Thread t owns the CH consecutive words [t CH, (t+1) CH) of the concatenated masks: their popcounts stay in
@@ -540,6 +554,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
                 run += cnt[u];
             }
         }
+        if (t < CBS_MAXSEQ) s_exact[t] = flagv;
         if (t == 0) {
             s_pre[E] = tot;
             if (p.nSeq == 1) {      // (one sequence: its tables need nothing from LDS)
@@ -572,9 +587,13 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     // depth and folds its accumulators into a running sum at the chunk boundaries: the same additions in the
     // same order, so a sequence gets the same bits whether it runs alone (split) or beside others (unsplit).
     const int CH = (p.nStages >= 48 && p.slabs) ? CBS_CHUNKS : 1;      // (the host refuses a deep layer without slabs)
+    int anyExact = 0;
+    for (int q = 0; q < p.nSeq; ++q) anyExact |= s_exact[q];
+    anyExact = __builtin_amdgcn_readfirstlane(anyExact);
     int SK = 1;
-    if (TP > 0 && CH > 1 && TP * MT * CH <= (int)gridDim.x) SK = CH;
-    if (p.forceSK > 0 && CH > 1) SK = p.forceSK >= CH ? CH : 1;         // (tests: 1 = unsplit, >= 4 = split)
+    if (TP > 0 && CH > 1 && TP * MT * CH <= (int)gridDim.x && !anyExact) SK = CH;
+    // (tests: 1 = unsplit, >= 4 = split -- but never more partial tiles than the workspace holds)
+    if (p.forceSK > 0 && CH > 1) SK = (p.forceSK >= CH && TP * MT * CH <= p.slabCap && !anyExact) ? CH : 1;
     const int CMB = MT * SK, items = TP * CMB;
     if (blockIdx.x == 0 && t == 0 && p.info) {
         p.info[CBS_INFO_SK] = SK;
@@ -674,6 +693,47 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         const float biasv = (t < BM && p.bias && m0 + t < p.K) ? p.bias[m0 + t] : 0.f;
         __syncthreads();
         CBS_STAMP_AT(10);
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane(s_exact[q]) != 0, 0)) {
+            // The sequence's state left the range of the f16 pairs (|x| >= 2^20, cbs_detect_kernel): its split state is
+            // not usable.  The tile is computed from prevInput and the plain filter bank instead, one f32 fma chain per
+            // output in (channel, ky, kx) order like conv2d_cg.py:342-349's sgemm -- orders of magnitude slower, and
+            // right: the layer never hands out numbers made from an overflowed operand.  (SK is 1 in such a launch.)
+            // (the arguments only this path needs are read through an opaque copy of the kernel-argument pointer:
+            //  the compiler would otherwise load them at kernel entry and carry them through the stage loop in
+            //  scalar registers it does not have)
+            const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            const CbsParams* pp = (const CbsParams*)ka;
+            const float* __restrict__ st = pp->seq[q].state;
+            const float* __restrict__ wf = pp->wPlain;
+            float* __restrict__ outx = pp->seq[q].out;
+            const float* biasx = pp->bias;
+            const int Cn = pp->rec >> 2, kH = pp->kH, kW = pp->kW, Wd = pp->W, Hd = pp->H, Kd = pp->K, relux = pp->relu;
+            const unsigned long long magicWx = pp->magicW;
+            const int HWx = Hd * Wd;
+            for (int o = t; o < BM * BN; o += NT) {
+                const int nl = o % BN, ml = o / BN, m = m0 + ml;
+                const int pix = s_tilePix[nl];
+                if (pix < 0 || m >= Kd) continue;
+                const int y = cbs_div(pix, magicWx), x = pix - y * Wd;
+                const float* wrow = wf + (long)m * Cn * kH * kW;
+                float acc = 0.f;
+                for (int c = 0; c < Cn; ++c)
+                    for (int ky = 0; ky < kH; ++ky) {
+                        const int yy = y + ky - kH / 2;
+                        for (int kx = 0; kx < kW; ++kx) {
+                            const int xx = x + kx - kW / 2;
+                            const bool in = yy >= 0 && yy < Hd && xx >= 0 && xx < Wd;
+                            const float v = in ? st[(long)c * HWx + (long)yy * Wd + xx] : 0.f;
+                            acc = fmaf(v, wrow[(c * kH + ky) * kW + kx], acc);
+                        }
+                    }
+                float v = acc + (biasx ? biasx[m] : 0.f);
+                if (relux) v = v <= 0.f ? 0.f : v;
+                outx[(long)m * HWx + pix] = v;
+            }
+            continue;
+        }
 
         const char* Sq = p.seq[q].S;
         const int bRecords = (int)min(p.stateBytes + CBS_SPAD, (long)0x7fffffff);
@@ -1189,22 +1249,27 @@ long cbinfer_split_state_bytes(int C, int H, int W, int kH, int kW) {
     return CBS_SPAD + (long)g.Hp * g.Wp * g.rec;
 }
 
+// prepared weights: [A fragments | stage table | pad to 16 B | plain f32 filter bank]
+static long cbs_plain_offset(long aBytes, int nStages) { return (aBytes + (long)nStages * 4 + 15) / 16 * 16; }
 long cbinfer_split_prepared_bytes(int C, int K, int kH, int kW) {
     const CbsGeom g = cbs_geom(C, 64, 64, kH, kW);
-    return (long)g.nStages * (cbs_kp(K) / 32) * 4096 + (long)g.nStages * 4;
+    return cbs_plain_offset((long)g.nStages * (cbs_kp(K) / 32) * 4096, g.nStages) + (long)K * C * kH * kW * 4;
 }
 
 // Workspace of a deep contraction (>= 48 stages; 0 bytes otherwise): 64 ints of launch info + one BM x BN partial
 // tile per work item of a split contraction (at most a grid of them; sized for one per tile of every sequence, which
 // an earlier form of the unsplit case used for its running sums)
+static long cbs_slab_capacity(int nSeq, int H, int W, int K) {
+    const int bm = cbs_bm(K), bn = bm >= 128 ? 128 : 64;
+    const long tiles = (long)nSeq * (((long)H * W + bn - 1) / bn) * (cbs_kp(K) / bm);
+    return tiles > 2l * cbs_num_cus() ? tiles : 2l * cbs_num_cus();
+}
 long cbinfer_split_workspace_bytes(int nSeq, int C, int H, int W, int K, int kH, int kW) {
     if (!cbs_supported(C, K, kH, kW)) return 0;
     const CbsGeom g = cbs_geom(C, H, W, kH, kW);
     if (g.nStages < 48) return 0;
     const int bm = cbs_bm(K), bn = bm >= 128 ? 128 : 64;
-    const long tiles = (long)nSeq * (((long)H * W + bn - 1) / bn) * (cbs_kp(K) / bm);
-    const long items = tiles > 2l * cbs_num_cus() ? tiles : 2l * cbs_num_cus();
-    return 256 + items * bm * bn * 4;
+    return 256 + cbs_slab_capacity(nSeq, H, W, K) * bm * bn * 4;
 }
 
 int cbinfer_split_prep_weights(const float* weight, void* prepared, int K, int C, int kH, int kW, int H, int W,
@@ -1215,9 +1280,11 @@ int cbinfer_split_prep_weights(const float* weight, void* prepared, int K, int C
     if ((long)g.Hp * g.Wp * g.rec >= (1l << 31)) return CB_ERR_UNSUPPORTED;
     const int KP = cbs_kp(K);
     const long total = (long)g.nStages * (KP / 32) * 4 * 64;
-    int* stageOff = (int*)((char*)prepared + (long)g.nStages * (KP / 32) * 4096);
+    const long aBytes = (long)g.nStages * (KP / 32) * 4096;
+    int* stageOff = (int*)((char*)prepared + aBytes);
+    float* wPlain = (float*)((char*)prepared + cbs_plain_offset(aBytes, g.nStages));
     hipLaunchKernelGGL(cbs_prep_kernel, dim3(cb_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, weight,
-                       (halfx8*)prepared, stageOff, g, K, KP, weightScale);
+                       (halfx8*)prepared, stageOff, wPlain, g, K, KP, weightScale);
     return cb_launch_status();
 }
 
@@ -1291,6 +1358,8 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
     for (int q = 0; q < nSeq; ++q) {
         CB_REQUIRE(seqs[q].splitState && seqs[q].output && seqs[q].frameMasks && seqs[q].idxOut && seqs[q].countOut);
         p.seq[q].S = (const char*)seqs[q].splitState;
+        p.seq[q].state = seqs[q].state;
+        p.seq[q].rangeFlag = seqs[q].state ? seqs[q].rangeFlag : nullptr;      // (no f32 state handed in: no exact path)
         p.seq[q].out = seqs[q].output;
         p.seq[q].masks = (unsigned long long*)seqs[q].frameMasks;
         p.seq[q].listOut = seqs[q].idxOut;
@@ -1301,10 +1370,11 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
     p.aBytes = (long)g.nStages * (KP / 32) * 4096;
     p.A = (const char*)prepared;
     p.stageOff = (const int*)((const char*)prepared + p.aBytes);
+    p.wPlain = (const float*)((const char*)prepared + cbs_plain_offset(p.aBytes, g.nStages));
     p.bias = bias;
     p.info = workspace ? (int*)workspace : nullptr;
     p.slabs = workspace ? (float*)((char*)workspace + 256) : nullptr;
-    p.K = K, p.KP = KP, p.H = H, p.W = W, p.Wp = g.Wp, p.rec = g.rec, p.nStages = g.nStages;
+    p.K = K, p.KP = KP, p.H = H, p.W = W, p.Wp = g.Wp, p.rec = g.rec, p.nStages = g.nStages, p.kH = kH, p.kW = kW;
     p.maskWords = (int)MW, p.wpr = cbinfer_mask_words_per_row(W), p.relu = relu, p.dummyBase = g.dummyBase;
     p.stateBytes = (long)g.Hp * g.Wp * g.rec;
     p.outScale = 1.0f / (weightScale * CBS_XSCALE);
@@ -1318,7 +1388,10 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
     if (const char* e = getenv("CBINFER_SPLIT_DBG")) p.dbg = atoi(e);
 #endif
     hipStream_t s = (hipStream_t)stream;
-    p.slabCap = 0;      // (sized by cbinfer_split_workspace_bytes for this very geometry: never exceeded)
+    // the workspace was sized by cbinfer_split_workspace_bytes for this very geometry: a split the kernel decides on
+    // itself (items <= grid <= 2 CUs) always fits, a forced one (forceSplit: tests, tuning) is refused beyond it
+    const long cap = cbs_slab_capacity(nSeq, H, W, K);
+    p.slabCap = (int)(cap > 0x7fffffffl ? 0x7fffffffl : cap);
     if (BM == 128) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG, true, 4>(p, 1, tail, s);
     // The 64-row tile moves 16 KB per stage, and what bounds its stage rate is the DMA in flight on the CU (bytes in
     // flight / latency): one sequence rarely has more tiles than there are CUs, so it runs one workgroup per CU with

@@ -28,12 +28,28 @@ class FramePipeline(object):
         self.stage1, self.stage2 = mods[:cut], mods[cut:]
         # a 1x1 tail that rides in its producer's second launch (CBConv2d._folded_tail) would be evaluated by stage 1
         # into a stage-2 module's state: where the cut separates the two, the tail keeps its own launch
+        # (the switch belongs to THIS pipeline: close() -- or dropping the pipeline -- hands the folding back)
+        self._unfolded = []
         for m in self.stage1:
             tail = m.__dict__.get('_fusedTail')
-            if tail is not None and any(tail is k for k in self.stage2):
+            if tail is not None and any(tail is k for k in self.stage2) and not m.__dict__.get('_noTailFold'):
                 m.__dict__['_noTailFold'] = True
+                self._unfolded.append(m)
         self.side = side_stream
         self._done = None       # event: stage 2 of the most recently submitted frame
+
+    def close(self):
+        """Give the network back as it was: heads whose 1x1 tail this pipeline kept in a launch of its own fold it
+        into their second launch again (the next frame goes through the general path once)."""
+        for m in self._unfolded:
+            m.__dict__.pop('_noTailFold', None)
+        self._unfolded = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # pragma: no cover  (interpreter shutdown)
+            pass
 
     def _private(self, h):
         """What stage 2 receives: a tensor (or tuple) no later frame's stage 1 will write to."""

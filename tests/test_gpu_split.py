@@ -342,3 +342,157 @@ def test_split_tail_in_the_second_launch(lib, oracle, nSeq, force, bias):
         dense = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(
             y.double(), dw1.double().view(C1, K, 1, 1), db1.double())), dw2.double().view(C2, C1, 1, 1), db2.double())
         assert float((dense - tfus[q].double()).abs().max()) <= FP32_TOL
+
+
+def _sum_abs(oracle, x, w, idx, kH, kW):
+    """sum |a||b| of every output of the changed pixels `idx` (double)."""
+    X = oracle.genXMatrix(x, idx, (kH, kW))
+    return np.abs(X).astype(np.float64) @ np.abs(w.reshape(w.shape[0], -1)).astype(np.float64).T      # [N, K]
+
+
+@pytest.mark.parametrize("C,K,H,W,nSeq,tail", [(16, 64, 24, 40, 1, False), (64, 256, 40, 60, 1, False),
+                                               (64, 256, 40, 60, 2, True), (64, 256, 40, 60, 1, True)])
+def test_split_range_flag_acts(lib, oracle, C, K, H, W, nSeq, tail):
+    """a state value beyond the f16 pair's range (|x| >= 2^20) must never produce silent
+    garbage.  The detection raises the layer's flag and the contraction launch of the SAME frame computes the layer
+    from prevInput with plain f32 arithmetic (cbs_exact_tile): outputs against the double-accumulated oracle within the
+    f32 chain's bound, in that frame and in the frames behind it (the flag is sticky), for one sequence and for two in
+    one launch, with and without the fused 1x1 tail in the second launch (the unsplit form of that launch)."""
+    import ctypes
+    C_ = lib.C
+    rng = np.random.default_rng(C + K + nSeq)
+    w = (rng.standard_normal((K, C, 7, 7)) / np.sqrt(C * 49)).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    L = Layer(lib, w, b, H, W, nSeq=nSeq)
+    os_ = [oracle.OracleCBConv2d(w, b, 0.1, withReLU=True, feedbackLoop=True, propChangeIndexes=True)
+           for _ in range(nSeq)]
+    C1, C2 = 64, 8
+    if tail:
+        w1 = (rng.standard_normal((C1, K)) / np.sqrt(K)).astype(np.float32)
+        b1 = rng.standard_normal(C1).astype(np.float32)
+        w2 = (rng.standard_normal((C2, C1)) / np.sqrt(C1)).astype(np.float32)
+        b2 = rng.standard_normal(C2).astype(np.float32)
+        dw1, db1, dw2, db2 = dev(w1), dev(b1), dev(w2), dev(b2)
+        w1p = torch.empty(C_.cbinfer_tail1x1_prepared_bytes(C1, K) // 4, device="cuda")
+        lib.check(C_.cbinfer_tail1x1_prep(dw1.data_ptr(), w1p.data_ptr(), C1, K, None))
+        tout = [torch.full((1, C2, H, W), float("inf"), device="cuda") for _ in range(nSeq)]
+        st = lib.SplitTail()
+        st.w1Prepared, st.b1, st.w2, st.b2 = w1p.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr()
+        st.C1, st.C2, st.relu1, st.relu2 = C1, C2, 1, 0
+        for q in range(nSeq):
+            st.output[q] = tout[q].data_ptr()
+
+    def frame(xs):
+        if not tail:
+            return L.frame([dev(x) for x in xs], 0.1, relu=True)
+        keep = [dev(x) for x in xs]
+        for q, x in enumerate(keep):
+            L.seqs[q].input, L.seqs[q].producerMask = x.data_ptr(), None
+        lib.check(C_.cbinfer_split_forward_tail(L.seqs, nSeq, 0, 0, 0, L.wp.data_ptr(), L.b.data_ptr(), C, H, W, K, 7, 7,
+                                                0.1, L.scale, 1, L.ws.data_ptr(), 0, ctypes.pointer(st), None))
+        torch.cuda.synchronize()
+
+    vids = [block_video(rng, C, H, W, 5, 0.15) for _ in range(nSeq)]
+    for t in range(5):
+        xs = [v[t].copy() for v in vids]
+        if t >= 2:
+            xs[0][0, 3, 5, 7] = 3.0e6 + t            # beyond 2^20 = 1.05e6, and changing from frame to frame
+        if t == 3:
+            xs[0][0, 1, 11, 13] = float(2 ** 20)      # the first value out of range, exactly
+        frame(xs)
+        assert int(L.flag.item()) == (1 if t >= 2 else 0), t
+        for q in range(nSeq):
+            got = os_[q].forward(xs[q])
+            assert np.array_equal(L.list(q), got[2]), (t, q)
+            assert np.array_equal(L.state[q].cpu().numpy(), os_[q].prevInput), (t, q)
+            n = got[2]
+            out = L.out[q].cpu().numpy().reshape(K, -1)[:, n].astype(np.float64)
+            ref = os_[q].prevOutput.reshape(K, -1)[:, n].astype(np.float64)
+            mag = _sum_abs(oracle, os_[q].prevInput, w, n, 7, 7).T + np.abs(b)[:, None]
+            err = np.abs(out - ref)
+            # the f32 fma chain: far inside n_k * 2^-24 * sum|a||b|; where no huge value is in reach that is <= 1e-4
+            assert np.all(err <= 64 * 2.0 ** -24 * mag + 1e-30), (t, q, float((err / mag).max()))
+            small = mag.max(axis=0) < 1e3
+            assert small.any() and err[:, small].max() <= FP32_TOL, (t, q)
+            if tail:
+                y = L.out[q].double()
+                dense = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(
+                    y, dw1.double().view(C1, K, 1, 1), db1.double())), dw2.double().view(C2, C1, 1, 1), db2.double())
+                te = (dense - tout[q].double()).abs().reshape(C2, -1)[:, torch.from_numpy(n.astype(np.int64)).cuda()]
+                ty = y.abs().reshape(K, -1)[:, torch.from_numpy(n.astype(np.int64)).cuda()].amax(dim=0)
+                assert bool((te.amax(dim=0) <= 1e-4 * torch.clamp(ty, min=1.0)).all()), (t, q)
+
+
+def test_split_forced_k_split_respects_the_workspace(lib, oracle):
+    """forceSplit >= 4 on a first frame (every pixel changed) would need 600 partial tiles where the
+    workspace holds 512 -- the kernel must fall back to the unsplit form (same bits) instead of writing past it."""
+    rng = np.random.default_rng(31)
+    C, K, H, W = 64, 256, 80, 120
+    w = (rng.standard_normal((K, C, 7, 7)) / np.sqrt(C * 49)).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    x = dev(rng.standard_normal((1, C, H, W)).astype(np.float32))
+    outs = []
+    for force in (4, 1):
+        L = Layer(lib, w, b, H, W)
+        guard = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")      # (allocated right behind the workspace)
+        L.frame([x], 0.1, relu=True, force=force)
+        assert int(guard.sum().item()) == 0
+        outs.append(L.out[0].clone())
+    assert torch.equal(outs[0], outs[1])
+    # the capacity the kernel was told about is the workspace's
+    cap = (lib.C.cbinfer_split_workspace_bytes(1, C, H, W, K, 7, 7) - 256) // (128 * 128 * 4)
+    assert cap == 512 and (H * W + 127) // 128 * 2 * 4 == 600
+
+
+@pytest.mark.parametrize("C,K,H,W", [(64, 256, 80, 120), (16, 64, 160, 240)])
+def test_split_hostile_data_accuracy_fullsize(lib, oracle, C, K, H, W, capsys):
+    """the two split-state layers of the bench network at FULL size on hostile data --
+    activations spanning 2^-20 ... 2^19 with ReLU-like sparsity, heavy-tailed weights -- against the double-accumulated
+    oracle, the f16-pair kernel and the library's exact-f32 MFMA kernel (CB_F32) and bf16x3 kernel (CB_F32S) side by
+    side, every pixel changed.  Reported: max |err| / sum|a||b| of each.  Asserted: the f16-pair form within
+    4 * 2^-22 * sum|a||b| + 2^-20 * sum|b| (the relative bound of 22-23 significant bits per operand plus the absolute
+    floor of terms dropped below the f16 normal range: activations below 2^-10 keep 11 bits), and no worse than 16x the
+    exact f32 chain's own error."""
+    from cbinfer_amd import conv2d_cg, _lib as L_
+    rng = np.random.default_rng(C * 7 + K)
+    mag_x = np.exp2(rng.uniform(-20, 19, (1, C, H, W)))
+    x = (rng.standard_normal((1, C, H, W)) * mag_x).astype(np.float32)
+    x = np.where(rng.uniform(size=x.shape) < 0.5, 0.0, np.abs(x)).astype(np.float32)      # ReLU-like: half zeros, >= 0
+    x = np.minimum(x, np.float32(2.0 ** 19.9))
+    w = (rng.standard_t(2.5, (K, C, 7, 7)) / np.sqrt(C * 49)).astype(np.float32)           # heavy tails
+    b = rng.standard_normal(K).astype(np.float32)
+    Ly = Layer(lib, w, b, H, W)
+    Ly.frame([dev(x)], 0.0)
+    assert int(Ly.flag.item()) == 0
+    idx = np.arange(H * W, dtype=np.int32)
+    assert np.array_equal(Ly.list(), idx)
+    X = oracle.genXMatrix(x, idx, (7, 7)).astype(np.float64)
+    wm = w.reshape(K, -1).astype(np.float64)
+    Y = (X @ wm.T + b[None, :].astype(np.float64)).T.reshape(K, H * W)
+    mag = (np.abs(X) @ np.abs(wm).T).T.reshape(K, H * W)
+    sumw = np.abs(wm).sum(axis=1)[:, None]
+    del X
+    res = {}
+    res["f16x2 split-state"] = np.abs(Ly.out[0].cpu().numpy().reshape(K, -1).astype(np.float64) - Y)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    idxd = torch.arange(H * W, dtype=torch.int32, device="cuda")
+    for name, arith in (("exact f32 MFMA", L_.CB_F32), ("bf16x3", L_.CB_F32S)):
+        out = torch.zeros(1, K, H, W, device="cuda")
+        conv2d_cg.convChanged(xd, idxd, wd, bd, out, withReLU=False, arith=arith)
+        torch.cuda.synchronize()
+        res[name] = np.abs(out.cpu().numpy().reshape(K, -1).astype(np.float64) - Y)
+    rel = {k: float((v / (mag + 1e-300)).max()) for k, v in res.items()}
+    with capsys.disabled():
+        print("\nhostile data %d->%d @%dx%d: max |err| / sum|a||b|: " % (C, K, H, W) +
+              ", ".join("%s %.3g (2^%.1f), max |err| %.3g" % (k, rel[k], np.log2(rel[k]), res[k].max())
+                        for k in res))
+    import json
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/hostile_accuracy_%d_%d.json" % (C, K), "w") as f:
+        json.dump({"layer": "%d->%d 7x7 @%dx%d" % (C, K, H, W), "rel_to_sum_abs": rel,
+                   "max_abs_err": {k: float(v.max()) for k, v in res.items()},
+                   "max_sum_abs": float(mag.max())}, f)
+    split = res["f16x2 split-state"]
+    assert np.all(split <= 4 * 2.0 ** -22 * mag + 2.0 ** -20 * sumw)
+    assert rel["f16x2 split-state"] <= 16 * max(rel["exact f32 MFMA"], 2.0 ** -24)

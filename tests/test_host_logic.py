@@ -31,8 +31,9 @@ def test_library_exports_every_declared_symbol():
     assert lib.cbinfer_split_supported(64, 256, 7, 7) == 1 and lib.cbinfer_split_supported(3, 16, 7, 7) == 0
     assert lib.cbinfer_split_state_bytes(64, 80, 120, 7, 7) == 4096 + (80 + 13) * (120 + 6) * 256
     assert lib.cbinfer_split_state_bytes(16, 160, 240, 7, 7) == 4096 + (160 + 13) * (240 + 7) * 64
-    assert lib.cbinfer_split_prepared_bytes(64, 256, 7, 7) == 98 * 8 * 4096 + 98 * 4
-    assert lib.cbinfer_split_prepared_bytes(16, 64, 7, 7) == 28 * 2 * 4096 + 28 * 4
+    # prepared weights: fragments, stage table (padded to 16 B), then the plain f32 filter bank (the exact path's)
+    assert lib.cbinfer_split_prepared_bytes(64, 256, 7, 7) == 98 * 8 * 4096 + 400 + 256 * 64 * 49 * 4
+    assert lib.cbinfer_split_prepared_bytes(16, 64, 7, 7) == 28 * 2 * 4096 + 112 + 64 * 16 * 49 * 4
     lib.cbinfer_mask_words.restype = ctypes.c_long
     assert lib.cbinfer_mask_words_per_row(480) == 8 and lib.cbinfer_mask_words(320, 480) == 2560
     assert lib.cbinfer_weights_kpad(8) == 32 and lib.cbinfer_weights_ckkpad(147, 0) == 160

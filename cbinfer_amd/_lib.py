@@ -77,6 +77,7 @@ _SIGNATURES = {
                                             _i, _vp, _i, _vp]),
     "cbinfer_max_pool2d": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cbinfer_pool_change_indexes": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "cbinfer_dilate_change_indexes": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "cbinfer_change_detection_fg": (_i, [_vp, _vp, _vp, _vp, _l, _f, _i, _vp]),
     "cbinfer_update_output_fg": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _vp]),
     "cbinfer_update_output_fg_list": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -145,7 +146,7 @@ def _load():
         fn = getattr(lib, name)     # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.cbinfer_abi_version() != 5:
+    if lib.cbinfer_abi_version() != 6:
         raise ImportError("cbinfer_amd: libcbinfer_hip.so ABI version mismatch")
     return lib
 

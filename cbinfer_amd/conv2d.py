@@ -26,8 +26,8 @@ import torch.nn.functional as F
 
 from . import _lib
 from ._lib import C, check, dtype_code, ptr, raw_stream, require_device, stream_ptr
-from .conv2d_cg import (ChangeIndexes, MaskChangeIndexes, changeDetection, changeIndexesExtr, genXMatrix,
-                        matrixMult, maxPool2d, newConvWorkspace, poolChangeIndexes, prepWeights, updateOutput)
+from .conv2d_cg import (ChangeIndexes, MaskChangeIndexes, changeDetection, changeIndexesExtr, dilateChangeIndexes,
+                        genXMatrix, matrixMult, maxPool2d, newConvWorkspace, poolChangeIndexes, prepWeights, updateOutput)
 from .conv2d_fg import cbconvFG, cbconvFG_deterministic
 
 
@@ -174,6 +174,12 @@ class CBConv2d(nn.Module):
         self.finegrained = False
         self.copyInput = True
         self.feedbackLoop = False
+        # Extension: a layer fed propagated change indexes skips its own change detection whatever its
+        # filter size and recomputes exactly the listed pixels (conv2d.py:180-190, :220) -- right for 1x1, short of
+        # the filter's reach for k > 1 (the reference's behaviour, kept as the default).  True: the incoming list is
+        # dilated by the filter support on the device first (cbinfer_dilate_change_indexes): every output pixel a
+        # listed input pixel reaches is recomputed, which is what the layer's own detection would have found.
+        self.dilatePropagatedIndexes = False
         self._setDefaultValues()
 
     # ---------------------------------------------------------------- state
@@ -208,7 +214,8 @@ class CBConv2d(nn.Module):
         for name, val in (('saveChangeMap', False), ('propChangeIndexes', False),
                           ('gatherComputationStats', False), ('finegrained', False),
                           ('copyInput', True), ('feedbackLoop', False), ('syncIndexes', False),
-                          ('deterministicFG', False), ('atomicFG', False), ('fgInPlace', False), ('exactF32', False), ('_work', None), ('_wprep', None),
+                          ('deterministicFG', False), ('atomicFG', False), ('fgInPlace', False), ('exactF32', False),
+                          ('dilatePropagatedIndexes', False), ('_work', None), ('_wprep', None),
                           ('_inputIsLiveState', False), ('_plan', None), ('_wrows', None), ('_lastIndexes', None)):
             if name not in self.__dict__:
                 self.__dict__[name] = val
@@ -673,6 +680,15 @@ class CBConv2d(nn.Module):
         assert input.dim() == 4 and input.size(0) == 1
         require_device(input)
         assert input.dtype == self.weight.dtype, "input and weights must have the same dtype"
+        if (changeIndexes is not None and self.dilatePropagatedIndexes and
+                (self.weight.size(2) > 1 or self.weight.size(3) > 1)):
+            size = (input.size(-2), input.size(-1))
+            if isinstance(changeIndexes, ChangeIndexes) and changeIndexes.size not in (None, size):
+                raise _lib.CBinferError("CBConv2d: the propagated change indexes address a %dx%d map, this layer "
+                                        "runs at %dx%d" % (changeIndexes.size + size))
+            dilated = dilateChangeIndexes(changeIndexes, size, (self.weight.size(2), self.weight.size(3)))
+            # (the reference-structured mode hands exact tensors on, conv2d_cg.py:207)
+            changeIndexes = dilated.tensor().clone() if self.syncIndexes else dilated
 
         # (re)allocate the state, +inf => the first frame is 100 % change (conv2d.py:192-199)
         if (self.prevInput.size() != input.size() or self.prevInput.dtype != input.dtype or
@@ -882,7 +898,7 @@ class CBConv2d(nn.Module):
     def _flags(self):
         return (self.threshold, self.feedbackLoop, self.copyInput, self.withReLU, self.propChangeIndexes,
                 self.syncIndexes, self.saveChangeMap, self.gatherComputationStats, self.finegrained,
-                self.atomicFG, self.fgInPlace, self.exactF32)
+                self.atomicFG, self.fgInPlace, self.exactF32, self.dilatePropagatedIndexes)
 
     def _make_plan(self, pooled, src, fn, args, srcSlot, result=None, rows=False, pmask=None):
         """Remember a finished sync-free call: fn(*args) with args[srcSlot] = source pointer, args[-1] =

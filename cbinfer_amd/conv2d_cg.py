@@ -352,6 +352,25 @@ def poolChangeIndexes(changeIndexes, inSize, outSize):
     return ChangeIndexes(out, ocount, (oH, oW))
 
 
+def dilateChangeIndexes(changeIndexes, size, filtSize):
+    """SURVEY 8f-4, consumers with k > 1: the list of OUTPUT pixels a kH x kW convolution must recompute when the
+    listed INPUT pixels of an H x W map changed -- their filter supports, ascending and duplicate-free -- as a
+    ChangeIndexes (device-side count, no host sync).  What changeDetection's dilation yields when every listed pixel
+    changed; the reference hands the undilated list on (conv2d.py:180-190)."""
+    idx, count, cap = _split_indexes(changeIndexes)
+    require_device(idx)
+    H, W = size
+    dev = idx.device
+    bits = torch.zeros(C.cbinfer_mask_words(H, W), dtype=torch.int64, device=dev)
+    out = torch.empty(H * W, dtype=torch.int32, device=dev)
+    ocount = torch.zeros(1, dtype=torch.int32, device=dev)
+    if cap > 0:
+        check(C.cbinfer_dilate_change_indexes(ptr(idx), min(cap, H * W), ptr(count), H, W, (filtSize[0] - 1) // 2,
+                                              (filtSize[1] - 1) // 2, ptr(bits), stream_ptr(idx)))
+        check(C.cbinfer_compact_bits(ptr(bits), W, H, ptr(out), ptr(ocount), None, None, stream_ptr(idx)))
+    return ChangeIndexes(out, ocount, (H, W))
+
+
 __all__ = ['ChangeIndexes', 'MaskChangeIndexes', 'convWorkspace', 'newConvWorkspace', 'changeDetection', 'changePropagation', 'changeIndexesExtr',
            'changeIndexesExtrAsync', 'genXMatrix', 'prepWeights', 'matrixMult', 'matrixMult_python',
-           'updateOutput', 'convChanged', 'maxPool2d', 'poolChangeIndexes', 'CBinferError']
+           'updateOutput', 'convChanged', 'maxPool2d', 'poolChangeIndexes', 'dilateChangeIndexes', 'CBinferError']

@@ -59,6 +59,38 @@ __global__ __launch_bounds__(256) void cb_pool_indexes_kernel(const int32_t* __r
     }
 }
 
+// SURVEY 8f-4, k > 1 consumers of propagated change indexes: every listed pixel (y, x) of an H x W map marks its
+// filter support -- rows y-kHH..y+kHH, columns x-kWH..x+kWH, clipped to the map -- in a row-padded bit mask; that is
+// the set of OUTPUT pixels of a kH x kW convolution the listed input pixels reach, i.e. what the layer's own change
+// detection (cbconv2d_cg_backend.cu:62-72) would mark if every listed pixel had changed.  One thread per (list entry,
+// row of the support); a run of set bits crosses at most one word boundary for kWH < 32.
+__global__ __launch_bounds__(256) void cb_dilate_indexes_kernel(const int32_t* __restrict__ list, int nHost,
+                                                               const int32_t* __restrict__ countDev, int H, int W,
+                                                               int kHH, int kWH, int wpr,
+                                                               unsigned long long* __restrict__ bits) {
+    const int N = countDev ? min(*countDev, nHost) : nHost;
+    const int rows = 2 * kHH + 1;
+    const long total = (long)N * rows;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / rows), r = (int)(i - (long)n * rows);
+        const int pos = list[n];
+        if ((unsigned)pos >= (unsigned)(H * W)) continue;      // (an out-of-map entry is dropped, as the contraction does)
+        const int y = pos / W, x = pos - y * W;
+        const int yy = y + r - kHH;
+        if (yy < 0 || yy >= H) continue;
+        const int x0 = max(x - kWH, 0), x1 = min(x + kWH, W - 1);
+        const int w0 = x0 >> 6, w1 = x1 >> 6;
+        const unsigned long long lo = ~0ull << (x0 & 63), hi = ~0ull >> (63 - (x1 & 63));
+        if (w0 == w1) {
+            atomicOr(bits + (long)yy * wpr + w0, lo & hi);
+        } else {
+            atomicOr(bits + (long)yy * wpr + w0, lo);
+            for (int w = w0 + 1; w < w1; ++w) atomicOr(bits + (long)yy * wpr + w, ~0ull);
+            atomicOr(bits + (long)yy * wpr + w1, hi);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void cb_detect_fg_kernel(const float* __restrict__ in,
                                                           const float* __restrict__ prev,
                                                           float* __restrict__ diffs,
@@ -153,6 +185,18 @@ int cbinfer_pool_change_indexes(const int32_t* changeIndexes, int numChanges, co
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(cb_pool_indexes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        changeIndexes, numChanges, countDev, iW, oH, oW, (oW + 63) / 64,
+                       (unsigned long long*)bitsOut);
+    return cb_launch_status();
+}
+
+int cbinfer_dilate_change_indexes(const int32_t* changeIndexes, int numChanges, const int32_t* countDev, int H, int W,
+                                  int kHHalf, int kWHalf, uint64_t* bitsOut, cbStream_t stream) {
+    CB_REQUIRE(changeIndexes && bitsOut && numChanges >= 0 && H > 0 && W > 0 && kHHalf >= 0 && kWHalf >= 0);
+    if (numChanges == 0) return CB_OK;
+    long blocks = ((long)numChanges * (2 * kHHalf + 1) + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(cb_dilate_indexes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       changeIndexes, numChanges, countDev, H, W, kHHalf, kWHalf, (W + 63) / 64,
                        (unsigned long long*)bitsOut);
     return cb_launch_status();
 }

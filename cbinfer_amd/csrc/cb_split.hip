@@ -4,7 +4,7 @@
 // cores eat.
 //
 //   state    beside prevInput [C,H,W] f32 (the module's buffer, unchanged), a pixel-major PRE-SPLIT copy
-//            S[Hp][Wp][C/16][hi|lo][16] of f16 pairs: x * 2^-4 = hi + lo * 2^-11 (22 significant bits; the
+//            S[Hp][Wp][C/16][hi|lo][16] of f16 pairs: x * 2^-4 = hi + lo * 2^-11 (22-23 significant bits; the
 //            detection kernel refreshes both at the changed pixels only -- feedback mode).  S has a zero
 //            border of the filter's half size, so a tap needs no bounds test, and a block of zero rows that
 //            list slots past the end point at.
@@ -16,9 +16,11 @@
 //            -- two x-adjacent taps), fetched by 8 lanes; an XOR swizzle of the 16-byte chunks makes the
 //            ds_read_b128 fragment reads of the [pixel][128 B] image conflict-free.
 //   product  v_mfma_f32_32x32x16_f16, three per 16 k: hi.hi into one accumulator, hi.lo + lo.hi into a
-//            second one (scaled 2^-11 at the end).  Error per product <= 3 * 2^-22 |a||b| -- within the
-//            bound tests/test_gpu_ops.py::test_split_contraction_accuracy holds the bf16x3 form to -- at
-//            HALF the matrix work and two thirds of the operand bytes of bf16x3.
+//            second one (scaled 2^-11 at the end).  Per product: two operand roundings of <= 2^-23 each and the
+//            dropped lo.lo term (<= 2^-24): <= 5 * 2^-24 |a||b| -- NARROWER than f32 operands (24 bits); measured
+//            beside the exact f32 chain in tests/test_gpu_split.py::test_split_hostile_data_accuracy_fullsize -- at
+//            HALF the matrix work and two thirds of the operand bytes of bf16x3.  A state value beyond the pair's
+//            range (|x| >= 2^20) raises the layer's flag and the contraction computes the layer in plain f32.
 //   ring     four (eight: the small tile alone on a CU) LDS stage buffers, all but one in flight, one s_barrier per stage, waits counted by
 //            hand (s_waitcnt vmcnt(N): the compiler does not track LDS-DMA against LDS reads).
 //   schedule persistent grid over (pixel tile, m-tile, k-slice) items of up to CBS_MAXSEQ independent sequences
@@ -61,7 +63,6 @@ typedef __attribute__((address_space(4))) const int cbs_const_int;
 #define CBS_XSCALE 0.0625f            // activations are stored as x * 2^-4 (range up to 2^20, see header)
 #define CBS_XSCALE_INV 16.f
 #define CBS_LO 2048.f                 // lo terms carry a factor 2^11
-#define CBS_F16_MINNORM 6.103515625e-05f
 #define CBS_F16_MAX 65504.f
 #define CBS_SPAD 4096                 // bytes in front of the records of a split state (see cbs_dma16: negative offsets)
 #define CBS_PRE_BIG 1536              // mask words of all sequences of a launch: 128-row tile
@@ -102,13 +103,16 @@ inline bool cbs_supported(int C, int K, int kH, int kW) {
 inline int cbs_bm(int K) { return K <= 64 ? 64 : 128; }
 inline int cbs_kp(int K) { const int bm = cbs_bm(K); return (K + bm - 1) / bm * bm; }
 
-// x (already scaled) = hi + lo / 2^11 with f16 hi, lo.  Terms that would be f16 subnormals are dropped to zero
-// BEFORE the residual is formed, so the result does not depend on whether the matrix unit flushes them.
+// x (already scaled) = hi + lo / 2^11 with f16 hi, lo, both rounded to nearest: |x - hi - lo / 2^11| <= 2^-23 |x|
+// (the residual of a round-to-nearest hi is at most half an ulp of hi, and lo keeps 11 bits of it).  f16 SUBNORMAL
+// terms are kept: v_mfma_f32_32x32x16_f16 honours subnormal operands on gfx950 (tools/micro/mfma_denorm.hip: every
+// product exact), so small values keep a relative bound down to 2^-24 * 2^-11 -- rounds 1-3 dropped such terms to zero
+// (not knowing what the matrix unit does with them) and carried an absolute floor of 2^-21 per activation instead.
 __device__ __forceinline__ void cbs_split(float x, _Float16& hi, _Float16& lo) {
-    const _Float16 h = fabsf(x) < CBS_F16_MINNORM ? (_Float16)0 : (_Float16)x;
+    const _Float16 h = (_Float16)x;
     const float r = (x - (float)h) * CBS_LO;          // exact difference, exact scaling
     hi = h;
-    lo = fabsf(r) < CBS_F16_MINNORM ? (_Float16)0 : (_Float16)r;
+    lo = (_Float16)r;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -54,7 +54,7 @@ typedef void* cbStream_t; /* hipStream_t */
  * (cbinfer_cbconv2d_forward_fg_masked and its parts).  4: split-state frame (cbinfer_split_*, several sequences
  * per launch), cbinfer_tail1x1_supported.  5: cbinfer_split_forward_tail (the 1x1 tail in the contraction's second
  * launch), cbinfer_split_tail_supported. */
-#define CBINFER_ABI_VERSION 5
+#define CBINFER_ABI_VERSION 6
 
 int cbinfer_abi_version(void);
 const char* cbinfer_status_string(int status);
@@ -273,6 +273,14 @@ int cbinfer_max_pool2d(const void* input, void* output, const int32_t* changeInd
  * duplicate-free list of changed OUTPUT pixels and its device-side count. */
 int cbinfer_pool_change_indexes(const int32_t* changeIndexes, int numChanges, const int32_t* countDev,
                                 int iW, int oH, int oW, uint64_t* bitsOut, cbStream_t stream);
+/* A CBConv2d fed propagated change indexes skips its own change detection whatever its filter size
+ * (conv2d.py:180-190, :220; __init__.py:68-77) and recomputes exactly the listed pixels -- right for 1x1, short of
+ * the filter's reach for k > 1.  This marks the filter support of every listed pixel (rows y +- kHHalf, columns
+ * x +- kWHalf, clipped) in a row-padded bit mask of the H x W map (bitsOut zero on entry; cbinfer_compact_bits makes
+ * the list): the output pixels the listed INPUT pixels reach -- what changeDetection's dilation
+ * (cbconv2d_cg_backend.cu:62-72) marks when every listed pixel changed.  CBConv2d.dilatePropagatedIndexes. */
+int cbinfer_dilate_change_indexes(const int32_t* changeIndexes, int numChanges, const int32_t* countDev, int H, int W,
+                                  int kHHalf, int kWHalf, uint64_t* bitsOut, cbStream_t stream);
 
 /* ---- a10-a12: fine-grained path ---------------------------------------------------------------
  * replaces changeDetectionFG, conv2d_fg.py:34-46 -> cbconv2d_fg_backend.cu:25-35 (kernel :7-23):

@@ -1348,3 +1348,77 @@ def test_module_range_flag_falls_back(pkg, oracle):
     assert not m._split_ok(torch.float32, H, W)
     pkg.clearMemory(m)
     assert m._split_ok(torch.float32, H, W) and not m.rangeExceeded()
+
+
+@pytest.mark.parametrize("sync", [False, True])
+@pytest.mark.parametrize("k", [3, 5])
+def test_propagated_indexes_into_a_kxk_consumer(pkg, oracle, sync, k):
+    """SURVEY 8f-4 remainder.  A CBConv2d fed propagated change indexes skips its own change
+    detection for ANY filter size in the reference (conv2d.py:180-190, :220; experiment-1 wiring,
+    sceneLabeling/modelLoader.py:41-44, __init__.py:68-77) and recomputes exactly the listed pixels with the state
+    update of :234-238.  (a) That behaviour, with a k x k consumer, against the oracle twin layer by layer (lists
+    bit-exact, states <= 1e-4), in both execution modes.  (b) The extension dilatePropagatedIndexes: the incoming list
+    dilated by the filter support on the device (cbinfer_dilate_change_indexes) == the oracle's changePropagation of
+    the producer's map, bit-exact incl. order, and with a threshold of 0 the network then equals the dense one -- which
+    the undilated reference behaviour does not."""
+    rng = np.random.default_rng(100 + k)
+    base = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, k, padding=k // 2), nn.ReLU(),
+                         nn.Conv2d(8, 4, 1)).cuda().eval()
+    H, W = 37, 70
+
+    def make(dilate):
+        cb = pkg.convert(base, threshold=0.0 if dilate else 0.05)
+        mods = [m for m in cb.children() if type(m) is pkg.CBConv2d]
+        assert len(mods) == 3
+        mods[0].propChangeIndexes = True          # the k x k layer takes its indexes from the first one ...
+        mods[1].propChangeIndexes = True          # ... and hands its own on to the 1x1 layer
+        mods[1].dilatePropagatedIndexes = dilate
+        pkg.setSyncIndexes(cb, sync)
+        return cb, mods
+
+    # (a) reference behaviour against the oracle twin
+    cb, mods = make(False)
+    twin = build_oracle_twin(oracle, cb, pkg)
+    x = rng.uniform(0, 1, (1, 3, H, W)).astype(np.float32)
+    with torch.no_grad():
+        for t in range(4):
+            x = x.copy()
+            for _ in range(3):
+                y0, x0 = rng.integers(0, H - 5), rng.integers(0, W - 5)
+                x[0, :, y0:y0 + 5, x0:x0 + 5] = rng.uniform(0, 1, (3, 5, 5))
+            h = torch.from_numpy(x).cuda()
+            for m, o in zip(cb.children(), twin):
+                h_in = _to_np(h)
+                h = m(h)
+                y_o = o.forward(h_in)
+                got = _to_np(h)
+                if isinstance(got, tuple):
+                    assert np.array_equal(got[2], y_o[2]), (t, type(m).__name__)
+                    got, y_o = got[1], y_o[1]
+                np.testing.assert_allclose(got, y_o, rtol=0, atol=FP32_TOL)
+            if t > 0:
+                assert 0 < mods[1].lastChangeIndexes().numel() < H * W
+    # (b) the dilated list, and the network it makes exact
+    cb, mods = make(True)
+    dense_err, undilated_err = 0.0, 0.0
+    cbu, _ = make(False)
+    for m in cbu.modules():
+        if type(m) is pkg.CBConv2d:
+            m.threshold = 0.0
+    with torch.no_grad():
+        for t in range(4):
+            x = x.copy()
+            y0, x0 = rng.integers(0, H - 6), rng.integers(0, W - 6)
+            x[0, :, y0:y0 + 6, x0:x0 + 6] = rng.uniform(0, 1, (3, 6, 6))
+            xin = torch.from_numpy(x).cuda()
+            y = cb(xin)
+            n_in = mods[0].lastChangeIndexes().tensor().cpu().numpy()
+            cm = np.zeros((1, 1, H, W), np.int8)
+            cm.reshape(-1)[n_in] = 1
+            want = oracle.changeIndexesExtr(oracle.changePropagation(cm.reshape(H, W), (k, k)))
+            assert np.array_equal(mods[1].lastChangeIndexes().tensor().cpu().numpy(), want), t
+            d = base(xin)
+            dense_err = max(dense_err, float((y - d).abs().max()))
+            undilated_err = max(undilated_err, float((cbu(xin) - d).abs().max()))
+    assert dense_err <= FP32_TOL
+    assert undilated_err > 1e-3          # (the reference's behaviour for k > 1: stale outputs around the changed pixels)

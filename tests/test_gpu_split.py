@@ -410,8 +410,9 @@ def test_split_range_flag_acts(lib, oracle, C, K, H, W, nSeq, tail):
             ref = os_[q].prevOutput.reshape(K, -1)[:, n].astype(np.float64)
             mag = _sum_abs(oracle, os_[q].prevInput, w, n, 7, 7).T + np.abs(b)[:, None]
             err = np.abs(out - ref)
-            # the f32 fma chain: far inside n_k * 2^-24 * sum|a||b|; where no huge value is in reach that is <= 1e-4
-            assert np.all(err <= 64 * 2.0 ** -24 * mag + 1e-30), (t, q, float((err / mag).max()))
+            # the f32 fma chain's own bound, n_k * 2^-24 * sum|a||b| (every add behind the huge term is rounded at ITS
+            # magnitude); where no huge value is in reach that is <= 1e-4
+            assert np.all(err <= C * 49 * 2.0 ** -24 * mag + 1e-30), (t, q, float((err / mag).max()))
             small = mag.max(axis=0) < 1e3
             assert small.any() and err[:, small].max() <= FP32_TOL, (t, q)
             if tail:
@@ -494,5 +495,5 @@ def test_split_hostile_data_accuracy_fullsize(lib, oracle, C, K, H, W, capsys):
                    "max_abs_err": {k: float(v.max()) for k, v in res.items()},
                    "max_sum_abs": float(mag.max())}, f)
     split = res["f16x2 split-state"]
-    assert np.all(split <= 4 * 2.0 ** -22 * mag + 2.0 ** -20 * sumw)
+    assert np.all(split <= 4 * 2.0 ** -22 * mag + 1e-30)
     assert rel["f16x2 split-state"] <= 16 * max(rel["exact f32 MFMA"], 2.0 ** -24)

@@ -1264,10 +1264,13 @@ def test_tail_folded_into_the_contraction_matches_its_own_launch(pkg, monkeypatc
                 assert torch.equal(ma.prevOutput, mb.prevOutput) and torch.equal(ma.prevInput, mb.prevInput), t
     assert all(done == fold for fold, done in seen)      # the folded form really ran, the other really did not
     # a pipeline cut between the layer and its tail, made AFTER frames have run through a folding call plan, takes
-    # effect at once
-    pkg.FramePipeline(folded, cut=len(kids) - 1)
+    # effect at once -- for as long as the pipeline lives (the switch is the pipeline's, not the net's)
+    pipe = pkg.FramePipeline(folded, cut=len(kids) - 1)
     y = run(folded, frames[-1], True)
     assert seen[-1] == (True, False) and torch.equal(y, run(own, frames[-1], False))
+    pipe.close()
+    y = run(folded, frames[-1], True)
+    assert seen[-1] == (True, True) and torch.equal(y, run(own, frames[-1], False))
 
 
 def test_module_leaves_and_reenters_the_split_path(pkg, oracle):

@@ -167,7 +167,7 @@ class FrameRunner(object):
 
 
 def build_bench_model(experiment=6, threshold=0.05, fuse_tail=True, fuse_pool=True, pool_clone=False,
-                      device="cuda"):
+                      device="cuda", fuse_detect=None):
     """(dense baseline, change-based test network) exactly as the headline measurement runs them: the
     reference's experiment preset (sceneLabeling/modelLoader.py:41-87) on the scene-labeling CNN, then the two
     execution-level fusions (pycbinfer.fuseTail1x1, fusePoolingIntoDetection) and CBPoolMax2d.cloneOutput.
@@ -181,6 +181,8 @@ def build_bench_model(experiment=6, threshold=0.05, fuse_tail=True, fuse_pool=Tr
             m.cloneOutput = bool(pool_clone)
     pycbinfer.fuseTail1x1(test, enabled=fuse_tail)
     pycbinfer.fusePoolingIntoDetection(test, enabled=fuse_pool)
+    # (a producer's launch doing the next layer's pooled detection: only where the pool is folded anyway)
+    pycbinfer.fuseDetectionIntoProducer(test, enabled=fuse_pool if fuse_detect is None else (fuse_detect and fuse_pool))
     return base, test
 
 
@@ -290,6 +292,7 @@ def inframe_layer_times(test, frames, start, reps=40):
             if (work is None or not work['selfc'] or not m.feedbackLoop or m.syncIndexes or isinstance(x, tuple)):
                 return None
             K, C, kH, kW = m.weight.shape
+            folded_detect = False
             lazy = x if isinstance(x, LazyPool) else None
             src = (lazy.source if lazy is not None else x).contiguous()
             Hh, Ww = (lazy.outSize[-2:] if lazy is not None else src.shape[-2:])
@@ -305,8 +308,14 @@ def inframe_layer_times(test, frames, start, reps=40):
                 q.input, q.producerMask = src.data_ptr(), ptr(pm)
                 pooled = int(lazy is not None)
                 pH, pW = (src.size(-2), src.size(-1)) if lazy is not None else (0, 0)
-                bracket(which, (mi, 'detect'), empty, sink, lambda: check(lib.cbinfer_split_detect(
-                    sp['seq'], 1, pooled, pH, pW, C, Hh, Ww, kH, kW, float(m.threshold), st)))
+                tokm = m._detect_token()
+                folded_detect = (lazy is not None and tokm is not None and
+                                 getattr(lazy.indexes, 'nextDetect', None) == tokm)
+                if folded_detect:       # (the producing layer's row-pair launch was this layer's detection)
+                    bracket(which, (mi, 'detect'), empty, sink, lambda: None)
+                else:
+                    bracket(which, (mi, 'detect'), empty, sink, lambda: check(lib.cbinfer_split_detect(
+                        sp['seq'], 1, pooled, pH, pW, C, Hh, Ww, kH, kW, float(m.threshold), st)))
                 tail = m._folded_tail(sp, Hh, Ww, src.device)
                 if tail is not None:
                     import ctypes
@@ -341,7 +350,18 @@ def inframe_layer_times(test, frames, start, reps=40):
                     det = lambda: check(dfn(ptr(src), ptr(m.prevInput), ptr(bits), Ww, Hh, C, (kH - 1) // 2,
                                             (kW - 1) // 2, float(m.threshold), 1, dt, st))
                 bracket(which, (mi, 'detect'), empty, sink, det)
-                if rows is not None:
+                pairs_tok = None
+                if rows is not None and mpath == 'rows' and lazy is None and m._pairs_ok(Hh, Ww):
+                    import ctypes
+                    nxt, pairs_tok = m._next_detect(Hh, Ww)
+                    nptr = ctypes.pointer(nxt) if nxt is not None else None
+                    conv = lambda: check(lib.cbinfer_conv_changed_rowpairs(
+                        ptr(m.prevInput), ptr(rows['bits']), ptr(rows['arrive']), ptr(rows['copy']),
+                        ptr(m._masked_call(mpath)[1]), ptr(m.bias.detach()), ptr(m.prevOutput), C, Hh, Ww, K, kH, kW,
+                        int(m.withReLU), nptr, st))
+                    kern = "cbp_rowpair_kernel (row pairs, persistent" + \
+                        ("; + the next layer's pooled change detection)" if nxt is not None else ")")
+                elif rows is not None:
                     kfn = lib.cbinfer_conv_changed_rows if mpath == 'rows' else lib.cbinfer_conv_changed_blocks
                     conv = lambda: check(kfn(ptr(m.prevInput), ptr(rows['bits']), ptr(rows['arrive']),
                                              ptr(rows['copy']), ptr(m._masked_call(mpath)[1]), ptr(m.bias.detach()),
@@ -357,8 +377,11 @@ def inframe_layer_times(test, frames, start, reps=40):
                 bracket(which, (mi, 'conv'), empty, sink, conv)
                 ci = (MaskChangeIndexes(rows['copy'], (Hh, Ww), work['idx'], work['count']) if rows is not None
                       else ChangeIndexes(work['idx'], work['count'], (Hh, Ww)))
+                if rows is not None:
+                    ci.nextDetect = pairs_tok
             info[mi] = dict(layer="conv %d->%d k%d @%dx%d" % (C, K, kH, Hh, Ww), conv_kernel=kern, count=ci,
-                            HW=Hh * Ww, C=C, K=K, k=kH * kW, s=s_el, pooled=lazy is not None)
+                            HW=Hh * Ww, C=C, K=K, k=kH * kW, s=s_el, pooled=lazy is not None,
+                            detect_folded=folded_detect)
             x = ('changeIndexes', m.prevOutput, ci) if m.propChangeIndexes else m.prevOutput
         return x
 
@@ -403,6 +426,7 @@ def inframe_layer_times(test, frames, start, reps=40):
         n = counts.get(mi, 0.0)
         rows.append(dict(layer=d['layer'], N=n, ratio=n / float(d['HW']), conv_kernel=d['conv_kernel'],
                          detect_ms=times[(mi, 'detect')] * 1e-3, detect_pooled=d['pooled'],
+                         detect_in_producer_launch=d['detect_folded'],
                          detect_bytes=(5 if d['pooled'] else 2) * d['C'] * d['HW'] * d['s'] + d['HW'] // 8,
                          conv_ms=times[(mi, 'conv')] * 1e-3, conv_flops=2.0 * n * d['C'] * d['k'] * d['K'],
                          conv_bytes=(n * d['C'] * d['k'] + d['K'] * d['C'] * d['k'] + n * d['K']) * d['s']))
@@ -494,7 +518,8 @@ def isolated_layers(test, ratio=0.10, reps=40):
         row = dict(layer="conv %d->%d k%d @%dx%d" % (C, K, kH, Hh, Ww), N=n, target_N=N, ratio=n / float(Hh * Ww),
                    pooled=pooled_next, kernels=("cbs_detect_kernel + cbs_conv_kernel" +
                                                 (" + cbs_reduce_tail_kernel" if tail is not None else "")) if split
-                   else "cb_detect_kernel + cb_rowconv_f32_kernel", call_us=pair_us,
+                   else ("cb_detect_kernel + cbp_rowpair_kernel" if (layer._plan and layer._plan.get('pairs'))
+                         else "cb_detect_kernel + cb_rowconv_f32_kernel"), call_us=pair_us,
                    detect_bytes=det_bytes, conv_flops=flops, conv_bytes=conv_bytes,
                    tail_flops=(2.0 * n * (tail.in_channels * tail.hidden_channels + tail.hidden_channels *
                                           tail.out_channels)) if tail is not None else 0.0)
@@ -562,6 +587,23 @@ def _bracketed_call(layer, feed, frame, which, sink):
             _chk(lib.cbinfer_split_conv_tail(seqs, nS, wp, bias, C_, Hh, Ww, K, kH, kW, scale, relu, ws, 0, a[18], st))
         else:
             _chk(lib.cbinfer_split_conv(seqs, nS, wp, bias, C_, Hh, Ww, K, kH, kW, scale, relu, ws, 0, st))
+        if which == "conv":
+            ev[1].record()
+    elif plan.get('pairs'):
+        a = list(plan['args'])
+        # cbinfer_cbconv2d_forward_rowpairs(input, state, out, bits, ctl, copy, wprep, bias, C, H, W, K, kH, kW, th, relu,
+        #                                   next, stream)
+        _, state, outp, bits, ctl, copy, wprep, bias, C_, Hh, Ww, K, kH, kW, th, relu, nxt = a[:17]
+        if which == "detect":
+            ev[0].record()
+        _chk(lib.cbinfer_change_detection_bits(frame.data_ptr(), state, bits, Ww, Hh, C_, (kH - 1) // 2, (kW - 1) // 2,
+                                               th, 1, 0, st))
+        if which == "detect":
+            ev[1].record()
+        else:
+            ev[0].record()
+        _chk(lib.cbinfer_conv_changed_rowpairs(state, bits, ctl, copy, wprep, bias, outp, C_, Hh, Ww, K, kH, kW, relu,
+                                               nxt, st))
         if which == "conv":
             ev[1].record()
     else:
@@ -1194,7 +1236,11 @@ def main():
             result["event_pair_ms"] = round(pair_us * 1e-3, 5)
             # the launches are parts of the frame: their in-frame durations -- each of which carries up to one
             # event pair of bracket overhead -- must fit into one step plus those overheads
-            n_meas = sum(("conv_ms" in r) * 2 + ("tail_ms" in r and "folded" not in r) for r in test_rows)
+            n_meas = sum(("conv_ms" in r) * (1 if r.get("detect_in_producer_launch") else 2) +
+                         ("tail_ms" in r and "folded" not in r) for r in test_rows)
+            for r in test_rows:
+                if r.get("detect_in_producer_launch"):
+                    r["detect_ms"] = 0.0          # (no launch: the bracket held nothing)
             tot = sum(r.get("conv_ms", 0.0) + r.get("detect_ms", 0.0) + r.get("tail_ms", 0.0) for r in test_rows)
             result["layers_check"] = {"sum_ms_in_frame": round(tot, 5), "measurements": n_meas,
                                       "ms_per_step": round(result["ms_per_step"], 5),
@@ -1207,7 +1253,8 @@ def main():
             meas = []
             for r in test_rows:
                 for k in ("detect_ms", "conv_ms", "tail_ms"):
-                    if k in r and not (k == "tail_ms" and "folded" in r):
+                    if k in r and not (k == "tail_ms" and "folded" in r) and \
+                            not (k == "detect_ms" and r.get("detect_in_producer_launch")):
                         meas.append((r, k))
             net = [max(r[k] * 1e3 - pair_us, 0.2) for r, k in meas]
             scale = result["ms_per_step"] * 1e3 / max(sum(net), 1e-9)

@@ -161,6 +161,25 @@ def fusePoolingIntoDetection(rootModule, enabled=True):
     return rootModule
 
 
+def fuseDetectionIntoProducer(rootModule, enabled=True):
+    """Execution-level fusion (no change of results): inside every nn.Sequential a run  CBConv2d (producer) ->
+    lazy CBPoolMax2d -> feedback-mode CBConv2d (consumer)  lets the PRODUCER's contraction launch also be the consumer's
+    pooled change detection when the producer runs on the row-pair kernel (cb_rowpair.hip: a workgroup owns whole 2x2
+    windows) and the consumer on the split-state kernels: one launch less per frame, and the freshly computed outputs
+    are compared with the consumer's state while they are still in the workgroup's LDS.  Decided per frame
+    (CBConv2d._next_detect): the first frames of a sequence, a frame after the consumer's state was restored or its
+    threshold changed run the separate detection.  Call after fusePoolingIntoDetection.  Returns rootModule."""
+    for seq in _sequentials(rootModule):
+        kids = list(seq.children())
+        for prod, pool, cons in zip(kids[:-2], kids[1:-1], kids[2:]):
+            if type(prod) == CBConv2d and type(pool) == CBPoolMax2d and type(cons) == CBConv2d:
+                if enabled and getattr(pool, 'lazy', False) and cons.feedbackLoop and prod.feedbackLoop:
+                    prod.__dict__['_fusedNext'] = (pool, cons)      # (plain references, not children)
+                else:
+                    prod.__dict__.pop('_fusedNext', None)
+    return rootModule
+
+
 _STATEFUL = (CBConv2d, CBPoolMax2d, CBTail1x1)
 
 
@@ -277,6 +296,7 @@ def tuneThresholdParameters(vidSeqReader, evalSequences, numFramesPerSeq, target
 
 
 __all__ = ['CBConv2d', 'CBPoolMax2d', 'CBTail1x1', 'ChangeIndexes', 'FramePipeline', 'SequenceBatch', 'convert', 'convertRecur', 'subsitute',
-           'mergeReLURecur', 'propChangeIndexesOf1x1', 'insertCBPooling', 'fusePoolingIntoDetection', 'fuseTail1x1',
+           'mergeReLURecur', 'propChangeIndexesOf1x1', 'insertCBPooling', 'fusePoolingIntoDetection',
+           'fuseDetectionIntoProducer', 'fuseTail1x1',
            'clearMemory', 'getStateTensors',
            'setSyncIndexes', 'tuneThresholdParameters']

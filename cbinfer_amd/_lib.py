@@ -42,6 +42,15 @@ class SplitTail(ctypes.Structure):
 
 
 _stp = ctypes.POINTER(SplitTail)
+
+
+class NextDetect(ctypes.Structure):
+    """cbNextDetect of include/cbinfer_hip.h: the next layer's detection state for the row-pair kernel."""
+    _fields_ = [("state", _vp), ("splitState", _vp), ("frameMasks", _vp), ("rangeFlag", _vp), ("H", _i), ("W", _i),
+                ("kH", _i), ("kW", _i), ("threshold", _f)]
+
+
+_ndp = ctypes.POINTER(NextDetect)
 _vpp = ctypes.POINTER(ctypes.c_void_p)
 
 _SIGNATURES = {
@@ -129,6 +138,10 @@ _SIGNATURES = {
                                         _stp, _vp]),
     "cbinfer_split_tail_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "cbinfer_split_conv_tail": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _stp, _vp]),
+    "cbinfer_rowpairs_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "cbinfer_conv_changed_rowpairs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ndp, _vp]),
+    "cbinfer_cbconv2d_forward_rowpairs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i,
+                                               _ndp, _vp]),
     "cbinfer_conv2d_fg_cpu": (None, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i]),
 }
 

@@ -278,6 +278,62 @@ class CBConv2d(nn.Module):
         fn = C.cbinfer_cbconv2d_forward_rows if path == 'rows' else C.cbinfer_cbconv2d_forward_blocks
         return fn, self._wrows[1]
 
+    def _pairs_ok(self, H, W):
+        """Does the row-segment frame of this layer run on the row-PAIR kernel (cb_rowpair.hip: persistent over the
+        non-empty (row pair, mask word) units, and able to do the next layer's pooled detection)?  Feedback mode, at
+        most 4 input and 16 output channels, 3x3 / 5x5 / 7x7; CBINFER_NO_ROWPAIRS=1 switches it off."""
+        K, Cin, kH, kW = self.weight.size()
+        return (self.feedbackLoop and os.environ.get('CBINFER_NO_ROWPAIRS', '0') != '1' and
+                bool(C.cbinfer_rowpairs_supported(Cin, K, kH, kW, H, W)))
+
+    def _detect_token(self):
+        """What a producer that ran this layer's pooled detection inside its own launch must have seen: the identity of
+        the state buffers and the threshold.  None while this layer cannot take such a detection (no split-state frame
+        yet, a state that was written from outside and must be re-split, a threshold that differs from last frame's)."""
+        sp = self._work.get('split') if self._work else None
+        if sp is None or sp['stateKey'] is None:
+            return None
+        prev = self._buffers['prevInput']
+        if sp['stateKey'] != (prev.data_ptr(), prev._version):
+            return None
+        th = float(self.threshold)
+        if self.__dict__.get('_pmaskThreshold') != th or self.__dict__.get('_rangeFallback'):
+            return None
+        return (id(self), prev.data_ptr(), sp['S'].data_ptr(), sp['bits'].data_ptr(), th)
+
+    def _detect_token_with(self, sp, prev):
+        return (id(self), prev.data_ptr(), sp['S'].data_ptr(), sp['bits'].data_ptr(), float(self.threshold))
+
+    def _next_detect(self, H, W):
+        """(cbNextDetect, token) if this layer's row-pair launch can also be the pooled change detection of the layer
+        behind the following CBPoolMax2d (pycbinfer.fuseDetectionIntoProducer), else (None, None)."""
+        link = self.__dict__.get('_fusedNext')
+        if (link is None or self.__dict__.get('_noNextFold') or os.environ.get('CBINFER_NO_NEXTFOLD', '0') == '1'):
+            return None, None
+        pool, cons = link
+        K = self.weight.size(0)
+        if (not getattr(pool, 'lazy', False) or pool.propChangeIndexes or type(cons) is not CBConv2d or
+                cons.in_channels != K or not cons.feedbackLoop or cons.syncIndexes or cons.saveChangeMap or
+                cons.gatherComputationStats or cons.finegrained or cons.weight.dtype != torch.float32):
+            return None, None
+        H2, W2 = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if pool.ceil_mode else (H // 2, W // 2)
+        prev2 = cons._buffers.get('prevInput')
+        if (prev2 is None or tuple(prev2.shape) != (1, K, H2, W2) or prev2.device != self.weight.device or
+                not cons._split_ok(torch.float32, H2, W2)):
+            return None, None
+        tok = cons._detect_token()
+        if tok is None:
+            return None, None
+        nd = self.__dict__.get('_nextStruct')
+        if nd is None or nd[0] != tok:
+            sp = cons._work['split']
+            st = _lib.NextDetect()
+            st.state, st.splitState, st.frameMasks = prev2.data_ptr(), sp['S'].data_ptr(), sp['bits'].data_ptr()
+            st.rangeFlag, st.H, st.W = sp['flag'].data_ptr(), H2, W2
+            st.kH, st.kW, st.threshold = cons.weight.size(2), cons.weight.size(3), float(cons.threshold)
+            nd = self.__dict__['_nextStruct'] = (tok, st)
+        return nd[1], tok
+
     def _rows_workspace(self, work, H, W, dev):
         if work['rows'] is None:
             words = C.cbinfer_mask_words(H, W)
@@ -447,13 +503,22 @@ class CBConv2d(nn.Module):
                 float(self.threshold), float(scale), int(bool(self.withReLU)), ptr(sp['ws'])]
         # the fused 1x1 tail behind this layer (pycbinfer.fuseTail1x1) rides in the contraction's second launch
         tail = self._folded_tail(sp, H, W, dev)
+        # the contraction alone (cbinfer_split_conv[_tail]): for the frames whose detection the PRODUCING layer's
+        # launch has done already (cb_rowpair.hip; its change indexes carry this layer's token)
+        cargs = [sp['seq'], 1, ptr(wp), ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(scale),
+                 int(bool(self.withReLU)), ptr(sp['ws']), 0]
         if tail is not None:
-            fn = C.cbinfer_split_forward_tail
+            fn, cfn = C.cbinfer_split_forward_tail, C.cbinfer_split_conv_tail
             args += [0, ctypes.pointer(sp['tail']), stream_ptr(src)]
+            cargs += [ctypes.pointer(sp['tail']), stream_ptr(src)]
         else:
-            fn = C.cbinfer_split_forward
+            fn, cfn = C.cbinfer_split_forward, C.cbinfer_split_conv
             args += [stream_ptr(src)]
-        check(fn(*args))
+            cargs += [stream_ptr(src)]
+        myTok = None if rebuilt else self._detect_token_with(sp, prev)
+        done = (lazy is not None and myTok is not None and
+                getattr(lazy.indexes, 'nextDetect', None) == myTok)
+        check(cfn(*cargs) if done else fn(*args))
         self._poll_range(sp)
         self.__dict__['_ranSplit'] = True
         self._inputIsLiveState = False
@@ -467,7 +532,10 @@ class CBConv2d(nn.Module):
                 flags=self._flags(), w=(w.data_ptr(), w._version), b=(b.data_ptr(), b._version),
                 state=(self._buffers['prevInput'].data_ptr(), self._buffers['prevOutput'].data_ptr()),
                 stateVersion=prev._version, stream=args[-1], work=work, args=args, seq=q, pmask=ptr(pmask),
-                indexes=self._lastIndexes, fn=fn, tail=tail, tailKey=tail._fold_key() if tail is not None else None)
+                indexes=self._lastIndexes, fn=fn, tail=tail, tailKey=tail._fold_key() if tail is not None else None,
+                convFn=cfn, convArgs=cargs,
+                detectToken=(id(self), prev.data_ptr(), sp['S'].data_ptr(), sp['bits'].data_ptr(),
+                             float(self.threshold)))
         if self.propChangeIndexes:
             return 'changeIndexes', self.prevOutput, self._lastIndexes
         return self.prevOutput
@@ -500,7 +568,10 @@ class CBConv2d(nn.Module):
                                          plan['tail']._fold_key() != plan['tailKey']):
             return None
         plan['seq'].input = src.data_ptr()
-        status = plan['fn'](*plan['args'])
+        if plan['pooled'] and getattr(inp.indexes, 'nextDetect', None) == plan['detectToken']:
+            status = plan['convFn'](*plan['convArgs'])      # (the producing layer's launch was this frame's detection)
+        else:
+            status = plan['fn'](*plan['args'])
         if status != 0:
             check(status)
         self._poll_range(plan['work']['split'])
@@ -817,7 +888,26 @@ class CBConv2d(nn.Module):
             self._forward_split(input, None, work)
             return self._lastIndexes
         path = self._rows_path(input.dtype, H, W) if (not have and work['selfc']) else None
-        if path:
+        if path == 'rows' and self._pairs_ok(H, W):
+            # the row-pair kernel: persistent over the non-empty units, and -- with a split-state consumer behind a lazy
+            # pool (pycbinfer.fuseDetectionIntoProducer) -- that consumer's pooled change detection in the same launch
+            rows = self._rows_workspace(work, H, W, input.device)
+            _, wprep = self._masked_call(path)
+            nxt, tok = self._next_detect(H, W)
+            fn = C.cbinfer_cbconv2d_forward_rowpairs
+            args = (ptr(input), ptr(prev), ptr(self.prevOutput), ptr(rows['bits']), ptr(rows['arrive']),
+                    ptr(rows['copy']), ptr(wprep), ptr(self.bias.detach()), Cin, H, W, K, kH, kW,
+                    float(self.threshold), int(bool(self.withReLU)),
+                    ctypes.pointer(nxt) if nxt is not None else None, stream_ptr(input))
+            check(fn(*args))
+            result = MaskChangeIndexes(rows['copy'], (H, W), work['idx'], work['count'])
+            result.nextDetect = tok
+            if not self._inputIsLiveState:
+                self._make_plan(False, input, fn, args, 0, rows=True)
+                if self._plan is not None:
+                    self._plan['pairs'], self._plan['nextToken'], self._plan['keep'] = True, tok, nxt
+            cap = 0      # (done)
+        elif path:
             rows = self._rows_workspace(work, H, W, input.device)
             fn, wprep = self._masked_call(path)
             args = (ptr(input), None, 0, 0, None, ptr(prev), ptr(self.prevOutput), ptr(rows['bits']),
@@ -941,6 +1031,11 @@ class CBConv2d(nn.Module):
                 (bufs['prevInput'].data_ptr(), bufs['prevOutput'].data_ptr()) != plan['state'] or
                 self._work is not plan['work'] or raw_stream(src.device.index) != plan['stream']):
             return None
+        if plan.get('pairs'):
+            # the next layer's detection rides in this launch: the plan holds only while that layer's state is the one
+            # the plan was made for (and starts to fold as soon as it can)
+            if self._next_detect(plan['shape'][-2], plan['shape'][-1])[1] != plan['nextToken']:
+                return None
         args = plan['args']
         args[plan['srcSlot']] = src.data_ptr()
         status = plan['fn'](*args)
@@ -960,6 +1055,7 @@ class CBConv2d(nn.Module):
             work = plan['work']
             self._lastIndexes = MaskChangeIndexes(work['rows']['copy'], work['key'][:2], work['idx'],
                                                   work['count'])
+            self._lastIndexes.nextDetect = plan.get('nextToken')
         else:
             self._lastIndexes = plan['indexes']
         if self.propChangeIndexes:

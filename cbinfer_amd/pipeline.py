@@ -35,6 +35,14 @@ class FramePipeline(object):
             if tail is not None and any(tail is k for k in self.stage2) and not m.__dict__.get('_noTailFold'):
                 m.__dict__['_noTailFold'] = True
                 self._unfolded.append(m)
+        # likewise a producer whose launch would do the pooled change detection of a stage-2 layer
+        # (pycbinfer.fuseDetectionIntoProducer): stage 2 receives a densely pooled private tensor and detects itself
+        self._nofold = []
+        for m in self.stage1:
+            link = m.__dict__.get('_fusedNext')
+            if link is not None and any(link[1] is k for k in self.stage2) and not m.__dict__.get('_noNextFold'):
+                m.__dict__['_noNextFold'] = True
+                self._nofold.append(m)
         self.side = side_stream
         self._done = None       # event: stage 2 of the most recently submitted frame
 
@@ -44,6 +52,9 @@ class FramePipeline(object):
         for m in self._unfolded:
             m.__dict__.pop('_noTailFold', None)
         self._unfolded = []
+        for m in getattr(self, '_nofold', []):
+            m.__dict__.pop('_noNextFold', None)
+        self._nofold = []
 
     def __del__(self):
         try:

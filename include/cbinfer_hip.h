@@ -457,6 +457,38 @@ int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int pooled, int
                                float weightScale, int relu, void* workspace, int forceSplit, const cbSplitTail* tail,
                                cbStream_t stream);
 
+/* ---- a5..a8 fused for a layer of few channels, ROW-PAIR form, with the NEXT layer's pooled change detection folded
+ * in (round 4).  Replaces, per frame, the launcher sequence genXMatrix -> matmul -> updateOutput
+ * (cbconv2d_cg_backend.cu:138-197, conv2d_cg.py:342-349) of a feedback-mode CBConv2d with at most 4 input and 16
+ * output channels AND -- when `next` names the split-state layer (cbinfer_split_*) behind a 2x2/stride-2 max pool --
+ * that layer's CBPoolMax2d (conv2d.py:49-78) + changeDetection with updateInputState (cbconv2d_cg_backend.cu:40-81):
+ * a workgroup owns a row PAIR of a 64-pixel mask word, i.e. whole pooling windows, so it compares the pooled values
+ * of the windows it rewrote with the next layer's state, refreshes that state (and its pre-split copy) and ORs the
+ * dilated changes into the next layer's frame mask itself.  The next layer then runs cbinfer_split_conv[_tail] WITHOUT
+ * cbinfer_split_detect.  Results are those of the separate launches (same predicate, same refresh, same mask); a
+ * window none of whose pixels changed is skipped exactly as the producer-mask shortcut of cbinfer_split_detect skips
+ * it, so the caller must fall back to the separate detection for one frame whenever that shortcut is not valid (fresh
+ * or restored next-layer state, changed next-layer threshold).
+ *   bits / maskCopy : as for cbinfer_conv_changed_rows; ctl: one int32, zero between launches (arrival counter)
+ *   prepared        : cbinfer_rowconv_prep_weights
+ *   next            : may be NULL (or next->state NULL): no folding */
+typedef struct {
+    float* state;             /* the next layer's prevInput [K, H, W] */
+    void* splitState;         /* its cbinfer_split_state_bytes(K, H, W, kH, kW) buffer */
+    uint64_t* frameMasks;     /* its frame mask (cbSplitSeq.frameMasks) */
+    int32_t* rangeFlag;       /* may be NULL */
+    int H, W, kH, kW;         /* the next layer's map size (behind the pool) and filter */
+    float threshold;
+} cbNextDetect;
+int cbinfer_rowpairs_supported(int C, int K, int kH, int kW, int H, int W);
+int cbinfer_conv_changed_rowpairs(const float* state, uint64_t* bits, int32_t* ctl, uint64_t* maskCopy,
+                                  const void* prepared, const float* bias, float* output, int C, int H, int W, int K,
+                                  int kH, int kW, int relu, const cbNextDetect* next, cbStream_t stream);
+int cbinfer_cbconv2d_forward_rowpairs(const float* input, float* prevInput, float* prevOutput, uint64_t* bits,
+                                      int32_t* ctl, uint64_t* maskCopy, const void* prepared, const float* bias, int C,
+                                      int H, int W, int K, int kH, int kW, float threshold, int relu,
+                                      const cbNextDetect* next, cbStream_t stream);
+
 /* replaces conv2d_fg_cpu, cbconv2d_fg_backend.cu:81-112: HOST pointers, host code, race-free. */
 void cbinfer_conv2d_fg_cpu(const float* input, const float* prevInput, float* output,
                            const float* weight, float threshold, int no, int ni, int h, int w,

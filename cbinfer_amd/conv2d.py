@@ -533,7 +533,7 @@ class CBConv2d(nn.Module):
                 state=(self._buffers['prevInput'].data_ptr(), self._buffers['prevOutput'].data_ptr()),
                 stateVersion=prev._version, stream=args[-1], work=work, args=args, seq=q, pmask=ptr(pmask),
                 indexes=self._lastIndexes, fn=fn, tail=tail, tailKey=tail._fold_key() if tail is not None else None,
-                convFn=cfn, convArgs=cargs,
+                convFn=cfn, convArgs=cargs, tailBlocked=bool(self.__dict__.get('_noTailFold')),
                 detectToken=(id(self), prev.data_ptr(), sp['S'].data_ptr(), sp['bits'].data_ptr(),
                              float(self.threshold)))
         if self.propChangeIndexes:
@@ -562,6 +562,8 @@ class CBConv2d(nn.Module):
                 prev._version != plan['stateVersion'] or
                 self._work is not plan['work'] or raw_stream(src.device.index) != plan['stream']):
             return None
+        if plan['tailBlocked'] != bool(self.__dict__.get('_noTailFold')):
+            return None      # (a FramePipeline took the tail's folding away, or gave it back)
         if plan['tail'] is not None and (self.__dict__.get('_fusedTail') is not plan['tail'] or
                                          self.__dict__.get('_noTailFold') or
                                          os.environ.get('CBINFER_NO_TAILFOLD', '0') == '1' or

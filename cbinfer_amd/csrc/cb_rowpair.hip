@@ -11,13 +11,16 @@
 //   unit      one workgroup iteration = one ROW PAIR x one 64-pixel mask word: output rows 2yo, 2yo+1, columns
 //             64 tx .. 64 tx + 63 -- i.e. exactly the 2x2 windows of the 32 pooled pixels (yo, 32 tx ..): the unit's
 //             workgroup owns every window pixel, so the pooled detection needs nobody else's results.
-//   schedule  a persistent grid (two workgroups per CU); every workgroup copies the layer's change mask into LDS,
-//             makes the ORDERED list of non-empty units with one scan and takes units blockIdx.x, + gridDim.x, ...
-//             The last workgroup out zeroes the mask for the next frame (arrival counter; nobody waits).
+//   schedule  a persistent grid of three four-wave workgroups per CU; workgroup b looks at the candidate units b,
+//             b + grid, b + 2 grid, ... (at most four; neighbouring units -- a changed block -- land on different
+//             workgroups), reads their two mask words in one burst and works through the non-empty ones.  (Round 4's
+//             first form let every workgroup copy the whole mask into LDS and scan it for an ordered list of the
+//             non-empty units: 13 us for 170 units, nearly all of it that prologue.)  The last workgroup out zeroes
+//             the mask for the next frame (arrival counter; nobody waits).
 //   gather    the (kH + 1) x (64 + kW - 1) input rows under the pair are staged once per channel in LDS (coalesced
 //             row loads); every B operand of every tap is a ds_read_b32 at `lane base + immediate tap offset`.
-//   product   v_mfma_f32_16x16x4_f32 (the exact f32 fma chain), one 16-pixel tile per wave, eight waves: up to
-//             four tiles per row; the weights in MFMA fragment order straight from L2 into registers
+//   product   v_mfma_f32_16x16x4_f32 (the exact f32 fma chain), two 16-pixel tiles per wave (four independent
+//             accumulation chains), two waves per row; the weights in MFMA fragment order straight from L2 into registers
 //             (cb_rowconv.hip's prepared layout).
 //   epilogue  bias / ReLU, scatter to prevOutput AND into an LDS tile [2][16][64] of the pair's outputs that was
 //             pre-filled with the old outputs; then, per pooled pixel whose window holds a changed pixel: 2x2 max,
@@ -34,9 +37,10 @@ namespace cbp {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 using cbs::halfx8;
 
-#define CBP_NT 512
-#define CBP_NW 8
-#define CBP_MAXWORDS 4096           // mask words of the layer (kept in LDS: 32 KB)
+#define CBP_NT 256
+#define CBP_NW 4
+#define CBP_MAXCAND 4               // candidate units per workgroup: the grid is at least units / 4
+#define CBP_MAXWORDS (1 << 20)
 
 struct PairNext {
     float* state;                   // the next layer's prevInput [K, H2, W2]; null: no folding
@@ -80,61 +84,51 @@ __device__ __forceinline__ int cbp_nth_bit(unsigned long long w, int r) {
 }
 
 template <int KH, int KW>
-__global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
+__global__ __launch_bounds__(CBP_NT, 3) void cbp_rowpair_kernel(PairParams p) {
     cb_touch_kernarg<sizeof(PairParams)>();
     constexpr int RS = 64 + KW - 1, PR = KH + 1, CS = cbp_plane_stride(KH, KW), S = KH * KW, G = (S + 3) / 4;
     constexpr int PH = (KH - 1) / 2, PW = (KW - 1) / 2;
-    __shared__ unsigned long long s_mask[CBP_MAXWORDS];
-    __shared__ unsigned short s_units[CBP_MAXWORDS];
     __shared__ float s_patch[4 * CS];
+    __shared__ __attribute__((aligned(16))) float s_w[G * 256];     // the weights, MFMA fragment order: [group][lane][4]
     __shared__ float s_out[2 * 16 * 64];          // [row][channel][x]: the pair's outputs after this frame
     __shared__ float s_P[16 * 33];                // pooled values [channel][xo]
     __shared__ unsigned s_chg[CBP_NW];
-    __shared__ int s_wsum[CBP_NW];
     __shared__ int s_last;
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int MW = p.MW, wpr = p.wpr, H = p.H, W = p.W, HW = H * W;
     const bool fold = p.next.state != nullptr;
-
-    // ---- the mask into LDS, a copy of it to its fixed address, the ordered list of non-empty units ----------------
-    for (int i = t; i < MW; i += CBP_NT) s_mask[i] = p.bits[i];
-    __syncthreads();
-    if (p.maskCopy)
-        for (int i = blockIdx.x * CBP_NT + t; i < MW; i += gridDim.x * CBP_NT) p.maskCopy[i] = s_mask[i];
     const int units = p.units;
-    const int CHU = (units + CBP_NT - 1) / CBP_NT, u0 = t * CHU;
-    int cnt = 0;
-    for (int u = u0; u < min(u0 + CHU, units); ++u) {
-        const int yo = u / wpr, tx = u - yo * wpr, ya = 2 * yo;
-        const unsigned long long w = s_mask[ya * wpr + tx] | (ya + 1 < H ? s_mask[(ya + 1) * wpr + tx] : 0ull);
-        cnt += w != 0ull;
-    }
-    int incl = cnt;
+
+    // ---- this workgroup's candidate units: blockIdx.x, + gridDim.x, ... (neighbouring units go to different
+    //      workgroups); their mask words are requested in one burst and are the same for every lane ---------------
+    unsigned long long cwA[CBP_MAXCAND], cwB[CBP_MAXCAND];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
+    for (int k = 0; k < CBP_MAXCAND; ++k) {
+        const int u = blockIdx.x + k * gridDim.x;
+        const int uc = min(u, units - 1);
+        const int yo = uc / wpr, tx = uc - yo * wpr, ya = 2 * yo;
+        const unsigned long long a0 = p.bits[ya * wpr + tx];
+        const unsigned long long b0 = p.bits[min(ya + 1, H - 1) * wpr + tx];
+        cwA[k] = u < units ? a0 : 0ull;
+        cwB[k] = (u < units && ya + 1 < H) ? b0 : 0ull;
     }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    int base = 0, nUnits = 0;
+    auto uniform64 = [](unsigned long long v) -> unsigned long long {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    bool any = false;
 #pragma unroll
-    for (int w = 0; w < CBP_NW; ++w) {
-        const int v = s_wsum[w];
-        base += w < wave ? v : 0;
-        nUnits += v;
-    }
-    nUnits = __builtin_amdgcn_readfirstlane(nUnits);
-    {
-        int pos = base + incl - cnt;
-        for (int u = u0; u < min(u0 + CHU, units); ++u) {
+    for (int k = 0; k < CBP_MAXCAND; ++k) {
+        cwA[k] = uniform64(cwA[k]), cwB[k] = uniform64(cwB[k]);
+        any |= (cwA[k] | cwB[k]) != 0ull;
+        const int u = blockIdx.x + k * gridDim.x;
+        if (p.maskCopy && u < units && t == 0) {      // this frame's mask stays available at its fixed address
             const int yo = u / wpr, tx = u - yo * wpr, ya = 2 * yo;
-            const unsigned long long w = s_mask[ya * wpr + tx] | (ya + 1 < H ? s_mask[(ya + 1) * wpr + tx] : 0ull);
-            if (w != 0ull) s_units[pos++] = (unsigned short)u;
+            p.maskCopy[ya * wpr + tx] = cwA[k];
+            if (ya + 1 < H) p.maskCopy[(ya + 1) * wpr + tx] = cwB[k];
         }
     }
-    __syncthreads();
 
     // ---- per-wave constants: the weights (fragment order, every wave the same 16 output channels) and the bias -----
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, G * 1024, 0x00020000);
@@ -142,98 +136,127 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
         __builtin_amdgcn_make_buffer_rsrc((void*)p.state, 0, (int)min((long)p.C * HW * 4, (long)0x7fffffff), 0x00020000);
     const __amdgpu_buffer_rsrc_t orsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)min((long)p.K * HW * 4, (long)0x7fffffff), 0x00020000);
-    floatx4 a[G];
+    // (the weights go through LDS, 16 bytes per lane and group of four k-steps, read back as fragments inside the
+    //  k-loop: held in registers -- 52 of them for 7x7 -- they pushed the kernel past the 128 registers that four
+    //  workgroups per CU allow)
     float bv[4];
-    if (blockIdx.x < (unsigned)nUnits) {
+    if (any) {
+        constexpr int WPT = (G * 64 + CBP_NT - 1) / CBP_NT;
+        floatx4 wv[WPT];
 #pragma unroll
-        for (int g = 0; g < G; ++g)
-            a[g] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, g * 1024, 0));
+        for (int i = 0; i < WPT; ++i)
+            wv[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                    wrsrc, min(t + CBP_NT * i, G * 64 - 1) * 16, 0, 0));
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[r] = p.bias ? p.bias[min(4 * (lane >> 4) + r, p.K - 1)] : 0.f;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            if (t + CBP_NT * i < G * 64) *(floatx4*)(s_w + (t + CBP_NT * i) * 4) = wv[i];
     }
+    // (visible to every wave behind the first barrier of the unit loop)
 
-    for (int it = blockIdx.x; it < nUnits; it += gridDim.x) {
-        const int u = s_units[it];
+#pragma unroll 1
+    for (int k = 0; k < CBP_MAXCAND; ++k) {
+        unsigned long long wordA = cwA[0], wordB = cwB[0];
+#pragma unroll
+        for (int j = 1; j < CBP_MAXCAND; ++j)
+            if (j == k) wordA = cwA[j], wordB = cwB[j];
+        if ((wordA | wordB) == 0ull) continue;      // (uniform)
+        const int u = blockIdx.x + k * gridDim.x;
         const int yo = u / wpr, tx = u - yo * wpr, ya = 2 * yo;
         const bool hasB = ya + 1 < H;
-        const unsigned long long wordA = s_mask[ya * wpr + tx], wordB = hasB ? s_mask[(ya + 1) * wpr + tx] : 0ull;
         // ---- requests, all in one burst: the patch, the pair's old outputs, the next layer's state ----------------
         constexpr int PTOT = 4 * PR * RS, PPT = (PTOT + CBP_NT - 1) / CBP_NT;
         float pv[PPT];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int e = t + CBP_NT * k;
+        for (int i = 0; i < PPT; ++i) {
+            const int e = t + CBP_NT * i;
             const int r = e / RS, j = e - r * RS;          // (compile-time divisor)
             const int c = r / PR, pr = r - c * PR;
             const int yy = ya + pr - PH, xx = tx * 64 - PW + j;
             const bool ok = e < PTOT && c < p.C && yy >= 0 && yy < H && xx >= 0 && xx < W;
             // (an invalid element gets an out-of-range offset: the buffer load returns 0 for it)
-            pv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                   srsrc, ok ? ((c * H + yy) * W + xx) * 4 : (1 << 30), 0, 0));
         }
-        float ov[4];
-        float s2 = 0.f;
-        const int c2 = t >> 5, xo = t & 31, gx = tx * 32 + xo;
-        const bool valid2 = fold && yo < p.next.H2 && gx < p.next.W2 && c2 < p.K;
+        constexpr int OPT = 2 * 16 * 64 / CBP_NT;       // old outputs per thread
+        float ov[OPT];
+        float s2[2] = {0.f, 0.f};
+        const int c2 = t >> 5, xo = t & 31, gx = tx * 32 + xo;        // pooled pixel xo, channels c2 and c2 + 8
+        const bool valid2 = fold && yo < p.next.H2 && gx < p.next.W2;
         const long H2W2 = fold ? (long)p.next.H2 * p.next.W2 : 0;
         if (fold) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = t + CBP_NT * k;
+            for (int i = 0; i < OPT; ++i) {
+                const int e = t + CBP_NT * i;
                 const int x = e & 63, m = (e >> 6) & 15, r = e >> 10;
                 const int yy = ya + r, xx = tx * 64 + x;
                 const bool ok = yy < H && xx < W && m < p.K;
-                ov[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                ov[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                       orsrc, ok ? (m * HW + yy * W + xx) * 4 : (1 << 30), 0, 0));
             }
-            // (clamped address, predicated use)
-            s2 = p.next.state[(long)min(c2, p.K - 1) * H2W2 + (long)min(yo, p.next.H2 - 1) * p.next.W2 +
-                              min(gx, p.next.W2 - 1)];
+            // (clamped addresses, predicated uses)
+            const long pos2 = (long)min(yo, p.next.H2 - 1) * p.next.W2 + min(gx, p.next.W2 - 1);
+            s2[0] = p.next.state[(long)min(c2, p.K - 1) * H2W2 + pos2];
+            s2[1] = p.next.state[(long)min(c2 + 8, p.K - 1) * H2W2 + pos2];
         }
         __syncthreads();        // (the previous unit's readers of s_patch / s_out / s_P are done)
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int e = t + CBP_NT * k;
+        for (int i = 0; i < PPT; ++i) {
+            const int e = t + CBP_NT * i;
             const int r = e / RS, j = e - r * RS;
             const int c = r / PR, pr = r - c * PR;
-            if (e < PTOT) s_patch[c * CS + pr * RS + j] = pv[k];
+            if (e < PTOT) s_patch[c * CS + pr * RS + j] = pv[i];
         }
         if (fold) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s_out[t + CBP_NT * k] = ov[k];
+            for (int i = 0; i < OPT; ++i) s_out[t + CBP_NT * i] = ov[i];
         }
         __syncthreads();
 
-        // ---- one 16-pixel tile per wave: waves 0-3 the first row's tiles, 4-7 the second row's -------------------
-        const int row = wave >> 2, tile = wave & 3;
+        // ---- two 16-pixel tiles per wave: waves 0, 1 the first row's tiles (0,1), (2,3); waves 2, 3 the second row's.
+        //      Four independent accumulation chains per wave keep the matrix pipe fed. ---------------------------------
+        const int row = wave >> 1, tile0 = 2 * (wave & 1);
         const unsigned long long word = row ? wordB : wordA;
         const int pc = __popcll(word);
-        const bool active = tile * 16 < pc;
-        const int n = tile * 16 + (lane & 15);
-        const int xl = cbp_nth_bit(word, n < pc ? n : 0);
-        if (active) {
-            const float* pl = s_patch + (lane >> 4) * CS + row * RS + xl;
-            floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (tile0 * 16 < pc) {
+            const int n0 = tile0 * 16 + (lane & 15), n1 = n0 + 16;
+            const int xl0 = cbp_nth_bit(word, n0 < pc ? n0 : 0), xl1 = cbp_nth_bit(word, n1 < pc ? n1 : 0);
+            const float* pl0 = s_patch + (lane >> 4) * CS + row * RS + xl0;
+            const float* pl1 = s_patch + (lane >> 4) * CS + row * RS + xl1;
+            const bool two = (tile0 + 1) * 16 < pc;      // (uniform over the wave)
+            floatx4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
+            const floatx4* wl = (const floatx4*)s_w + lane;
+            floatx4 ag = wl[0];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const int ky = s / KW, kx = s - ky * KW;
-                const float b = pl[ky * RS + kx];
-                if (s & 1)
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s >> 2][s & 3], b, acc1, 0, 0, 0);
-                else
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s >> 2][s & 3], b, acc0, 0, 0, 0);
+                const float b0 = pl0[ky * RS + kx], b1 = pl1[ky * RS + kx];
+                if ((s & 3) == 0) ag = wl[(s >> 2) * 64];
+                const float av = ag[s & 3];
+                if (s & 1) {
+                    acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc01, 0, 0, 0);
+                    if (two) acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc11, 0, 0, 0);
+                } else {
+                    acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc00, 0, 0, 0);
+                    if (two) acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc10, 0, 0, 0);
+                }
             }
-            const floatx4 acc = acc0 + acc1;
-            if (n < pc) {
-                const int pix = (ya + row) * W + tx * 64 + xl;
+            const floatx4 accA = acc00 + acc01, accB = acc10 + acc11;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = 4 * (lane >> 4) + r;
-                    float v = acc[r] + bv[r];
-                    if (p.relu) v = v <= 0.f ? 0.f : v;
-                    if (m < p.K) {
-                        p.out[(long)m * HW + pix] = v;
-                        s_out[(row * 16 + m) * 64 + xl] = v;
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int n = h2 ? n1 : n0, xl = h2 ? xl1 : xl0;
+                if (n < pc) {
+                    const int pix = (ya + row) * W + tx * 64 + xl;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = 4 * (lane >> 4) + r;
+                        float v = (h2 ? accB[r] : accA[r]) + bv[r];
+                        if (p.relu) v = v <= 0.f ? 0.f : v;
+                        if (m < p.K) {
+                            p.out[(long)m * HW + pix] = v;
+                            s_out[(row * 16 + m) * 64 + xl] = v;
+                        }
                     }
                 }
             }
@@ -241,16 +264,22 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
         if (!fold) continue;
         __syncthreads();
 
-        // ---- the next layer's detection for the 32 pooled pixels of this unit: thread = (channel c2, pooled xo) ----
+        // ---- the next layer's detection for the 32 pooled pixels of this unit: thread = (pooled xo; channels c2, c2+8)
         const unsigned long long tw = wordA | wordB;
         const bool touched = ((tw >> (2 * xo)) & 3ull) != 0ull;
         const int cx1 = (tx * 64 + 2 * xo + 1 < W) ? 2 * xo + 1 : 2 * xo, r1 = hasB ? 16 * 64 : 0;
-        const float* so = s_out + min(c2, 15) * 64;
-        const float pooled = fmaxf(fmaxf(so[2 * xo], so[cx1]), fmaxf(so[r1 + 2 * xo], so[r1 + cx1]));
-        const bool chg = valid2 && touched && cb_changed(s2, pooled, p.next.th);
+        float pooled[2];
+        bool chg = false;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const float* so = s_out + (c2 + 8 * h2) * 64;
+            pooled[h2] = fmaxf(fmaxf(so[2 * xo], so[cx1]), fmaxf(so[r1 + 2 * xo], so[r1 + cx1]));
+            chg |= (c2 + 8 * h2 < p.K) && cb_changed(s2[h2], pooled[h2], p.next.th);
+            s_P[(c2 + 8 * h2) * 33 + xo] = pooled[h2];
+        }
+        chg = chg && valid2 && touched;
         const unsigned long long bal = __ballot(chg);
         if (lane == 0) s_chg[wave] = (unsigned)(bal | (bal >> 32));
-        s_P[min(c2, 15) * 33 + xo] = pooled;
         __syncthreads();
         unsigned m32 = 0;
 #pragma unroll
@@ -258,7 +287,12 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
         m32 = __builtin_amdgcn_readfirstlane(m32);
         if (m32 == 0u) continue;        // (uniform)
         // feedback: refresh the f32 state at the changed pooled pixels only (.cu:74-80) ...
-        if (valid2 && ((m32 >> xo) & 1u)) p.next.state[(long)c2 * H2W2 + (long)yo * p.next.W2 + gx] = pooled;
+        if (valid2 && ((m32 >> xo) & 1u)) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+                if (c2 + 8 * h2 < p.K)
+                    p.next.state[(long)(c2 + 8 * h2) * H2W2 + (long)yo * p.next.W2 + gx] = pooled[h2];
+        }
         // ... and its pre-split pixel-major copy: thread = (pooled pixel, 8-channel half), whole 16-byte pieces
         if (t < 64) {
             const int pl2 = t >> 1, half = t & 1;
@@ -311,7 +345,7 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
         }
     }
 
-    // ---- last workgroup out zeroes the mask (every workgroup copied it into its LDS before anything else) ---------
+    // ---- last workgroup out zeroes the mask (every workgroup read its words before anything else) -----------------
     __syncthreads();
     if (t == 0) s_last = __hip_atomic_fetch_add(p.ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -372,8 +406,10 @@ int cbinfer_conv_changed_rowpairs(const float* state, uint64_t* bits, int32_t* c
         p.next.Wp = g.Wp, p.next.rec = g.rec, p.next.padY = g.padY, p.next.padXL = g.padXL;
         p.next.th = next->threshold;
     }
-    int grid = 2 * cbp_num_cus();
+    // three workgroups of four waves per CU (136 registers, 32 KB of LDS each); at most CBP_MAXCAND candidate units each
+    int grid = 3 * cbp_num_cus();
     if (grid > p.units) grid = p.units;
+    if ((long)grid * CBP_MAXCAND < p.units) grid = (p.units + CBP_MAXCAND - 1) / CBP_MAXCAND;
     if (kH == 7)
         hipLaunchKernelGGL((cbp_rowpair_kernel<7, 7>), dim3(grid), dim3(CBP_NT), 0, (hipStream_t)stream, p);
     else if (kH == 5)

@@ -16,7 +16,8 @@
 //             workgroups), reads their two mask words in one burst and works through the non-empty ones.  (Round 4's
 //             first form let every workgroup copy the whole mask into LDS and scan it for an ordered list of the
 //             non-empty units: 13 us for 170 units, nearly all of it that prologue.)  The last workgroup out zeroes
-//             the mask for the next frame (arrival counter; nobody waits).
+//             the mask for the next frame (arrival counter; nobody waits) -- second form; now every workgroup zeroes
+//             the words of its own units, which nobody else reads.
 //   gather    the (kH + 1) x (64 + kW - 1) input rows under the pair are staged once per channel in LDS (coalesced
 //             row loads); every B operand of every tap is a ds_read_b32 at `lane base + immediate tap offset`.
 //   product   v_mfma_f32_16x16x4_f32 (the exact f32 fma chain), two 16-pixel tiles per wave (four independent
@@ -93,10 +94,9 @@ __global__ __launch_bounds__(CBP_NT, 3) void cbp_rowpair_kernel(PairParams p) {
     __shared__ float s_out[2 * 16 * 64];          // [row][channel][x]: the pair's outputs after this frame
     __shared__ float s_P[16 * 33];                // pooled values [channel][xo]
     __shared__ unsigned s_chg[CBP_NW];
-    __shared__ int s_last;
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int MW = p.MW, wpr = p.wpr, H = p.H, W = p.W, HW = H * W;
+    const int wpr = p.wpr, H = p.H, W = p.W, HW = H * W;
     const bool fold = p.next.state != nullptr;
     const int units = p.units;
 
@@ -123,10 +123,17 @@ __global__ __launch_bounds__(CBP_NT, 3) void cbp_rowpair_kernel(PairParams p) {
         cwA[k] = uniform64(cwA[k]), cwB[k] = uniform64(cwB[k]);
         any |= (cwA[k] | cwB[k]) != 0ull;
         const int u = blockIdx.x + k * gridDim.x;
-        if (p.maskCopy && u < units && t == 0) {      // this frame's mask stays available at its fixed address
+        if (u < units && t == 0) {
+            // A unit's two mask words belong to this workgroup alone: it leaves the frame's copy at its fixed address
+            // and zeroes them for the next frame's detection itself.  (No arrival counter: 768 workgroups counting
+            // themselves on ONE word took 9 of this launch's 19 us -- a returning atomic per 11 ns.)
             const int yo = u / wpr, tx = u - yo * wpr, ya = 2 * yo;
-            p.maskCopy[ya * wpr + tx] = cwA[k];
-            if (ya + 1 < H) p.maskCopy[(ya + 1) * wpr + tx] = cwB[k];
+            if (p.maskCopy) {
+                p.maskCopy[ya * wpr + tx] = cwA[k];
+                if (ya + 1 < H) p.maskCopy[(ya + 1) * wpr + tx] = cwB[k];
+            }
+            if (cwA[k]) p.bits[ya * wpr + tx] = 0ull;
+            if (cwB[k]) p.bits[(ya + 1) * wpr + tx] = 0ull;
         }
     }
 
@@ -345,14 +352,6 @@ __global__ __launch_bounds__(CBP_NT, 3) void cbp_rowpair_kernel(PairParams p) {
         }
     }
 
-    // ---- last workgroup out zeroes the mask (every workgroup read its words before anything else) -----------------
-    __syncthreads();
-    if (t == 0) s_last = __hip_atomic_fetch_add(p.ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (s_last == (int)gridDim.x - 1) {
-        for (int i = t; i < MW; i += CBP_NT) p.bits[i] = 0ull;
-        if (t == 0) __hip_atomic_store(p.ctl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 static int cbp_num_cus() {

@@ -341,6 +341,7 @@ struct CbsParams {
     long stateBytes, aBytes;
     float outScale;
     unsigned long long magicMW, magicWpr, magicW, magicMT;   // floor(2^32 / d) + 1: x / d = (x * magic) >> 32 for x d < 2^32
+    int arriveShards;                 // arrival counters in the second mask slot (lines of their own): min(8, MW / 16)
     int forceSK;                      // > 0: tuning / test aid
     int dbg;                          // diagnostic ablations (builds with -DCBS_DBG only; CBINFER_SPLIT_DBG)
 };
@@ -940,14 +941,31 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
 #endif
     }
 
-    // last workgroup out zeroes the masks (every workgroup copied them into its LDS before its first barrier)
+    // Last workgroup out zeroes the masks (every workgroup copied them into its LDS before its first barrier).  The
+    // workgroups count themselves on SHARDED counters -- lines of their own in the unused second mask slot, a top
+    // counter behind them: a returning atomic on ONE word is served every 11 ns, so a grid of 256-512 workgroups that
+    // finish together spent 3-6 us of the launch queueing for their tickets (round 4; the row-pair kernel's first
+    // form showed it: 9 us for 768 workgroups).
     __syncthreads();
     if (t == 0) {
         int* ctl = (int*)(p.seq[0].masks + 2 * (long)MW);
-        s_wsum[0] = __hip_atomic_fetch_add(ctl + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nSh = p.arriveShards;
+        int last = 0;
+        if (nSh <= 1) {
+            last = __hip_atomic_fetch_add(ctl + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+        } else {
+            const int sh = blockIdx.x % nSh, expected = ((int)gridDim.x - sh + nSh - 1) / nSh;
+            int* c = (int*)(p.seq[0].masks + (long)MW) + sh * 32;
+            if (__hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1) {
+                __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int active = min(nSh, (int)gridDim.x);
+                last = __hip_atomic_fetch_add(ctl + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == active - 1;
+            }
+        }
+        s_wsum[0] = last;
     }
     __syncthreads();
-    if (s_wsum[0] == (int)gridDim.x - 1) {
+    if (s_wsum[0]) {
         for (int i = t; i < E; i += NT) {
             const int q = cbs_div(i, p.magicMW), w = i - q * MW;
             ((unsigned long long*)s_maskPtr[q])[w] = 0ull;
@@ -1330,6 +1348,7 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
     p.magicW = (1ull << 32) / (unsigned long long)W + 1ull;
     p.magicMT = (1ull << 32) / (unsigned long long)(KP / BM) + 1ull;
     p.forceSK = forceSplit;
+    p.arriveShards = (int)(MW / 16 < 8 ? MW / 16 : 8);
     p.dbg = 0;
 #ifdef CBS_DBG
     if (const char* e = getenv("CBINFER_SPLIT_DBG")) p.dbg = atoi(e);

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(CBP_NT, 3) void cbp_rowpair_kernel(PairParams p) {
             const int r = e / RS, j = e - r * RS;          // (compile-time divisor)
             const int c = r / PR, pr = r - c * PR;
             const int yy = ya + pr - PH, xx = tx * 64 - PW + j;
-            const bool ok = e < PTOT && c < p.C && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const bool ok = (e < PTOT) & (c < p.C) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);      // (no short circuit: a branch each)
             // (an invalid element gets an out-of-range offset: the buffer load returns 0 for it)
             pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                   srsrc, ok ? ((c * H + yy) * W + xx) * 4 : (1 << 30), 0, 0));
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(CBP_NT, 3) void cbp_rowpair_kernel(PairParams p) {
                 const int e = t + CBP_NT * i;
                 const int x = e & 63, m = (e >> 6) & 15, r = e >> 10;
                 const int yy = ya + r, xx = tx * 64 + x;
-                const bool ok = yy < H && xx < W && m < p.K;
+                const bool ok = (yy < H) & (xx < W) & (m < p.K);
                 ov[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                       orsrc, ok ? (m * HW + yy * W + xx) * 4 : (1 << 30), 0, 0));
             }
@@ -231,23 +231,38 @@ __global__ __launch_bounds__(CBP_NT, 3) void cbp_rowpair_kernel(PairParams p) {
             const int xl0 = cbp_nth_bit(word, n0 < pc ? n0 : 0), xl1 = cbp_nth_bit(word, n1 < pc ? n1 : 0);
             const float* pl0 = s_patch + (lane >> 4) * CS + row * RS + xl0;
             const float* pl1 = s_patch + (lane >> 4) * CS + row * RS + xl1;
-            const bool two = (tile0 + 1) * 16 < pc;      // (uniform over the wave)
+            // (the second tile is multiplied whether it exists or not -- its lanes then read the first changed pixel's
+            //  columns, and nothing of it is stored: no branch inside the k-loop, which otherwise came out as read ->
+            //  wait -> one matrix instruction -> branch, 98 times over: 5 of this kernel's first 18 us)
             floatx4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
             const floatx4* wl = (const floatx4*)s_w + lane;
-            floatx4 ag = wl[0];
+            floatx4 ag[G];
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int ky = s / KW, kx = s - ky * KW;
-                const float b0 = pl0[ky * RS + kx], b1 = pl1[ky * RS + kx];
-                if ((s & 3) == 0) ag = wl[(s >> 2) * 64];
-                const float av = ag[s & 3];
-                if (s & 1) {
-                    acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc01, 0, 0, 0);
-                    if (two) acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc11, 0, 0, 0);
-                } else {
-                    acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc00, 0, 0, 0);
-                    if (two) acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc10, 0, 0, 0);
+            for (int g = 0; g < G; ++g) ag[g] = wl[g * 64];
+            // one filter row at a time: the B operands of row ky + 1 are read while row ky is multiplied
+            float b0[KW], b1[KW], nb0[KW], nb1[KW];
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) b0[kx] = pl0[kx], b1[kx] = pl1[kx];
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) {
+                if (ky + 1 < KH) {
+#pragma unroll
+                    for (int kx = 0; kx < KW; ++kx) nb0[kx] = pl0[(ky + 1) * RS + kx], nb1[kx] = pl1[(ky + 1) * RS + kx];
                 }
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx) {
+                    const int s = ky * KW + kx;
+                    const float av = ag[s >> 2][s & 3];
+                    if (s & 1) {
+                        acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0[kx], acc01, 0, 0, 0);
+                        acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[kx], acc11, 0, 0, 0);
+                    } else {
+                        acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0[kx], acc00, 0, 0, 0);
+                        acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[kx], acc10, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx) b0[kx] = nb0[kx], b1[kx] = nb1[kx];
             }
             const floatx4 accA = acc00 + acc01, accB = acc10 + acc11;
 #pragma unroll

@@ -11,7 +11,7 @@
 //   unit      one workgroup iteration = one ROW PAIR x one 64-pixel mask word: output rows 2yo, 2yo+1, columns
 //             64 tx .. 64 tx + 63 -- i.e. exactly the 2x2 windows of the 32 pooled pixels (yo, 32 tx ..): the unit's
 //             workgroup owns every window pixel, so the pooled detection needs nobody else's results.
-//   schedule  a persistent grid of three four-wave workgroups per CU; workgroup b looks at the candidate units b,
+//   schedule  a persistent grid of four four-wave workgroups per CU; workgroup b looks at the candidate units b,
 //             b + grid, b + 2 grid, ... (at most four; neighbouring units -- a changed block -- land on different
 //             workgroups), reads their two mask words in one burst and works through the non-empty ones.  (Round 4's
 //             first form let every workgroup copy the whole mask into LDS and scan it for an ordered list of the
@@ -84,14 +84,32 @@ __device__ __forceinline__ int cbp_nth_bit(unsigned long long w, int r) {
     return pos;
 }
 
+#ifdef CBP_STAMP
+// diagnostic build only (make EXTRA=-DCBP_STAMP; tools/pair_stamps.py): per-workgroup phase stamps of its FIRST non-empty
+// unit, 100 MHz constant clock: 0 entry, 1 mask words known, 2 weights in LDS / requests issued, 3 patch staged,
+// 4 k-loop + stores done, 5 pooled detection decided, 6 unit done, 7 kernel exit
+__device__ unsigned long long cbp_stamp_buf[4096 * 8];
+#define CBP_STAMP_AT(i)                                                                                  \
+    do {                                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 4096 && ((i) == 0 || (i) == 1 || (i) == 7 || cbp_first))    \
+            cbp_stamp_buf[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                      \
+    } while (0)
+#else
+#define CBP_STAMP_AT(i)
+#endif
+
 template <int KH, int KW>
-__global__ __launch_bounds__(CBP_NT, 3) void cbp_rowpair_kernel(PairParams p) {
+__global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
     cb_touch_kernarg<sizeof(PairParams)>();
+#ifdef CBP_STAMP
+    bool cbp_first = true;
+#endif
+    CBP_STAMP_AT(0);
     constexpr int RS = 64 + KW - 1, PR = KH + 1, CS = cbp_plane_stride(KH, KW), S = KH * KW, G = (S + 3) / 4;
     constexpr int PH = (KH - 1) / 2, PW = (KW - 1) / 2;
     __shared__ float s_patch[4 * CS];
     __shared__ __attribute__((aligned(16))) float s_w[G * 256];     // the weights, MFMA fragment order: [group][lane][4]
-    __shared__ float s_out[2 * 16 * 64];          // [row][channel][x]: the pair's outputs after this frame
+    __shared__ __attribute__((aligned(16))) float s_out[2 * 16 * 64];          // [row][channel][x]: the pair's outputs after this frame
     __shared__ float s_P[16 * 33];                // pooled values [channel][xo]
     __shared__ unsigned s_chg[CBP_NW];
 
@@ -99,6 +117,19 @@ __global__ __launch_bounds__(CBP_NT, 3) void cbp_rowpair_kernel(PairParams p) {
     const int wpr = p.wpr, H = p.H, W = p.W, HW = H * W;
     const bool fold = p.next.state != nullptr;
     const int units = p.units;
+
+    // ---- requested first, before anybody knows whether this workgroup has work: the weights (fragment order, every
+    //      wave the same 16 output channels; they go through LDS, 16 bytes per lane and group of four k-steps -- held
+    //      in registers, 52 of them for 7x7, they cost the third workgroup per CU) and the bias.  Their round trip runs
+    //      beside the mask words' (1.5 us: the detection's atomics leave them at the memory side).
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, G * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.state, 0, (int)min((long)p.C * HW * 4, (long)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)min((long)p.K * HW * 4, (long)0x7fffffff), 0x00020000);
+    constexpr int WPT = (G * 64 + CBP_NT - 1) / CBP_NT;
+    floatx4 wv[WPT];
+    float bv[4];
 
     // ---- this workgroup's candidate units: blockIdx.x, + gridDim.x, ... (neighbouring units go to different
     //      workgroups); their mask words are requested in one burst and are the same for every lane ---------------
@@ -113,6 +144,12 @@ __global__ __launch_bounds__(CBP_NT, 3) void cbp_rowpair_kernel(PairParams p) {
         cwA[k] = u < units ? a0 : 0ull;
         cwB[k] = (u < units && ya + 1 < H) ? b0 : 0ull;
     }
+#pragma unroll
+    for (int i = 0; i < WPT; ++i)
+        wv[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                wrsrc, min(t + CBP_NT * i, G * 64 - 1) * 16, 0, 0));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = p.bias ? p.bias[min(4 * (lane >> 4) + r, p.K - 1)] : 0.f;
     auto uniform64 = [](unsigned long long v) -> unsigned long long {
         return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
                (unsigned)__builtin_amdgcn_readfirstlane((int)v);
@@ -121,45 +158,44 @@ __global__ __launch_bounds__(CBP_NT, 3) void cbp_rowpair_kernel(PairParams p) {
 #pragma unroll
     for (int k = 0; k < CBP_MAXCAND; ++k) {
         cwA[k] = uniform64(cwA[k]), cwB[k] = uniform64(cwB[k]);
+        if (k == CBP_MAXCAND - 1) CBP_STAMP_AT(1);
         any |= (cwA[k] | cwB[k]) != 0ull;
-        const int u = blockIdx.x + k * gridDim.x;
-        if (u < units && t == 0) {
-            // A unit's two mask words belong to this workgroup alone: it leaves the frame's copy at its fixed address
-            // and zeroes them for the next frame's detection itself.  (No arrival counter: 768 workgroups counting
-            // themselves on ONE word took 9 of this launch's 19 us -- a returning atomic per 11 ns.)
-            const int yo = u / wpr, tx = u - yo * wpr, ya = 2 * yo;
-            if (p.maskCopy) {
-                p.maskCopy[ya * wpr + tx] = cwA[k];
-                if (ya + 1 < H) p.maskCopy[(ya + 1) * wpr + tx] = cwB[k];
+    }
+    // A unit's two mask words belong to this workgroup alone: it leaves the frame's copy at its fixed address and zeroes
+    // them for the next frame's detection itself, AT THE END (no arrival counter: 768 workgroups counting themselves on
+    // one word took 9 of this launch's first 19 us -- a returning atomic per 11 ns).  Why at the end: with the stores
+    // issued here, right behind the words' loads, workgroups that read their inputs a few microseconds into the launch
+    // (late starters of a grid beyond the resident four per CU; the same with a deliberate delay) sporadically computed
+    // whole units from wrong operands -- stale state or weights, by the pattern of the errors -- while identical code
+    // with the stores behind the last load of the workgroup never did (tmp experiments of round 4, DESIGN A.8).  The
+    // rule kept here: no store is issued while a load of this wave is still being waited for by a COUNTED vmcnt.
+    auto finish = [&]() {
+        if (t == 0) {
+#pragma unroll
+            for (int k = 0; k < CBP_MAXCAND; ++k) {
+                const int u = blockIdx.x + k * gridDim.x;
+                if (u < units) {
+                    const int yo = u / wpr, tx = u - yo * wpr, ya = 2 * yo;
+                    if (p.maskCopy) {
+                        p.maskCopy[ya * wpr + tx] = cwA[k];
+                        if (ya + 1 < H) p.maskCopy[(ya + 1) * wpr + tx] = cwB[k];
+                    }
+                    if (cwA[k]) p.bits[ya * wpr + tx] = 0ull;
+                    if (cwB[k]) p.bits[(ya + 1) * wpr + tx] = 0ull;
+                }
             }
-            if (cwA[k]) p.bits[ya * wpr + tx] = 0ull;
-            if (cwB[k]) p.bits[(ya + 1) * wpr + tx] = 0ull;
         }
+    };
+    if (!any) {
+        // (the weight and bias loads requested above are waited for before the wave stores anything or ends)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        finish();
+        CBP_STAMP_AT(7);
+        return;
     }
-
-    // ---- per-wave constants: the weights (fragment order, every wave the same 16 output channels) and the bias -----
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, G * 1024, 0x00020000);
-    const __amdgpu_buffer_rsrc_t srsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.state, 0, (int)min((long)p.C * HW * 4, (long)0x7fffffff), 0x00020000);
-    const __amdgpu_buffer_rsrc_t orsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)min((long)p.K * HW * 4, (long)0x7fffffff), 0x00020000);
-    // (the weights go through LDS, 16 bytes per lane and group of four k-steps, read back as fragments inside the
-    //  k-loop: held in registers -- 52 of them for 7x7 -- they pushed the kernel past the 128 registers that four
-    //  workgroups per CU allow)
-    float bv[4];
-    if (any) {
-        constexpr int WPT = (G * 64 + CBP_NT - 1) / CBP_NT;
-        floatx4 wv[WPT];
 #pragma unroll
-        for (int i = 0; i < WPT; ++i)
-            wv[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                    wrsrc, min(t + CBP_NT * i, G * 64 - 1) * 16, 0, 0));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[r] = p.bias ? p.bias[min(4 * (lane >> 4) + r, p.K - 1)] : 0.f;
-#pragma unroll
-        for (int i = 0; i < WPT; ++i)
-            if (t + CBP_NT * i < G * 64) *(floatx4*)(s_w + (t + CBP_NT * i) * 4) = wv[i];
-    }
+    for (int i = 0; i < WPT; ++i)
+        if (t + CBP_NT * i < G * 64) *(floatx4*)(s_w + (t + CBP_NT * i) * 4) = wv[i];
     // (visible to every wave behind the first barrier of the unit loop)
 
 #pragma unroll 1
@@ -172,55 +208,92 @@ __global__ __launch_bounds__(CBP_NT, 3) void cbp_rowpair_kernel(PairParams p) {
         const int u = blockIdx.x + k * gridDim.x;
         const int yo = u / wpr, tx = u - yo * wpr, ya = 2 * yo;
         const bool hasB = ya + 1 < H;
-        // ---- requests, all in one burst: the patch, the pair's old outputs, the next layer's state ----------------
-        constexpr int PTOT = 4 * PR * RS, PPT = (PTOT + CBP_NT - 1) / CBP_NT;
-        float pv[PPT];
+        // (the previous unit's stores -- outputs, the next layer's state and mask -- have left before this unit's loads
+        //  are counted: see the rule above)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- requests, all in one burst: the patch, the pair's old outputs, the next layer's state.  16 bytes per
+        //      lane wherever rows allow it (the 64 columns of the word; the kW - 1 columns beside them by dword): seven
+        //      load instructions per thread instead of nineteen -- a CU takes in about 11 bytes per cycle however they
+        //      are requested, but every instruction is a slot in its memory pipe.
+        constexpr int PROWS = 4 * PR;                       // patch rows: plane x row
+        constexpr int PX4 = (PROWS * 16 + CBP_NT - 1) / CBP_NT, PED = (PROWS * (KW - 1) + CBP_NT - 1) / CBP_NT;
+        floatx4 pv4[PX4];
+        float pe[PED];
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
+        for (int i = 0; i < PX4; ++i) {
             const int e = t + CBP_NT * i;
-            const int r = e / RS, j = e - r * RS;          // (compile-time divisor)
+            const int r = e >> 4, j4 = (e & 15) * 4;
             const int c = r / PR, pr = r - c * PR;
-            const int yy = ya + pr - PH, xx = tx * 64 - PW + j;
-            const bool ok = (e < PTOT) & (c < p.C) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);      // (no short circuit: a branch each)
-            // (an invalid element gets an out-of-range offset: the buffer load returns 0 for it)
-            pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            const int yy = ya + pr - PH, xx = tx * 64 + j4;
+            const bool ok = (r < PROWS) & (c < p.C) & (yy >= 0) & (yy < H) & (xx < W);      // (no short circuit: a branch each)
+            // (an invalid piece gets an out-of-range offset: the buffer load returns 0 for it)
+            floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                        srsrc, ok ? ((c * H + yy) * W + xx) * 4 : (1 << 30), 0, 0));
+            // (columns beyond the map's right edge are the next row's first pixels, not padding)
+            if (xx + 1 >= W) v[1] = 0.f;
+            if (xx + 2 >= W) v[2] = 0.f;
+            if (xx + 3 >= W) v[3] = 0.f;
+            pv4[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < PED; ++i) {
+            const int e = t + CBP_NT * i;
+            const int r = e / (KW - 1), j = e - r * (KW - 1);      // j < PW: left of the word, else right of it
+            const int c = r / PR, pr = r - c * PR;
+            const int yy = ya + pr - PH, xx = j < PW ? tx * 64 - PW + j : tx * 64 + 64 + (j - PW);
+            const bool ok = (r < PROWS) & (c < p.C) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+            pe[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                   srsrc, ok ? ((c * H + yy) * W + xx) * 4 : (1 << 30), 0, 0));
         }
-        constexpr int OPT = 2 * 16 * 64 / CBP_NT;       // old outputs per thread
-        float ov[OPT];
+        constexpr int OX4 = 2 * 16 * 16 / CBP_NT;       // old outputs: [row][channel][16 pieces of 4 columns]
+        floatx4 ov4[OX4];
         float s2[2] = {0.f, 0.f};
         const int c2 = t >> 5, xo = t & 31, gx = tx * 32 + xo;        // pooled pixel xo, channels c2 and c2 + 8
         const bool valid2 = fold && yo < p.next.H2 && gx < p.next.W2;
         const long H2W2 = fold ? (long)p.next.H2 * p.next.W2 : 0;
         if (fold) {
 #pragma unroll
-            for (int i = 0; i < OPT; ++i) {
+            for (int i = 0; i < OX4; ++i) {
                 const int e = t + CBP_NT * i;
-                const int x = e & 63, m = (e >> 6) & 15, r = e >> 10;
-                const int yy = ya + r, xx = tx * 64 + x;
+                const int x4 = (e & 15) * 4, m = (e >> 4) & 15, r = e >> 8;
+                const int yy = ya + r, xx = tx * 64 + x4;
                 const bool ok = (yy < H) & (xx < W) & (m < p.K);
-                ov[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      orsrc, ok ? (m * HW + yy * W + xx) * 4 : (1 << 30), 0, 0));
+                // (columns beyond the map's edge come back as the next row's pixels: no window of a valid pooled pixel
+                //  reads them -- cx1 below)
+                ov4[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         orsrc, ok ? (m * HW + yy * W + xx) * 4 : (1 << 30), 0, 0));
             }
             // (clamped addresses, predicated uses)
             const long pos2 = (long)min(yo, p.next.H2 - 1) * p.next.W2 + min(gx, p.next.W2 - 1);
             s2[0] = p.next.state[(long)min(c2, p.K - 1) * H2W2 + pos2];
             s2[1] = p.next.state[(long)min(c2 + 8, p.K - 1) * H2W2 + pos2];
         }
+        CBP_STAMP_AT(2);
         __syncthreads();        // (the previous unit's readers of s_patch / s_out / s_P are done)
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
+        for (int i = 0; i < PX4; ++i) {
             const int e = t + CBP_NT * i;
-            const int r = e / RS, j = e - r * RS;
+            const int r = e >> 4, j4 = (e & 15) * 4;
             const int c = r / PR, pr = r - c * PR;
-            if (e < PTOT) s_patch[c * CS + pr * RS + j] = pv[i];
+            if (r < PROWS) {
+                float* d = s_patch + c * CS + pr * RS + PW + j4;      // (PW columns in: not 16-byte aligned)
+                d[0] = pv4[i][0], d[1] = pv4[i][1], d[2] = pv4[i][2], d[3] = pv4[i][3];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PED; ++i) {
+            const int e = t + CBP_NT * i;
+            const int r = e / (KW - 1), j = e - r * (KW - 1);
+            const int c = r / PR, pr = r - c * PR;
+            if (r < PROWS) s_patch[c * CS + pr * RS + (j < PW ? j : 64 + j)] = pe[i];
         }
         if (fold) {
 #pragma unroll
-            for (int i = 0; i < OPT; ++i) s_out[t + CBP_NT * i] = ov[i];
+            for (int i = 0; i < OX4; ++i) *(floatx4*)(s_out + (t + CBP_NT * i) * 4) = ov4[i];
         }
         __syncthreads();
 
+        CBP_STAMP_AT(3);
         // ---- two 16-pixel tiles per wave: waves 0, 1 the first row's tiles (0,1), (2,3); waves 2, 3 the second row's.
         //      Four independent accumulation chains per wave keep the matrix pipe fed. ---------------------------------
         const int row = wave >> 1, tile0 = 2 * (wave & 1);
@@ -285,6 +358,7 @@ __global__ __launch_bounds__(CBP_NT, 3) void cbp_rowpair_kernel(PairParams p) {
         }
         if (!fold) continue;
         __syncthreads();
+        CBP_STAMP_AT(4);
 
         // ---- the next layer's detection for the 32 pooled pixels of this unit: thread = (pooled xo; channels c2, c2+8)
         const unsigned long long tw = wordA | wordB;
@@ -307,6 +381,7 @@ __global__ __launch_bounds__(CBP_NT, 3) void cbp_rowpair_kernel(PairParams p) {
 #pragma unroll
         for (int w = 0; w < CBP_NW; ++w) m32 |= s_chg[w];
         m32 = __builtin_amdgcn_readfirstlane(m32);
+        CBP_STAMP_AT(5);
         if (m32 == 0u) continue;        // (uniform)
         // feedback: refresh the f32 state at the changed pooled pixels only (.cu:74-80) ...
         if (valid2 && ((m32 >> xo) & 1u)) {
@@ -365,8 +440,14 @@ __global__ __launch_bounds__(CBP_NT, 3) void cbp_rowpair_kernel(PairParams p) {
                 if (v) atomicOr(&p.next.masks[(long)yy * wpr2 + t2], v);
             }
         }
+        CBP_STAMP_AT(6);
+#ifdef CBP_STAMP
+        cbp_first = false;
+#endif
     }
-
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    finish();
+    CBP_STAMP_AT(7);
 }
 
 static int cbp_num_cus() {
@@ -384,6 +465,17 @@ static int cbp_num_cus() {
 
 }  // namespace cbp
 using namespace cbp;
+
+#ifdef CBP_STAMP
+extern "C" int cbinfer_debug_pair_stamps(void* host, long bytes, int clear) {
+    if (clear) {
+        void* d = nullptr;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(cbp_stamp_buf)) != hipSuccess) return -1;
+        return (int)hipMemset(d, 0, sizeof(cbp_stamp_buf));
+    }
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cbp_stamp_buf), (size_t)bytes);
+}
+#endif
 
 extern "C" {
 
@@ -420,8 +512,19 @@ int cbinfer_conv_changed_rowpairs(const float* state, uint64_t* bits, int32_t* c
         p.next.Wp = g.Wp, p.next.rec = g.rec, p.next.padY = g.padY, p.next.padXL = g.padXL;
         p.next.th = next->threshold;
     }
-    // three workgroups of four waves per CU (136 registers, 32 KB of LDS each); at most CBP_MAXCAND candidate units each
-    int grid = 3 * cbp_num_cus();
+    // four workgroups of four waves per CU are resident (<= 128 registers, 32 KB of LDS each); a workgroup's units are
+    // worked through one after the other (8 us each, mostly round trips to memory), so up to eight workgroups per CU
+    // are started -- one candidate unit each at 480x320: the empty ones are gone after 1.8 us -- and at most
+    // CBP_MAXCAND candidates each beyond that
+    int grid = 8 * cbp_num_cus();
+    {
+        static int perCU = -1;
+        if (perCU < 0) {
+            const char* e = getenv("CBINFER_PAIR_WGS_PER_CU");      // tuning aid
+            perCU = e ? atoi(e) : 0;
+        }
+        if (perCU > 0) grid = perCU * cbp_num_cus();
+    }
     if (grid > p.units) grid = p.units;
     if ((long)grid * CBP_MAXCAND < p.units) grid = (p.units + CBP_MAXCAND - 1) / CBP_MAXCAND;
     if (kH == 7)

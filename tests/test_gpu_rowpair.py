@@ -203,3 +203,35 @@ def test_bench_network_with_and_without_the_folded_detection(lib):
     assert folded[11] is False and folded[12] is True and folded[13] is False and folded[15] is True, folded
     assert cf[0]._plan is not None and cf[0]._plan.get('pairs') and cf[0]._plan.get('nextToken') is not None
     assert cs[0]._plan is not None and cs[0]._plan.get('pairs') and cs[0]._plan.get('nextToken') is None
+
+
+def test_rowpair_network_tracks_the_row_segment_kernel_over_many_frames(lib, monkeypatch):
+    """Regression test of round 4's sporadic failure (workgroups that read their inputs a few microseconds into the
+    launch computed whole units from wrong operands while the mask words' zeroing stores were issued at the start of
+    the workgroup): 100 frames of the bench walk through the bench network on the row-pair kernel -- with the folded
+    detection and without it -- against the same network on round 2's row-segment kernel (CBINFER_NO_ROWPAIRS=1;
+    another summation order, so <= 1e-4 instead of bit for bit), every layer's state after every frame."""
+    import pycbinfer as pkg
+    import bench
+    nets = {}
+    monkeypatch.setenv("CBINFER_NO_ROWPAIRS", "0")
+    _, nets["fold"] = bench.build_bench_model()
+    _, nets["sep"] = bench.build_bench_model(fuse_detect=False)
+    _, nets["rows"] = bench.build_bench_model(fuse_detect=False)
+    convs = {k: [m for m in n.children() if type(m) is pkg.CBConv2d] for k, n in nets.items()}
+    frames = bench.bench_video(1234).frames(2 + 32)
+    walk = frames[2:]
+    seq = frames[:2] + [walk[bench.pingpong(i, len(walk))] for i in range(100)]
+    with torch.no_grad():
+        for t, f in enumerate(seq):
+            ya, yb = nets["fold"](f), nets["sep"](f)
+            monkeypatch.setenv("CBINFER_NO_ROWPAIRS", "1")
+            yr = nets["rows"](f)
+            monkeypatch.setenv("CBINFER_NO_ROWPAIRS", "0")
+            assert torch.equal(ya, yb), t
+            for a, b, r in zip(convs["fold"], convs["sep"], convs["rows"]):
+                assert torch.equal(a.prevOutput, b.prevOutput) and torch.equal(a.prevInput, b.prevInput), t
+                assert float((a.prevOutput - r.prevOutput).abs().max()) <= FP32_TOL, t
+                assert float((a.prevInput - r.prevInput).abs().max()) <= 2 * FP32_TOL, t
+    assert convs["fold"][0]._plan.get('pairs') and convs["fold"][0]._plan.get('nextToken') is not None
+    assert convs["rows"][0]._plan is not None and not convs["rows"][0]._plan.get('pairs')

@@ -51,6 +51,15 @@ class NextDetect(ctypes.Structure):
 
 
 _ndp = ctypes.POINTER(NextDetect)
+
+
+class PairSeq(ctypes.Structure):
+    """cbPairSeq of include/cbinfer_hip.h."""
+    _fields_ = [("state", _vp), ("output", _vp), ("bits", _vp), ("maskCopy", _vp), ("nextState", _vp),
+                ("nextSplitState", _vp), ("nextFrameMasks", _vp), ("nextRangeFlag", _vp)]
+
+
+_psp = ctypes.POINTER(PairSeq)
 _vpp = ctypes.POINTER(ctypes.c_void_p)
 
 _SIGNATURES = {
@@ -140,6 +149,7 @@ _SIGNATURES = {
     "cbinfer_split_conv_tail": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _stp, _vp]),
     "cbinfer_rowpairs_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "cbinfer_conv_changed_rowpairs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ndp, _vp]),
+    "cbinfer_conv_changed_rowpairs_batched": (_i, [_psp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ndp, _vp]),
     "cbinfer_cbconv2d_forward_rowpairs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i,
                                                _ndp, _vp]),
     "cbinfer_conv2d_fg_cpu": (None, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i]),

@@ -161,6 +161,15 @@ class SequenceBatch(object):
                 L['a_bits'] = _ptr_array(L['bits'])
                 L['a_arrive'] = _ptr_array(L['arrive'])
                 L['a_copy'] = _ptr_array(L['copy'])
+                # the row-pair kernel (the modules' own choice for such a layer: the same arithmetic, so a sequence
+                # gets the same bits alone and inside a batch), one launch for all sequences
+                L['pairs'] = m._pairs_ok(h, w)
+                if L['pairs']:
+                    ps = (_lib.PairSeq * S)()
+                    for q in range(S):
+                        ps[q].state, ps[q].output = L['prevInput'][q].data_ptr(), L['prevOutput'][q].data_ptr()
+                        ps[q].bits, ps[q].maskCopy = L['bits'][q].data_ptr(), L['copy'][q].data_ptr()
+                    L['pseq'] = ps
             else:
                 raise CBinferError("SequenceBatch: the %d->%d layer has no batched kernel at %dx%d" % (Cin, K, h, w))
             layers.append(L)
@@ -168,6 +177,22 @@ class SequenceBatch(object):
             shape = (1, K, h, w)
         if pooledFrom is not None:
             raise CBinferError("SequenceBatch: a lazy pool needs a consuming CBConv2d")
+        # a row-pair layer whose consumer behind the lazy pool is a split-state layer does that layer's pooled change
+        # detection inside its own launch (pycbinfer.fuseDetectionIntoProducer; cb_rowpair.hip)
+        for li, L in enumerate(layers):
+            if (L['kind'] == 'split' and L.get('pooled') is not None and layers[L['pooled'][0]].get('pairs') and
+                    layers[L['pooled'][0]]['K'] == 16 and L['C'] == 16 and L['pooled'][0] == li - 1 and
+                    layers[li - 1]['m'].__dict__.get('_fusedNext') is not None and
+                    os.environ.get('CBINFER_NO_NEXTFOLD', '0') != '1'):
+                P = layers[li - 1]
+                nd = _lib.NextDetect()
+                nd.H, nd.W, nd.kH, nd.kW = L['H'], L['W'], L['kH'], L['kW']
+                for q in range(S):
+                    P['pseq'][q].nextState = L['prevInput'][q].data_ptr()
+                    P['pseq'][q].nextSplitState = L['S'][q].data_ptr()
+                    P['pseq'][q].nextFrameMasks = L['masks'][q].data_ptr()
+                    P['pseq'][q].nextRangeFlag = L['flag'].data_ptr()
+                P['next'] = (li, nd)
         for L in layers:
             L['wkey'] = self._weight_key(L['m'])
         self.layers = layers
@@ -223,10 +248,25 @@ class SequenceBatch(object):
                 check(C.cbinfer_change_detection_bits_batched(a_in, L['a_state'], L['a_bits'], S, L['W'], L['H'],
                                                               L['C'], (L['kH'] - 1) // 2, (L['kW'] - 1) // 2,
                                                               float(m.threshold), 1, st))
-                check(C.cbinfer_conv_changed_rows_batched(L['a_state'], L['a_bits'], L['a_arrive'], L['a_copy'],
-                                                          L['a_out'], S, ptr(L['wp']), ptr(m.bias.detach()), L['C'],
-                                                          L['H'], L['W'], L['K'], L['kH'], L['kW'],
-                                                          int(bool(m.withReLU)), st))
+                if L.get('pairs'):
+                    nptr = None
+                    if L.get('next') is not None:
+                        ni, nd = L['next']
+                        Ln = self.layers[ni]
+                        # (the same condition as the producer-mask shortcut of the consumer's own detection: not on
+                        #  the first frame, not on the first frame after a change of its threshold)
+                        if (not first) and Ln['th'] == float(Ln['m'].threshold):
+                            nd.threshold = float(Ln['m'].threshold)
+                            nptr = ctypes.pointer(nd)
+                            Ln['detected'] = True
+                    check(C.cbinfer_conv_changed_rowpairs_batched(L['pseq'], S, ptr(L['wp']), ptr(m.bias.detach()),
+                                                                  L['C'], L['H'], L['W'], L['K'], L['kH'], L['kW'],
+                                                                  int(bool(m.withReLU)), nptr, st))
+                else:
+                    check(C.cbinfer_conv_changed_rows_batched(L['a_state'], L['a_bits'], L['a_arrive'], L['a_copy'],
+                                                              L['a_out'], S, ptr(L['wp']), ptr(m.bias.detach()), L['C'],
+                                                              L['H'], L['W'], L['K'], L['kH'], L['kW'],
+                                                              int(bool(m.withReLU)), st))
             elif L['kind'] == 'split':
                 seqs = L['seqs']
                 pooled = L['pooled']
@@ -247,7 +287,15 @@ class SequenceBatch(object):
                 args = [seqs, S, int(pooled is not None), pooled[1] if pooled else 0, pooled[2] if pooled else 0,
                         ptr(L['wp']), ptr(m.bias.detach()), L['C'], L['H'], L['W'], L['K'], L['kH'], L['kW'],
                         float(m.threshold), float(L['scale']), int(bool(m.withReLU)), ptr(L['ws'])]
-                if L.get('tail') is not None:
+                if L.pop('detected', False):
+                    # (the producing layer's row-pair launch was this frame's detection: the contraction alone)
+                    cargs = [seqs, S, ptr(L['wp']), ptr(m.bias.detach()), L['C'], L['H'], L['W'], L['K'], L['kH'],
+                             L['kW'], float(L['scale']), int(bool(m.withReLU)), ptr(L['ws']), 0]
+                    if L.get('tail') is not None:
+                        check(C.cbinfer_split_conv_tail(*(cargs + [ctypes.pointer(L['tail']), st])))
+                    else:
+                        check(C.cbinfer_split_conv(*(cargs + [st])))
+                elif L.get('tail') is not None:
                     check(C.cbinfer_split_forward_tail(*(args + [0, ctypes.pointer(L['tail']), st])))
                 else:
                     check(C.cbinfer_split_forward(*(args + [st])))

@@ -43,24 +43,26 @@ using cbs::halfx8;
 #define CBP_MAXCAND 4               // candidate units per workgroup: the grid is at least units / 4
 #define CBP_MAXWORDS (1 << 20)
 
-struct PairNext {
-    float* state;                   // the next layer's prevInput [K, H2, W2]; null: no folding
-    char* S;                        // its split state
-    unsigned long long* masks;      // its frame mask (the detection ORs into it)
-    int* rangeFlag;
-    int H2, W2, wpr2, kHH, kWH, Wp, rec, padY, padXL;
+struct PairNext {                   // geometry of the next layer's detection (fold != 0)
+    int fold, H2, W2, wpr2, kHH, kWH, Wp, rec, padY, padXL;
     float th;
 };
-struct PairParams {
+struct PairSeq {                    // the tensors of ONE sequence (several sequences per launch: cbPairSeq)
     const float* state;             // prevInput [C,H,W]: what the gather reads (conv2d.py:242)
+    float* out;                     // prevOutput [K,H,W]
+    unsigned long long* bits;       // change mask of this frame (every workgroup zeroes the words of its units)
+    unsigned long long* maskCopy;
+    float* nstate;                  // the next layer's prevInput [K, H2, W2]
+    char* nS;                       // its split state
+    unsigned long long* nmasks;     // its frame mask (the detection ORs into it)
+    int* nflag;                     // its range flag (may be null)
+};
+struct PairParams {
     const float* wq;                // cbinfer_rowconv_prep_weights layout
     const float* bias;
-    float* out;                     // prevOutput [K,H,W]
-    unsigned long long* bits;       // change mask of this frame (zeroed by the last workgroup out)
-    int* ctl;                       // arrival counter (zero between launches)
-    unsigned long long* maskCopy;
-    int C, H, W, K, relu, wpr, MW, units;
+    int C, H, W, K, relu, wpr, MW, units, nSeq;
     PairNext next;
+    PairSeq seq[CBINFER_SPLIT_MAX_SEQUENCES];
 };
 
 __host__ __device__ constexpr int cbp_plane_stride(int kH, int kW) {
@@ -115,18 +117,16 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wpr = p.wpr, H = p.H, W = p.W, HW = H * W;
-    const bool fold = p.next.state != nullptr;
-    const int units = p.units;
+    const bool fold = p.next.fold != 0;
+    const int unitsSeq = p.units, units = p.units * p.nSeq;       // candidate unit u: sequence u / unitsSeq
+    // (the per-sequence tensors come out of the kernel-argument table by the unit's sequence index: scalar loads)
+    const PairSeq* tab = ((const PairParams*)__builtin_amdgcn_kernarg_segment_ptr())->seq;
 
     // ---- requested first, before anybody knows whether this workgroup has work: the weights (fragment order, every
     //      wave the same 16 output channels; they go through LDS, 16 bytes per lane and group of four k-steps -- held
     //      in registers, 52 of them for 7x7, they cost the third workgroup per CU) and the bias.  Their round trip runs
     //      beside the mask words' (1.5 us: the detection's atomics leave them at the memory side).
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, G * 1024, 0x00020000);
-    const __amdgpu_buffer_rsrc_t srsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.state, 0, (int)min((long)p.C * HW * 4, (long)0x7fffffff), 0x00020000);
-    const __amdgpu_buffer_rsrc_t orsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)min((long)p.K * HW * 4, (long)0x7fffffff), 0x00020000);
     constexpr int WPT = (G * 64 + CBP_NT - 1) / CBP_NT;
     floatx4 wv[WPT];
     float bv[4];
@@ -138,9 +138,11 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
     for (int k = 0; k < CBP_MAXCAND; ++k) {
         const int u = blockIdx.x + k * gridDim.x;
         const int uc = min(u, units - 1);
-        const int yo = uc / wpr, tx = uc - yo * wpr, ya = 2 * yo;
-        const unsigned long long a0 = p.bits[ya * wpr + tx];
-        const unsigned long long b0 = p.bits[min(ya + 1, H - 1) * wpr + tx];
+        const int q = uc / unitsSeq, ul = uc - q * unitsSeq;
+        const int yo = ul / wpr, tx = ul - yo * wpr, ya = 2 * yo;
+        const unsigned long long* bq = tab[q].bits;
+        const unsigned long long a0 = bq[ya * wpr + tx];
+        const unsigned long long b0 = bq[min(ya + 1, H - 1) * wpr + tx];
         cwA[k] = u < units ? a0 : 0ull;
         cwB[k] = (u < units && ya + 1 < H) ? b0 : 0ull;
     }
@@ -175,13 +177,16 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
             for (int k = 0; k < CBP_MAXCAND; ++k) {
                 const int u = blockIdx.x + k * gridDim.x;
                 if (u < units) {
-                    const int yo = u / wpr, tx = u - yo * wpr, ya = 2 * yo;
-                    if (p.maskCopy) {
-                        p.maskCopy[ya * wpr + tx] = cwA[k];
-                        if (ya + 1 < H) p.maskCopy[(ya + 1) * wpr + tx] = cwB[k];
+                    const int q = u / unitsSeq, ul = u - q * unitsSeq;
+                    const int yo = ul / wpr, tx = ul - yo * wpr, ya = 2 * yo;
+                    unsigned long long* mc = tab[q].maskCopy;
+                    unsigned long long* bq = tab[q].bits;
+                    if (mc) {
+                        mc[ya * wpr + tx] = cwA[k];
+                        if (ya + 1 < H) mc[(ya + 1) * wpr + tx] = cwB[k];
                     }
-                    if (cwA[k]) p.bits[ya * wpr + tx] = 0ull;
-                    if (cwB[k]) p.bits[(ya + 1) * wpr + tx] = 0ull;
+                    if (cwA[k]) bq[ya * wpr + tx] = 0ull;
+                    if (cwB[k]) bq[(ya + 1) * wpr + tx] = 0ull;
                 }
             }
         }
@@ -206,8 +211,14 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
             if (j == k) wordA = cwA[j], wordB = cwB[j];
         if ((wordA | wordB) == 0ull) continue;      // (uniform)
         const int u = blockIdx.x + k * gridDim.x;
-        const int yo = u / wpr, tx = u - yo * wpr, ya = 2 * yo;
+        const int q = u / unitsSeq, ul = u - q * unitsSeq;
+        const int yo = ul / wpr, tx = ul - yo * wpr, ya = 2 * yo;
         const bool hasB = ya + 1 < H;
+        const PairSeq sq = tab[q];
+        const __amdgpu_buffer_rsrc_t srsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)sq.state, 0, (int)min((long)p.C * HW * 4, (long)0x7fffffff), 0x00020000);
+        const __amdgpu_buffer_rsrc_t orsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)sq.out, 0, (int)min((long)p.K * HW * 4, (long)0x7fffffff), 0x00020000);
         // (the previous unit's stores -- outputs, the next layer's state and mask -- have left before this unit's loads
         //  are counted: see the rule above)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -265,8 +276,8 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
             }
             // (clamped addresses, predicated uses)
             const long pos2 = (long)min(yo, p.next.H2 - 1) * p.next.W2 + min(gx, p.next.W2 - 1);
-            s2[0] = p.next.state[(long)min(c2, p.K - 1) * H2W2 + pos2];
-            s2[1] = p.next.state[(long)min(c2 + 8, p.K - 1) * H2W2 + pos2];
+            s2[0] = sq.nstate[(long)min(c2, p.K - 1) * H2W2 + pos2];
+            s2[1] = sq.nstate[(long)min(c2 + 8, p.K - 1) * H2W2 + pos2];
         }
         CBP_STAMP_AT(2);
         __syncthreads();        // (the previous unit's readers of s_patch / s_out / s_P are done)
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
                         float v = (h2 ? accB[r] : accA[r]) + bv[r];
                         if (p.relu) v = v <= 0.f ? 0.f : v;
                         if (m < p.K) {
-                            p.out[(long)m * HW + pix] = v;
+                            sq.out[(long)m * HW + pix] = v;
                             s_out[(row * 16 + m) * 64 + xl] = v;
                         }
                     }
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2)
                 if (c2 + 8 * h2 < p.K)
-                    p.next.state[(long)(c2 + 8 * h2) * H2W2 + (long)yo * p.next.W2 + gx] = pooled[h2];
+                    sq.nstate[(long)(c2 + 8 * h2) * H2W2 + (long)yo * p.next.W2 + gx] = pooled[h2];
         }
         // ... and its pre-split pixel-major copy: thread = (pooled pixel, 8-channel half), whole 16-byte pieces
         if (t < 64) {
@@ -405,11 +416,11 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
                     cbs::cbs_split(v, h, l);
                     hi[j] = h, lo[j] = l;
                 }
-                char* rec = p.next.S + CBS_SPAD +
+                char* rec = sq.nS + CBS_SPAD +
                             ((long)(yo + p.next.padY) * p.next.Wp + (tx * 32 + pl2 + p.next.padXL)) * p.next.rec + half * 16;
                 *(halfx8*)rec = hi;
                 *(halfx8*)(rec + 32) = lo;
-                if (over && p.next.rangeFlag) *p.next.rangeFlag = 1;
+                if (over && sq.nflag) *sq.nflag = 1;
             }
         }
         // dilation by the next layer's filter support, ORed into its frame mask: the 32 pooled pixels are one half
@@ -437,7 +448,7 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
                 if (yy < 0 || yy >= p.next.H2) continue;
                 const unsigned long long v = which == 0 ? D : (which == 1 ? SR : SL);
                 const int t2 = which == 0 ? w2 : (which == 1 ? w2 + 1 : w2 - 1);
-                if (v) atomicOr(&p.next.masks[(long)yy * wpr2 + t2], v);
+                if (v) atomicOr(&sq.nmasks[(long)yy * wpr2 + t2], v);
             }
         }
         CBP_STAMP_AT(6);
@@ -487,53 +498,86 @@ int cbinfer_rowpairs_supported(int C, int K, int kH, int kW, int H, int W) {
     return 1;
 }
 
-int cbinfer_conv_changed_rowpairs(const float* state, uint64_t* bits, int32_t* ctl, uint64_t* maskCopy,
-                                  const void* prepared, const float* bias, float* output, int C, int H, int W, int K,
-                                  int kH, int kW, int relu, const cbNextDetect* next, cbStream_t stream) {
-    CB_REQUIRE(state && bits && ctl && prepared && output);
+static int cbp_launch(const cbPairSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H, int W,
+                      int K, int kH, int kW, int relu, const cbNextDetect* next, cbStream_t stream) {
+    CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBINFER_SPLIT_MAX_SEQUENCES && prepared);
     if (!cbinfer_rowpairs_supported(C, K, kH, kW, H, W)) return CB_ERR_UNSUPPORTED;
     PairParams p;
-    p.state = state, p.wq = (const float*)prepared, p.bias = bias, p.out = output;
-    p.bits = (unsigned long long*)bits, p.ctl = ctl, p.maskCopy = (unsigned long long*)maskCopy;
-    p.C = C, p.H = H, p.W = W, p.K = K, p.relu = relu;
+    p.wq = (const float*)prepared, p.bias = bias;
+    p.C = C, p.H = H, p.W = W, p.K = K, p.relu = relu, p.nSeq = nSeq;
     p.wpr = cbinfer_mask_words_per_row(W), p.MW = (int)cbinfer_mask_words(H, W);
     p.units = ((H + 1) / 2) * p.wpr;
-    p.next.state = nullptr;
-    if (next && next->state) {
+    p.next.fold = 0;
+    const bool fold = next != nullptr && next->H > 0 && seqs[0].nextState != nullptr;
+    if (fold) {
         // the layer behind the 2x2/stride-2 pool: K channels at (H/2 or (H+1)/2) x (W/2 or (W+1)/2), split-state form
-        CB_REQUIRE(next->splitState && next->frameMasks);
         CB_REQUIRE((next->H == H / 2 || next->H == (H + 1) / 2) && (next->W == W / 2 || next->W == (W + 1) / 2));
         if (K != 16 || !cbs::cbs_supported(K, 1, next->kH, next->kW)) return CB_ERR_UNSUPPORTED;
         const cbs::CbsGeom g = cbs::cbs_geom(K, next->H, next->W, next->kH, next->kW);
-        p.next.state = next->state, p.next.S = (char*)next->splitState;
-        p.next.masks = (unsigned long long*)next->frameMasks, p.next.rangeFlag = next->rangeFlag;
+        p.next.fold = 1;
         p.next.H2 = next->H, p.next.W2 = next->W, p.next.wpr2 = cbinfer_mask_words_per_row(next->W);
         p.next.kHH = (next->kH - 1) / 2, p.next.kWH = (next->kW - 1) / 2;
         p.next.Wp = g.Wp, p.next.rec = g.rec, p.next.padY = g.padY, p.next.padXL = g.padXL;
         p.next.th = next->threshold;
     }
+    for (int q = 0; q < nSeq; ++q) {
+        CB_REQUIRE(seqs[q].state && seqs[q].output && seqs[q].bits);
+        p.seq[q].state = seqs[q].state, p.seq[q].out = seqs[q].output;
+        p.seq[q].bits = (unsigned long long*)seqs[q].bits, p.seq[q].maskCopy = (unsigned long long*)seqs[q].maskCopy;
+        p.seq[q].nstate = nullptr, p.seq[q].nS = nullptr, p.seq[q].nmasks = nullptr, p.seq[q].nflag = nullptr;
+        if (fold) {
+            CB_REQUIRE(seqs[q].nextState && seqs[q].nextSplitState && seqs[q].nextFrameMasks);
+            p.seq[q].nstate = seqs[q].nextState, p.seq[q].nS = (char*)seqs[q].nextSplitState;
+            p.seq[q].nmasks = (unsigned long long*)seqs[q].nextFrameMasks, p.seq[q].nflag = seqs[q].nextRangeFlag;
+        }
+    }
+    const long total = (long)p.units * nSeq;
     // four workgroups of four waves per CU are resident (<= 128 registers, 32 KB of LDS each); a workgroup's units are
     // worked through one after the other (8 us each, mostly round trips to memory), so up to eight workgroups per CU
     // are started -- one candidate unit each at 480x320: the empty ones are gone after 1.8 us -- and at most
     // CBP_MAXCAND candidates each beyond that
-    int grid = 8 * cbp_num_cus();
+    long grid = 8l * cbp_num_cus();
     {
         static int perCU = -1;
         if (perCU < 0) {
             const char* e = getenv("CBINFER_PAIR_WGS_PER_CU");      // tuning aid
             perCU = e ? atoi(e) : 0;
         }
-        if (perCU > 0) grid = perCU * cbp_num_cus();
+        if (perCU > 0) grid = (long)perCU * cbp_num_cus();
     }
-    if (grid > p.units) grid = p.units;
-    if ((long)grid * CBP_MAXCAND < p.units) grid = (p.units + CBP_MAXCAND - 1) / CBP_MAXCAND;
+    if (grid > total) grid = total;
+    if (grid * CBP_MAXCAND < total) grid = (total + CBP_MAXCAND - 1) / CBP_MAXCAND;
     if (kH == 7)
-        hipLaunchKernelGGL((cbp_rowpair_kernel<7, 7>), dim3(grid), dim3(CBP_NT), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((cbp_rowpair_kernel<7, 7>), dim3((unsigned)grid), dim3(CBP_NT), 0, (hipStream_t)stream, p);
     else if (kH == 5)
-        hipLaunchKernelGGL((cbp_rowpair_kernel<5, 5>), dim3(grid), dim3(CBP_NT), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((cbp_rowpair_kernel<5, 5>), dim3((unsigned)grid), dim3(CBP_NT), 0, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL((cbp_rowpair_kernel<3, 3>), dim3(grid), dim3(CBP_NT), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((cbp_rowpair_kernel<3, 3>), dim3((unsigned)grid), dim3(CBP_NT), 0, (hipStream_t)stream, p);
     return cb_launch_status();
+}
+
+int cbinfer_conv_changed_rowpairs(const float* state, uint64_t* bits, int32_t* ctl, uint64_t* maskCopy,
+                                  const void* prepared, const float* bias, float* output, int C, int H, int W, int K,
+                                  int kH, int kW, int relu, const cbNextDetect* next, cbStream_t stream) {
+    (void)ctl;      // (was: an arrival counter; every workgroup now zeroes the mask words of its own units)
+    cbPairSeq sq;
+    sq.state = state, sq.output = output, sq.bits = bits, sq.maskCopy = maskCopy;
+    sq.nextState = nullptr, sq.nextSplitState = nullptr, sq.nextFrameMasks = nullptr, sq.nextRangeFlag = nullptr;
+    if (next && next->state) {
+        CB_REQUIRE(next->splitState && next->frameMasks);
+        sq.nextState = next->state, sq.nextSplitState = next->splitState;
+        sq.nextFrameMasks = next->frameMasks, sq.nextRangeFlag = next->rangeFlag;
+    }
+    return cbp_launch(&sq, 1, prepared, bias, C, H, W, K, kH, kW, relu, sq.nextState ? next : nullptr, stream);
+}
+
+// nSeq sequences in one launch (own tensors each, shared weights); `next` gives the next layer's geometry and threshold
+// (its pointer fields are ignored: the per-sequence ones of cbPairSeq count), NULL or a sequence table without
+// nextState: no folding
+int cbinfer_conv_changed_rowpairs_batched(const cbPairSeq* seqs, int nSeq, const void* prepared, const float* bias,
+                                          int C, int H, int W, int K, int kH, int kW, int relu,
+                                          const cbNextDetect* next, cbStream_t stream) {
+    return cbp_launch(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, relu, next, stream);
 }
 
 // One frame of a feedback-mode CBConv2d (conv2d.py:178-259) on the row-pair kernel: detection with feedback refresh,

@@ -469,7 +469,8 @@ int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int pooled, int
  * window none of whose pixels changed is skipped exactly as the producer-mask shortcut of cbinfer_split_detect skips
  * it, so the caller must fall back to the separate detection for one frame whenever that shortcut is not valid (fresh
  * or restored next-layer state, changed next-layer threshold).
- *   bits / maskCopy : as for cbinfer_conv_changed_rows; ctl: one int32, zero between launches (arrival counter)
+ *   bits / maskCopy : as for cbinfer_conv_changed_rows (every workgroup zeroes the mask words of its own units); ctl:
+ *                     unused (kept for the signature: one int32)
  *   prepared        : cbinfer_rowconv_prep_weights
  *   next            : may be NULL (or next->state NULL): no folding */
 typedef struct {
@@ -480,7 +481,20 @@ typedef struct {
     int H, W, kH, kW;         /* the next layer's map size (behind the pool) and filter */
     float threshold;
 } cbNextDetect;
+typedef struct {                /* ONE sequence's tensors for the batched form (own state each, shared weights) */
+    const float* state;         /* prevInput [C,H,W] */
+    float* output;              /* prevOutput [K,H,W] */
+    uint64_t* bits;
+    uint64_t* maskCopy;         /* may be NULL */
+    float* nextState;           /* the next layer's tensors as in cbNextDetect; NULL: no folding */
+    void* nextSplitState;
+    uint64_t* nextFrameMasks;
+    int32_t* nextRangeFlag;     /* may be NULL */
+} cbPairSeq;
 int cbinfer_rowpairs_supported(int C, int K, int kH, int kW, int H, int W);
+int cbinfer_conv_changed_rowpairs_batched(const cbPairSeq* seqs, int nSeq, const void* prepared, const float* bias,
+                                          int C, int H, int W, int K, int kH, int kW, int relu,
+                                          const cbNextDetect* next, cbStream_t stream);
 int cbinfer_conv_changed_rowpairs(const float* state, uint64_t* bits, int32_t* ctl, uint64_t* maskCopy,
                                   const void* prepared, const float* bias, float* output, int C, int H, int W, int K,
                                   int kH, int kW, int relu, const cbNextDetect* next, cbStream_t stream);

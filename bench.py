@@ -80,6 +80,9 @@ def parse():
                     help="skip the extra measurement with frame pipelining (pycbinfer.FramePipeline: the 64->256 "
                          "layer + tail of frame t on a side stream while the first two layers of frame t+1 run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the bounded samples of BASELINE configs 3 (change-ratio sweep, coarse- and fine-grained) "
+                         "and 4 (OpenPose fp16)")
     ap.add_argument("--no-isolated", action="store_true",
                     help="skip the per-layer isolated measurement at an exact post-dilation ratio (SURVEY 8d)")
     ap.add_argument("--cpu-baseline-only", action="store_true",
@@ -629,6 +632,75 @@ def _bracketed_call(layer, feed, frame, which, sink):
 def _chk(status):
     from cbinfer_amd._lib import check
     check(status)
+
+
+
+def secondary_configs(args):
+    """BASELINE.json configs[2] (fine-grained + CBPoolMax2d, sweep of the change ratio) and configs[3] (OpenPose T=2,
+    368x654, coarse-grained fp16) in the driver line -- bounded samples of what tools/sweep.py measures in full:
+    three ratios of the sweep (1 / 10 / 50 % of the pixels re-drawn per frame in 16x16 blocks) for the coarse-grained
+    experiment 6 network of the headline and the fine-grained experiment 7 network (in-place form), and the OpenPose
+    network (random weights, 10 % of the input re-drawn per frame) in the reference's two modes, each beside the dense
+    network on the same GPU, the better of eager / graph-replayed launches for every network."""
+    import pycbinfer
+    from cbinfer_amd import workloads
+    steps, warm = 40, 5
+
+    def measure(model, frames, mode, steps=steps, warm=warm):
+        runner = FrameRunner(model, frames[0], mode)
+        runner.prime(frames[:2])
+        for f in frames[2:2 + warm]:
+            runner.step(f)
+        seq = frames[2 + warm:2 + warm + steps]
+        return len(seq) / timed_loop(runner, seq, len(seq), lambda: None)
+
+    def ratios(model):
+        out = []
+        for m in model.modules():
+            if type(m) is pycbinfer.CBConv2d and m.lastChangeIndexes() is not None:
+                ci = m.lastChangeIndexes()
+                out.append(round(ci.numel() / float(ci.size[0] * ci.size[1]), 3))
+        return out
+    out = {"config3_sweep": [], "what": secondary_configs.__doc__.replace("\n    ", " ")}
+    n = 2 + warm + steps
+    for ratio in (0.01, 0.10, 0.50):
+        vid = workloads.SyntheticVideo(H=H, W=W, ratio=ratio, block=16, seed=7)
+        frames = vid.frames(n)
+        base, cg = build_bench_model(6, args.threshold)
+        dense = max(measure(base, frames, m) for m in ("graph", "eager"))
+        fcg = max(measure(cg, frames, m) for m in ("graph", "eager"))
+        _, fg = workloads.sceneLabelingModels(experimentIdx=7, threshold=args.threshold)
+        for m in fg.modules():
+            if type(m) is pycbinfer.CBConv2d:
+                m.fgInPlace = True
+        pycbinfer.fuseTail1x1(fg)
+        ffg = max(measure(fg, frames, m) for m in ("graph", "eager"))
+        out["config3_sweep"].append({"input_change": vid.ratio, "dense_fps": dense, "cg_exp6_fps": fcg,
+                                     "cg_speedup": fcg / dense, "cg_post_dilation_ratio_per_layer": ratios(cg),
+                                     "fg_exp7_inplace_fps": ffg, "fg_speedup": ffg / dense,
+                                     "fg_touched_ratio_per_layer": ratios(fg)})
+        del base, cg, fg, frames
+        torch.cuda.synchronize()
+    Hp, Wp = 368, 654
+    vid = workloads.SyntheticVideo(H=Hp, W=672, ratio=0.10, block=16, seed=3)
+    psteps = 20
+    frames = [(f[:, :, :, :Wp] * (255.0 / 256.0) - 0.5).half().contiguous() for f in vid.frames(2 + 3 + psteps)]
+    base = workloads.OpenPoseModel(T=2).cuda().half()
+    test = workloads.convertOpenPose(workloads.OpenPoseModel(T=2).cuda().half(), threshold=0.02)
+    testf = workloads.convertOpenPose(workloads.OpenPoseModel(T=2).cuda().half(), threshold=0.02, feedbackLoop=True)
+    dense = max(measure(base, frames, m, psteps, 3) for m in ("graph", "eager"))
+    cb = max(measure(test, frames, m, psteps, 3) for m in ("graph", "eager"))
+    cbf = max(measure(testf, frames, m, psteps, 3) for m in ("graph", "eager"))
+    rs = ratios(test)
+    pose_ops = workloads.openPoseDenseOps(2, Hp, Wp)
+    out["config4_openpose_fp16"] = {
+        "dense_fps": dense, "cb_fps": cb, "speedup": cb / dense, "cb_feedback_mode_fps": cbf,
+        "feedback_speedup": cbf / dense, "effective_gflops": cb * pose_ops / 1e9, "dense_ops_per_frame": pose_ops,
+        "mean_post_dilation_ratio": sum(rs) / max(1, len(rs)), "layers": len(rs),
+        "note": "36 converted convs, fp16 (cg_half path: list kernels of rounds 1-2, f16 MFMA / f32 accumulation), random "
+                "weights: only a few percent of the pixels per layer exceed the threshold, so the frame is ~75 "
+                "latency-bound launches -- the path at full size rather than a representative speed-up"}
+    return out
 
 
 
@@ -1347,6 +1419,14 @@ def main():
             result["isolated_layers_note"] = isolated_layers.__doc__.split("\n\n")[0].replace("\n    ", " ")
         except Exception as e:      # the headline must not depend on it
             result["isolated_layers"] = "failed: %r" % (e,)
+
+    # BASELINE.json configs[2] and [3] (bounded samples; tools/sweep.py has the full tables)
+    if world == 1 and S == 1 and not args.no_secondary:
+        try:
+            sec = secondary_configs(args)
+            result.setdefault("variants", {}).update(sec)
+        except Exception as e:      # the headline must not depend on it
+            result.setdefault("variants", {})["secondary_failed"] = repr(e)
 
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(args)

@@ -1425,3 +1425,35 @@ def test_propagated_indexes_into_a_kxk_consumer(pkg, oracle, sync, k):
             undilated_err = max(undilated_err, float((cbu(xin) - d).abs().max()))
     assert dense_err <= FP32_TOL
     assert undilated_err > 1e-3          # (the reference's behaviour for k > 1: stale outputs around the changed pixels)
+
+
+@pytest.mark.parametrize("ratio", [0.01, 0.50])
+@pytest.mark.parametrize("form", ["default", "inplace"])
+def test_fg_fullsize_sweep_ends_track_dense(pkg, form, ratio):
+    """BASELINE config 3 at the two ENDS of its sweep: fine-grained CBConv2d + the
+    scene-labeling network at 480x320 with 1 % and with 50 % of the pixels re-drawn per frame (16x16 blocks, the
+    sweep's generator).  (a) threshold 0: after a walk of frames the network equals the dense network on the last frame
+    within 1e-4; (b) the sweep's threshold 0.05: it stays within the sum of what the dropped sub-threshold changes can
+    amount to (a loose end-to-end bar, as for the coarse-grained network) and recomputes at most the touched pixels."""
+    from cbinfer_amd import workloads
+    for th in (0.0, 0.05):
+        base, test = workloads.sceneLabelingModels(experimentIdx=7, threshold=th, seed=3)
+        cbs = [m for m in test.modules() if type(m) is pkg.CBConv2d]
+        for m in cbs:
+            assert m.finegrained
+            m.fgInPlace = form == "inplace"
+        if form == "inplace":
+            pkg.fuseTail1x1(test)
+        vid = workloads.SyntheticVideo(H=320, W=480, ratio=ratio, block=16, seed=31)
+        with torch.no_grad():
+            for f in vid.frames(5):
+                y = test(f.clone())
+            ref = base(vid.frame)
+            err = (y - ref).abs().max().item()
+            assert err <= (1e-4 if th == 0.0 else 0.5), (th, err)
+        # the first layer's touched pixels: the re-drawn blocks dilated by the 7x7 support, nothing like the whole map
+        # at 1 %, (nearly) all of it at 50 %
+        ci = cbs[0].lastChangeIndexes()
+        if ci is not None:
+            frac = ci.numel() / float(320 * 480)
+            assert (frac < 0.05) if ratio == 0.01 else (frac > 0.5), (ratio, frac)

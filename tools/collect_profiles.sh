@@ -16,12 +16,12 @@ run() { "$@"; rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "killed: $
 run timeout -k 10 420 python3 $R/bench.py > $O/bench.json 2> $O/bench.err || exit 1
 echo "bench done"
 run timeout -k 10 420 rocprofv3 --kernel-trace --stats -d $O/stats -o s --output-format csv -- \
-    python3 $R/bench.py --no-cpu-baseline --multi 0 > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
+    python3 $R/bench.py --no-cpu-baseline --multi 0 --no-secondary > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
 echo "stats done"
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$O/pmc_$(echo $c | tr A-Z a-z | sed 's/_size//')
   run timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d $d -o p --output-format csv -- \
-      python3 $R/bench.py --mode eager --steps 40 --warmup 5 --min-seconds 0 --no-cpu-baseline --no-dense --multi 0 --no-variants --no-last-frame --no-pipelined \
+      python3 $R/bench.py --mode eager --steps 40 --warmup 5 --min-seconds 0 --no-cpu-baseline --no-dense --multi 0 --no-variants --no-last-frame --no-pipelined --no-secondary --no-isolated \
       > $d.json 2> $d.err || exit 1
   echo "$c done"
 done
@@ -47,12 +47,17 @@ for sub, c in (("fg_pmc_fetch", "FETCH_SIZE"), ("fg_pmc_write", "WRITE_SIZE")):
         print("fg %-72s n=%4d %s median %10.2f KB" % (k, len(v), c, statistics.median(v[3:] or v)))
 PY
 echo "fg done"
+# OpenPose T=2 fp16 (config 4)
+run timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/pose_stats -o s --output-format csv -- \
+    python3 $R/tools/pose_target.py > $O/pose_target.txt 2> $O/pose_stats.err || exit 1
+echo "pose done"
 # keep the summaries, drop the bulky raw traces (gpurun merges at most 64 MiB back)
 mkdir -p $O/keep
 cp $O/bench.json $O/bench_under_rocprof.json $O/pmc_traffic.json $O/pmc_traffic.txt $O/fg_target.txt $O/keep/ 2>/dev/null
-for d in stats fg_stats; do
+cp $O/pose_target.txt $O/keep/ 2>/dev/null
+for d in stats fg_stats pose_stats; do
   f=$(find $O/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/keep/${d}_kernel_stats.csv
 done
 f=$(find $O/stats -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 $R/tools/trace_summary.py $f > $O/keep/kernel_trace_summary.txt 2>/dev/null
-rm -rf $O/stats $O/fg_stats $O/pmc_fetch $O/pmc_write $O/fg_pmc_fetch $O/fg_pmc_write
+rm -rf $O/stats $O/fg_stats $O/pose_stats $O/pmc_fetch $O/pmc_write $O/fg_pmc_fetch $O/fg_pmc_write
 ls -la $O/keep

@@ -32,7 +32,7 @@ fetch, write = load("pmc_fetch", "FETCH_SIZE"), load("pmc_write", "WRITE_SIZE")
 L1, L2, L3, TAIL = ("conv 3->16 k7 @320x480", "conv 16->64 k7 @160x240", "conv 64->256 k7 @80x120",
                     "tail 1x1 256->64->8 @80x120")
 # the kernel of every layer in the bench workload (first pattern that matches), by the bench's layer label
-LAYER = [("cb_rowconv_f32_kernel", L1),
+LAYER = [("cbp_rowpair_kernel", L1), ("cb_rowconv_f32_kernel", L1),
          ("cbs_conv_kernel<64, 64", L2), ("cb_blockconv_kernel", L2),
          ("cbs_conv_kernel<128, 128", L3), ("cb_mfma_f32_kernel<4, 2, 2, 1, 2, true", L3),
          ("cb_mfma_f32_kernel<2, 4, 2, 1, 2, true", L3), ("cb_mfma_f32_kernel<2, 2, 2, 1, 2, true", L3),
@@ -42,9 +42,9 @@ ADDS = [("cbs_reduce_tail_kernel", L3), ("cbs_reduce_kernel", L3), ("cb_splitk_r
 table = {}
 extra = {}
 for name in sorted(set(fetch) | set(write)):
-    if "cb_" not in name and "cbs" not in name:
+    if "cb_" not in name and "cbs" not in name and "cbp" not in name:
         continue
-    short = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void cbs::", "cbs::")[:90]
+    short = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void cbs::", "cbs::").replace("void cbp::", "cbp::")[:90]
     # steady state: drop the first dispatches (100 %-change first frame, priming)
     f = fetch.get(name, [])[3:] or fetch.get(name, [])
     w = write.get(name, [])[3:] or write.get(name, [])

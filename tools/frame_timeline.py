@@ -23,10 +23,11 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 
 def short(n):
     return n.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace(
-        "void cbs::", "cbs::")
+        "void cbs::", "cbs::").replace("void cbp::", "cbp::")
 
 
-starts = [i - 1 for i, r in enumerate(rows) if "cb_rowconv_f32_kernel" in r["Kernel_Name"] and i > 0]
+starts = [i - 1 for i, r in enumerate(rows)
+          if ("cb_rowconv_f32_kernel" in r["Kernel_Name"] or "cbp_rowpair_kernel" in r["Kernel_Name"]) and i > 0]
 groups = collections.defaultdict(list)
 for a, b in zip(starts[:-1], starts[1:]):
     fr = rows[a:b]

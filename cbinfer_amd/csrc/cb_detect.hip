@@ -99,6 +99,10 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
     T k0 = T(0), k1 = T(0), k2 = T(0), k3 = T(0);
     if (valid) {
         int c = g;
+        // update == 2 (round 4): the layer is NOT in feedback mode and keeps a copy of its input (conv2d.py:234-236,
+        // prevInput.copy_(input)): every value read for the comparison is written to the state right here -- same
+        // thread, behind its own read of the old value -- instead of by a full-tensor copy launch behind this one.
+        const bool copyAll = update == 2;
 #pragma unroll 1
         for (; c + 3 * G < C; c += 4 * G) {  // 8 independent loads in flight per lane
             const T s0 = state[(long)c * HW + p], x0 = ldin(c);
@@ -108,6 +112,10 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
             chg |= cb_changed(s0, x0, th) | cb_changed(s1, x1, th) | cb_changed(s2, x2, th) |
                    cb_changed(s3, x3, th);
             k0 = x0, k1 = x1, k2 = x2, k3 = x3;
+            if (copyAll) {
+                state[(long)c * HW + p] = x0, state[(long)(c + G) * HW + p] = x1;
+                state[(long)(c + 2 * G) * HW + p] = x2, state[(long)(c + 3 * G) * HW + p] = x3;
+            }
         }
         if (keep && c == g) {   // fewer than four channels for this wave: the same, value by value
             if (c < C) k0 = ldin(c);
@@ -116,8 +124,17 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
             if (c < C) chg |= cb_changed(state[(long)c * HW + p], k0, th);
             if (c + G < C) chg |= cb_changed(state[(long)(c + G) * HW + p], k1, th);
             if (c + 2 * G < C) chg |= cb_changed(state[(long)(c + 2 * G) * HW + p], k2, th);
+            if (copyAll) {
+                if (c < C) state[(long)c * HW + p] = k0;
+                if (c + G < C) state[(long)(c + G) * HW + p] = k1;
+                if (c + 2 * G < C) state[(long)(c + 2 * G) * HW + p] = k2;
+            }
         } else {
-            for (; c < C; c += G) chg |= cb_changed(state[(long)c * HW + p], ldin(c), th);
+            for (; c < C; c += G) {
+                const T xv = ldin(c);
+                chg |= cb_changed(state[(long)c * HW + p], xv, th);
+                if (copyAll) state[(long)c * HW + p] = xv;
+            }
         }
     }
 
@@ -130,7 +147,7 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
     if (m == 0) return;  // uniform over the workgroup
 
     // feedback: refresh the state at the (pre-dilation) changed pixels only (.cu:74-80)
-    if (update && ((m >> lane) & 1ull)) {
+    if (update == 1 && ((m >> lane) & 1ull)) {
         if (keep) {
             if (g < C) state[(long)g * HW + p] = k0;
             if (g + G < C) state[(long)(g + G) * HW + p] = k1;

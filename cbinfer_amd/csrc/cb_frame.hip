@@ -20,28 +20,27 @@ extern "C" int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void
         // detection -> [state copy] -> self-compacting fused kernel: 2 launches per layer and frame.
         // `bits` is a cbinfer_frame_mask_bytes(H,W) buffer (two alternating masks + parity).
         CB_REQUIRE(!haveIndexes && bits && !mapOut);
+        // (not in feedback mode, own copy of the input kept -- conv2d.py:234-236: the detection writes every value
+        //  it reads into the state itself, updateInputState = 2; rounds 1-3 issued a full-tensor copy behind it: 36
+        //  launches and 166 us of a 890 us OpenPose frame)
+        const bool copyAll = !feedbackLoop && copyInput && prevInput != input;
         st = cbinfer_change_detection_frame(input, prevInput, bits, W, H, C, (kH - 1) / 2, (kW - 1) / 2,
-                                            threshold, feedbackLoop, edt, stream);
+                                            threshold, feedbackLoop ? 1 : (copyAll ? 2 : 0), edt, stream);
         if (st != CB_OK) return st;
-        if (!feedbackLoop && copyInput && prevInput != input) {
-            const size_t bytes = (size_t)C * H * W * (dtype == CB_F16 ? 2 : 4);
-            hipError_t e = hipMemcpyAsync(prevInput, input, bytes, hipMemcpyDeviceToDevice,
-                                          (hipStream_t)stream);
-            if (e != hipSuccess) return (int)e;
-        }
         const void* src = (feedbackLoop || copyInput) ? prevInput : input;
         return cbinfer_conv_changed_from_mask(src, bits, idx, countDev, weightsPrepared, bias, prevOutput,
                                               C, H, W, K, kH, kW, relu, workspace, dtype, stream);
     }
     if (!haveIndexes) {
         CB_REQUIRE(bits != nullptr);
+        const bool copyAll = !feedbackLoop && copyInput && prevInput != input;      // (as above: updateInputState = 2)
         st = cbinfer_change_detection_bits(input, prevInput, bits, W, H, C, (kH - 1) / 2, (kW - 1) / 2,
-                                           threshold, feedbackLoop, edt, stream);
+                                           threshold, feedbackLoop ? 1 : (copyAll ? 2 : 0), edt, stream);
         if (st != CB_OK) return st;
         st = cbinfer_compact_bits(bits, W, H, idx, countDev, nullptr, mapOut, stream);
         if (st != CB_OK) return st;
     }
-    if (!feedbackLoop && copyInput && prevInput != input) {
+    if (haveIndexes && !feedbackLoop && copyInput && prevInput != input) {      // (propagated indexes: no detection ran)
         const size_t bytes = (size_t)C * H * W * (dtype == CB_F16 ? 2 : 4);
         hipError_t e = hipMemcpyAsync(prevInput, input, bytes, hipMemcpyDeviceToDevice,
                                       (hipStream_t)stream);
@@ -144,14 +143,10 @@ static int cb_forward_masked(int blocks, const float* input, const float* prePoo
         if (st != CB_OK) return st;
         return contract(prevInput);
     }
+    const bool copyAll = !feedbackLoop && copyInput && prevInput != input;      // (updateInputState = 2: cb_detect.hip)
     st = cbinfer_change_detection_bits(input, prevInput, bits, W, H, C, (kH - 1) / 2, (kW - 1) / 2, threshold,
-                                       feedbackLoop, CB_F32, stream);
+                                       feedbackLoop ? 1 : (copyAll ? 2 : 0), CB_F32, stream);
     if (st != CB_OK) return st;
-    if (!feedbackLoop && copyInput && prevInput != input) {
-        hipError_t e = hipMemcpyAsync(prevInput, input, (size_t)C * H * W * 4, hipMemcpyDeviceToDevice,
-                                      (hipStream_t)stream);
-        if (e != hipSuccess) return (int)e;
-    }
     return contract((feedbackLoop || copyInput) ? prevInput : input);
 }
 

@@ -75,7 +75,10 @@ int cbinfer_weights_ckkpad(int Ckk, int dtype);
  * half: cbconv2d_cg_half_backend.cu:10-88.
  * change(p) = OR_c |state[c,p] - in[c,p]| > th (strict; half: compared in half precision after one
  * rounding of the difference).  A changed pixel marks its (2kHHalf+1)x(2kWHalf+1) neighbourhood in
- * changeMap [H,W] int8 and, if updateInputState, gets in[:,p] copied into state[:,p].
+ * changeMap [H,W] int8 and, if updateInputState == 1, gets in[:,p] copied into state[:,p] (the feedback refresh).
+ * updateInputState == 2 (round 4): EVERY pixel's in[:,p] is copied into state[:,p] in the same pass -- the
+ * reference's prevInput.copy_(input) of a layer that is not in feedback mode (conv2d.py:234-236) without the
+ * full-tensor copy launch behind the detection.
  * The map is zeroed by the library (the reference's caller does it, conv2d_cg.py:105). */
 int cbinfer_change_detection(const void* input, void* state, int8_t* changeMap, int W, int H, int C,
                              int kHHalf, int kWHalf, float threshold, int updateInputState,

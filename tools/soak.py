@@ -25,6 +25,7 @@ def main():
                 m.cloneOutput = False
         pycbinfer.fuseTail1x1(test)              # (the tail in the contraction's second launch, as the bench runs it)
         pycbinfer.fusePoolingIntoDetection(test)
+        pycbinfer.fuseDetectionIntoProducer(test)    # (the 16->64 layer's pooled detection in the 3->16 layer's launch)
         seqs.append((base, test, workloads.SyntheticVideo(H=320, W=480, ratio=0.05 + 0.05 * q, block=32,
                                                           seed=100 + q), torch.cuda.Stream()))
     torch.cuda.synchronize()

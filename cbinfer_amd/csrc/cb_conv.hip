@@ -209,6 +209,34 @@ struct ConvParams {
 #define CB_SEAM_INFO 1020
 
 #define CB_SELFC_MAXW 4096
+// arrival counters of the self-compacting launches, on lines of their own in the free part of the ticket header
+#define CB_ARRIVE_SHARDS 640
+#define CB_ARRIVE_NSH 8
+
+// "Every workgroup has read the mask": the last workgroup to get here flips the parity for the next frame.  The
+// workgroups count themselves on SHARDED counters (a top counter behind them): a returning atomic on ONE word is
+// served every 11 ns, so the 512 workgroups of a launch that finds nothing to do -- the common case of a deep layer
+// of a network whose change has died out further up -- spent 5.6 us of their 7.3 queueing for their tickets (round 4).
+__device__ __forceinline__ void cb_arrive_and_flip(unsigned long long* frameMasks, int maskWords, int* tickets, int par) {
+    int* ctl = (int*)(frameMasks + 2 * (long)maskWords);
+    bool last;
+    if (tickets == nullptr) {
+        last = __hip_atomic_fetch_add(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    } else {
+        const int sh = blockIdx.x % CB_ARRIVE_NSH, expected = ((int)gridDim.x - sh + CB_ARRIVE_NSH - 1) / CB_ARRIVE_NSH;
+        int* c = tickets + CB_ARRIVE_SHARDS + sh * 32;
+        last = false;
+        if (__hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1) {
+            __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int active = min(CB_ARRIVE_NSH, (int)gridDim.x);
+            last = __hip_atomic_fetch_add(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == active - 1;
+        }
+    }
+    if (last) {
+        __hip_atomic_store(ctl + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ctl, par ^ 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // r-th (0-based) set bit of w, r < popcount(w)
 __device__ __forceinline__ int cb_select_bit(unsigned long long w, int r) {
@@ -1053,14 +1081,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
     if (SELFC) {
         // every workgroup has read the mask: the last one to get here flips the parity for the next frame
         __syncthreads();
-        if (t == 0) {
-            int* ctl = (int*)(p.frameMasks + 2 * (long)p.maskWords);
-            const int d = __hip_atomic_fetch_add(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d == (int)gridDim.x - 1) {
-                __hip_atomic_store(ctl + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(ctl, par ^ 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+        if (t == 0) cb_arrive_and_flip(p.frameMasks, p.maskWords, p.tickets, par);
     }
 }
 
@@ -1561,14 +1582,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
     if (SELFC) {
         // every workgroup has read the mask: the last one to get here flips the parity for the next frame
         __syncthreads();
-        if (t == 0) {
-            int* ctl = (int*)(p.frameMasks + 2 * (long)p.maskWords);
-            const int d = __hip_atomic_fetch_add(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d == (int)gridDim.x - 1) {
-                __hip_atomic_store(ctl + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(ctl, par ^ 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+        if (t == 0) cb_arrive_and_flip(p.frameMasks, p.maskWords, p.tickets, par);
     }
 }
 

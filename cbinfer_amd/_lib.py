@@ -85,6 +85,11 @@ _SIGNATURES = {
                                   _vp, _l, _vp, _i, _vp]),
     "cbinfer_cbconv2d_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
                                       _i, _f, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "cbinfer_cbconv2d_forward_after": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f,
+                                            _i, _i, _i, _vp, _i, _vp]),
+    "cbinfer_change_detection_frame_after": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "cbinfer_conv_changed_from_mask_after": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
+                                                  _i, _vp, _i, _vp]),
     "cbinfer_frame_mask_bytes": (_l, [_i, _i]),
     "cbinfer_frame_mask_max_words": (_i, []),
     "cbinfer_change_detection_frame": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
@@ -169,7 +174,7 @@ def _load():
         fn = getattr(lib, name)     # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.cbinfer_abi_version() != 6:
+    if lib.cbinfer_abi_version() != 7:
         raise ImportError("cbinfer_amd: libcbinfer_hip.so ABI version mismatch")
     return lib
 

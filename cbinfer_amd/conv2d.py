@@ -35,6 +35,9 @@ def _same_shape(t, shape):
     return t is not None and tuple(t.size()) == tuple(shape)
 
 
+_NO_CHAIN = os.environ.get('CBINFER_NO_CHAIN', '0') == '1'
+
+
 class LazyPool(object):
     """What a CBPoolMax2d with lazy=True hands to the next module instead of a pooled tensor: the pool's
     INPUT and the pooled size.  A feedback-mode CBConv2d folds the pooling into its change detection
@@ -194,6 +197,7 @@ class CBConv2d(nn.Module):
         self.prevInput = self.weight.detach().new_zeros(0)
         self.prevOutput = self.weight.detach().new_zeros(0)
         self.__dict__['_rangeFallback'] = False
+        self.__dict__['_upSeen'] = None
         if hasattr(self, 'compStats'):
             self.compStats = None
         # device work buffers (not part of the module state)
@@ -932,7 +936,17 @@ class CBConv2d(nn.Module):
                     int(work['selfc'] and not have), arith, stream_ptr(input))
             check(C.cbinfer_cbconv2d_forward(*args))
             if not have and not self._inputIsLiveState:
-                self._make_plan(False, input, C.cbinfer_cbconv2d_forward, args, 0)
+                if work['selfc'] and mapOut is None:
+                    # replayed through the chained entry: a frame in which the layer that produced `input` rewrote
+                    # nothing ends both launches at once (_upstream_count decides per frame whether that may be said)
+                    cargs = (None,) + args[:6] + args[7:19] + (args[21], args[23], args[24])
+                    self._make_plan(False, input, C.cbinfer_cbconv2d_forward_after, cargs, 1)
+                    if self._plan is not None:
+                        self._plan['chain'] = True
+                else:
+                    self._make_plan(False, input, C.cbinfer_cbconv2d_forward, args, 0)
+            if work['selfc'] and not have:
+                self._publish_count(work['count'])
         if mapOut is not None:
             # (a view of the module's work buffer, rewritten by the next frame -- clone it to keep it; the
             #  reference allocates a fresh map per frame)
@@ -1040,9 +1054,15 @@ class CBConv2d(nn.Module):
                 return None
         args = plan['args']
         args[plan['srcSlot']] = src.data_ptr()
+        chain = plan.get('chain')
+        if chain:
+            up = self.__dict__.get('_upNow')
+            args[0] = up.data_ptr() if up is not None else None
         status = plan['fn'](*args)
         if status != 0:
             check(status)
+        if chain:
+            self._publish_count(plan['work']['count'])
         self._inputIsLiveState = False
         if plan['result'] is not None:          # fine-grained in-place frame: prevOutput or its relu'd copy
             res = plan['result']
@@ -1064,7 +1084,37 @@ class CBConv2d(nn.Module):
             return 'changeIndexes', bufs['prevOutput'], self._lastIndexes
         return bufs['prevOutput']
 
+    # ---------------------------------------------------------------- chains of change-based layers
+    # A layer whose self-compacting contraction ran leaves its change count on the device (work['count']) and says so
+    # on its output buffer: (module, frame serial, buffer version, count).  The next CBConv2d that is handed this
+    # very buffer may tell its two launches where that count is (cbinfer_cbconv2d_forward_after): zero there and the
+    # frame is over for it after a scalar load each -- the buffer is what it was, nothing can have changed.  What
+    # makes that exact is checked here, on the host, every frame: the tag is of the producer's LATEST forward, nobody
+    # wrote to the buffer through torch since (version counter), this layer's previous forward consumed the
+    # producer's previous frame from the same buffer, and nobody rewrote this layer's state through torch either.
+    # (Threshold and mode are pinned by the plan that carries the call.)  CBINFER_NO_CHAIN=1 switches it off.
+    def _publish_count(self, count):
+        out = self._buffers['prevOutput']
+        out._cbProduced = (self, self.__dict__.get('_serial', 0), out._version, count)
+
+    def _note_upstream(self, inp):
+        d = self.__dict__
+        d['_serial'] = d.get('_serial', 0) + 1
+        tag = getattr(inp, '_cbProduced', None) if type(inp) is torch.Tensor else None
+        seen, now = None, None
+        if tag is not None:
+            prod, serial, version, count = tag
+            pin = self._buffers.get('prevInput')
+            if (prod is not self and prod.__dict__.get('_serial') == serial and inp._version == version and
+                    pin is not None and not _NO_CHAIN):
+                seen = (prod, serial, inp.data_ptr(), pin.data_ptr(), pin._version)
+                last = d.get('_upSeen')
+                if last is not None and last[0] is prod and last[1] == serial - 1 and last[2:] == seen[2:]:
+                    now = count
+        d['_upSeen'], d['_upNow'] = seen, now
+
     def forward(self, inp):
+        self._note_upstream(inp)
         if self.__dict__.get('_plan') is not None:
             out = self._run_plan(inp)
             if out is not None:

@@ -204,11 +204,24 @@ struct ConvParams {
     int dbg;                          // diagnostic ablations (CBINFER_CONV_DBG): 1 no gather loads, 2 no weight loads
     int xcdMap;                       // XCD-aware item order (CBINFER_XCD_MAP=0 switches it off)
     int seam;                         // split-K slices are summed by a second launch (cb_splitk_reduce_kernel)
+    const int32_t* upstream;          // SELFC, optional: the producing layer's change count of this frame (0: skip)
 };
 // the split-K geometry of a launch, left behind the tickets for cb_splitk_reduce_kernel: {SK, tiles, N}
 #define CB_SEAM_INFO 1020
 
 #define CB_SELFC_MAXW 4096
+// The layer that produced this layer's input published a change count of zero for this frame: the detection in front
+// of this launch returned at once and left the mask empty, the frame does not exist for this layer -- no mask to read
+// or zero, no parity to flip (the mask the parity selects is still the clean one).  Its own count goes out as zero,
+// so that the layer behind it is skipped the same way.
+#define CB_UPSTREAM_IDLE_EXIT                                                          \
+    if (SELFC && p.upstream && *p.upstream == 0) {                                     \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                     \
+            p.countOut[0] = 0;                                                         \
+            if (p.seam) p.tickets[CB_SEAM_INFO] = 0;                                   \
+        }                                                                              \
+        return;                                                                        \
+    }
 // arrival counters of the self-compacting launches, on lines of their own in the free part of the ticket header
 #define CB_ARRIVE_SHARDS 640
 #define CB_ARRIVE_NSH 8
@@ -375,6 +388,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
 #endif
     CB_STAMP_AT(0);
     const int t = threadIdx.x;
+    CB_UPSTREAM_IDLE_EXIT
     // ---- SELFC: stream compaction folded into this kernel -------------------------------------------
     // Every workgroup rebuilds the exclusive popcount prefix of the frame's change mask (<= 32 KB, L2
     // resident) in LDS; a tile's pixels are then found by rank (binary search over the prefix + select
@@ -1169,6 +1183,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
     static_assert(KS == 1 || 2 * (A_STAGE + B_STAGE) * 2 >= WM * WN * 64 * 16 * 4, "reduce buffer");
 
     const int t = threadIdx.x;
+    CB_UPSTREAM_IDLE_EXIT
     // ---- SELFC: stream compaction folded into this kernel -------------------------------------------
     // Every workgroup rebuilds the exclusive popcount prefix of the frame's change mask (<= 32 KB, L2
     // resident) in LDS; a tile's pixels are then found by rank (binary search over the prefix + select
@@ -1892,7 +1907,8 @@ int cbinfer_conv_changed(const void* input, const int32_t* changeList, int numCh
 static int cb_conv_from_mask(const void* input, uint64_t* frameMasks, int32_t* idxOut,
                              int32_t* countOut, const void* weightsPrepared, const void* bias,
                              void* output, int C, int H, int W, int K, int kH, int kW, int relu,
-                             void* workspace, int dtype, cbStream_t stream, int accumulate, void* reluOut) {
+                             void* workspace, int dtype, cbStream_t stream, int accumulate, void* reluOut,
+                             const int32_t* upstream = nullptr) {
     CB_REQUIRE(input && frameMasks && idxOut && countOut && weightsPrepared && output && C > 0 && H > 0 &&
                W > 0 && K > 0 && kH > 0 && kW > 0);
     if (dtype != CB_F32 && dtype != CB_F16 && dtype != CB_F32S) return CB_ERR_BADARG;
@@ -1920,6 +1936,7 @@ static int cb_conv_from_mask(const void* input, uint64_t* frameMasks, int32_t* i
     p.wpr = cbinfer_mask_words_per_row(W);
     p.listOut = idxOut;
     p.countOut = countOut;
+    p.upstream = upstream;
     if (workspace) {
         p.tickets = (int*)workspace;
         p.slabs = (float*)((char*)workspace + 4096);
@@ -1938,6 +1955,16 @@ int cbinfer_conv_changed_from_mask(const void* input, uint64_t* frameMasks, int3
                                    void* workspace, int dtype, cbStream_t stream) {
     return cb_conv_from_mask(input, frameMasks, idxOut, countOut, weightsPrepared, bias, output, C, H, W, K,
                              kH, kW, relu, workspace, dtype, stream, 0, nullptr);
+}
+
+// upstreamCount (optional, device): the change count the layer that produced `input`'s source published this frame;
+// zero ends the launch at once with countOut = 0 and the masks untouched (cbinfer_cbconv2d_forward_after).
+int cbinfer_conv_changed_from_mask_after(const int32_t* upstreamCount, const void* input, uint64_t* frameMasks,
+                                         int32_t* idxOut, int32_t* countOut, const void* weightsPrepared,
+                                         const void* bias, void* output, int C, int H, int W, int K, int kH, int kW,
+                                         int relu, void* workspace, int dtype, cbStream_t stream) {
+    return cb_conv_from_mask(input, frameMasks, idxOut, countOut, weightsPrepared, bias, output, C, H, W, K,
+                             kH, kW, relu, workspace, dtype, stream, 0, nullptr, upstreamCount);
 }
 
 // Fine-grained form: `delta` holds the thresholded per-value differences (0 where unchanged); the kernel

@@ -42,8 +42,12 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
                                                         const int* __restrict__ parity, long altWords,
                                                         int pH, int pW,
                                                         const unsigned long long* __restrict__ prodMask,
-                                                        DetBatch batch) {
-    cb_touch_kernarg<104 + sizeof(DetBatch)>();
+                                                        const int* __restrict__ upstream, DetBatch batch) {
+    cb_touch_kernarg<112 + sizeof(DetBatch)>();
+    // `upstream`: the change count the layer that PRODUCED `in` published this frame.  Zero: it rewrote no output
+    // pixel, `in` is bit for bit what this layer compared (and, not in feedback mode, copied) last frame, nothing can
+    // exceed the threshold -- the launch is over after one scalar load (cbinfer_cbconv2d_forward_after).
+    if (upstream && *upstream == 0) return;
     int yb = blockIdx.y;
     if (batch.nSeq > 1) {
         const int q = (int)blockIdx.y / H;
@@ -386,7 +390,7 @@ template <typename T, bool BITS, bool POOL = false>
 int launch_detect(const void* input, void* state, int8_t* map, uint64_t* bits, int W, int H, int C,
                   int kHH, int kWH, float th, int update, hipStream_t s, const int* parity = nullptr,
                   long altWords = 0, int pH = 0, int pW = 0, const uint64_t* prodMask = nullptr,
-                  const DetBatch* batch = nullptr) {
+                  const DetBatch* batch = nullptr, const int* upstream = nullptr) {
     const int wpr = cbinfer_mask_words_per_row(W);
     const int G = detect_groups(C);
     DetBatch b;
@@ -396,7 +400,7 @@ int launch_detect(const void* input, void* state, int8_t* map, uint64_t* bits, i
     dim3 grid(wpr, H * b.nSeq), block(64 * G);
     hipLaunchKernelGGL((cb_detect_kernel<T, BITS, POOL>), grid, block, 0, s, (const T*)input, (T*)state,
                        map, (unsigned long long*)bits, W, H, C, kHH, kWH, th, update, wpr, parity, altWords,
-                       pH, pW, (const unsigned long long*)prodMask, b);
+                       pH, pW, (const unsigned long long*)prodMask, upstream, b);
     return cb_launch_status();
 }
 
@@ -475,9 +479,10 @@ int cbinfer_change_detection_bits_pooled(const void* prePool, int pH, int pW, co
 
 // Frame-pipeline form: frameMasks = [2][words] masks followed by {parity, done}; the detection ORs into
 // the mask the parity selects (cbinfer_conv_changed_from_mask consumes it and flips the parity).
-int cbinfer_change_detection_frame(const void* input, void* state, uint64_t* frameMasks, int W, int H,
-                                   int C, int kHHalf, int kWHalf, float threshold,
-                                   int updateInputState, int dtype, cbStream_t stream) {
+// upstreamCount (optional, device): see cb_detect_kernel -- a zero there ends the launch at once.
+int cbinfer_change_detection_frame_after(const int32_t* upstreamCount, const void* input, void* state,
+                                         uint64_t* frameMasks, int W, int H, int C, int kHHalf, int kWHalf,
+                                         float threshold, int updateInputState, int dtype, cbStream_t stream) {
     CB_REQUIRE(input && state && frameMasks && W > 0 && H > 0 && C > 0 && kHHalf >= 0 && kWHalf >= 0);
     if (kWHalf > 63 || H > 65535) return CB_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -485,11 +490,20 @@ int cbinfer_change_detection_frame(const void* input, void* state, uint64_t* fra
     const int* parity = (const int*)(frameMasks + 2 * words);
     if (dtype == CB_F32)
         return launch_detect<float, true>(input, state, nullptr, frameMasks, W, H, C, kHHalf, kWHalf,
-                                          threshold, updateInputState, s, parity, words);
+                                          threshold, updateInputState, s, parity, words, 0, 0, nullptr, nullptr,
+                                          upstreamCount);
     if (dtype == CB_F16)
         return launch_detect<cb_half, true>(input, state, nullptr, frameMasks, W, H, C, kHHalf, kWHalf,
-                                            threshold, updateInputState, s, parity, words);
+                                            threshold, updateInputState, s, parity, words, 0, 0, nullptr, nullptr,
+                                            upstreamCount);
     return CB_ERR_BADARG;
+}
+
+int cbinfer_change_detection_frame(const void* input, void* state, uint64_t* frameMasks, int W, int H,
+                                   int C, int kHHalf, int kWHalf, float threshold,
+                                   int updateInputState, int dtype, cbStream_t stream) {
+    return cbinfer_change_detection_frame_after(nullptr, input, state, frameMasks, W, H, C, kHHalf, kWHalf, threshold,
+                                                updateInputState, dtype, stream);
 }
 
 // The same with the 2x2/stride-2 max pool in front of the layer folded in: `prePool` is [C, pH, pW],

@@ -4,13 +4,11 @@
 // hipGraph capture: no allocation, no synchronisation, no memset node.
 #include "cb_common.h"
 
-extern "C" int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void* prevOutput,
-                                        uint64_t* bits, int32_t* idx, int32_t* countDev,
-                                        int8_t* mapOut, const void* weightsPrepared, const void* bias,
-                                        int C, int H, int W, int K, int kH, int kW, float threshold,
-                                        int feedbackLoop, int copyInput, int relu, int haveIndexes,
-                                        int capN, void* workspace, int selfCompact, int dtype,
-                                        cbStream_t stream) {
+static int cb_forward(const int32_t* upstreamCount, const void* input, void* prevInput, void* prevOutput,
+                      uint64_t* bits, int32_t* idx, int32_t* countDev, int8_t* mapOut, const void* weightsPrepared,
+                      const void* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
+                      int feedbackLoop, int copyInput, int relu, int haveIndexes, int capN, void* workspace,
+                      int selfCompact, int dtype, cbStream_t stream) {
     CB_REQUIRE(input && prevInput && prevOutput && idx && countDev && weightsPrepared);
     CB_REQUIRE(dtype == CB_F32 || dtype == CB_F16 || dtype == CB_F32S);
     CB_REQUIRE(capN >= 0 && capN <= H * W);
@@ -24,13 +22,15 @@ extern "C" int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void
         //  it reads into the state itself, updateInputState = 2; rounds 1-3 issued a full-tensor copy behind it: 36
         //  launches and 166 us of a 890 us OpenPose frame)
         const bool copyAll = !feedbackLoop && copyInput && prevInput != input;
-        st = cbinfer_change_detection_frame(input, prevInput, bits, W, H, C, (kH - 1) / 2, (kW - 1) / 2,
-                                            threshold, feedbackLoop ? 1 : (copyAll ? 2 : 0), edt, stream);
+        st = cbinfer_change_detection_frame_after(upstreamCount, input, prevInput, bits, W, H, C, (kH - 1) / 2,
+                                                  (kW - 1) / 2, threshold, feedbackLoop ? 1 : (copyAll ? 2 : 0), edt,
+                                                  stream);
         if (st != CB_OK) return st;
         const void* src = (feedbackLoop || copyInput) ? prevInput : input;
-        return cbinfer_conv_changed_from_mask(src, bits, idx, countDev, weightsPrepared, bias, prevOutput,
-                                              C, H, W, K, kH, kW, relu, workspace, dtype, stream);
+        return cbinfer_conv_changed_from_mask_after(upstreamCount, src, bits, idx, countDev, weightsPrepared, bias,
+                                                    prevOutput, C, H, W, K, kH, kW, relu, workspace, dtype, stream);
     }
+    CB_REQUIRE(upstreamCount == nullptr);      // (only the two-launch frame knows how to skip itself)
     if (!haveIndexes) {
         CB_REQUIRE(bits != nullptr);
         const bool copyAll = !feedbackLoop && copyInput && prevInput != input;      // (as above: updateInputState = 2)
@@ -52,6 +52,39 @@ extern "C" int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void
     return cbinfer_conv_changed(src, idx, capN, countDev, weightsPrepared, bias, prevOutput, C, H, W, K,
                                 kH, kW, relu, 0, bits, bits ? cbinfer_mask_words(H, W) : 0, workspace,
                                 dtype, stream);
+}
+
+extern "C" int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void* prevOutput,
+                                        uint64_t* bits, int32_t* idx, int32_t* countDev,
+                                        int8_t* mapOut, const void* weightsPrepared, const void* bias,
+                                        int C, int H, int W, int K, int kH, int kW, float threshold,
+                                        int feedbackLoop, int copyInput, int relu, int haveIndexes,
+                                        int capN, void* workspace, int selfCompact, int dtype,
+                                        cbStream_t stream) {
+    return cb_forward(nullptr, input, prevInput, prevOutput, bits, idx, countDev, mapOut, weightsPrepared, bias, C, H,
+                      W, K, kH, kW, threshold, feedbackLoop, copyInput, relu, haveIndexes, capN, workspace,
+                      selfCompact, dtype, stream);
+}
+
+// The self-compacting frame of a layer whose input is the OUTPUT BUFFER of another change-based layer, untouched in
+// between (conv -> conv chains; the reference has no counterpart -- every one of its layers runs its detection over
+// the whole input, conv2d.py:228-233).  upstreamCount: the device word that layer's contraction left its change count
+// in this frame (its countDev).  Zero there means not one output pixel was rewritten: the input is bit for bit what
+// this layer compared with its state last frame -- and (not in feedback mode) copied into it, or (feedback mode)
+// left within the threshold of it -- so the detection would find nothing and the contraction would have nothing to
+// do.  Both launches then return after one scalar load, countDev receives 0 (the next layer of the chain is skipped
+// the same way) and masks, parity, state and output stay as they are.  The CALLER guarantees the premise: same input
+// buffer and same threshold as in this layer's previous frame, which saw the producer's previous frame; no writer to
+// the buffer other than that producer.  selfCompact form only (upstreamCount = NULL: cbinfer_cbconv2d_forward).
+extern "C" int cbinfer_cbconv2d_forward_after(const int32_t* upstreamCount, const void* input, void* prevInput,
+                                              void* prevOutput, uint64_t* bits, int32_t* idx, int32_t* countDev,
+                                              const void* weightsPrepared, const void* bias, int C, int H, int W,
+                                              int K, int kH, int kW, float threshold, int feedbackLoop,
+                                              int copyInput, int relu, void* workspace, int dtype,
+                                              cbStream_t stream) {
+    return cb_forward(upstreamCount, input, prevInput, prevOutput, bits, idx, countDev, nullptr, weightsPrepared, bias,
+                      C, H, W, K, kH, kW, threshold, feedbackLoop, copyInput, relu, 0, H * W, workspace, 1, dtype,
+                      stream);
 }
 
 // The same for a feedback-mode layer that sits behind a 2x2/stride-2 max pool, with the pool folded into

@@ -53,8 +53,9 @@ typedef void* cbStream_t; /* hipStream_t */
  * cbinfer_weights_ckkpad(Ckk, dtype).  3: fine-grained frame on the mask-driven contractions
  * (cbinfer_cbconv2d_forward_fg_masked and its parts).  4: split-state frame (cbinfer_split_*, several sequences
  * per launch), cbinfer_tail1x1_supported.  5: cbinfer_split_forward_tail (the 1x1 tail in the contraction's second
- * launch), cbinfer_split_tail_supported. */
-#define CBINFER_ABI_VERSION 6
+ * launch), cbinfer_split_tail_supported.  6: row-pair frame (cbinfer_*rowpairs*), cbinfer_dilate_change_indexes,
+ * updateInputState = 2.  7: chained layers (cbinfer_*_after: the producer's change count ends an idle frame). */
+#define CBINFER_ABI_VERSION 7
 
 int cbinfer_abi_version(void);
 const char* cbinfer_status_string(int status);
@@ -203,6 +204,27 @@ int cbinfer_cbconv2d_forward_pooled(const void* prePool, int pH, int pW, void* p
 int cbinfer_conv_changed_from_mask(const void* input, uint64_t* frameMasks, int32_t* idxOut,
                                    int32_t* countOut, const void* weightsPrepared, const void* bias,
                                    void* output, int C, int H, int W, int K, int kH, int kW, int relu,
+                                   void* workspace, int dtype, cbStream_t stream);
+/* Chains of change-based layers (conv -> conv, the producer's output buffer handed on untouched; no counterpart in
+ * the reference, whose every layer scans its whole input, conv2d.py:228-233): upstreamCount is the device word the
+ * PRODUCING layer's contraction left its change count in this frame (its countDev).  Zero there: the producer
+ * rewrote no output pixel, this layer's input is bit for bit what it compared with its state last frame, the
+ * detection could find nothing -- both launches return after one scalar load, countDev receives 0 (so that the
+ * next layer of the chain is skipped the same way), masks, parity, state and output stay as they are.  Non-zero
+ * (or upstreamCount = NULL): cbinfer_cbconv2d_forward(selfCompact=1) exactly.  The CALLER guarantees the premise:
+ * same input buffer and threshold as in this layer's previous frame, which followed the producer's previous frame;
+ * no other writer to that buffer.  (cbinfer_amd/conv2d.py: CBConv2d._upstream_count checks it per frame.) */
+int cbinfer_change_detection_frame_after(const int32_t* upstreamCount, const void* input, void* state,
+                                         uint64_t* frameMasks, int W, int H, int C, int kHHalf, int kWHalf,
+                                         float threshold, int updateInputState, int dtype, cbStream_t stream);
+int cbinfer_conv_changed_from_mask_after(const int32_t* upstreamCount, const void* input, uint64_t* frameMasks,
+                                         int32_t* idxOut, int32_t* countOut, const void* weightsPrepared,
+                                         const void* bias, void* output, int C, int H, int W, int K, int kH, int kW,
+                                         int relu, void* workspace, int dtype, cbStream_t stream);
+int cbinfer_cbconv2d_forward_after(const int32_t* upstreamCount, const void* input, void* prevInput,
+                                   void* prevOutput, uint64_t* bits, int32_t* idx, int32_t* countDev,
+                                   const void* weightsPrepared, const void* bias, int C, int H, int W, int K, int kH,
+                                   int kW, float threshold, int feedbackLoop, int copyInput, int relu,
                                    void* workspace, int dtype, cbStream_t stream);
 
 /* ---- a5..a8 fused, row-segment form (fp32, small filter banks) ----------------------------------

@@ -1457,3 +1457,114 @@ def test_fg_fullsize_sweep_ends_track_dense(pkg, form, ratio):
         if ci is not None:
             frac = ci.numel() / float(320 * 480)
             assert (frac < 0.05) if ratio == 0.01 else (frac > 0.5), (ratio, frac)
+
+
+def _chain_net(pkg, dtype, feedback, seed):
+    torch.manual_seed(seed)
+    convs = [nn.Conv2d(24, 64, 3, padding=1), nn.Conv2d(64, 64, 3, padding=1), nn.Conv2d(64, 32, 1),
+             nn.Conv2d(32, 48, 5, padding=2)]
+    net = nn.Sequential(*[pkg.CBConv2d(c.cuda().to(dtype).eval(), 0.05) for c in convs])
+    for m in net:
+        m.withReLU, m.feedbackLoop = True, feedback
+    return net
+
+
+def _chain_frames(rng, n, C, H, W, dtype):
+    """Frames with changed blocks, exact repeats (the first layer finds nothing), sub-threshold drift (it finds
+    nothing either) and drift in ONE pixel that the first layer recomputes but whose output stays below the second
+    layer's threshold."""
+    x = rng.standard_normal((1, C, H, W)).astype(np.float32)
+    frames = []
+    for t in range(n):
+        kind = ("block", "same", "block", "drift", "same", "same", "block", "tiny")[t % 8]
+        x = x.copy()
+        if kind == "block":
+            y0, x0 = rng.integers(0, H - 8), rng.integers(0, W - 8)
+            x[0, :, y0:y0 + 8, x0:x0 + 8] = rng.standard_normal((C, 8, 8))
+        elif kind == "tiny":
+            x[0, 0, rng.integers(0, H), rng.integers(0, W)] += 0.06
+        f = x if kind != "drift" else (x + rng.uniform(-0.01, 0.01, x.shape)).astype(np.float32)
+        frames.append(torch.from_numpy(f).cuda().to(dtype))
+    return frames
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("feedback", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_chained_layers_skip_idle_frames_bit_identically(pkg, dtype, feedback, monkeypatch):
+    """Round 4: a CBConv2d fed the output buffer of another one hands the producer's change count to its two launches
+    (cbinfer_cbconv2d_forward_after); a zero there ends them at once.  Same network, same frames, with the chain on
+    and off (every layer scanning its whole input, as the reference does, conv2d.py:228-233): outputs, states and
+    change lists bit-identical in every frame, and the skip must really have been offered on the idle frames."""
+    from cbinfer_amd import conv2d as c2
+    H, W = 46, 81
+    outs = {}
+    for name in ("CBINFER_NO_ROWCONV", "CBINFER_NO_BLOCKCONV", "CBINFER_NO_SPLIT"):
+        monkeypatch.setenv(name, "1")      # every layer on the list kernels (the chained entry is theirs), fp32 too
+    for chain in (True, False):
+        monkeypatch.setattr(c2, "_NO_CHAIN", not chain)
+        net = _chain_net(pkg, dtype, feedback, 5)
+        frames = _chain_frames(np.random.default_rng(7), 24, 24, H, W, dtype)
+        rec, offered = [], []
+        with torch.no_grad():
+            for f in frames:
+                y = net(f)
+                rec.append([y.clone()] + [m.prevInput.clone() for m in net] +
+                           [m.lastChangeIndexes().tensor().clone() for m in net])
+                offered.append([m.__dict__.get('_upNow') is not None for m in net])
+        outs[chain] = rec
+        if chain:
+            assert not any(o[0] for o in offered)                  # the first layer has no producer
+            assert all(all(o[1:]) for o in offered[3:]), offered   # plans and tags in place from the third frame on
+            counts = [[int(t.numel()) for t in r[-4:]] for r in rec]
+            assert any(c[0] == 0 and c[1] == 0 for c in counts[3:])         # idle frames: skipped down the chain
+            assert any(c[0] > 0 and c[3] > 0 for c in counts[3:])           # and frames that went all the way
+        else:
+            assert not any(any(o) for o in offered)
+    for t, (a, b) in enumerate(zip(outs[True], outs[False])):
+        for i, (u, v) in enumerate(zip(a, b)):
+            assert torch.equal(u, v), (t, i)
+
+
+@pytest.mark.gpu
+def test_chained_layers_do_not_skip_what_they_must_see(pkg, monkeypatch):
+    """The premises of the skip, each broken once: (a) somebody writes to the producer's output buffer through torch
+    between the layers; (b) the consumer misses one of the producer's frames; (c) the consumer's state is rewritten
+    through torch; (d) the threshold of the consumer moves (feedback mode: its state lies within the OLD threshold of
+    the input).  Every case against the same calls with the chain switched off."""
+    from cbinfer_amd import conv2d as c2
+    dtype, H, W = torch.float16, 40, 72
+    res = {}
+    for chain in (True, False):
+        monkeypatch.setattr(c2, "_NO_CHAIN", not chain)
+        torch.manual_seed(3)
+        p = pkg.CBConv2d(nn.Conv2d(16, 32, 3, padding=1).cuda().half().eval(), 0.05)
+        c = pkg.CBConv2d(nn.Conv2d(32, 32, 3, padding=1).cuda().half().eval(), 0.05)
+        c.feedbackLoop = True
+        rng = np.random.default_rng(11)
+        x = torch.from_numpy(rng.standard_normal((1, 16, H, W)).astype(np.float32)).cuda().half()
+        x2 = x.clone()
+        x2[0, :, 5:13, 9:17] += 1.0
+        log = []
+        with torch.no_grad():
+            for f in (x, x2, x2, x2):                    # warm: plans, tags, two idle frames
+                log.append(c(p(f)).clone())
+            mid = p(x2)                                  # (a) idle producer frame, then an in-place torch write
+            mid[0, :, 20:24, 30:34] += 0.5
+            log.append(c(mid).clone())
+            log.append(c(p(x2)).clone())
+            x3 = x2.clone()
+            x3[0, :, 25:30, 40:50] -= 1.0
+            p(x3)                                        # (b) a producer frame the consumer never sees ...
+            log.append(c(p(x3)).clone())                 # ... then an idle one it is handed
+            log.append(c(p(x3)).clone())
+            c.prevInput[0, :, 2:4, 2:4] += 0.25          # (c) the consumer's state rewritten through torch
+            log.append(c(p(x3)).clone())
+            log.append(c(p(x3)).clone())
+            c.threshold = 0.001                          # (d) a smaller threshold on an idle frame
+            log.append(c(p(x3 + 0.004)).clone())
+            log.append(c(p(x3 + 0.004)).clone())
+            log.append(c(p(x3 + 0.004)).clone())
+        res[chain] = log
+    for t, (a, b) in enumerate(zip(res[True], res[False])):
+        assert torch.equal(a, b), t

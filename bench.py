@@ -692,14 +692,30 @@ def secondary_configs(args):
     cb = max(measure(test, frames, m, psteps, 3) for m in ("graph", "eager"))
     cbf = max(measure(testf, frames, m, psteps, 3) for m in ("graph", "eager"))
     rs = ratios(test)
+    # the same network with every layer scanning its whole input, as the reference's layers do (conv2d.py:228-233):
+    # what the chained entry (cbinfer_cbconv2d_forward_after) contributes on this data
+    from cbinfer_amd import conv2d as _c2
+    _c2._NO_CHAIN = True
+    try:
+        plain = workloads.convertOpenPose(workloads.OpenPoseModel(T=2).cuda().half(), threshold=0.02)
+        cbu = max(measure(plain, frames, m, psteps, 3) for m in ("graph", "eager"))
+        del plain
+    finally:
+        _c2._NO_CHAIN = os.environ.get("CBINFER_NO_CHAIN", "0") == "1"
     pose_ops = workloads.openPoseDenseOps(2, Hp, Wp)
     out["config4_openpose_fp16"] = {
         "dense_fps": dense, "cb_fps": cb, "speedup": cb / dense, "cb_feedback_mode_fps": cbf,
-        "feedback_speedup": cbf / dense, "effective_gflops": cb * pose_ops / 1e9, "dense_ops_per_frame": pose_ops,
+        "feedback_speedup": cbf / dense, "cb_unchained_fps": cbu, "unchained_speedup": cbu / dense,
+        "effective_gflops": cb * pose_ops / 1e9, "dense_ops_per_frame": pose_ops,
         "mean_post_dilation_ratio": sum(rs) / max(1, len(rs)), "layers": len(rs),
-        "note": "36 converted convs, fp16 (cg_half path: list kernels of rounds 1-2, f16 MFMA / f32 accumulation), random "
-                "weights: only a few percent of the pixels per layer exceed the threshold, so the frame is ~75 "
-                "latency-bound launches -- the path at full size rather than a representative speed-up"}
+        "layers_without_change": sum(1 for r in rs if r == 0.0),
+        "note": "36 converted convs, fp16 (cg_half path: list kernels of rounds 1-2, f16 MFMA / f32 accumulation), RANDOM "
+                "weights: the change dies out behind the fifth conv (layers_without_change of the 36 recompute nothing "
+                "in any frame), so most of the frame is launches that find nothing to do.  cb_fps: a layer fed "
+                "another layer's output buffer reads that layer's change count and returns at once when it is zero "
+                "(exact: the buffer is what it compared last frame); cb_unchained_fps: every layer scans its whole "
+                "input as the reference does.  The path at full size, not a representative speed-up -- trained "
+                "weights carry change deeper into the network"}
     return out
 
 

@@ -968,8 +968,8 @@ def main():
             v = dict(fuse_tail=not args.no_fuse_tail, fuse_pool=not args.no_fuse_pool,
                      pool_clone=args.pool_clone, pattern=args.pattern)
             v.update(variant or {})
-            base, test = build_bench_model(args.experiment, args.threshold, v['fuse_tail'], v['fuse_pool'],
-                                           v['pool_clone'])
+            base, test = build_bench_model(v.get('experiment', args.experiment), args.threshold, v['fuse_tail'],
+                                           v['fuse_pool'], v['pool_clone'])
             vid = bench_video(shard.sequence_seed(1234) + 7919 * (seq0 + q), args.ratio, args.block,
                               v['pattern'])
             # 2 priming frames + a walk of nframes frames, all resident in HBM (1.8 MB each); the timed
@@ -1262,6 +1262,7 @@ def main():
         for name, var in (("exact_f32", dict(env=dict(CBINFER_EXACT_F32="1"))),
                           ("bf16x3", dict(env=dict(CBINFER_ARITH="bf16x3"))),
                           ("reference_structured", dict(fuse_tail=False, fuse_pool=False, pool_clone=True)),
+                          ("no_feedback_experiment2", dict(experiment=2, fuse_tail=False, fuse_pool=False)),
                           ("pattern_region", dict(pattern="region"))):
             if name == "pattern_region" and args.pattern == "region":
                 continue
@@ -1288,6 +1289,11 @@ def main():
                 result["variants"][name]["arithmetic"] = (
                     "every contraction on the exact f32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32: an f32 fma chain, "
                     "bitwise), list kernels of rounds 1-2: the f32 number as the reference's sgemm defines it")
+            if name == "no_feedback_experiment2":
+                result["variants"][name]["what"] = (
+                    "sceneLabeling/modelLoader.py:45-47: what convert() makes -- feedbackLoop=False, copyInput=True, "
+                    "nn.MaxPool2d, dense 1x1 layers -- the 16->64 and 64->256 layers on the split-state kernels with "
+                    "every value of the frame copied into both states by the detection (CBINFER_SPLIT_COPY_ALL, round 4)")
             if name == "bf16x3":
                 result["variants"][name]["arithmetic"] = (
                     "f32 operands as three bf16 terms (24 bits), the six products above 2^-24, f32 accumulation: "

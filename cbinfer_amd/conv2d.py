@@ -376,7 +376,8 @@ class CBConv2d(nn.Module):
         channels, default arithmetic (f16-pair products; exactF32 / CBINFER_ARITH=bf16x3 keep the other forms);
         CBINFER_NO_SPLIT=1 switches it off."""
         K, Cin, kH, kW = self.weight.size()
-        return (dtype == torch.float32 and self.feedbackLoop and not self.syncIndexes and not self.saveChangeMap
+        return (dtype == torch.float32 and (self.feedbackLoop or self.copyInput)
+                and not self.syncIndexes and not self.saveChangeMap
                 and not self.finegrained and self._arith_code(dtype) == _lib.CB_F32S
                 and not self.__dict__.get('_rangeFallback')
                 and os.environ.get('CBINFER_NO_SPLIT', '0') != '1'
@@ -502,7 +503,9 @@ class CBConv2d(nn.Module):
         q.frameMasks, q.producerMask = sp['bits'].data_ptr(), ptr(pmask)
         q.output, q.idxOut, q.countOut = self.prevOutput.data_ptr(), work['idx'].data_ptr(), work['count'].data_ptr()
         q.rangeFlag, q.maskCopy = sp['flag'].data_ptr(), sp['copy'].data_ptr()
-        args = [sp['seq'], 1, int(lazy is not None), src.size(-2) if lazy is not None else 0,
+        # (mode: bit 0 = behind a folded pool, bit 1 = not in feedback mode -- both states take every value of the frame)
+        args = [sp['seq'], 1, int(lazy is not None) | (0 if self.feedbackLoop else 2),
+                src.size(-2) if lazy is not None else 0,
                 src.size(-1) if lazy is not None else 0, ptr(wp), ptr(self.bias.detach()), Cin, H, W, K, kH, kW,
                 float(self.threshold), float(scale), int(bool(self.withReLU)), ptr(sp['ws'])]
         # the fused 1x1 tail behind this layer (pycbinfer.fuseTail1x1) rides in the contraction's second launch

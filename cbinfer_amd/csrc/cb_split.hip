@@ -169,6 +169,8 @@ struct CbsDetArgs {
     int W, H, C, kHH, kWH, wpr, pH, pW, Wp, rec, padY, padXL;
     long words;
     float th;
+    int copyAll;      // the layer is NOT in feedback mode and keeps a copy of its input (conv2d.py:234-236): both
+                      // states take EVERY value of the frame, not only those of the changed pixels (round 4)
 };
 
 __device__ __forceinline__ unsigned long long cbs_valid_mask(int W, int tile) {
@@ -247,10 +249,12 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
     unsigned long long m = 0;
     for (int i = 0; i < G; ++i) m |= sm[i];
     CBS_DET_STAMP(2);
-    if (m == 0) return;   // uniform over the workgroup
+    if (m == 0 && !a.copyAll) return;   // uniform over the workgroup
+    // the pixels whose states take the new values: the changed ones (feedback mode), or all of the segment
+    const unsigned long long upd = a.copyAll ? cbs_valid_mask(W, tx) : m;
 
     // feedback: refresh the f32 state at the (pre-dilation) changed pixels only (.cu:74-80) ...
-    if ((m >> lane) & 1ull) {
+    if ((upd >> lane) & 1ull) {
         state[(long)g * HW + p] = k0;
         state[(long)(g + G) * HW + p] = k1;
         state[(long)(g + 2 * G) * HW + p] = k2;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
         const int t = threadIdx.x;
         if (t < 64 * parts) {
             const int pl = t / parts, part = t % parts;
-            if (((m >> pl) & 1ull) != 0ull) {
+            if (((upd >> pl) & 1ull) != 0ull) {
                 const int grp = part >> 1, half = part & 1;
                 halfx8 hi, lo;
                 bool over = false;
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
     }
 
     CBS_DET_STAMP(4);
+    if (m == 0) return;
     // dilation of the 64-pixel word (+ the parts spilling into the neighbour words), ORed into the frame mask
     unsigned long long D = m, SR = 0, SL = 0;
     for (int d = 1; d <= a.kWH; ++d) {
@@ -1275,9 +1280,10 @@ int cbinfer_split_state_rebuild(const float* state, void* splitState, int C, int
 
 // Detection of up to CBS_MAXSEQ sequences in one launch (see cbSplitSeq in the header).  pooled != 0: `input` is
 // the tensor in front of a 2x2/stride-2 max pool, [C,pH,pW].
-int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, int C, int H, int W,
+int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, int C, int H, int W,
                          int kH, int kW, float threshold, cbStream_t stream) {
-    CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && H > 0 && W > 0);
+    CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && H > 0 && W > 0 && mode >= 0 && mode <= 3);
+    const int pooled = mode & 1;      // bit 1 (CBINFER_SPLIT_COPY_ALL): not in feedback mode, every value goes to the states
     if (!cbs_supported(C, 1, kH, kW) || H > 65535) return CB_ERR_UNSUPPORTED;
     if (pooled) CB_REQUIRE((H == pH / 2 || H == (pH + 1) / 2) && (W == pW / 2 || W == (pW + 1) / 2));
     const CbsGeom g = cbs_geom(C, H, W, kH, kW);
@@ -1296,6 +1302,7 @@ int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, i
     a.Wp = g.Wp, a.rec = g.rec, a.padY = g.padY, a.padXL = g.padXL;
     a.words = cbinfer_mask_words(H, W);
     a.th = threshold;
+    a.copyAll = (mode >> 1) & 1;
     dim3 grid(a.wpr, H, nSeq), block(64 * (C / 4));
     if (pooled)
         hipLaunchKernelGGL(cbs_detect_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
@@ -1406,13 +1413,13 @@ int cbinfer_split_conv_tail(const cbSplitSeq* seqs, int nSeq, const void* prepar
 // cbinfer_split_forward + the fused 1x1 tail behind the layer (cbinfer_tail1x1's arithmetic and weight layout) in
 // the contraction's second launch: conv1x1 (K -> C1) -> [relu1] -> conv1x1 (C1 -> C2) -> [relu2] at the changed pixels,
 // into tail->output[sequence] [C2,H,W].  forceSplit as for cbinfer_split_conv.
-int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared,
+int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, const void* prepared,
                                const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
                                float weightScale, int relu, void* workspace, int forceSplit, const cbSplitTail* tail,
                                cbStream_t stream) {
     CB_REQUIRE(tail);
     if (!cbinfer_split_tail_supported(C, K, kH, kW, tail->C1, tail->C2)) return CB_ERR_UNSUPPORTED;
-    const int st = cbinfer_split_detect(seqs, nSeq, pooled, pH, pW, C, H, W, kH, kW, threshold, stream);
+    const int st = cbinfer_split_detect(seqs, nSeq, mode, pH, pW, C, H, W, kH, kW, threshold, stream);
     if (st != CB_OK) return st;
     return cbinfer_split_conv_tail(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace,
                                    forceSplit, tail, stream);
@@ -1420,10 +1427,10 @@ int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int pooled, int
 
 // One frame of a feedback-mode CBConv2d (conv2d.py:178-259) of every sequence: detection (+ pooling) + refresh of
 // both states, then the contraction.
-int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared,
+int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, const void* prepared,
                           const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
                           float weightScale, int relu, void* workspace, cbStream_t stream) {
-    const int st = cbinfer_split_detect(seqs, nSeq, pooled, pH, pW, C, H, W, kH, kW, threshold, stream);
+    const int st = cbinfer_split_detect(seqs, nSeq, mode, pH, pW, C, H, W, kH, kW, threshold, stream);
     if (st != CB_OK) return st;
     return cbs_split_conv(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace, 0, nullptr,
                           stream);

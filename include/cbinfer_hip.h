@@ -405,9 +405,16 @@ int cbinfer_tail1x1(const float* input, const int32_t* changeList, int numChange
  *                over fixed k-ranges, whether these are computed by four workgroups (few tiles: slabs + a reduce
  *                launch) or one after the other by the same one (many tiles): a sequence gets the same bits alone
  *                and inside a batch.
- * pooled != 0: `input` is the tensor in FRONT of a 2x2/stride-2 max pool [C,pH,pW] (CBPoolMax2d folded into the
- * detection, see cbinfer_cbconv2d_forward_pooled); producerMask as for cbinfer_change_detection_bits_pooled. */
+ * mode bit 0 (CBINFER_SPLIT_POOLED): `input` is the tensor in FRONT of a 2x2/stride-2 max pool [C,pH,pW] (CBPoolMax2d
+ * folded into the detection, see cbinfer_cbconv2d_forward_pooled); producerMask as for
+ * cbinfer_change_detection_bits_pooled.  mode bit 1 (CBINFER_SPLIT_COPY_ALL, round 4): the layer is NOT in feedback
+ * mode and keeps a copy of its input (feedbackLoop=False, copyInput=True: what convert() makes, conv2d.py:234-236,
+ * `prevInput.copy_(input)`): the detection writes EVERY value of the frame into prevInput and into the pre-split
+ * copy, not only those of the changed pixels -- the gather then reads this frame's input everywhere, as the
+ * reference's does. */
 #define CBINFER_SPLIT_MAX_SEQUENCES 8
+#define CBINFER_SPLIT_POOLED 1
+#define CBINFER_SPLIT_COPY_ALL 2
 typedef struct {
     const float* input;           /* this frame's layer input (or the pool's input) */
     float* state;                 /* prevInput [C,H,W] */
@@ -432,7 +439,7 @@ int cbinfer_split_prep_weights(const float* weight, void* prepared, int K, int C
 int cbinfer_split_state_init(void* splitState, int C, int H, int W, int kH, int kW, cbStream_t stream);
 int cbinfer_split_state_rebuild(const float* state, void* splitState, int C, int H, int W, int kH, int kW,
                                 int32_t* rangeFlag, cbStream_t stream);
-int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, int C, int H, int W,
+int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, int C, int H, int W,
                          int kH, int kW, float threshold, cbStream_t stream);
 int cbinfer_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
                        int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
@@ -455,7 +462,7 @@ typedef struct {
 int cbinfer_tail1x1_batched(const cbTailSeq* seqs, int nSeq, int numChanges, const float* w1Prepared,
                             const float* b1, const float* w2, const float* b2, int C0, int C1, int C2, int H, int W,
                             int relu1, int relu2, cbStream_t stream);
-int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared,
+int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, const void* prepared,
                           const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
                           float weightScale, int relu, void* workspace, cbStream_t stream);
 /* The layer + the fused 1x1 tail behind it (sceneLabeling/modelLoader.py:45-47: the dense conv1x1 -> ReLU -> conv1x1
@@ -477,7 +484,7 @@ int cbinfer_split_tail_supported(int C, int K, int kH, int kW, int C1, int C2);
 int cbinfer_split_conv_tail(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
                             int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
                             const cbSplitTail* tail, cbStream_t stream);
-int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared,
+int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, const void* prepared,
                                const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
                                float weightScale, int relu, void* workspace, int forceSplit, const cbSplitTail* tail,
                                cbStream_t stream);

@@ -1568,3 +1568,39 @@ def test_chained_layers_do_not_skip_what_they_must_see(pkg, monkeypatch):
         res[chain] = log
     for t, (a, b) in enumerate(zip(res[True], res[False])):
         assert torch.equal(a, b), t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(16, 64, 48, 80), (64, 256, 30, 44)])
+def test_module_without_feedback_runs_on_the_split_state_kernels(pkg, oracle, shape):
+    """Round 4 (missing #3): what convert() makes -- feedbackLoop=False, copyInput=True,
+    conv2d.py:234-236 -- on the split-state kernels: the detection writes EVERY value of the frame into prevInput and
+    into its pre-split copy (CBINFER_SPLIT_COPY_ALL), so the gather sees this frame's input everywhere, sub-threshold
+    drift in the halo of the changed pixels included.  Every frame against the oracle's state machine: change list
+    bit-exact, prevInput == the frame bit for bit, outputs <= 1e-4; and the split-state kernel must really have run."""
+    rng = np.random.default_rng(61)
+    C, K, H, W = shape
+    conv = nn.Conv2d(C, K, 7, padding=3).cuda().eval()
+    m = pkg.CBConv2d(conv, 0.1)
+    m.withReLU = True
+    assert not m.feedbackLoop and m.copyInput
+    o = oracle.OracleCBConv2d(conv.weight.detach().cpu().numpy(), conv.bias.detach().cpu().numpy(), 0.1,
+                              withReLU=True, feedbackLoop=False, propChangeIndexes=True)
+    x = rng.standard_normal((1, C, H, W)).astype(np.float32)
+    ran = []
+    with torch.no_grad():
+        for t in range(8):
+            x = x.copy()
+            if t not in (3, 4):            # (two frames in which nothing exceeds the threshold)
+                for _ in range(2):
+                    y0, x0 = rng.integers(0, H - 8), rng.integers(0, W - 8)
+                    x[0, :, y0:y0 + 8, x0:x0 + 8] = rng.standard_normal((C, 8, 8))
+            xn = (x + rng.uniform(-0.03, 0.03, x.shape)).astype(np.float32)      # sub-threshold drift everywhere
+            out = m(torch.from_numpy(xn).cuda())
+            ran.append(bool(m.__dict__.get('_ranSplit')) or bool(m._plan and m._plan.get('split')))
+            got = o.forward(xn)
+            assert np.array_equal(m.lastChangeIndexes().tensor().cpu().numpy(), got[2]), t
+            assert np.array_equal(m.prevInput.cpu().numpy(), xn), t
+            err = np.abs(out.cpu().numpy() - o.prevOutput).max()
+            assert err <= FP32_TOL, (t, err)
+    assert ran == [True] * 8, ran

@@ -20,7 +20,8 @@ _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 class SplitSeq(ctypes.Structure):
     """cbSplitSeq of include/cbinfer_hip.h: the buffers of ONE sequence for the split-state entry points."""
     _fields_ = [("input", _vp), ("state", _vp), ("splitState", _vp), ("frameMasks", _vp), ("producerMask", _vp),
-                ("output", _vp), ("idxOut", _vp), ("countOut", _vp), ("rangeFlag", _vp), ("maskCopy", _vp)]
+                ("output", _vp), ("idxOut", _vp), ("countOut", _vp), ("rangeFlag", _vp), ("maskCopy", _vp),
+                ("delta", _vp), ("reluOut", _vp)]
 
 
 _sp = ctypes.POINTER(SplitSeq)
@@ -148,6 +149,7 @@ _SIGNATURES = {
     "cbinfer_split_detect": (_i, [_sp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "cbinfer_split_conv": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp]),
     "cbinfer_split_forward": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _vp]),
+    "cbinfer_split_forward_fg": (_i, [_sp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     "cbinfer_split_forward_tail": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _i,
                                         _stp, _vp]),
     "cbinfer_split_tail_supported": (_i, [_i, _i, _i, _i, _i, _i]),

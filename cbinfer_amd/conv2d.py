@@ -388,6 +388,18 @@ class CBConv2d(nn.Module):
                 and C.cbinfer_mask_words(H, W) <= C.cbinfer_split_max_mask_words(K)
                 and H * W * W < (1 << 32))
 
+    def _split_fg_ok(self, dtype, H, W):
+        """Does this layer's fine-grained in-place frame run on the split-state kernels (cbinfer_split_forward_fg)?
+        As _split_ok, for a layer in fine-grained mode."""
+        K, Cin, kH, kW = self.weight.size()
+        return (dtype == torch.float32 and self._arith_code(dtype) == _lib.CB_F32S
+                and not self.__dict__.get('_rangeFallback')
+                and os.environ.get('CBINFER_NO_SPLIT', '0') != '1' and os.environ.get('CBINFER_NO_SPLIT_FG', '0') != '1'
+                and os.environ.get('CBINFER_ARITH', 'f16x2') == 'f16x2'
+                and bool(C.cbinfer_split_supported(Cin, K, kH, kW))
+                and C.cbinfer_mask_words(H, W) <= C.cbinfer_split_max_mask_words(K)
+                and H * W * W < (1 << 32))
+
     def _split_weights(self, H, W):
         """(prepared buffer, power-of-two weight scale): max |w| * scale in [2^13, 2^14)."""
         w = self.weight
@@ -673,6 +685,33 @@ class CBConv2d(nn.Module):
                 relu = work['relu']
             if not self.prevInput.is_contiguous():
                 self.prevInput = self.prevInput.contiguous()
+            if self._split_fg_ok(x.dtype, H, W):
+                # the fine-grained frame on the split-state kernels (round 4): the detection leaves the thresholded
+                # differences of EVERY value as f16 pairs in the pixel-major records, the LDS-DMA contraction adds
+                # W * delta to prevOutput at the mask's pixels
+                sp = self._split_workspace(work, H, W, x.device)
+                wp, scale = self._split_weights(H, W)
+                q = sp['seq'][0]
+                q.input, q.state, q.splitState = x.data_ptr(), self.prevInput.data_ptr(), sp['S'].data_ptr()
+                q.frameMasks, q.producerMask = sp['bits'].data_ptr(), None
+                q.output, q.idxOut, q.countOut = (self.prevOutput.data_ptr(), work['idx'].data_ptr(),
+                                                  work['count'].data_ptr())
+                q.rangeFlag, q.maskCopy = sp['flag'].data_ptr(), sp['copy'].data_ptr()
+                q.delta, q.reluOut = work['delta'].data_ptr(), ptr(relu)
+                sp['stateKey'] = None      # (the records hold differences now: a coarse-grained frame re-splits the state)
+                args = [sp['seq'], 1, ptr(wp), Cin, H, W, K, kH, kW, float(self.threshold), float(scale),
+                        ptr(sp['ws']), stream_ptr(x)]
+                check(C.cbinfer_split_forward_fg(*args))
+                self._poll_range(sp)
+                self.__dict__['_ranSplit'] = True
+                result = relu if self.withReLU else self.prevOutput
+                self._lastIndexes = MaskChangeIndexes(sp['copy'], (H, W), work['idx'], work['count'], made=True)
+                if self.propChangeIndexes:
+                    result = ('changeIndexes', result, self._lastIndexes)
+                self._make_plan(False, x, C.cbinfer_split_forward_fg, args, None, result=result)
+                if self._plan is not None:
+                    self._plan.update(fgSplit=True, seq=q, wsplit=(wp, scale), relu=relu)
+                return result
             if path:
                 rows = self._rows_workspace(work, H, W, x.device)
                 args = (int(path == 'blocks'), ptr(x), ptr(self.prevInput), ptr(work['delta']),
@@ -1056,7 +1095,10 @@ class CBConv2d(nn.Module):
             if self._next_detect(plan['shape'][-2], plan['shape'][-1])[1] != plan['nextToken']:
                 return None
         args = plan['args']
-        args[plan['srcSlot']] = src.data_ptr()
+        if plan.get('fgSplit'):
+            plan['seq'].input = src.data_ptr()
+        else:
+            args[plan['srcSlot']] = src.data_ptr()
         chain = plan.get('chain')
         if chain:
             up = self.__dict__.get('_upNow')
@@ -1066,6 +1108,8 @@ class CBConv2d(nn.Module):
             check(status)
         if chain:
             self._publish_count(plan['work']['count'])
+        if plan.get('fgSplit'):
+            self._poll_range(plan['work']['split'])
         self._inputIsLiveState = False
         if plan['result'] is not None:          # fine-grained in-place frame: prevOutput or its relu'd copy
             res = plan['result']

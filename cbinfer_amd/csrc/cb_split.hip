@@ -163,6 +163,7 @@ struct CbsDetSeq {
     unsigned long long* masks;            // frame mask: [words], zeroed by the contraction (cbSplitSeq.frameMasks)
     const unsigned long long* prodMask;   // POOL: the producing layer's change mask of this frame, or null
     int* rangeFlag;                       // set to 1 when a refreshed value leaves the f16 pair's range
+    float* delta;                         // fine-grained mode: the thresholded differences [C,H,W] (f32, every value)
 };
 struct CbsDetArgs {
     CbsDetSeq seq[CBS_MAXSEQ];
@@ -171,6 +172,9 @@ struct CbsDetArgs {
     float th;
     int copyAll;      // the layer is NOT in feedback mode and keeps a copy of its input (conv2d.py:234-236): both
                       // states take EVERY value of the frame, not only those of the changed pixels (round 4)
+    int fg;           // fine-grained frame (conv2d.py:160-176, cbconv2d_fg_backend.cu:7-23; implies copyAll): prevInput
+                      // takes the frame, the PRE-SPLIT copy takes d = in - prev where |d| > th and 0 elsewhere -- the
+                      // operand of out += W * delta -- and so does the f32 delta tensor (the exact path's operand)
 };
 
 __device__ __forceinline__ unsigned long long cbs_valid_mask(int W, int tile) {
@@ -236,9 +240,18 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
         const float s1 = state[(long)(g + G) * HW + p], x1 = ldin(g + G);
         const float s2 = state[(long)(g + 2 * G) * HW + p], x2 = ldin(g + 2 * G);
         const float s3 = state[(long)(g + 3 * G) * HW + p], x3 = ldin(g + 3 * G);
-        chg = cb_changed(s0, x0, a.th) | cb_changed(s1, x1, a.th) | cb_changed(s2, x2, a.th) |
-              cb_changed(s3, x3, a.th);
+        const bool c0 = cb_changed(s0, x0, a.th), c1 = cb_changed(s1, x1, a.th), c2 = cb_changed(s2, x2, a.th),
+                   c3 = cb_changed(s3, x3, a.th);
+        chg = c0 | c1 | c2 | c3;
         k0 = x0, k1 = x1, k2 = x2, k3 = x3;
+        if (a.fg) {      // per VALUE: the state takes the input, the records (and the delta tensor) the difference
+            float* dl = sq.delta;
+            state[(long)g * HW + p] = x0, state[(long)(g + G) * HW + p] = x1;
+            state[(long)(g + 2 * G) * HW + p] = x2, state[(long)(g + 3 * G) * HW + p] = x3;
+            k0 = c0 ? x0 - s0 : 0.f, k1 = c1 ? x1 - s1 : 0.f, k2 = c2 ? x2 - s2 : 0.f, k3 = c3 ? x3 - s3 : 0.f;
+            dl[(long)g * HW + p] = k0, dl[(long)(g + G) * HW + p] = k1;
+            dl[(long)(g + 2 * G) * HW + p] = k2, dl[(long)(g + 3 * G) * HW + p] = k3;
+        }
     }
 
     __shared__ unsigned long long sm[16];
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
     const unsigned long long upd = a.copyAll ? cbs_valid_mask(W, tx) : m;
 
     // feedback: refresh the f32 state at the (pre-dilation) changed pixels only (.cu:74-80) ...
-    if ((upd >> lane) & 1ull) {
+    if (!a.fg && ((upd >> lane) & 1ull)) {
         state[(long)g * HW + p] = k0;
         state[(long)(g + G) * HW + p] = k1;
         state[(long)(g + 2 * G) * HW + p] = k2;
@@ -331,6 +344,7 @@ struct CbsSeq {
     int32_t* listOut;                 // change list (by-product), capacity H*W
     int32_t* countOut;
     unsigned long long* maskCopy;     // optional: this frame's change mask, at a fixed address
+    float* reluOut;                   // accumulate form only, optional: second plane set kept at relu(out)
 };
 struct CbsParams {
     CbsSeq seq[CBS_MAXSEQ];
@@ -348,6 +362,8 @@ struct CbsParams {
     unsigned long long magicMW, magicWpr, magicW, magicMT;   // floor(2^32 / d) + 1: x / d = (x * magic) >> 32 for x d < 2^32
     int arriveShards;                 // arrival counters in the second mask slot (lines of their own): min(8, MW / 16)
     int forceSK;                      // > 0: tuning / test aid
+    int accumulate;                   // fine-grained frame: out += W * delta (no bias, no ReLU on `out`; reluOut beside it)
+    int splitRounds;                  // a deep contraction is split along k while its work items <= splitRounds x grid
     int dbg;                          // diagnostic ablations (builds with -DCBS_DBG only; CBINFER_SPLIT_DBG)
 };
 // diagnostic ablations are a build option (make EXTRA=-DCBS_DBG; tools/split_dbg_run.sh): 1 every pixel-operand
@@ -544,7 +560,10 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     for (int q = 0; q < p.nSeq; ++q) anyExact |= s_exact[q];
     anyExact = __builtin_amdgcn_readfirstlane(anyExact);
     int SK = 1;
-    if (TP > 0 && CH > 1 && TP * MT * CH <= (int)gridDim.x && !anyExact) SK = CH;
+    // (round 4: up to splitRounds = 2 work items per workgroup -- 65..128 tiles used to run unsplit, a quarter to a half of
+    //  the CUs walking the whole depth while the others idled: 67 us where two rounds of quarter-depth items take 34)
+    if (TP > 0 && CH > 1 && TP * MT * CH <= p.splitRounds * (int)gridDim.x && TP * MT * CH <= p.slabCap && !anyExact)
+        SK = CH;
     // (tests: 1 = unsplit, >= 4 = split -- but never more partial tiles than the workspace holds)
     if (p.forceSK > 0 && CH > 1) SK = (p.forceSK >= CH && TP * MT * CH <= p.slabCap && !anyExact) ? CH : 1;
     const int CMB = MT * SK, items = TP * CMB;
@@ -683,6 +702,11 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
                     }
                 float v = acc + (biasx ? biasx[m] : 0.f);
                 if (relux) v = v <= 0.f ? 0.f : v;
+                if (pp->accumulate) {      // (fine-grained: `st` is the delta tensor)
+                    v += outx[(long)m * HWx + pix];
+                    float* rp = pp->seq[q].reluOut;
+                    if (rp) rp[(long)m * HWx + pix] = v <= 0.f ? 0.f : v;
+                }
                 outx[(long)m * HWx + pix] = v;
             }
             continue;
@@ -902,7 +926,18 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         CBS_STAMP_AT(7);
 
         // ---- epilogue: C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-        float* __restrict__ out = p.seq[q].out;
+        float* out = p.seq[q].out;
+        // (the accumulate form's arguments through an opaque copy of the argument pointer, like the exact path's: read
+        //  here, not at kernel entry)
+        int accum;
+        float* reluPlane;
+        {
+            const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            const CbsParams* pp = (const CbsParams*)ka;
+            accum = pp->accumulate;
+            reluPlane = accum ? pp->seq[q].reluOut : nullptr;
+        }
         if (CBS_DBGBIT(32)) continue;
         if (SK > 1) {
             // partial tile -> slab [BM/4][BN] float4 (four consecutive output channels of a pixel), plain stores:
@@ -937,7 +972,13 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
                 if (folds > 0) v = run[j][r] + v;        // (the last chunk joins the running sum)
                 v = fmaf(v, p.outScale, s_bias[ml]);      // (an explicit fma here, in the reduce launch and in the
                 if (p.relu) v = v <= 0.f ? 0.f : v;        //  fused tail: one rounding at all three sites)
-                if (pix >= 0 && m < p.K) out[(long)m * HW + pix] = v;
+                if (pix >= 0 && m < p.K) {
+                    if (accum) {      // fine-grained: the sum of the products joins what the output holds
+                        v += out[(long)m * HW + pix];
+                        if (reluPlane) reluPlane[(long)m * HW + pix] = v <= 0.f ? 0.f : v;
+                    }
+                    out[(long)m * HW + pix] = v;
+                }
             }
         }
         CBS_STAMP_AT(5);
@@ -1027,6 +1068,11 @@ __global__ __launch_bounds__(256) void cbs_reduce_kernel(CbsParams p, int BM, in
             if (m + e >= p.K) continue;
             float v = fmaf(sv[e], p.outScale, p.bias ? p.bias[m + e] : 0.f);
             if (p.relu) v = v <= 0.f ? 0.f : v;
+            if (p.accumulate) {
+                v += out[(long)(m + e) * HW + pix];
+                float* rp = p.seq[q].reluOut;
+                if (rp) rp[(long)(m + e) * HW + pix] = v <= 0.f ? 0.f : v;
+            }
             out[(long)(m + e) * HW + pix] = v;
         }
     }
@@ -1282,8 +1328,10 @@ int cbinfer_split_state_rebuild(const float* state, void* splitState, int C, int
 // the tensor in front of a 2x2/stride-2 max pool, [C,pH,pW].
 int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, int C, int H, int W,
                          int kH, int kW, float threshold, cbStream_t stream) {
-    CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && H > 0 && W > 0 && mode >= 0 && mode <= 3);
+    CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && H > 0 && W > 0 && mode >= 0 && mode <= 7);
     const int pooled = mode & 1;      // bit 1 (CBINFER_SPLIT_COPY_ALL): not in feedback mode, every value goes to the states
+    const int fg = (mode >> 2) & 1;   // bit 2 (CBINFER_SPLIT_FG): fine-grained frame, the pre-split copy takes the differences
+    CB_REQUIRE(!(fg && pooled));
     if (!cbs_supported(C, 1, kH, kW) || H > 65535) return CB_ERR_UNSUPPORTED;
     if (pooled) CB_REQUIRE((H == pH / 2 || H == (pH + 1) / 2) && (W == pW / 2 || W == (pW + 1) / 2));
     const CbsGeom g = cbs_geom(C, H, W, kH, kW);
@@ -1296,13 +1344,16 @@ int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int
         a.seq[q].masks = (unsigned long long*)seqs[q].frameMasks;
         a.seq[q].prodMask = pooled ? (const unsigned long long*)seqs[q].producerMask : nullptr;
         a.seq[q].rangeFlag = seqs[q].rangeFlag;
+        a.seq[q].delta = seqs[q].delta;
+        if (fg) CB_REQUIRE(seqs[q].delta != nullptr);
     }
     a.W = W, a.H = H, a.C = C, a.kHH = (kH - 1) / 2, a.kWH = (kW - 1) / 2;
     a.wpr = cbinfer_mask_words_per_row(W), a.pH = pH, a.pW = pW;
     a.Wp = g.Wp, a.rec = g.rec, a.padY = g.padY, a.padXL = g.padXL;
     a.words = cbinfer_mask_words(H, W);
     a.th = threshold;
-    a.copyAll = (mode >> 1) & 1;
+    a.copyAll = ((mode >> 1) & 1) | fg;
+    a.fg = fg;
     dim3 grid(a.wpr, H, nSeq), block(64 * (C / 4));
     if (pooled)
         hipLaunchKernelGGL(cbs_detect_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
@@ -1315,7 +1366,7 @@ int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int
 // outScale = 1 / (weightScale * 2^-4).  forceSplit > 0 overrides the k-split decision (tests, tuning).
 static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
                           int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
-                          const CbsTailArgs* tail, cbStream_t stream) {
+                          const CbsTailArgs* tail, cbStream_t stream, int accumulate = 0) {
     if (workspace == nullptr && cbs_supported(C, K, kH, kW) && cbs_geom(C, H, W, kH, kW).nStages >= 48)
         return CB_ERR_BADARG;      // a deep contraction needs its workspace (cbinfer_split_workspace_bytes)
     CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && prepared && H > 0 && W > 0 && weightScale > 0.f);
@@ -1330,8 +1381,10 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
     for (int q = 0; q < nSeq; ++q) {
         CB_REQUIRE(seqs[q].splitState && seqs[q].output && seqs[q].frameMasks && seqs[q].idxOut && seqs[q].countOut);
         p.seq[q].S = (const char*)seqs[q].splitState;
-        p.seq[q].state = seqs[q].state;
-        p.seq[q].rangeFlag = seqs[q].state ? seqs[q].rangeFlag : nullptr;      // (no f32 state handed in: no exact path)
+        // (what the exact path contracts in plain f32: the layer state -- or, fine-grained, the delta tensor)
+        p.seq[q].state = accumulate ? seqs[q].delta : seqs[q].state;
+        p.seq[q].reluOut = accumulate ? seqs[q].reluOut : nullptr;
+        p.seq[q].rangeFlag = p.seq[q].state ? seqs[q].rangeFlag : nullptr;      // (no f32 operand handed in: no exact path)
         p.seq[q].out = seqs[q].output;
         p.seq[q].masks = (unsigned long long*)seqs[q].frameMasks;
         p.seq[q].listOut = seqs[q].idxOut;
@@ -1355,6 +1408,15 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
     p.magicW = (1ull << 32) / (unsigned long long)W + 1ull;
     p.magicMT = (1ull << 32) / (unsigned long long)(KP / BM) + 1ull;
     p.forceSK = forceSplit;
+    p.accumulate = accumulate;
+    {
+        static int rounds = -1;      // CBINFER_SPLIT_ROUNDS (tuning aid; default 2)
+        if (rounds < 0) {
+            const char* e = getenv("CBINFER_SPLIT_ROUNDS");
+            rounds = e && atoi(e) > 0 ? atoi(e) : 2;
+        }
+        p.splitRounds = rounds;
+    }
     p.arriveShards = (int)(MW / 16 < 8 ? MW / 16 : 8);
     p.dbg = 0;
 #ifdef CBS_DBG
@@ -1423,6 +1485,19 @@ int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int mode, int p
     if (st != CB_OK) return st;
     return cbinfer_split_conv_tail(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace,
                                    forceSplit, tail, stream);
+}
+
+// One FINE-GRAINED frame (CBConv2d.forward_fg, conv2d.py:160-176 -> conv2d_fg.py:75-85; cbinfer_cbconv2d_forward_fg's
+// contract) on the split-state kernels: the detection writes the frame into prevInput, d = in - prev where |d| > th
+// (0 elsewhere) into `delta` and, as f16 pairs, into the pre-split records of EVERY pixel, and the dilated any-channel
+// mask; the contraction ADDS W * delta to `output` at the mask's pixels (reluOut, if given, kept at relu(output)
+// there).  No bias, deterministic.  A |d| >= 2^20 trips the range flag: the launch then contracts `delta` in plain f32.
+int cbinfer_split_forward_fg(const cbSplitSeq* seqs, int nSeq, const void* prepared, int C, int H, int W, int K, int kH,
+                             int kW, float threshold, float weightScale, void* workspace, cbStream_t stream) {
+    const int st = cbinfer_split_detect(seqs, nSeq, CBINFER_SPLIT_FG, 0, 0, C, H, W, kH, kW, threshold, stream);
+    if (st != CB_OK) return st;
+    return cbs_split_conv(seqs, nSeq, prepared, nullptr, C, H, W, K, kH, kW, weightScale, 0, workspace, 0, nullptr,
+                          stream, 1);
 }
 
 // One frame of a feedback-mode CBConv2d (conv2d.py:178-259) of every sequence: detection (+ pooling) + refresh of

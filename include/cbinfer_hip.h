@@ -415,6 +415,7 @@ int cbinfer_tail1x1(const float* input, const int32_t* changeList, int numChange
 #define CBINFER_SPLIT_MAX_SEQUENCES 8
 #define CBINFER_SPLIT_POOLED 1
 #define CBINFER_SPLIT_COPY_ALL 2
+#define CBINFER_SPLIT_FG 4        /* cbinfer_split_detect only: the fine-grained frame's detection (cbinfer_split_forward_fg) */
 typedef struct {
     const float* input;           /* this frame's layer input (or the pool's input) */
     float* state;                 /* prevInput [C,H,W] */
@@ -427,6 +428,9 @@ typedef struct {
     int32_t* rangeFlag;           /* may be NULL */
     uint64_t* maskCopy;           /* may be NULL: receives this frame's change mask (cbinfer_mask_words words) at a
                                      fixed address -- the producerMask of the next layer's pooled detection */
+    float* delta;                 /* fine-grained frame only (cbinfer_split_forward_fg): [C,H,W] f32, the thresholded
+                                     differences of this frame (every value written) */
+    float* reluOut;               /* fine-grained frame only, may be NULL: [K,H,W] kept at relu(output) */
 } cbSplitSeq;
 int cbinfer_split_supported(int C, int K, int kH, int kW);
 int cbinfer_split_max_sequences(void);
@@ -465,6 +469,14 @@ int cbinfer_tail1x1_batched(const cbTailSeq* seqs, int nSeq, int numChanges, con
 int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, const void* prepared,
                           const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
                           float weightScale, int relu, void* workspace, cbStream_t stream);
+/* The FINE-GRAINED frame (CBConv2d.forward_fg, conv2d.py:160-176 -> conv2d_fg.py:75-85: changeDetectionFG,
+ * torch.nonzero, updateOutputFG's K*kH*kW atomicAdds per changed value, cbconv2d_fg_backend.cu:7-66) on the
+ * split-state kernels (round 4), same contract as cbinfer_cbconv2d_forward_fg with refreshState = 1: prevInput
+ * (`state`) takes the frame, `delta` the thresholded differences, `output` += conv(weights, delta) at the pixels of
+ * the dilated any-channel mask, `reluOut` (optional) = relu(output) there; idxOut / countOut / maskCopy as for
+ * cbinfer_split_forward.  No bias; fixed summation order. */
+int cbinfer_split_forward_fg(const cbSplitSeq* seqs, int nSeq, const void* prepared, int C, int H, int W, int K, int kH,
+                             int kW, float threshold, float weightScale, void* workspace, cbStream_t stream);
 /* The layer + the fused 1x1 tail behind it (sceneLabeling/modelLoader.py:45-47: the dense conv1x1 -> ReLU -> conv1x1
  * the experiments keep; cbinfer_tail1x1 evaluates it at the changed pixels) with the tail folded into the second
  * launch of a deep contraction: the launch that finishes the layer's outputs -- summing the partial tiles of a split

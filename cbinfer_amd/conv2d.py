@@ -38,6 +38,26 @@ def _same_shape(t, shape):
 _NO_CHAIN = os.environ.get('CBINFER_NO_CHAIN', '0') == '1'
 
 
+def _no_tag():
+    return None
+
+
+class _Produced(object):
+    """What a CBConv2d leaves on its output buffer for the next layer (CBConv2d._note_upstream): who wrote it, in which
+    of its frames, the buffer's version counter then, and where the frame's change count is.  Never travels: a pickled
+    or deep-copied tensor carries None instead."""
+    __slots__ = ('module', 'serial', 'version', 'count')
+
+    def __init__(self, module, serial, version, count):
+        self.module, self.serial, self.version, self.count = module, serial, version, count
+
+    def __reduce__(self):
+        return _no_tag, ()
+
+    def __deepcopy__(self, memo):
+        return None
+
+
 class LazyPool(object):
     """What a CBPoolMax2d with lazy=True hands to the next module instead of a pooled tensor: the pool's
     INPUT and the pooled size.  A feedback-mode CBConv2d folds the pooling into its change detection
@@ -1142,7 +1162,7 @@ class CBConv2d(nn.Module):
     # (Threshold and mode are pinned by the plan that carries the call.)  CBINFER_NO_CHAIN=1 switches it off.
     def _publish_count(self, count):
         out = self._buffers['prevOutput']
-        out._cbProduced = (self, self.__dict__.get('_serial', 0), out._version, count)
+        out._cbProduced = _Produced(self, self.__dict__.get('_serial', 0), out._version, count)
 
     def _note_upstream(self, inp):
         d = self.__dict__
@@ -1150,7 +1170,7 @@ class CBConv2d(nn.Module):
         tag = getattr(inp, '_cbProduced', None) if type(inp) is torch.Tensor else None
         seen, now = None, None
         if tag is not None:
-            prod, serial, version, count = tag
+            prod, serial, version, count = tag.module, tag.serial, tag.version, tag.count
             pin = self._buffers.get('prevInput')
             if (prod is not self and prod.__dict__.get('_serial') == serial and inp._version == version and
                     pin is not None and not _NO_CHAIN):

@@ -1658,3 +1658,33 @@ def test_fine_grained_frame_on_the_split_state_kernels(pkg, oracle, shape, monke
     assert ranA == [False] + [True] * 7 and not any(ranB), (ranA, ranB)
     for t, (u, v) in enumerate(zip(a, b)):
         assert (u - v).abs().max().item() <= FP32_TOL, t
+
+
+@pytest.mark.gpu
+def test_chain_tags_do_not_travel_with_copies(pkg):
+    """The tag a CBConv2d leaves on its output buffer names the module and a device word: a deep copy or a pickle of
+    a network that has run frames must not drag either along, and the copy must run (and chain) on its own."""
+    import copy
+    import io
+    torch.manual_seed(2)
+    net = nn.Sequential(pkg.CBConv2d(nn.Conv2d(32, 64, 3, padding=1).cuda().half().eval(), 0.05),
+                        pkg.CBConv2d(nn.Conv2d(64, 64, 3, padding=1).cuda().half().eval(), 0.05))
+    x = torch.randn(1, 32, 40, 72, device="cuda").half()
+    with torch.no_grad():
+        for _ in range(4):
+            y = net(x)
+        assert net[1].__dict__.get('_upNow') is not None
+        twin = copy.deepcopy(net)
+        assert getattr(twin[0].prevOutput, '_cbProduced', None) is None
+        buf = io.BytesIO()
+        torch.save(net, buf)
+        buf.seek(0)
+        back = torch.load(buf, weights_only=False)
+        assert getattr(back[0].prevOutput, '_cbProduced', None) is None
+        for other in (twin, back):
+            x2 = x.clone()
+            x2[0, :, 4:12, 8:16] += 1.0
+            for f in (x, x2, x2, x2):
+                a, b = net(f), other(f)
+                assert torch.equal(a, b)
+            assert other[1].__dict__.get('_upNow') is not None

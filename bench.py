@@ -1164,7 +1164,7 @@ def main():
                 calibration[cand] = max(calibration.get(cand, 0.0), S * csteps / cel)
                 del cseqs
             mode = max(calibration, key=calibration.get)
-            if world > 1:       # every rank must run the same launch form
+            if shard.dist is not None:       # every rank must run the same launch form
                 mode = "graph" if shard.broadcast_flag(mode == "graph", 0) else "eager"
     args.mode = mode
 
@@ -1178,6 +1178,7 @@ def main():
     total_frames, elapsed = shard.aggregate(steps_timed * S, elapsed, device="cuda")
     fps = total_frames / elapsed
 
+    dist_backend = shard.backend if shard.dist is not None else None
     if rank != 0:
         shard.finish()
         return
@@ -1216,7 +1217,8 @@ def main():
                    "launch": args.mode, "launch_calibration_fps": calibration, "threshold": args.threshold,
                    "pool_clone": bool(args.pool_clone),
                    "pool_fused_into_detection": not args.no_fuse_pool,
-                   "tail_1x1_fused": not args.no_fuse_tail},
+                   "tail_1x1_fused": not args.no_fuse_tail,
+                   "dist_backend": dist_backend},
         # dense op count per frame: compStats.totalInputValues of the converted layers (conv2d.py:216)
         # + the 1x1 tail the experiment leaves unconverted
         "effective_gflops": fps * dense_ops / 1e9,

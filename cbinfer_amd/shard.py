@@ -52,7 +52,14 @@ class SequenceShard(object):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
-        if self.world > 1:
+        # CBINFER_FORCE_DIST=1: the process group (and every collective of the N > 1 control flow) also for ONE rank --
+        # the only way to run the RCCL branch on a one-GPU box (tests/test_gpu_shard.py)
+        forced = self.world == 1 and os.environ.get("CBINFER_FORCE_DIST", "0") == "1"
+        if forced:
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        if self.world > 1 or forced:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if backend is None:

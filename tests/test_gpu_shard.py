@@ -53,3 +53,23 @@ def test_bench_still_refuses_by_default():
     from cbinfer_amd.shard import visible_gpu_count
     if visible_gpu_count() < 7:
         assert out.returncode != 0 and b"--gpus 7 requested but only" in out.stderr
+
+
+def test_bench_control_flow_over_rccl_with_one_rank():
+    """The RCCL ("nccl") branch of SequenceShard -- device tensors in agree_max / broadcast_flag / aggregate, barriers
+    on the device -- had never run: the builder has one GPU and RCCL refuses two ranks on one device.
+    CBINFER_FORCE_DIST=1 makes bench.py open the process group for its single rank as well, so every collective of the
+    N > 1 control flow executes over RCCL once (world size 1: no peer, the same calls)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT",
+                                                            "CBINFER_DIST_BACKEND")}
+    env.update(CBINFER_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+           "--min-seconds", "0.05", "--mode", "auto", "--multi", "0", "--no-variants", "--no-secondary",
+           "--no-isolated", "--no-cpu-baseline", "--no-dense", "--no-pipelined", "--no-last-frame"]
+    out = subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["config"]["dist_backend"] == "nccl" and r["n_gpus"] == 1 and r["value"] > 0
+    assert r["steps"] % 20 == 0 and r["config"]["launch"] in ("graph", "eager")

@@ -408,6 +408,67 @@ class CBConv2d(nn.Module):
                 and C.cbinfer_mask_words(H, W) <= C.cbinfer_split_max_mask_words(K)
                 and H * W * W < (1 << 32))
 
+    def _hsplit_ok(self, dtype, H, W):
+        """Does this fp16 layer's sync-free frame run on the split-state machinery (cbinfer_hsplit_forward: pixel-major
+        f16 copy of the state, LDS-DMA contraction)?  Input channels a multiple of 64, feedback mode or a layer that
+        keeps a copy of its input; CBINFER_NO_HSPLIT=1 (or CBINFER_NO_SPLIT=1) switches it off."""
+        K, Cin, kH, kW = self.weight.size()
+        return (dtype == torch.float16 and (self.feedbackLoop or self.copyInput)
+                and not self.syncIndexes and not self.saveChangeMap and not self.finegrained
+                and os.environ.get('CBINFER_NO_SPLIT', '0') != '1' and os.environ.get('CBINFER_NO_HSPLIT', '0') != '1'
+                and os.environ.get('CBINFER_NO_SELFCOMPACT', '0') != '1'
+                and bool(C.cbinfer_hsplit_supported(Cin, K, kH, kW))
+                and C.cbinfer_mask_words(H, W) <= C.cbinfer_hsplit_max_mask_words(K)
+                and C.cbinfer_hsplit_state_bytes(Cin, H, W, kH, kW) < (1 << 31) and H * W * W < (1 << 32))
+
+    def _forward_hsplit(self, input, work):
+        """One fp16 frame on the split-state machinery: detection + refresh of prevInput and of its pixel-major copy,
+        then the LDS-DMA contraction."""
+        K, Cin, kH, kW = self.weight.size()
+        H, W = input.size(-2), input.size(-1)
+        dev = input.device
+        hs = work.get('hsplit')
+        if hs is None:
+            S = torch.empty(C.cbinfer_hsplit_state_bytes(Cin, H, W, kH, kW), dtype=torch.uint8, device=dev)
+            check(C.cbinfer_hsplit_state_init(ptr(S), Cin, H, W, kH, kW, stream_ptr(S)))
+            wsBytes = C.cbinfer_hsplit_workspace_bytes(Cin, H, W, K, kH, kW)
+            hs = work['hsplit'] = dict(
+                S=S, bits=torch.zeros(C.cbinfer_frame_mask_bytes(H, W) // 8, dtype=torch.int64, device=dev),
+                copy=torch.zeros(C.cbinfer_mask_words(H, W), dtype=torch.int64, device=dev),
+                ws=torch.zeros(wsBytes, dtype=torch.uint8, device=dev) if wsBytes > 0 else None, stateKey=None)
+        w = self.weight
+        key = ('hsplit', w.data_ptr(), w._version, w.device, H, W)
+        if self._wrows is None or self._wrows[0] != key:
+            wp = torch.empty(C.cbinfer_hsplit_prepared_bytes(Cin, K, kH, kW), dtype=torch.uint8, device=dev)
+            check(C.cbinfer_hsplit_prep_weights(ptr(w.detach().contiguous()), ptr(wp), K, Cin, kH, kW, H, W,
+                                                stream_ptr(w)))
+            self._wrows = (key, wp)
+        wp = self._wrows[1]
+        prev = self.prevInput
+        if not prev.is_contiguous():
+            prev = self.prevInput = prev.contiguous()
+        stateKey = (prev.data_ptr(), prev._version)
+        if hs['stateKey'] != stateKey:
+            # first frame on this path, or prevInput was (re)allocated or written by somebody else: the pixel-major
+            # copy is made again from it
+            check(C.cbinfer_hsplit_state_rebuild(ptr(prev), ptr(hs['S']), Cin, H, W, kH, kW, stream_ptr(input)))
+            hs['stateKey'] = stateKey
+        args = (None, ptr(input), ptr(prev), ptr(hs['S']), ptr(hs['bits']), ptr(self.prevOutput), ptr(work['idx']),
+                ptr(work['count']), ptr(hs['copy']), ptr(wp), ptr(self.bias.detach()), Cin, H, W, K, kH, kW,
+                float(self.threshold), int(bool(self.feedbackLoop)), int(bool(self.withReLU)), ptr(hs['ws']),
+                stream_ptr(input))
+        check(C.cbinfer_hsplit_forward(*args))
+        self.__dict__['_ranSplit'] = True      # (a frame on any OTHER path invalidates hs['stateKey'], see forward)
+        self._publish_count(work['count'])
+        if not self._inputIsLiveState:
+            self._make_plan(False, input, C.cbinfer_hsplit_forward, args, 1)
+            if self._plan is not None:
+                self._plan.update(chain=True, stateVersion=prev._version)
+        result = MaskChangeIndexes(hs['copy'], (H, W), work['idx'], work['count'], made=True)
+        if self._plan is not None:
+            self._plan['indexes'] = result
+        return result
+
     def _split_fg_ok(self, dtype, H, W):
         """Does this layer's fine-grained in-place frame run on the split-state kernels (cbinfer_split_forward_fg)?
         As _split_ok, for a layer in fine-grained mode."""
@@ -955,6 +1016,9 @@ class CBConv2d(nn.Module):
         if not have and work['selfc'] and self._split_ok(input.dtype, H, W):
             self._forward_split(input, None, work)
             return self._lastIndexes
+        if not have and work['selfc'] and mapOut is None and self._hsplit_ok(input.dtype, H, W):
+            self._lastIndexes = self._forward_hsplit(input, work)
+            return self._lastIndexes
         path = self._rows_path(input.dtype, H, W) if (not have and work['selfc']) else None
         if path == 'rows' and self._pairs_ok(H, W):
             # the row-pair kernel: persistent over the non-empty units, and -- with a split-state consumer behind a lazy
@@ -1109,6 +1173,8 @@ class CBConv2d(nn.Module):
                 (bufs['prevInput'].data_ptr(), bufs['prevOutput'].data_ptr()) != plan['state'] or
                 self._work is not plan['work'] or raw_stream(src.device.index) != plan['stream']):
             return None
+        if plan.get('stateVersion') is not None and bufs['prevInput']._version != plan['stateVersion']:
+            return None      # (somebody wrote prevInput through torch: its pixel-major copy must be made again)
         if plan.get('pairs'):
             # the next layer's detection rides in this launch: the plan holds only while that layer's state is the one
             # the plan was made for (and starts to fold as soon as it can)
@@ -1201,6 +1267,9 @@ class CBConv2d(nn.Module):
             sp = self._work.get('split') if self._work else None
             if sp is not None:
                 sp['stateKey'] = None
+            hs = self._work.get('hsplit') if self._work else None
+            if hs is not None:
+                hs['stateKey'] = None
         return out
 
     def __repr__(self):

@@ -364,6 +364,9 @@ struct CbsParams {
     int forceSK;                      // > 0: tuning / test aid
     int accumulate;                   // fine-grained frame: out += W * delta (no bias, no ReLU on `out`; reluOut beside it)
     int splitRounds;                  // a deep contraction is split along k while its work items <= splitRounds x grid
+    int halfOut;                      // fp16 layer (cbs_conv_kernel<..., HALF>): bias and outputs are f16
+    const int* upstream;              // optional (one sequence): the producing layer's change count of this frame; 0 ends
+                                      // the launch at once (cbinfer_cbconv2d_forward_after's contract)
     int dbg;                          // diagnostic ablations (builds with -DCBS_DBG only; CBINFER_SPLIT_DBG)
 };
 // diagnostic ablations are a build option (make EXTRA=-DCBS_DBG; tools/split_dbg_run.sh): 1 every pixel-operand
@@ -416,9 +419,20 @@ __device__ __forceinline__ int cbs_div(int x, unsigned long long magic) {
 }
 
 // BM x BN output tile per workgroup, WM x WN waves, each wave TN = BN/WN/32 column tiles of one 32-row tile.
-template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING>
+// HALF (round 4): the fp16 layers (cbconv2d_cg_half_backend.cu:146-197): tensors, state and weights are f16 as they
+// come -- ONE plane, a stage is 64 k = the same 128 bytes of a pixel's record and the same 4 KB weight block per row
+// tile, so DMA, ring, swizzle and fragment addresses are the f16-pair form's; what differs is the matrix work of a
+// stage (four k-steps of one product instead of two of three), no scale, and f16 outputs.
+template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING, bool HALF = false>
 __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     cb_touch_kernarg<sizeof(CbsParams)>();
+    if (HALF && p.upstream && *p.upstream == 0) {      // (the detection in front returned the same way: the mask is empty)
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            p.seq[0].countOut[0] = 0;
+            if (p.info) p.info[CBS_INFO_SK] = 1;      // (nothing for the second launch)
+        }
+        return;
+    }
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TN = BN / WN / 32;
     static_assert(BM == 32 * WM, "one 32-row tile per wave");
@@ -662,10 +676,11 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         }
         CBS_STAMP_AT(9);
         // (the m-tile's bias for the epilogue: requested now, put into LDS once the ring is primed)
-        const float biasv = (t < BM && p.bias && m0 + t < p.K) ? p.bias[m0 + t] : 0.f;
+        const float biasv = (t < BM && p.bias && m0 + t < p.K)
+                                ? (HALF ? (float)((const _Float16*)p.bias)[m0 + t] : p.bias[m0 + t]) : 0.f;
         __syncthreads();
         CBS_STAMP_AT(10);
-        if (__builtin_expect(__builtin_amdgcn_readfirstlane(s_exact[q]) != 0, 0)) {
+        if (!HALF && __builtin_expect(__builtin_amdgcn_readfirstlane(s_exact[q]) != 0, 0)) {
             // The sequence's state left the range of the f16 pairs (|x| >= 2^20, cbs_detect_kernel): its split state is
             // not usable.  The tile is computed from prevInput and the plain filter bank instead, one f32 fma chain per
             // output in (channel, ky, kx) order like conv2d_cg.py:342-349's sgemm -- orders of magnitude slower, and
@@ -777,7 +792,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
                 for (int i = 0; i < 16; ++i) {
                     // (the first chunk's sum is taken as it is: 0 + x would turn a -0 into +0 where the split form,
                     //  which adds the second slab to the first, keeps it)
-                    const float c = acc1[j][i] + acc2[j][i] * lo2;
+                    const float c = HALF ? acc1[j][i] : acc1[j][i] + acc2[j][i] * lo2;
                     run[j][i] = folds > 0 ? run[j][i] + c : c;
                     acc1[j][i] = 0.f, acc2[j][i] = 0.f;
                 }
@@ -825,9 +840,18 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             for (int j = 0; j < TN; ++j) readB(s, f, j);
         };
         // the 6 TN matrix instructions of a stage, numbered i = (ks * TN + j) * 3 + term
-        constexpr int NM = 6 * TN;
+        // (HALF: 4 TN, i = ks * TN + j, one product each, fragment e = k-step ks of the stage's four)
+        constexpr int NM = HALF ? 4 * TN : 6 * TN;
         auto mmaRange = [&](const Frags& f, int i0, int i1) {
             if (CBS_DBGBIT(2)) return;
+            if constexpr (HALF) {
+#pragma unroll
+                for (int i = i0; i < (i1 < NM ? i1 : NM); ++i) {
+                    const int ks = i / TN, j = i % TN;
+                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[ks], f.b[j * 4 + ks], acc1[j], 0, 0, 0);
+                }
+                return;
+            }
 #pragma unroll
             for (int i = i0; i < i1; ++i) {
                 const int ks = i / (3 * TN), j = (i / 3) % TN, term = i % 3;
@@ -949,10 +973,14 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int mq = wm * 8 + 2 * r4 + h;
-                    slab[mq * BN + nl] = make_float4(acc1[j][4 * r4] + acc2[j][4 * r4] * lo2,
-                                                     acc1[j][4 * r4 + 1] + acc2[j][4 * r4 + 1] * lo2,
-                                                     acc1[j][4 * r4 + 2] + acc2[j][4 * r4 + 2] * lo2,
-                                                     acc1[j][4 * r4 + 3] + acc2[j][4 * r4 + 3] * lo2);
+                    if (HALF)
+                        slab[mq * BN + nl] = make_float4(acc1[j][4 * r4], acc1[j][4 * r4 + 1], acc1[j][4 * r4 + 2],
+                                                         acc1[j][4 * r4 + 3]);
+                    else
+                        slab[mq * BN + nl] = make_float4(acc1[j][4 * r4] + acc2[j][4 * r4] * lo2,
+                                                         acc1[j][4 * r4 + 1] + acc2[j][4 * r4 + 1] * lo2,
+                                                         acc1[j][4 * r4 + 2] + acc2[j][4 * r4 + 2] * lo2,
+                                                         acc1[j][4 * r4 + 3] + acc2[j][4 * r4 + 3] * lo2);
                 }
             }
             CBS_STAMP_AT(5);
@@ -968,10 +996,14 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, m = m0 + ml;
-                float v = acc1[j][r] + acc2[j][r] * lo2;
+                float v = HALF ? acc1[j][r] : acc1[j][r] + acc2[j][r] * lo2;
                 if (folds > 0) v = run[j][r] + v;        // (the last chunk joins the running sum)
                 v = fmaf(v, p.outScale, s_bias[ml]);      // (an explicit fma here, in the reduce launch and in the
                 if (p.relu) v = v <= 0.f ? 0.f : v;        //  fused tail: one rounding at all three sites)
+                if (HALF) {
+                    if (pix >= 0 && m < p.K) ((_Float16*)out)[(long)m * HW + pix] = (_Float16)v;
+                    continue;
+                }
                 if (pix >= 0 && m < p.K) {
                     if (accum) {      // fine-grained: the sum of the products joins what the output holds
                         v += out[(long)m * HW + pix];
@@ -1066,8 +1098,13 @@ __global__ __launch_bounds__(256) void cbs_reduce_kernel(CbsParams p, int BM, in
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (m + e >= p.K) continue;
-            float v = fmaf(sv[e], p.outScale, p.bias ? p.bias[m + e] : 0.f);
+            const float bv = !p.bias ? 0.f : (p.halfOut ? (float)((const _Float16*)p.bias)[m + e] : p.bias[m + e]);
+            float v = fmaf(sv[e], p.outScale, bv);
             if (p.relu) v = v <= 0.f ? 0.f : v;
+            if (p.halfOut) {      // (fp16 layer: bias and outputs are f16)
+                ((_Float16*)out)[(long)(m + e) * HW + pix] = (_Float16)v;
+                continue;
+            }
             if (p.accumulate) {
                 v += out[(long)(m + e) * HW + pix];
                 float* rp = p.seq[q].reluOut;
@@ -1218,13 +1255,13 @@ int cbs_num_cus() {
     return cus;
 }
 
-template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING>
+template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING, bool HALF = false>
 int cbs_launch_conv(const CbsParams& p, int perCU, const CbsTailArgs* tail, hipStream_t s) {
     if ((long)p.nSeq * p.maskWords > PRE_CAP) return CB_ERR_UNSUPPORTED;
     const bool second = p.slabs && (p.nStages >= 48 || p.forceSK > 0);
     if (tail && !second) return CB_ERR_UNSUPPORTED;      // (the fused tail reads the launch info of a deep contraction)
     dim3 grid((unsigned)(perCU * cbs_num_cus())), block(64 * WM * WN);
-    hipLaunchKernelGGL((cbs_conv_kernel<BM, BN, WM, WN, PRE_CAP, MASK_LDS, RING>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((cbs_conv_kernel<BM, BN, WM, WN, PRE_CAP, MASK_LDS, RING, HALF>), grid, block, 0, s, p);
     int st = cb_launch_status();
     if (st != CB_OK) return st;
     if (tail) {
@@ -1409,6 +1446,8 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
     p.magicMT = (1ull << 32) / (unsigned long long)(KP / BM) + 1ull;
     p.forceSK = forceSplit;
     p.accumulate = accumulate;
+    p.halfOut = 0;
+    p.upstream = nullptr;
     {
         static int rounds = -1;      // CBINFER_SPLIT_ROUNDS (tuning aid; default 2)
         if (rounds < 0) {
@@ -1509,6 +1548,309 @@ int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int mode, int pH, in
     if (st != CB_OK) return st;
     return cbs_split_conv(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace, 0, nullptr,
                           stream);
+}
+
+}  // extern "C"
+
+// ===================================================================================================
+// fp16 layers on the split-state machinery ("hsplit", round 4): the fused a1 + a5..a8 path of a CBConv2d in half
+// precision (cbconv2d_cg_half_backend.cu:10-88, :146-197; conv2d.py:178-259) for layers whose input channels are a
+// multiple of 64.  The state is kept a second time pixel-major, [Hp][Wp][C] f16 with the zero border and dummy rows
+// of the f16-pair form -- no split: the values are f16 already -- so a stage is 64 channels of one tap = 128 bytes of
+// a pixel's record, and cbs_conv_kernel<..., HALF> runs DMA, ring and fragment reads unchanged with one
+// v_mfma_f32_32x32x16_f16 per 16 k (f32 accumulation, outputs rounded to f16 once: the arithmetic of rounds 1-2's
+// fp16 list kernel, another summation order).
+// ===================================================================================================
+namespace cbs {
+
+__host__ __device__ inline CbsGeom cbh_geom(int C, int H, int W, int kH, int kW) {
+    CbsGeom g;
+    g.C = C, g.G = C / 64, g.H = H, g.W = W, g.kH = kH, g.kW = kW;      // (G: stages per tap)
+    g.padY = kH / 2, g.padXL = kW / 2, g.padXR = kW / 2;
+    g.pair = 0, g.kWs = kW;
+    g.Wp = W + g.padXL + g.padXR;
+    g.Hp = H + 4 * g.padY + 1;
+    g.rec = C * 2;
+    g.nStages = kH * kW * g.G;
+    g.dummyBase = ((H + 2 * g.padY) * g.Wp) * g.rec;
+    return g;
+}
+inline bool cbh_supported(int C, int K, int kH, int kW) {
+    return C >= 64 && C <= 1024 && C % 64 == 0 && K >= 1 && K <= 1024 && (kH & 1) && (kW & 1) && kH <= 15 && kW <= 15 &&
+           cbh_geom(C, 64, 64, kH, kW).nStages >= 4;
+}
+
+// weights [K,C,kH,kW] f16 -> [stage][row tile of 32][k-step 0..3][lane][8 f16] (the A-fragment order of the f16-pair
+// form with the (k-step, plane) index read as the k-step of four) + the stage table
+__global__ __launch_bounds__(256) void cbh_prep_kernel(const _Float16* __restrict__ w, halfx8* __restrict__ A,
+                                                      int* __restrict__ stageOff, CbsGeom g, int K, int KP) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < g.nStages) {
+        const int s = (int)idx, tap = s / g.G, sub = s % g.G;
+        stageOff[s] = ((tap / g.kW) * g.Wp + tap % g.kW) * g.rec + sub * 128;
+    }
+    const int RT = KP / 32;
+    const long total = (long)g.nStages * RT * 4 * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const long blk = idx >> 6;
+    const int ks = (int)(blk & 3);
+    const int rt = (int)((blk >> 2) % RT), stage = (int)((blk >> 2) / RT);
+    const int m = rt * 32 + (lane & 31);
+    const int tap = stage / g.G, sub = stage % g.G, ky = tap / g.kW, kx = tap % g.kW;
+    halfx8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = sub * 64 + ks * 16 + 8 * (lane >> 5) + j;
+        o[j] = m < K ? w[(((long)m * g.C + c) * g.kH + ky) * g.kW + kx] : (_Float16)0;
+    }
+    A[idx] = o;
+}
+
+// pixel-major state: zero everywhere, +inf at the image pixels (the f16 state starts as +inf, conv2d.py:192-199)
+__global__ __launch_bounds__(256) void cbh_state_init_kernel(uint4* __restrict__ S, CbsGeom g) {
+    const long chunks = (long)g.Hp * g.Wp * (g.rec / 16);
+    if (blockIdx.x == 0) S[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);     // the CBS_SPAD bytes in front (256 x 16)
+    S += CBS_SPAD / 16;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / (g.rec / 16);
+        const int py = (int)(pix / g.Wp), px = (int)(pix % g.Wp);
+        const bool inside = py >= g.padY && py < g.padY + g.H && px >= g.padXL && px < g.padXL + g.W;
+        const unsigned v = inside ? 0x7c007c00u : 0u;
+        S[i] = make_uint4(v, v, v, v);
+    }
+}
+
+// the pixel-major copy made again from the [C,H,W] state (restored states; the border is left alone)
+__global__ __launch_bounds__(256) void cbh_state_rebuild_kernel(const _Float16* __restrict__ state,
+                                                               char* __restrict__ S, CbsGeom g) {
+    const long HW = (long)g.H * g.W;
+    const int parts = g.C / 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW * parts; i += (long)gridDim.x * blockDim.x) {
+        const int part = (int)(i / HW);
+        const long pix = i % HW;                       // (consecutive threads: consecutive pixels of one channel)
+        const int y = (int)(pix / g.W), x = (int)(pix % g.W);
+        halfx8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = state[(long)(part * 8 + j) * HW + pix];
+        *(halfx8*)(S + CBS_SPAD + ((long)(y + g.padY) * g.Wp + (x + g.padXL)) * g.rec + part * 16) = v;
+    }
+}
+
+// Change detection of an fp16 layer with the second state: one workgroup = one 64-pixel row segment, 16 waves, the
+// channels in groups of 64 (wave g: four of them), predicate and dilation as cb_detect_kernel<cb_half> (v_sub_f16,
+// strict >, cbconv2d_cg_half_backend.cu:24-35).  copyAll (no feedback loop, copyInput): one pass -- every value
+// compared goes straight into prevInput, and group by group through LDS into the pixel records.  Feedback mode: a
+// first pass compares, a second one writes the changed pixels' values into both states.
+struct CbhDetArgs {
+    const _Float16* in;
+    _Float16* state;
+    char* S;
+    unsigned long long* masks;
+    int W, H, C, kHH, kWH, wpr, Wp, rec, padY, padXL;
+    float th;
+    int copyAll;
+    const int* upstream;      // optional: the producing layer's change count of this frame (0: nothing to look at)
+};
+__global__ __launch_bounds__(1024) void cbh_detect_kernel(CbhDetArgs a) {
+    cb_touch_kernarg<sizeof(CbhDetArgs)>();
+    if (a.upstream && *a.upstream == 0) return;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, t = threadIdx.x;
+    const int tx = blockIdx.x, y = blockIdx.y;
+    const int W = a.W, H = a.H, C = a.C;
+    const int x = tx * 64 + lane;
+    const bool valid = x < W;
+    const long HW = (long)H * W;
+    const long p = (long)y * W + x;
+    const _Float16* __restrict__ in = a.in;
+    _Float16* state = a.state;
+    const cb_half th = cb_threshold(a.th, (cb_half*)nullptr);
+    __shared__ unsigned long long sm[16];
+    __shared__ _Float16 T[64][66];
+    const unsigned long long vm = cbs_valid_mask(W, tx);
+    char* const recRow = a.S + CBS_SPAD + ((long)(y + a.padY) * a.Wp + (tx * 64 + a.padXL)) * a.rec;
+
+    // one channel group: [compare] -> [state <- input at the lanes of upd] -> [records of the pixels of upd]
+    auto group = [&](int cg, bool compare, bool write, unsigned long long upd, bool& chg) {
+        const int c0 = cg * 64 + g * 4;
+        _Float16 x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+        if (valid) {
+            x0 = in[(long)c0 * HW + p], x1 = in[(long)(c0 + 1) * HW + p];
+            x2 = in[(long)(c0 + 2) * HW + p], x3 = in[(long)(c0 + 3) * HW + p];
+            if (compare) {
+                const _Float16 s0 = state[(long)c0 * HW + p], s1 = state[(long)(c0 + 1) * HW + p];
+                const _Float16 s2 = state[(long)(c0 + 2) * HW + p], s3 = state[(long)(c0 + 3) * HW + p];
+                chg |= cb_changed(s0, x0, th) | cb_changed(s1, x1, th) | cb_changed(s2, x2, th) | cb_changed(s3, x3, th);
+            }
+        }
+        if (!write) return;
+        if ((upd >> lane) & 1ull) {
+            state[(long)c0 * HW + p] = x0, state[(long)(c0 + 1) * HW + p] = x1;
+            state[(long)(c0 + 2) * HW + p] = x2, state[(long)(c0 + 3) * HW + p] = x3;
+        }
+        __syncthreads();      // (the previous group's records have been read out of T)
+        T[g * 4][lane] = x0, T[g * 4 + 1][lane] = x1, T[g * 4 + 2][lane] = x2, T[g * 4 + 3][lane] = x3;
+        __syncthreads();
+        if (t < 512) {
+            const int pl = t >> 3, c8 = t & 7;
+            if ((upd >> pl) & 1ull) {
+                halfx8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = T[c8 * 8 + j][pl];
+                *(halfx8*)(recRow + (long)pl * a.rec + cg * 128 + c8 * 16) = v;
+            }
+        }
+    };
+
+    const int NG = C >> 6;
+    bool chg = false;
+    for (int cg = 0; cg < NG; ++cg) group(cg, true, a.copyAll != 0, vm, chg);
+    const unsigned long long b = __ballot(chg);
+    if (lane == 0) sm[g] = b;
+    __syncthreads();
+    unsigned long long m = 0;
+    for (int i = 0; i < 16; ++i) m |= sm[i];
+    if (m == 0) return;      // uniform over the workgroup
+    if (!a.copyAll) {        // feedback: both states take the changed pixels' values (.cu:74-80 of the half backend)
+        bool dummy = false;
+        for (int cg = 0; cg < NG; ++cg) group(cg, false, true, m, dummy);
+    }
+
+    unsigned long long D = m, SR = 0, SL = 0;
+    for (int d = 1; d <= a.kWH; ++d) {
+        D |= (m << d) | (m >> d);
+        SR |= m >> (64 - d);
+        SL |= m << (64 - d);
+    }
+    D &= vm;
+    SR = (tx + 1 < a.wpr) ? (SR & cbs_valid_mask(W, tx + 1)) : 0ull;
+    if (tx == 0) SL = 0;
+    if (g == 0) {
+        const int items = 3 * (2 * a.kHH + 1);
+        for (int i = lane; i < items; i += 64) {
+            const int yy = y + i / 3 - a.kHH;
+            const int which = i % 3;
+            if (yy < 0 || yy >= H) continue;
+            const unsigned long long v = which == 0 ? D : (which == 1 ? SR : SL);
+            const int t2 = which == 0 ? tx : (which == 1 ? tx + 1 : tx - 1);
+            if (v) atomicOr(&a.masks[(long)yy * a.wpr + t2], v);
+        }
+    }
+}
+
+}  // namespace cbs
+
+extern "C" {
+
+int cbinfer_hsplit_supported(int C, int K, int kH, int kW) { return cbh_supported(C, K, kH, kW) ? 1 : 0; }
+// mask words (cbinfer_mask_words(H,W)) the contraction of a K-channel fp16 layer takes
+long cbinfer_hsplit_max_mask_words(int K) { (void)K; return CBS_PRE_MID; }
+long cbinfer_hsplit_state_bytes(int C, int H, int W, int kH, int kW) {
+    const CbsGeom g = cbh_geom(C, H, W, kH, kW);
+    return CBS_SPAD + (long)g.Hp * g.Wp * g.rec;
+}
+long cbinfer_hsplit_prepared_bytes(int C, int K, int kH, int kW) {
+    const CbsGeom g = cbh_geom(C, 64, 64, kH, kW);
+    return cbs_plain_offset((long)g.nStages * (cbs_kp(K) / 32) * 4096, g.nStages);
+}
+long cbinfer_hsplit_workspace_bytes(int C, int H, int W, int K, int kH, int kW) {
+    if (!cbh_supported(C, K, kH, kW)) return 0;
+    if (cbh_geom(C, H, W, kH, kW).nStages < 48) return 0;
+    const int bm = cbs_bm(K), bn = bm >= 128 ? 128 : 64;
+    return 256 + cbs_slab_capacity(1, H, W, K) * bm * bn * 4;
+}
+int cbinfer_hsplit_prep_weights(const void* weight, void* prepared, int K, int C, int kH, int kW, int H, int W,
+                                cbStream_t stream) {
+    CB_REQUIRE(weight && prepared && H > 0 && W > 0);
+    if (!cbh_supported(C, K, kH, kW)) return CB_ERR_UNSUPPORTED;
+    const CbsGeom g = cbh_geom(C, H, W, kH, kW);
+    if ((long)g.Hp * g.Wp * g.rec >= (1l << 31)) return CB_ERR_UNSUPPORTED;
+    const int KP = cbs_kp(K);
+    const long total = (long)g.nStages * (KP / 32) * 4 * 64;
+    const long aBytes = (long)g.nStages * (KP / 32) * 4096;
+    hipLaunchKernelGGL(cbh_prep_kernel, dim3(cb_div_up(total > g.nStages ? total : g.nStages, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const _Float16*)weight, (halfx8*)prepared,
+                       (int*)((char*)prepared + aBytes), g, K, KP);
+    return cb_launch_status();
+}
+int cbinfer_hsplit_state_init(void* pixelState, int C, int H, int W, int kH, int kW, cbStream_t stream) {
+    CB_REQUIRE(pixelState && H > 0 && W > 0);
+    if (!cbh_supported(C, 1, kH, kW)) return CB_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(cbh_state_init_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (uint4*)pixelState,
+                       cbh_geom(C, H, W, kH, kW));
+    return cb_launch_status();
+}
+int cbinfer_hsplit_state_rebuild(const void* state, void* pixelState, int C, int H, int W, int kH, int kW,
+                                 cbStream_t stream) {
+    CB_REQUIRE(state && pixelState && H > 0 && W > 0);
+    if (!cbh_supported(C, 1, kH, kW)) return CB_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(cbh_state_rebuild_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)state, (char*)pixelState, cbh_geom(C, H, W, kH, kW));
+    return cb_launch_status();
+}
+
+// One frame of an fp16 CBConv2d (conv2d.py:178-259 on the half backend): detection + refresh of prevInput and of its
+// pixel-major copy (feedbackLoop: at the changed pixels; else every value -- the layer keeps a copy of its input),
+// then the LDS-DMA contraction (+ the reduce launch of a deep one).  All tensors f16; frameMasks / idxOut / countOut /
+// maskCopy as for cbinfer_split_forward; upstreamCount (optional) as for cbinfer_cbconv2d_forward_after.
+int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, void* state, void* pixelState, uint64_t* frameMasks, void* output,
+                           int32_t* idxOut, int32_t* countOut, uint64_t* maskCopy, const void* prepared,
+                           const void* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
+                           int feedbackLoop, int relu, void* workspace, cbStream_t stream) {
+    CB_REQUIRE(input && state && pixelState && frameMasks && output && idxOut && countOut && prepared && H > 0 && W > 0);
+    if (!cbh_supported(C, K, kH, kW) || H > 65535) return CB_ERR_UNSUPPORTED;
+    const CbsGeom g = cbh_geom(C, H, W, kH, kW);
+    const int KP = cbs_kp(K), BM = cbs_bm(K);
+    const long MW = cbinfer_mask_words(H, W);
+    if (MW > CBS_PRE_MID || (long)g.Hp * g.Wp * g.rec >= (1l << 31) || (long)H * W * W >= (1l << 32))
+        return CB_ERR_UNSUPPORTED;
+    if (workspace == nullptr && g.nStages >= 48) return CB_ERR_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    CbhDetArgs a;
+    a.in = (const _Float16*)input, a.state = (_Float16*)state, a.S = (char*)pixelState;
+    a.masks = (unsigned long long*)frameMasks;
+    a.W = W, a.H = H, a.C = C, a.kHH = (kH - 1) / 2, a.kWH = (kW - 1) / 2, a.wpr = cbinfer_mask_words_per_row(W);
+    a.Wp = g.Wp, a.rec = g.rec, a.padY = g.padY, a.padXL = g.padXL, a.th = threshold, a.copyAll = feedbackLoop ? 0 : 1;
+    a.upstream = upstreamCount;
+    hipLaunchKernelGGL(cbh_detect_kernel, dim3(a.wpr, H), dim3(1024), 0, s, a);
+    int st = cb_launch_status();
+    if (st != CB_OK) return st;
+
+    CbsParams p;
+    for (int q = 0; q < CBS_MAXSEQ; ++q) p.seq[q] = CbsSeq{};
+    p.seq[0].S = (const char*)pixelState;
+    p.seq[0].state = nullptr, p.seq[0].rangeFlag = nullptr, p.seq[0].reluOut = nullptr;
+    p.seq[0].out = (float*)output;
+    p.seq[0].masks = (unsigned long long*)frameMasks;
+    p.seq[0].listOut = idxOut, p.seq[0].countOut = countOut;
+    p.seq[0].maskCopy = (unsigned long long*)maskCopy;
+    p.nSeq = 1;
+    p.aBytes = (long)g.nStages * (KP / 32) * 4096;
+    p.A = (const char*)prepared;
+    p.stageOff = (const int*)((const char*)prepared + p.aBytes);
+    p.wPlain = nullptr;
+    p.bias = (const float*)bias;      // (f16 values: cbs_conv_kernel<..., HALF> and the reduce launch read them as such)
+    p.info = workspace ? (int*)workspace : nullptr;
+    p.slabs = workspace ? (float*)((char*)workspace + 256) : nullptr;
+    p.K = K, p.KP = KP, p.H = H, p.W = W, p.Wp = g.Wp, p.rec = g.rec, p.nStages = g.nStages, p.kH = kH, p.kW = kW;
+    p.maskWords = (int)MW, p.wpr = a.wpr, p.relu = relu, p.dummyBase = g.dummyBase;
+    p.stateBytes = (long)g.Hp * g.Wp * g.rec;
+    p.outScale = 1.0f;
+    p.magicMW = (1ull << 32) / (unsigned long long)MW + 1ull;
+    p.magicWpr = (1ull << 32) / (unsigned long long)p.wpr + 1ull;
+    p.magicW = (1ull << 32) / (unsigned long long)W + 1ull;
+    p.magicMT = (1ull << 32) / (unsigned long long)(KP / BM) + 1ull;
+    p.forceSK = 0, p.accumulate = 0, p.halfOut = 1, p.splitRounds = 2, p.dbg = 0;
+    p.upstream = upstreamCount;
+    p.arriveShards = (int)(MW / 16 < 8 ? MW / 16 : 8);
+    const long cap = cbs_slab_capacity(1, H, W, K);
+    p.slabCap = (int)(cap > 0x7fffffffl ? 0x7fffffffl : cap);
+    if (BM == 128) {
+        if (MW <= CBS_PRE_BIG) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG, true, 4, true>(p, 1, nullptr, s);
+        return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_MID, false, 4, true>(p, 1, nullptr, s);
+    }
+    if (MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 8, true>(p, 1, nullptr, s);
+    return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 8, true>(p, 1, nullptr, s);
 }
 
 }  // extern "C"

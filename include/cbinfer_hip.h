@@ -501,6 +501,32 @@ int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int mode, int p
                                float weightScale, int relu, void* workspace, int forceSplit, const cbSplitTail* tail,
                                cbStream_t stream);
 
+/* ---- fp16 layers on the split-state machinery (round 4): the frame of a CBConv2d in half precision
+ * (cbconv2d_cg_half_backend.cu:10-88 change detection, :146-197 genXMatrix / updateOutput around an fp16 matmul;
+ * conv2d.py:178-259) whose input channels are a multiple of 64.  Beside prevInput [C,H,W] f16 the layer keeps a
+ * pixel-major copy [Hp][Wp][C] f16 with a zero border (cbinfer_hsplit_state_bytes; no split -- the values are f16
+ * already), so that a pixel's 64 channels of one tap are 128 contiguous bytes and both operands of the contraction go
+ * global -> LDS by LDS-DMA; v_mfma_f32_32x32x16_f16, f32 accumulation, outputs rounded to f16 once (the arithmetic
+ * of cbinfer_conv_changed with CB_F16, another summation order).  feedbackLoop = 1: both states take the changed
+ * pixels' values (.cu:74-80 of the half backend); 0: every value of the frame (the layer keeps a copy of its input,
+ * conv2d.py:234-236).  frameMasks: cbinfer_frame_mask_bytes(H,W) bytes, zero once; workspace:
+ * cbinfer_hsplit_workspace_bytes (0 for fewer than 48 k-stages), zero once; upstreamCount: optional, as for
+ * cbinfer_cbconv2d_forward_after.  idxOut / countOut / maskCopy as for cbinfer_split_forward. */
+int cbinfer_hsplit_supported(int C, int K, int kH, int kW);
+long cbinfer_hsplit_max_mask_words(int K);
+long cbinfer_hsplit_state_bytes(int C, int H, int W, int kH, int kW);
+long cbinfer_hsplit_prepared_bytes(int C, int K, int kH, int kW);
+long cbinfer_hsplit_workspace_bytes(int C, int H, int W, int K, int kH, int kW);
+int cbinfer_hsplit_prep_weights(const void* weight, void* prepared, int K, int C, int kH, int kW, int H, int W,
+                                cbStream_t stream);
+int cbinfer_hsplit_state_init(void* pixelState, int C, int H, int W, int kH, int kW, cbStream_t stream);
+int cbinfer_hsplit_state_rebuild(const void* state, void* pixelState, int C, int H, int W, int kH, int kW,
+                                 cbStream_t stream);
+int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, void* state, void* pixelState,
+                           uint64_t* frameMasks, void* output, int32_t* idxOut, int32_t* countOut, uint64_t* maskCopy,
+                           const void* prepared, const void* bias, int C, int H, int W, int K, int kH, int kW,
+                           float threshold, int feedbackLoop, int relu, void* workspace, cbStream_t stream);
+
 /* ---- a5..a8 fused for a layer of few channels, ROW-PAIR form, with the NEXT layer's pooled change detection folded
  * in (round 4).  Replaces, per frame, the launcher sequence genXMatrix -> matmul -> updateOutput
  * (cbconv2d_cg_backend.cu:138-197, conv2d_cg.py:342-349) of a feedback-mode CBConv2d with at most 4 input and 16

@@ -1688,3 +1688,53 @@ def test_chain_tags_do_not_travel_with_copies(pkg):
                 a, b = net(f), other(f)
                 assert torch.equal(a, b)
             assert other[1].__dict__.get('_upNow') is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("feedback", [False, True])
+@pytest.mark.parametrize("shape", [(64, 64, 3, 46, 81), (128, 128, 3, 45, 67), (128, 38, 3, 30, 44), (512, 64, 1, 33, 50),
+                                   (128, 128, 7, 30, 44), (192, 160, 3, 24, 40)])
+def test_half_layers_on_the_split_state_machinery(pkg, oracle, shape, feedback, monkeypatch):
+    """Round 4: fp16 layers whose input channels are a multiple of 64 keep a pixel-major f16
+    copy of their state and contract by LDS-DMA (cbinfer_hsplit_forward; cbconv2d_cg_half_backend.cu:10-88, :146-197).
+    Every frame against the oracle's half state machine: change list bit-exact, prevInput bit-exact (the whole frame
+    without feedback loop, the changed pixels with it), outputs within 2 fp16 ulp of the layer's largest output
+    (DESIGN section 6's fp16 bar); the same frames on rounds 1-2's list kernel agree to the same bar; shallow and deep
+    (>= 48 k-stages: k-split + reduce launch) contractions, 64- and 128-row tiles, odd map widths."""
+    from cbinfer_amd import _lib
+    C, K, k, H, W = shape
+    torch.manual_seed(5)
+    conv = nn.Conv2d(C, K, k, padding=k // 2).cuda().half().eval()
+
+    def run(hsplit):
+        monkeypatch.setenv("CBINFER_NO_HSPLIT", "0" if hsplit else "1")
+        m = pkg.CBConv2d(conv, 0.1)
+        m.withReLU, m.feedbackLoop = True, feedback
+        o = oracle.OracleCBConv2dHalf(conv.weight.detach().cpu().numpy(), conv.bias.detach().cpu().numpy(), 0.1,
+                                      withReLU=True, feedbackLoop=feedback, propChangeIndexes=True)
+        r = np.random.default_rng(73)
+        x = r.standard_normal((1, C, H, W)).astype(np.float16)
+        outs, ran = [], []
+        with torch.no_grad():
+            for t in range(7):
+                x = x.copy()
+                if t not in (3, 4):
+                    for _ in range(2):
+                        y0, x0 = r.integers(0, H - 8), r.integers(0, W - 8)
+                        x[0, :, y0:y0 + 8, x0:x0 + 8] = r.standard_normal((C, 8, 8)).astype(np.float16)
+                xn = (x.astype(np.float32) + r.uniform(-0.03, 0.03, x.shape)).astype(np.float16)
+                out = m(torch.from_numpy(xn).cuda())
+                ran.append(bool(m._plan and m._plan.get('fn') is _lib.C.cbinfer_hsplit_forward))
+                got = o.forward(xn)
+                assert np.array_equal(m.lastChangeIndexes().tensor().cpu().numpy(), got[2]), (hsplit, t)
+                assert np.array_equal(m.prevInput.cpu().numpy(), o.prevInput), (hsplit, t)
+                ref = o.prevOutput.astype(np.float32)
+                tol = 2 * 2.0 ** -10 * max(1.0, float(np.abs(ref[np.isfinite(ref)]).max()))
+                err = np.abs(out.float().cpu().numpy() - ref).max()
+                assert err <= tol, (hsplit, t, err, tol)
+                outs.append(out.clone())
+        return outs, ran
+
+    a, ranA = run(True)
+    b, ranB = run(False)
+    assert all(ranA[1:]) and not any(ranB), (ranA, ranB)

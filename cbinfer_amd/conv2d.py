@@ -418,6 +418,10 @@ class CBConv2d(nn.Module):
                 and os.environ.get('CBINFER_NO_SPLIT', '0') != '1' and os.environ.get('CBINFER_NO_HSPLIT', '0') != '1'
                 and os.environ.get('CBINFER_NO_SELFCOMPACT', '0') != '1'
                 and bool(C.cbinfer_hsplit_supported(Cin, K, kH, kW))
+                # (a deep contraction -- 48 k-stages and more: 7x7 on 128 channels, 3x3 on 512 -- brings a second launch
+                #  that also runs, and costs its 2.5 us, in frames in which the layer has nothing to do: OpenPose's
+                #  eleven such layers lost more there than the four busy ones gained; CBINFER_HSPLIT_DEEP=1 takes them)
+                and (kH * kW * (Cin // 64) < 48 or os.environ.get('CBINFER_HSPLIT_DEEP', '0') == '1')
                 and C.cbinfer_mask_words(H, W) <= C.cbinfer_hsplit_max_mask_words(K)
                 and C.cbinfer_hsplit_state_bytes(Cin, H, W, kH, kW) < (1 << 31) and H * W * W < (1 << 32))
 

@@ -1708,6 +1708,7 @@ def test_half_layers_on_the_split_state_machinery(pkg, oracle, shape, feedback, 
 
     def run(hsplit):
         monkeypatch.setenv("CBINFER_NO_HSPLIT", "0" if hsplit else "1")
+        monkeypatch.setenv("CBINFER_HSPLIT_DEEP", "1")      # (the module leaves deep contractions to the list kernel by default)
         m = pkg.CBConv2d(conv, 0.1)
         m.withReLU, m.feedbackLoop = True, feedback
         o = oracle.OracleCBConv2dHalf(conv.weight.detach().cpu().numpy(), conv.bias.detach().cpu().numpy(), 0.1,

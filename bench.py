@@ -709,7 +709,8 @@ def secondary_configs(args):
         "effective_gflops": cb * pose_ops / 1e9, "dense_ops_per_frame": pose_ops,
         "mean_post_dilation_ratio": sum(rs) / max(1, len(rs)), "layers": len(rs),
         "layers_without_change": sum(1 for r in rs if r == 0.0),
-        "note": "36 converted convs, fp16 (cg_half path: list kernels of rounds 1-2, f16 MFMA / f32 accumulation), RANDOM "
+        "note": "36 converted convs, fp16 (cg_half path, f16 MFMA / f32 accumulation: layers of 64 n input channels and fewer "
+                "than 48 k-stages on the fp16 split-state kernels of round 4, the others on rounds 1-2's list kernels), RANDOM "
                 "weights: the change dies out behind the fifth conv (layers_without_change of the 36 recompute nothing "
                 "in any frame), so most of the frame is launches that find nothing to do.  cb_fps: a layer fed "
                 "another layer's output buffer reads that layer's change count and returns at once when it is zero "

@@ -425,7 +425,7 @@ __device__ __forceinline__ int cbs_div(int x, unsigned long long magic) {
 // stage (four k-steps of one product instead of two of three), no scale, and f16 outputs.
 template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING, bool HALF = false>
 __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
-    cb_touch_kernarg<sizeof(CbsParams)>();
+    // (before anything else -- the burst over the kilobyte of arguments included: an idle frame is this one load)
     if (HALF && p.upstream && *p.upstream == 0) {      // (the detection in front returned the same way: the mask is empty)
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             p.seq[0].countOut[0] = 0;
@@ -433,6 +433,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         }
         return;
     }
+    cb_touch_kernarg<sizeof(CbsParams)>();
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TN = BN / WN / 32;
     static_assert(BM == 32 * WM, "one 32-row tile per wave");
@@ -1637,8 +1638,9 @@ __global__ __launch_bounds__(256) void cbh_state_rebuild_kernel(const _Float16* 
     }
 }
 
-// Change detection of an fp16 layer with the second state: one workgroup = one 64-pixel row segment, 16 waves, the
-// channels in groups of 64 (wave g: four of them), predicate and dilation as cb_detect_kernel<cb_half> (v_sub_f16,
+// Change detection of an fp16 layer with the second state: one workgroup = one 64-pixel row segment, 8 waves, the
+// channels in groups of 64 (wave g: eight of them -- sixteen 128-byte loads in flight per wave: with four, the
+// 64-channel 368x654 layer of OpenPose ran at 2.9 TB/s), predicate and dilation as cb_detect_kernel<cb_half> (v_sub_f16,
 // strict >, cbconv2d_cg_half_backend.cu:24-35).  copyAll (no feedback loop, copyInput): one pass -- every value
 // compared goes straight into prevInput, and group by group through LDS into the pixel records.  Feedback mode: a
 // first pass compares, a second one writes the changed pixels' values into both states.
@@ -1652,9 +1654,9 @@ struct CbhDetArgs {
     int copyAll;
     const int* upstream;      // optional: the producing layer's change count of this frame (0: nothing to look at)
 };
-__global__ __launch_bounds__(1024) void cbh_detect_kernel(CbhDetArgs a) {
-    cb_touch_kernarg<sizeof(CbhDetArgs)>();
+__global__ __launch_bounds__(512) void cbh_detect_kernel(CbhDetArgs a) {
     if (a.upstream && *a.upstream == 0) return;
+    cb_touch_kernarg<sizeof(CbhDetArgs)>();
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, t = threadIdx.x;
     const int tx = blockIdx.x, y = blockIdx.y;
     const int W = a.W, H = a.H, C = a.C;
@@ -1665,33 +1667,38 @@ __global__ __launch_bounds__(1024) void cbh_detect_kernel(CbhDetArgs a) {
     const _Float16* __restrict__ in = a.in;
     _Float16* state = a.state;
     const cb_half th = cb_threshold(a.th, (cb_half*)nullptr);
-    __shared__ unsigned long long sm[16];
+    __shared__ unsigned long long sm[8];
     __shared__ _Float16 T[64][66];
     const unsigned long long vm = cbs_valid_mask(W, tx);
     char* const recRow = a.S + CBS_SPAD + ((long)(y + a.padY) * a.Wp + (tx * 64 + a.padXL)) * a.rec;
 
     // one channel group: [compare] -> [state <- input at the lanes of upd] -> [records of the pixels of upd]
     auto group = [&](int cg, bool compare, bool write, unsigned long long upd, bool& chg) {
-        const int c0 = cg * 64 + g * 4;
-        _Float16 x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+        const int c0 = cg * 64 + g * 8;
+        _Float16 xv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[i] = (_Float16)0;
         if (valid) {
-            x0 = in[(long)c0 * HW + p], x1 = in[(long)(c0 + 1) * HW + p];
-            x2 = in[(long)(c0 + 2) * HW + p], x3 = in[(long)(c0 + 3) * HW + p];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xv[i] = in[(long)(c0 + i) * HW + p];
             if (compare) {
-                const _Float16 s0 = state[(long)c0 * HW + p], s1 = state[(long)(c0 + 1) * HW + p];
-                const _Float16 s2 = state[(long)(c0 + 2) * HW + p], s3 = state[(long)(c0 + 3) * HW + p];
-                chg |= cb_changed(s0, x0, th) | cb_changed(s1, x1, th) | cb_changed(s2, x2, th) | cb_changed(s3, x3, th);
+                _Float16 sv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sv[i] = state[(long)(c0 + i) * HW + p];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) chg |= cb_changed(sv[i], xv[i], th);
             }
         }
         if (!write) return;
         if ((upd >> lane) & 1ull) {
-            state[(long)c0 * HW + p] = x0, state[(long)(c0 + 1) * HW + p] = x1;
-            state[(long)(c0 + 2) * HW + p] = x2, state[(long)(c0 + 3) * HW + p] = x3;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) state[(long)(c0 + i) * HW + p] = xv[i];
         }
         __syncthreads();      // (the previous group's records have been read out of T)
-        T[g * 4][lane] = x0, T[g * 4 + 1][lane] = x1, T[g * 4 + 2][lane] = x2, T[g * 4 + 3][lane] = x3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) T[g * 8 + i][lane] = xv[i];
         __syncthreads();
-        if (t < 512) {
+        {
             const int pl = t >> 3, c8 = t & 7;
             if ((upd >> pl) & 1ull) {
                 halfx8 v;
@@ -1709,7 +1716,7 @@ __global__ __launch_bounds__(1024) void cbh_detect_kernel(CbhDetArgs a) {
     if (lane == 0) sm[g] = b;
     __syncthreads();
     unsigned long long m = 0;
-    for (int i = 0; i < 16; ++i) m |= sm[i];
+    for (int i = 0; i < 8; ++i) m |= sm[i];
     if (m == 0) return;      // uniform over the workgroup
     if (!a.copyAll) {        // feedback: both states take the changed pixels' values (.cu:74-80 of the half backend)
         bool dummy = false;
@@ -1812,7 +1819,7 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, void
     a.W = W, a.H = H, a.C = C, a.kHH = (kH - 1) / 2, a.kWH = (kW - 1) / 2, a.wpr = cbinfer_mask_words_per_row(W);
     a.Wp = g.Wp, a.rec = g.rec, a.padY = g.padY, a.padXL = g.padXL, a.th = threshold, a.copyAll = feedbackLoop ? 0 : 1;
     a.upstream = upstreamCount;
-    hipLaunchKernelGGL(cbh_detect_kernel, dim3(a.wpr, H), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(cbh_detect_kernel, dim3(a.wpr, H), dim3(512), 0, s, a);
     int st = cb_launch_status();
     if (st != CB_OK) return st;
 

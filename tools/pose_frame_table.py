@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""One steady-state frame of tools/pose_target.py from a rocprofv3 --kernel-trace CSV: the launches in order with their
+durations (device timestamps), and totals by kernel.  usage: pose_frame_table.py <dir with *_kernel_trace.csv> [frame]"""
+import collections
+import csv
+import glob
+import re
+import sys
+
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+det = [i for i, r in enumerate(rows) if "detect" in r["Kernel_Name"]]
+frame = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+a, b = det[frame * 36], det[(frame + 1) * 36]
+t0 = int(rows[a]["Start_Timestamp"])
+agg = collections.defaultdict(lambda: [0, 0.0])
+for r in rows[a:b]:
+    name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")[:70]
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    agg[name][0] += 1
+    agg[name][1] += d
+    print("%8.1f %7.2f  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, d, name))
+print("frame span %.1f us (serialised by the tracer), %d launches" % ((int(rows[b]["Start_Timestamp"]) - t0) / 1e3, b - a))
+for n, (c, d) in sorted(agg.items(), key=lambda x: -x[1][1]):
+    print("%4d x %7.2f us = %8.1f us  %s" % (c, d / c, d, n))

@@ -41,6 +41,13 @@ struct cb_traits<cb_half> {
 // change predicate, one channel value
 //   fp32: fabs(state - in) > th                                  (cbconv2d_cg_backend.cu:22,56)
 //   fp16: d = __hsub(state, in); d > th16 | d < -th16            (cbconv2d_cg_half_backend.cu:27-28)
+// bit-for-bit inequality (a value that equals the state is not written again by the copy-all detections)
+__device__ __forceinline__ bool cb_differs(float s, float x) {
+    return __builtin_bit_cast(unsigned, s) != __builtin_bit_cast(unsigned, x);
+}
+__device__ __forceinline__ bool cb_differs(cb_half s, cb_half x) {
+    return __builtin_bit_cast(unsigned short, s) != __builtin_bit_cast(unsigned short, x);
+}
 __device__ __forceinline__ bool cb_changed(float s, float x, float th) {
     return fabsf(s - x) > th;
 }

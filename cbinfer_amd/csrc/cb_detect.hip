@@ -116,28 +116,31 @@ __global__ __launch_bounds__(1024) void cb_detect_kernel(const T* __restrict__ i
             chg |= cb_changed(s0, x0, th) | cb_changed(s1, x1, th) | cb_changed(s2, x2, th) |
                    cb_changed(s3, x3, th);
             k0 = x0, k1 = x1, k2 = x2, k3 = x3;
-            if (copyAll) {
-                state[(long)c * HW + p] = x0, state[(long)(c + G) * HW + p] = x1;
-                state[(long)(c + 2 * G) * HW + p] = x2, state[(long)(c + 3 * G) * HW + p] = x3;
+            if (copyAll) {      // (only what differs: behind another change-based layer that is almost nothing)
+                if (cb_differs(s0, x0)) state[(long)c * HW + p] = x0;
+                if (cb_differs(s1, x1)) state[(long)(c + G) * HW + p] = x1;
+                if (cb_differs(s2, x2)) state[(long)(c + 2 * G) * HW + p] = x2;
+                if (cb_differs(s3, x3)) state[(long)(c + 3 * G) * HW + p] = x3;
             }
         }
         if (keep && c == g) {   // fewer than four channels for this wave: the same, value by value
             if (c < C) k0 = ldin(c);
             if (c + G < C) k1 = ldin(c + G);
             if (c + 2 * G < C) k2 = ldin(c + 2 * G);
-            if (c < C) chg |= cb_changed(state[(long)c * HW + p], k0, th);
-            if (c + G < C) chg |= cb_changed(state[(long)(c + G) * HW + p], k1, th);
-            if (c + 2 * G < C) chg |= cb_changed(state[(long)(c + 2 * G) * HW + p], k2, th);
+            T t0 = T(0), t1 = T(0), t2 = T(0);
+            if (c < C) t0 = state[(long)c * HW + p], chg |= cb_changed(t0, k0, th);
+            if (c + G < C) t1 = state[(long)(c + G) * HW + p], chg |= cb_changed(t1, k1, th);
+            if (c + 2 * G < C) t2 = state[(long)(c + 2 * G) * HW + p], chg |= cb_changed(t2, k2, th);
             if (copyAll) {
-                if (c < C) state[(long)c * HW + p] = k0;
-                if (c + G < C) state[(long)(c + G) * HW + p] = k1;
-                if (c + 2 * G < C) state[(long)(c + 2 * G) * HW + p] = k2;
+                if (c < C && cb_differs(t0, k0)) state[(long)c * HW + p] = k0;
+                if (c + G < C && cb_differs(t1, k1)) state[(long)(c + G) * HW + p] = k1;
+                if (c + 2 * G < C && cb_differs(t2, k2)) state[(long)(c + 2 * G) * HW + p] = k2;
             }
         } else {
             for (; c < C; c += G) {
-                const T xv = ldin(c);
-                chg |= cb_changed(state[(long)c * HW + p], xv, th);
-                if (copyAll) state[(long)c * HW + p] = xv;
+                const T xv = ldin(c), sv = state[(long)c * HW + p];
+                chg |= cb_changed(sv, xv, th);
+                if (copyAll && cb_differs(sv, xv)) state[(long)c * HW + p] = xv;
             }
         }
     }

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
 
     // C == 4 G: four channels per wave, eight independent loads in flight per lane
     bool chg = false;
+    unsigned dbits = 0xfu;      // copy-all form: which of this lane's four values differ from the state bit for bit
     float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f;
     if (valid) {
         const float s0 = state[(long)g * HW + p], x0 = ldin(g);
@@ -244,6 +245,9 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
                    c3 = cb_changed(s3, x3, a.th);
         chg = c0 | c1 | c2 | c3;
         k0 = x0, k1 = x1, k2 = x2, k3 = x3;
+        if (a.copyAll && !a.fg)
+            dbits = (unsigned)cb_differs(s0, x0) | (cb_differs(s1, x1) << 1) | (cb_differs(s2, x2) << 2) |
+                    (cb_differs(s3, x3) << 3);
         if (a.fg) {      // per VALUE: the state takes the input, the records (and the delta tensor) the difference
             float* dl = sq.delta;
             state[(long)g * HW + p] = x0, state[(long)(g + G) * HW + p] = x1;
@@ -254,24 +258,27 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
         }
     }
 
-    __shared__ unsigned long long sm[16];
+    __shared__ unsigned long long sm[16], smd[16];
     __shared__ float T[64][65];
-    const unsigned long long b = __ballot(chg);
-    if (lane == 0) sm[g] = b;
+    const unsigned long long b = __ballot(chg), bd = __ballot(valid && dbits != 0u);
+    if (lane == 0) sm[g] = b, smd[g] = bd;
     __syncthreads();
-    unsigned long long m = 0;
-    for (int i = 0; i < G; ++i) m |= sm[i];
+    unsigned long long m = 0, md = 0;
+    for (int i = 0; i < G; ++i) m |= sm[i], md |= smd[i];
     CBS_DET_STAMP(2);
     if (m == 0 && !a.copyAll) return;   // uniform over the workgroup
-    // the pixels whose states take the new values: the changed ones (feedback mode), or all of the segment
-    const unsigned long long upd = a.copyAll ? cbs_valid_mask(W, tx) : m;
+    // the pixels whose states take the new values: the changed ones (feedback mode), or -- copy-all -- those of the
+    // segment that hold a value that differs from the state bit for bit (behind another change-based layer the frame is
+    // bit-identical to the last one wherever that layer recomputed nothing); fine-grained: all (the records hold deltas)
+    const unsigned long long upd = a.fg ? cbs_valid_mask(W, tx) : (a.copyAll ? md : m);
+    if (upd == 0) return;               // (copy-all, nothing differs: nothing above the threshold either)
 
     // feedback: refresh the f32 state at the (pre-dilation) changed pixels only (.cu:74-80) ...
     if (!a.fg && ((upd >> lane) & 1ull)) {
-        state[(long)g * HW + p] = k0;
-        state[(long)(g + G) * HW + p] = k1;
-        state[(long)(g + 2 * G) * HW + p] = k2;
-        state[(long)(g + 3 * G) * HW + p] = k3;
+        if (dbits & 1u) state[(long)g * HW + p] = k0;
+        if (dbits & 2u) state[(long)(g + G) * HW + p] = k1;
+        if (dbits & 4u) state[(long)(g + 2 * G) * HW + p] = k2;
+        if (dbits & 8u) state[(long)(g + 3 * G) * HW + p] = k3;
     }
     // ... and the split state: [channel][pixel] through LDS, out as records
     T[g][lane] = k0;
@@ -1673,9 +1680,14 @@ __global__ __launch_bounds__(512) void cbh_detect_kernel(CbhDetArgs a) {
     char* const recRow = a.S + CBS_SPAD + ((long)(y + a.padY) * a.Wp + (tx * 64 + a.padXL)) * a.rec;
 
     // one channel group: [compare] -> [state <- input at the lanes of upd] -> [records of the pixels of upd]
+    // (copy-all form: a value that equals the state bit for bit is not written again, and a pixel none of whose 64
+    //  values of the group differs keeps its record -- the input of a layer behind another change-based layer is
+    //  bit-identical to last frame's wherever that layer recomputed nothing, i.e. almost everywhere)
+    __shared__ unsigned long long smDiff[2][8];
     auto group = [&](int cg, bool compare, bool write, unsigned long long upd, bool& chg) {
         const int c0 = cg * 64 + g * 8;
         _Float16 xv[8];
+        unsigned diffBits = 0;      // bit i: channel c0 + i of this lane's pixel differs from the state
 #pragma unroll
         for (int i = 0; i < 8; ++i) xv[i] = (_Float16)0;
         if (valid) {
@@ -1686,21 +1698,34 @@ __global__ __launch_bounds__(512) void cbh_detect_kernel(CbhDetArgs a) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) sv[i] = state[(long)(c0 + i) * HW + p];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) chg |= cb_changed(sv[i], xv[i], th);
+                for (int i = 0; i < 8; ++i) {
+                    chg |= cb_changed(sv[i], xv[i], th);
+                    diffBits |= (__builtin_bit_cast(unsigned short, sv[i]) != __builtin_bit_cast(unsigned short, xv[i]))
+                                << i;
+                }
+            } else {
+                diffBits = 0xffu;
             }
         }
         if (!write) return;
         if ((upd >> lane) & 1ull) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) state[(long)(c0 + i) * HW + p] = xv[i];
+            for (int i = 0; i < 8; ++i)
+                if ((diffBits >> i) & 1u) state[(long)(c0 + i) * HW + p] = xv[i];
         }
+        const unsigned long long db = __ballot(diffBits != 0u);
+        if (lane == 0) smDiff[cg & 1][g] = db;
         __syncthreads();      // (the previous group's records have been read out of T)
 #pragma unroll
         for (int i = 0; i < 8; ++i) T[g * 8 + i][lane] = xv[i];
         __syncthreads();
         {
+            unsigned long long rd = 0ull;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rd |= smDiff[cg & 1][i];
+            rd &= upd;
             const int pl = t >> 3, c8 = t & 7;
-            if ((upd >> pl) & 1ull) {
+            if ((rd >> pl) & 1ull) {
                 halfx8 v;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = T[c8 * 8 + j][pl];

@@ -1832,11 +1832,25 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, void
     CB_REQUIRE(input && state && pixelState && frameMasks && output && idxOut && countOut && prepared && H > 0 && W > 0);
     if (!cbh_supported(C, K, kH, kW) || H > 65535) return CB_ERR_UNSUPPORTED;
     const CbsGeom g = cbh_geom(C, H, W, kH, kW);
-    const int KP = cbs_kp(K), BM = cbs_bm(K);
+    const int KP = cbs_kp(K);
+    int BM = cbs_bm(K);
     const long MW = cbinfer_mask_words(H, W);
     if (MW > CBS_PRE_MID || (long)g.Hp * g.Wp * g.rec >= (1l << 31) || (long)H * W * W >= (1l << 32))
         return CB_ERR_UNSUPPORTED;
     if (workspace == nullptr && g.nStages >= 48) return CB_ERR_BADARG;
+    // The 128-row tile pays when there are tiles enough for every CU.  A shallow contraction on a map that would give
+    // fewer than four 128 x 128 tiles per CU even if EVERY pixel changed -- at the change ratios this path is for it
+    // then gives a fraction of one -- runs on 64 x 64 tiles instead (the prepared weights are per 32-row tile: either
+    // tile height reads them): OpenPose's 128->128 @184x327 at 24 % change 21 -> 12 us, 128->256 @92x163 19 -> 10 us.
+    {
+        static int small = -1;
+        if (small < 0) {
+            const char* e = getenv("CBINFER_HSPLIT_SMALL_TILES");
+            small = e ? atoi(e) : 1;
+        }
+        const long full128 = (((long)H * W + 127) / 128) * (KP / 128);
+        if (small && BM == 128 && g.nStages < 48 && full128 < 4l * cbs_num_cus()) BM = 64;
+    }
     hipStream_t s = (hipStream_t)stream;
     CbhDetArgs a;
     a.in = (const _Float16*)input, a.state = (_Float16*)state, a.S = (char*)pixelState;
@@ -1881,7 +1895,25 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, void
         if (MW <= CBS_PRE_BIG) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG, true, 4, true>(p, 1, nullptr, s);
         return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_MID, false, 4, true>(p, 1, nullptr, s);
     }
-    if (MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 8, true>(p, 1, nullptr, s);
+    if (MW <= CBS_PRE_SMALL) {
+        // (two workgroups per CU with four-stage rings: these contractions are shallow -- 9 to 36 stages -- and a layer
+        //  sent here from the 128-row tile has two to four times the items)
+        static int two = -1;
+        if (two < 0) {
+            const char* e = getenv("CBINFER_HSPLIT_TWO_PER_CU");
+            two = e ? atoi(e) : 1;
+        }
+        if (two) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 4, true>(p, 2, nullptr, s);
+        return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 8, true>(p, 1, nullptr, s);
+    }
+    // (a large map -- OpenPose's 64-channel 368x654 layer: 541 tiles of nine stages at 14 % change -- has more tiles than
+    //  CUs and little depth: two workgroups per CU with three-stage rings (68 KB each beside the 20 KB prefix))
+    static int big2 = -1;
+    if (big2 < 0) {
+        const char* e = getenv("CBINFER_HSPLIT_BIG2");
+        big2 = e ? atoi(e) : 1;
+    }
+    if (big2) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 3, true>(p, 2, nullptr, s);
     return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 8, true>(p, 1, nullptr, s);
 }
 

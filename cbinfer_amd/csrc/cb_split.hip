@@ -1482,6 +1482,16 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
     if (nSeq == 1 && MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 8>(p, 1, tail, s);
     if ((long)nSeq * MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 4>(p, 2, tail, s);
     if ((long)nSeq * MW <= CBS_PRE_MID2) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID2, false, 4>(p, 2, tail, s);
+    {
+        // (five and more sequences: two workgroups per CU with three-stage rings beside the 20 KB prefix -- the
+        //  workgroups' prologues and epilogues overlap each other's stage loops; CBINFER_SPLIT_BIG2=0: one per CU, eight stages)
+        static int big2 = -1;
+        if (big2 < 0) {
+            const char* e = getenv("CBINFER_SPLIT_BIG2");
+            big2 = e ? atoi(e) : 1;
+        }
+        if (big2) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 3>(p, 2, tail, s);
+    }
     return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 8>(p, 1, tail, s);
 }
 

@@ -395,10 +395,13 @@ int cbinfer_tail1x1(const float* input, const int32_t* changeList, int numChange
  * cbinfer_split_state_init once, then maintained by cbinfer_split_detect), from which the contraction gathers
  * by LDS-DMA.  Arithmetic: x * 2^-4 = hi + lo * 2^-11 with f16 hi, lo (weights likewise, scaled by the power of
  * two weightScale that brings max|w| into [2^13, 2^14)); products hi.hi + (hi.lo + lo.hi) 2^-11 on the f16 MFMA,
- * f32 accumulation: |error| <= 3 * 2^-22 |a||b| per product.  Range of the state values: |x| < 2^20; a refreshed
- * value beyond it sets *rangeFlag (the result is then not meaningful).
+ * f32 accumulation: |error| <= 5 * 2^-24 |a||b| per product (two operand roundings of 2^-23 and the dropped lo.lo
+ * term; measured beside the exact f32 chain in tests/test_gpu_split.py).  Range of the state values: |x| < 2^20; a
+ * refreshed value beyond it sets *rangeFlag, and from that launch on the contraction computes the sequence's tiles from
+ * `state` in plain f32 (slow, right) until the caller moves the layer to another arithmetic.
  *   frameMasks : cbinfer_frame_mask_bytes(H,W) bytes, zero on first use: ONE mask (cbinfer_mask_words words) the
- *                detection ORs into and the contraction zeroes again, + an arrival counter behind it
+ *                detection ORs into and the contraction zeroes again; the second slot holds the (sharded) arrival
+ *                counters of the contraction's workgroups
  *   idxOut     : change list of the frame (H*W ints), countOut its length -- by-products, ascending order
  *   workspace  : cbinfer_split_workspace_bytes(nSeq, ...) bytes, zero on first use (0 bytes / NULL for layers of
  *                fewer than 48 k-stages).  A deep contraction is ALWAYS the left-to-right sum of four partial sums

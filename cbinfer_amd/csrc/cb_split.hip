@@ -1032,6 +1032,8 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     // counter behind them: a returning atomic on ONE word is served every 11 ns, so a grid of 256-512 workgroups that
     // finish together spent 3-6 us of the launch queueing for their tickets (round 4; the row-pair kernel's first
     // form showed it: 9 us for 768 workgroups).
+    // (all masks empty -- every workgroup sees that alike: there is nothing to zero and nobody to wait for)
+    if (totAll == 0) return;
     __syncthreads();
     if (t == 0) {
         int* ctl = (int*)(p.seq[0].masks + 2 * (long)MW);
@@ -1744,9 +1746,12 @@ __global__ __launch_bounds__(512) void cbh_detect_kernel(CbhDetArgs a) {
         }
     };
 
+    // (copy-all form: the channel groups are independent -- each compares, copies and ORs its own finds into the mask
+    //  -- and go to workgroups of their own, blockIdx.z: a 512-channel 46x81 layer took eight dependent rounds, 15 us)
     const int NG = C >> 6;
+    const int cgBeg = a.copyAll ? (int)blockIdx.z : 0, cgEnd = a.copyAll ? cgBeg + 1 : NG;
     bool chg = false;
-    for (int cg = 0; cg < NG; ++cg) group(cg, true, a.copyAll != 0, vm, chg);
+    for (int cg = cgBeg; cg < cgEnd; ++cg) group(cg, true, a.copyAll != 0, vm, chg);
     const unsigned long long b = __ballot(chg);
     if (lane == 0) sm[g] = b;
     __syncthreads();
@@ -1868,7 +1873,7 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, void
     a.W = W, a.H = H, a.C = C, a.kHH = (kH - 1) / 2, a.kWH = (kW - 1) / 2, a.wpr = cbinfer_mask_words_per_row(W);
     a.Wp = g.Wp, a.rec = g.rec, a.padY = g.padY, a.padXL = g.padXL, a.th = threshold, a.copyAll = feedbackLoop ? 0 : 1;
     a.upstream = upstreamCount;
-    hipLaunchKernelGGL(cbh_detect_kernel, dim3(a.wpr, H), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(cbh_detect_kernel, dim3(a.wpr, H, a.copyAll ? C / 64 : 1), dim3(512), 0, s, a);
     int st = cb_launch_status();
     if (st != CB_OK) return st;
 

@@ -692,6 +692,47 @@ def secondary_configs(args):
     cb = max(measure(test, frames, m, psteps, 3) for m in ("graph", "eager"))
     cbf = max(measure(testf, frames, m, psteps, 3) for m in ("graph", "eager"))
     rs = ratios(test)
+    # a roofline entry for config 4: the contraction launches of a frame as ONE figure -- f16 MFMA
+    # flops of the recomputed pixels over the time of every contraction launch of the frame, the idle ones included --
+    # and the detection launches as bytes over time (kernel durations: in-process kernel trace of eager frames)
+    pose_roofline = None
+    try:
+        convs = [m for m in test.modules() if type(m) is pycbinfer.CBConv2d]
+        flops = byts = 0.0
+        for m in convs:
+            ci = m.lastChangeIndexes()
+            n = float(ci.numel()) if ci is not None else 0.0
+            K, Cc, kh, kw = m.weight.shape
+            hw = float(m.prevInput.size(-1) * m.prevInput.size(-2))
+            flops += 2.0 * n * Cc * kh * kw * K
+            byts += 2.0 * Cc * hw * 2 + hw / 8      # input + state read (f16), the mask
+        walk = frames[5:]
+
+        def pstep(i):
+            with torch.no_grad():
+                test(walk[pingpong(i, len(walk))])
+        got = traced_kernel_durations(pstep, 12)
+        if got[0] is not None:
+            k = got[0]
+            conv_us = sum(v["launches_per_frame"] * v["avg_us"] for n, v in k.items()
+                          if "conv_kernel" in n or "cb_mfma" in n or "reduce" in n)
+            det_us = sum(v["launches_per_frame"] * v["avg_us"] for n, v in k.items() if "detect" in n)
+            pose_roofline = {
+                "contractions": {"bound": "mfma", "flops_per_frame": flops, "us_per_frame": conv_us,
+                                 "achieved": flops / conv_us / 1e6, "peak": 2500.0, "unit": "TFLOP/s",
+                                 "frac": flops / conv_us / 1e6 / 2500.0,
+                                 "note": "f16 MFMA flops of the recomputed pixels (2 N C k K summed over the 36 layers, "
+                                         "one frame) over the summed durations of ALL contraction launches of the frame "
+                                         "-- 31 of them find nothing to do and are launch floor; peak = dense f16 MFMA"},
+                "detections": {"bound": "hbm", "bytes_per_frame": byts, "us_per_frame": det_us,
+                               "achieved": byts / det_us / 1e3, "peak": 8000.0, "unit": "GB/s",
+                               "frac": byts / det_us / 1e3 / 8000.0,
+                               "note": "SURVEY 8(d) bytes (input + state read, mask) of ALL 36 detections over the "
+                                       "summed durations of the detection launches of the frame; chained idle layers "
+                                       "read one word and return, so this counts bytes they never move -- an upper bound"},
+                "kernels": {n[:60]: v for n, v in sorted(k.items(), key=lambda x: -x[1]["avg_us"] * x[1]["launches_per_frame"])[:8]}}
+    except Exception as e:      # (an add-on: never at the expense of the line)
+        pose_roofline = {"error": repr(e)}
     # the same network with every layer scanning its whole input, as the reference's layers do (conv2d.py:228-233):
     # what the chained entry (cbinfer_cbconv2d_forward_after) contributes on this data
     from cbinfer_amd import conv2d as _c2
@@ -709,6 +750,7 @@ def secondary_configs(args):
         "effective_gflops": cb * pose_ops / 1e9, "dense_ops_per_frame": pose_ops,
         "mean_post_dilation_ratio": sum(rs) / max(1, len(rs)), "layers": len(rs),
         "layers_without_change": sum(1 for r in rs if r == 0.0),
+        "roofline": pose_roofline,
         "note": "36 converted convs, fp16 (cg_half path, f16 MFMA / f32 accumulation: layers of 64 n input channels and fewer "
                 "than 48 k-stages on the fp16 split-state kernels of round 4, the others on rounds 1-2's list kernels), RANDOM "
                 "weights: the change dies out behind the fifth conv (layers_without_change of the 36 recompute nothing "

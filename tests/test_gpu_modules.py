@@ -1739,3 +1739,50 @@ def test_half_layers_on_the_split_state_machinery(pkg, oracle, shape, feedback, 
     a, ranA = run(True)
     b, ranB = run(False)
     assert all(ranA[1:]) and not any(ranB), (ranA, ranB)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("feedback", [False, True])
+def test_openpose_fullsize_chain_on_and_off_bit_identical(pkg, feedback, monkeypatch):
+    """BASELINE config 4 as the bench runs it (OpenPose T=2, 368x654, fp16, threshold 0.02, random weights: the change
+    dies out behind the fifth conv) over 40 frames, with the chained launches (cbinfer_*_after: a layer skips its frame
+    on the device when its producer's change count is zero) and with every layer scanning its whole input: the two
+    heat-map outputs bit-identical in every frame, eager and replayed from a hipGraph."""
+    from cbinfer_amd import conv2d as c2, workloads
+    H, W = 368, 654
+    vid = workloads.SyntheticVideo(H=H, W=672, ratio=0.10, block=16, seed=3)
+    frames = [(f[:, :, :, :W] * (255.0 / 256.0) - 0.5).half().contiguous() for f in vid.frames(40)]
+    outs = {}
+    for chain in (True, False):
+        monkeypatch.setattr(c2, "_NO_CHAIN", not chain)
+        torch.manual_seed(0)
+        net = workloads.convertOpenPose(workloads.OpenPoseModel(T=2).cuda().half(), threshold=0.02,
+                                        feedbackLoop=feedback)
+        got = []
+        with torch.no_grad():
+            for f in frames[:24]:
+                y = net(f)
+                got.append([t.clone() for t in (y if isinstance(y, (tuple, list)) else [y])])
+            static = frames[24].clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                y = net(static)
+            torch.cuda.current_stream().wait_stream(side)
+            got.append([t.clone() for t in (y if isinstance(y, (tuple, list)) else [y])])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                y = net(static)
+            for f in frames[25:]:
+                static.copy_(f)
+                g.replay()
+                got.append([t.clone() for t in (y if isinstance(y, (tuple, list)) else [y])])
+        torch.cuda.synchronize()
+        if chain:
+            convs = [m for m in net.modules() if type(m) is pkg.CBConv2d]
+            assert sum(1 for m in convs if m.__dict__.get('_upNow') is not None) >= 20      # the chain was offered
+        outs[chain] = got
+    assert len(outs[True]) == len(outs[False]) == 40
+    for t, (a, b) in enumerate(zip(outs[True], outs[False])):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v), t

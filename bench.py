@@ -1487,6 +1487,7 @@ def main():
                 split = "split-state" in r["conv_kernel"]
                 exact = "cb_mfma_f32_kernel" == r["conv_kernel"]
                 dur_us, dur_src = r["conv_us_in_frame"], "HIP events (layers[].conv_us_in_frame)"
+                first_us = None
                 if ktrace is not None and split:
                     # the launches of this contraction: the 128-row-tile kernel and the second launch behind it
                     mine = [d for n, d in ktrace.items() if ("cbs_conv_kernel<128" in n.replace(" ", "") or
@@ -1494,6 +1495,8 @@ def main():
                     if mine:
                         dur_us = sum(d["avg_us"] * min(d["launches_per_frame"], 1.0) for d in mine)
                         dur_src = "kernel trace: " + " + ".join("%.2f us" % d["avg_us"] for d in mine)
+                        firsts = [d["avg_us"] for n, d in ktrace.items() if "cbs_conv_kernel<128" in n.replace(" ", "")]
+                        first_us = firsts[0] if firsts else None
                 ach = r["conv_flops"] / (dur_us * 1e-6) / 1e12
                 ceiling = F16X2_CEILING_TFLOPS if split else (FP32_MFMA_PEAK_TFLOPS if exact else BF16X3_CEILING_TFLOPS)
                 traffic, traffic_src = measured_traffic("conv", r["layer"])
@@ -1511,6 +1514,9 @@ def main():
                                     "%.1f TFLOP/s = 2.5 PFLOP/s of bf16 MFMA / 6 products per multiply (bf16x3)"
                                     % BF16X3_CEILING_TFLOPS),
                     "f32_mfma_peak": FP32_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
+                    # (the contraction launch alone -- the second launch also scatters the layer's outputs and
+                    #  evaluates the 1x1 tail, work `achieved` does not count)
+                    "frac_first_launch_alone": (r["conv_flops"] / (first_us * 1e-6) / 1e12 / ceiling) if first_us else None,
                     "traffic": traffic, "traffic_source": traffic_src,
                     "avg_duration_us": dur_us, "avg_duration_source": dur_src,
                     "avg_duration_us_hip_events_bracketed": r["conv_ms"] * 1e3,

@@ -1786,3 +1786,40 @@ def test_openpose_fullsize_chain_on_and_off_bit_identical(pkg, feedback, monkeyp
     for t, (a, b) in enumerate(zip(outs[True], outs[False])):
         for u, v in zip(a, b):
             assert torch.equal(u, v), t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("feedback", [False, True])
+def test_half_split_state_layer_follows_a_restored_state(pkg, oracle, feedback):
+    """eval03.py:88-95 restores layer states from outside.  An fp16 layer on the split-state machinery keeps a
+    pixel-major copy of prevInput: after prevInput (and prevOutput) are overwritten through torch the copy must be
+    made again -- every following frame against the oracle whose state was set the same way."""
+    C, K, H, W = 128, 96, 33, 50
+    torch.manual_seed(9)
+    conv = nn.Conv2d(C, K, 3, padding=1).cuda().half().eval()
+    m = pkg.CBConv2d(conv, 0.1)
+    m.withReLU, m.feedbackLoop = True, feedback
+    o = oracle.OracleCBConv2dHalf(conv.weight.detach().cpu().numpy(), conv.bias.detach().cpu().numpy(), 0.1,
+                                  withReLU=True, feedbackLoop=feedback, propChangeIndexes=True)
+    r = np.random.default_rng(79)
+    x = r.standard_normal((1, C, H, W)).astype(np.float16)
+    saved = None
+    with torch.no_grad():
+        for t in range(9):
+            x = x.copy()
+            y0, x0 = r.integers(0, H - 8), r.integers(0, W - 8)
+            x[0, :, y0:y0 + 8, x0:x0 + 8] = r.standard_normal((C, 8, 8)).astype(np.float16)
+            if t == 6:      # back to the state after frame 2
+                m.prevInput.copy_(torch.from_numpy(saved[0]).cuda())
+                m.prevOutput.copy_(torch.from_numpy(saved[1]).cuda())
+                o.prevInput, o.prevOutput = saved[0].copy(), saved[1].copy()
+            out = m(torch.from_numpy(x).cuda())
+            got = o.forward(x)
+            assert np.array_equal(m.lastChangeIndexes().tensor().cpu().numpy(), got[2]), t
+            assert np.array_equal(m.prevInput.cpu().numpy(), o.prevInput), t
+            ref = o.prevOutput.astype(np.float32)
+            tol = 2 * 2.0 ** -10 * max(1.0, float(np.abs(ref).max()))
+            assert np.abs(out.float().cpu().numpy() - ref).max() <= tol, t
+            if t == 2:
+                saved = (m.prevInput.cpu().numpy().copy(), m.prevOutput.cpu().numpy().copy())
+    assert m._plan is not None and m._plan.get('stateVersion') is not None      # (the split-state path, with its plan)

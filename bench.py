@@ -743,10 +743,18 @@ def secondary_configs(args):
         del plain
     finally:
         _c2._NO_CHAIN = os.environ.get("CBINFER_NO_CHAIN", "0") == "1"
+    # ... and with the three VGG pools change-based as well (pycbinfer.insertCBPooling: what sceneLabeling/modelLoader.py:
+    # 62-78 does by hand for the scene-labeling experiments 5/6 -- the pose converter of the reference leaves the pools
+    # dense, so this is an option beside the configuration, not the configuration)
+    cbp = workloads.convertOpenPose(workloads.OpenPoseModel(T=2).cuda().half(), threshold=0.02)
+    pycbinfer.insertCBPooling(cbp, cloneOutput=False)
+    cbpool = max(measure(cbp, frames, m, psteps, 3) for m in ("graph", "eager"))
+    del cbp
     pose_ops = workloads.openPoseDenseOps(2, Hp, Wp)
     out["config4_openpose_fp16"] = {
         "dense_fps": dense, "cb_fps": cb, "speedup": cb / dense, "cb_feedback_mode_fps": cbf,
         "feedback_speedup": cbf / dense, "cb_unchained_fps": cbu, "unchained_speedup": cbu / dense,
+        "cb_with_change_based_pools_fps": cbpool, "change_based_pools_speedup": cbpool / dense,
         "effective_gflops": cb * pose_ops / 1e9, "dense_ops_per_frame": pose_ops,
         "mean_post_dilation_ratio": sum(rs) / max(1, len(rs)), "layers": len(rs),
         "layers_without_change": sum(1 for r in rs if r == 0.0),

@@ -675,9 +675,19 @@ def secondary_configs(args):
                 m.fgInPlace = True
         pycbinfer.fuseTail1x1(fg)
         ffg = max(measure(fg, frames, m) for m in ("graph", "eager"))
+        # BASELINE.json configs[2] word for word: fine-grained convs + CBPoolMax2d
+        _, fp = workloads.sceneLabelingModels(experimentIdx=7, threshold=args.threshold)
+        for m in fp.modules():
+            if type(m) is pycbinfer.CBConv2d:
+                m.fgInPlace = True
+        pycbinfer.insertCBPooling(fp, cloneOutput=False)
+        pycbinfer.fuseTail1x1(fp)
+        ffp = max(measure(fp, frames, m) for m in ("graph", "eager"))
+        del fp
         out["config3_sweep"].append({"input_change": vid.ratio, "dense_fps": dense, "cg_exp6_fps": fcg,
                                      "cg_speedup": fcg / dense, "cg_post_dilation_ratio_per_layer": ratios(cg),
                                      "fg_exp7_inplace_fps": ffg, "fg_speedup": ffg / dense,
+                                     "fg_inplace_with_cbpoolmax2d_fps": ffp,
                                      "fg_touched_ratio_per_layer": ratios(fg)})
         del base, cg, fg, frames
         torch.cuda.synchronize()

@@ -1823,3 +1823,25 @@ def test_half_split_state_layer_follows_a_restored_state(pkg, oracle, feedback):
             if t == 2:
                 saved = (m.prevInput.cpu().numpy().copy(), m.prevOutput.cpu().numpy().copy())
     assert m._plan is not None and m._plan.get('stateVersion') is not None      # (the split-state path, with its plan)
+
+
+@pytest.mark.gpu
+def test_fg_with_change_based_pools_fullsize_threshold_zero(pkg):
+    """BASELINE.json configs[2] word for word -- fine-grained CBConv2d + CBPoolMax2d -- at 480x320: the fine-grained
+    head hands the pixels it touched to the change-based pool (an extension: the reference's forward_fg hands on no
+    indexes, conv2d.py:160-176), which recomputes the windows that hold one.  With threshold 0 the network must track
+    the dense one."""
+    from cbinfer_amd import workloads
+    base, fg = workloads.sceneLabelingModels(experimentIdx=7, threshold=0.0)
+    for m in fg.modules():
+        if type(m) is pkg.CBConv2d:
+            m.fgInPlace = True
+    pkg.insertCBPooling(fg, cloneOutput=False)
+    pkg.fuseTail1x1(fg)
+    assert sum(1 for m in fg.modules() if type(m) is pkg.CBPoolMax2d) == 2
+    vid = workloads.SyntheticVideo(H=320, W=480, ratio=0.1, block=16, seed=5)
+    worst = 0.0
+    with torch.no_grad():
+        for f in vid.frames(10):
+            worst = max(worst, (fg(f) - base(f)).abs().max().item())
+    assert worst <= FP32_TOL, worst

@@ -682,6 +682,7 @@ def secondary_configs(args):
                 m.fgInPlace = True
         pycbinfer.insertCBPooling(fp, cloneOutput=False)
         pycbinfer.fuseTail1x1(fp)
+        pycbinfer.fusePoolingIntoDetection(fp)      # (the pools in the fine-grained detections: no launch of their own)
         ffp = max(measure(fp, frames, m) for m in ("graph", "eager"))
         del fp
         out["config3_sweep"].append({"input_change": vid.ratio, "dense_fps": dense, "cg_exp6_fps": fcg,

@@ -156,8 +156,11 @@ def fusePoolingIntoDetection(rootModule, enabled=True):
         kids = list(seq.children())
         for pool, consumer in zip(kids[:-1], kids[1:]):
             if type(pool) == CBPoolMax2d:
-                pool.lazy = bool(enabled and type(consumer) == CBConv2d and consumer.feedbackLoop and
-                                 not consumer.finegrained and not pool.propChangeIndexes)
+                # (a feedback-mode layer, or -- round 4 -- a fine-grained one in its in-place form: its split-state frame
+                #  takes the pool's input as it is, cbinfer_split_forward_fg; other fine-grained frames pool first)
+                pool.lazy = bool(enabled and type(consumer) == CBConv2d and not pool.propChangeIndexes and
+                                 ((consumer.feedbackLoop and not consumer.finegrained) or
+                                  (consumer.finegrained and consumer.fgInPlace)))
     return rootModule
 
 

@@ -149,7 +149,7 @@ _SIGNATURES = {
     "cbinfer_split_detect": (_i, [_sp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "cbinfer_split_conv": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp]),
     "cbinfer_split_forward": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _vp]),
-    "cbinfer_split_forward_fg": (_i, [_sp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp]),
+    "cbinfer_split_forward_fg": (_i, [_sp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     "cbinfer_hsplit_supported": (_i, [_i, _i, _i, _i]),
     "cbinfer_hsplit_max_mask_words": (_l, [_i]),
     "cbinfer_hsplit_state_bytes": (_l, [_i, _i, _i, _i, _i]),

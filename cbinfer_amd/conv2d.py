@@ -737,7 +737,58 @@ class CBConv2d(nn.Module):
             work['relu'] = None
         return work
 
+    def _forward_fg_split(self, src, lazy, H, W, work, relu):
+        """The fine-grained in-place frame on the split-state kernels (round 4): the detection leaves the thresholded
+        differences of EVERY value as f16 pairs in the pixel-major records, the LDS-DMA contraction adds W * delta to
+        prevOutput at the mask's pixels.  `lazy`: the layer sits behind a CBPoolMax2d folded into its detection -- `src`
+        is the pool's INPUT, H x W the pooled size."""
+        K, Cin, kH, kW = self.weight.size()
+        sp = self._split_workspace(work, H, W, src.device)
+        wp, scale = self._split_weights(H, W)
+        q = sp['seq'][0]
+        q.input, q.state, q.splitState = src.data_ptr(), self.prevInput.data_ptr(), sp['S'].data_ptr()
+        q.frameMasks, q.producerMask = sp['bits'].data_ptr(), None
+        q.output, q.idxOut, q.countOut = (self.prevOutput.data_ptr(), work['idx'].data_ptr(),
+                                          work['count'].data_ptr())
+        q.rangeFlag, q.maskCopy = sp['flag'].data_ptr(), sp['copy'].data_ptr()
+        q.delta, q.reluOut = work['delta'].data_ptr(), ptr(relu)
+        sp['stateKey'] = None      # (the records hold differences now: a coarse-grained frame re-splits the state)
+        pooled = lazy is not None
+        args = [sp['seq'], 1, int(pooled), src.size(-2) if pooled else 0, src.size(-1) if pooled else 0, ptr(wp),
+                Cin, H, W, K, kH, kW, float(self.threshold), float(scale), ptr(sp['ws']), stream_ptr(src)]
+        check(C.cbinfer_split_forward_fg(*args))
+        self._poll_range(sp)
+        self.__dict__['_ranSplit'] = True
+        result = relu if self.withReLU else self.prevOutput
+        self._lastIndexes = MaskChangeIndexes(sp['copy'], (H, W), work['idx'], work['count'], made=True)
+        if self.propChangeIndexes:
+            result = ('changeIndexes', result, self._lastIndexes)
+        self._make_plan(pooled, src, C.cbinfer_split_forward_fg, args, None, result=result)
+        if self._plan is not None:
+            self._plan.update(fgSplit=True, seq=q, wsplit=(wp, scale), relu=relu)
+        return result
+
     def forward_fg(self, inp):
+        if isinstance(inp, LazyPool):
+            # behind a CBPoolMax2d folded into the detection (pycbinfer.fusePoolingIntoDetection): the in-place frame
+            # on the split-state kernels takes the pool's input as it is; anything else pools first
+            lazy, size = inp, tuple(inp.outSize)
+            src = lazy.source.detach()
+            H, W = size[-2], size[-1]
+            if (self.fgInPlace and not self.atomicFG and src.is_cuda and src.dtype == torch.float32 and
+                    src.is_contiguous() and tuple(self.prevInput.size()) == size and
+                    C.cbinfer_mask_words(H, W) <= C.cbinfer_frame_mask_max_words() and
+                    os.environ.get('CBINFER_NO_SELFCOMPACT', '0') != '1' and self._split_fg_ok(src.dtype, H, W)):
+                if not self.prevInput.is_contiguous():
+                    self.prevInput = self.prevInput.contiguous()
+                work = self._fg_workspace(self.prevInput)
+                relu = None
+                if self.withReLU:
+                    if work['relu'] is None:
+                        work['relu'] = F.relu(self.prevOutput)
+                    relu = work['relu']
+                return self._forward_fg_split(src, lazy, H, W, work, relu)
+            inp = lazy.tensor()
         x = inp.detach()
         K, Cin, kH, kW = self.weight.size()
         if self.prevInput.size() != x.size():
@@ -771,32 +822,7 @@ class CBConv2d(nn.Module):
             if not self.prevInput.is_contiguous():
                 self.prevInput = self.prevInput.contiguous()
             if self._split_fg_ok(x.dtype, H, W):
-                # the fine-grained frame on the split-state kernels (round 4): the detection leaves the thresholded
-                # differences of EVERY value as f16 pairs in the pixel-major records, the LDS-DMA contraction adds
-                # W * delta to prevOutput at the mask's pixels
-                sp = self._split_workspace(work, H, W, x.device)
-                wp, scale = self._split_weights(H, W)
-                q = sp['seq'][0]
-                q.input, q.state, q.splitState = x.data_ptr(), self.prevInput.data_ptr(), sp['S'].data_ptr()
-                q.frameMasks, q.producerMask = sp['bits'].data_ptr(), None
-                q.output, q.idxOut, q.countOut = (self.prevOutput.data_ptr(), work['idx'].data_ptr(),
-                                                  work['count'].data_ptr())
-                q.rangeFlag, q.maskCopy = sp['flag'].data_ptr(), sp['copy'].data_ptr()
-                q.delta, q.reluOut = work['delta'].data_ptr(), ptr(relu)
-                sp['stateKey'] = None      # (the records hold differences now: a coarse-grained frame re-splits the state)
-                args = [sp['seq'], 1, ptr(wp), Cin, H, W, K, kH, kW, float(self.threshold), float(scale),
-                        ptr(sp['ws']), stream_ptr(x)]
-                check(C.cbinfer_split_forward_fg(*args))
-                self._poll_range(sp)
-                self.__dict__['_ranSplit'] = True
-                result = relu if self.withReLU else self.prevOutput
-                self._lastIndexes = MaskChangeIndexes(sp['copy'], (H, W), work['idx'], work['count'], made=True)
-                if self.propChangeIndexes:
-                    result = ('changeIndexes', result, self._lastIndexes)
-                self._make_plan(False, x, C.cbinfer_split_forward_fg, args, None, result=result)
-                if self._plan is not None:
-                    self._plan.update(fgSplit=True, seq=q, wsplit=(wp, scale), relu=relu)
-                return result
+                return self._forward_fg_split(x, None, H, W, work, relu)
             if path:
                 rows = self._rows_workspace(work, H, W, x.device)
                 args = (int(path == 'blocks'), ptr(x), ptr(self.prevInput), ptr(work['delta']),

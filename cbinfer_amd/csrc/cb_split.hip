@@ -1378,7 +1378,6 @@ int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int
     CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && H > 0 && W > 0 && mode >= 0 && mode <= 7);
     const int pooled = mode & 1;      // bit 1 (CBINFER_SPLIT_COPY_ALL): not in feedback mode, every value goes to the states
     const int fg = (mode >> 2) & 1;   // bit 2 (CBINFER_SPLIT_FG): fine-grained frame, the pre-split copy takes the differences
-    CB_REQUIRE(!(fg && pooled));
     if (!cbs_supported(C, 1, kH, kW) || H > 65535) return CB_ERR_UNSUPPORTED;
     if (pooled) CB_REQUIRE((H == pH / 2 || H == (pH + 1) / 2) && (W == pW / 2 || W == (pW + 1) / 2));
     const CbsGeom g = cbs_geom(C, H, W, kH, kW);
@@ -1389,7 +1388,9 @@ int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int
         a.seq[q].state = seqs[q].state;
         a.seq[q].S = (char*)seqs[q].splitState;
         a.seq[q].masks = (unsigned long long*)seqs[q].frameMasks;
-        a.seq[q].prodMask = pooled ? (const unsigned long long*)seqs[q].producerMask : nullptr;
+        // (fine-grained: every record is rewritten every frame -- a segment the producer did not touch holds last frame's
+        //  differences and must be zeroed: no producer-mask shortcut)
+        a.seq[q].prodMask = (pooled && !fg) ? (const unsigned long long*)seqs[q].producerMask : nullptr;
         a.seq[q].rangeFlag = seqs[q].rangeFlag;
         a.seq[q].delta = seqs[q].delta;
         if (fg) CB_REQUIRE(seqs[q].delta != nullptr);
@@ -1551,9 +1552,13 @@ int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int mode, int p
 // (0 elsewhere) into `delta` and, as f16 pairs, into the pre-split records of EVERY pixel, and the dilated any-channel
 // mask; the contraction ADDS W * delta to `output` at the mask's pixels (reluOut, if given, kept at relu(output)
 // there).  No bias, deterministic.  A |d| >= 2^20 trips the range flag: the launch then contracts `delta` in plain f32.
-int cbinfer_split_forward_fg(const cbSplitSeq* seqs, int nSeq, const void* prepared, int C, int H, int W, int K, int kH,
-                             int kW, float threshold, float weightScale, void* workspace, cbStream_t stream) {
-    const int st = cbinfer_split_detect(seqs, nSeq, CBINFER_SPLIT_FG, 0, 0, C, H, W, kH, kW, threshold, stream);
+// pooled != 0: `input` is the tensor in FRONT of a 2x2/stride-2 max pool [C,pH,pW] (a CBPoolMax2d folded into the
+// detection: configs[2] of BASELINE.json, fine-grained convs + CBPoolMax2d, without the pool's launch).
+int cbinfer_split_forward_fg(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared, int C,
+                             int H, int W, int K, int kH, int kW, float threshold, float weightScale, void* workspace,
+                             cbStream_t stream) {
+    const int st = cbinfer_split_detect(seqs, nSeq, CBINFER_SPLIT_FG | (pooled ? CBINFER_SPLIT_POOLED : 0), pH, pW, C, H, W,
+                                        kH, kW, threshold, stream);
     if (st != CB_OK) return st;
     return cbs_split_conv(seqs, nSeq, prepared, nullptr, C, H, W, K, kH, kW, weightScale, 0, workspace, 0, nullptr,
                           stream, 1);

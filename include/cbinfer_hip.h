@@ -477,9 +477,11 @@ int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int mode, int pH, in
  * split-state kernels (round 4), same contract as cbinfer_cbconv2d_forward_fg with refreshState = 1: prevInput
  * (`state`) takes the frame, `delta` the thresholded differences, `output` += conv(weights, delta) at the pixels of
  * the dilated any-channel mask, `reluOut` (optional) = relu(output) there; idxOut / countOut / maskCopy as for
- * cbinfer_split_forward.  No bias; fixed summation order. */
-int cbinfer_split_forward_fg(const cbSplitSeq* seqs, int nSeq, const void* prepared, int C, int H, int W, int K, int kH,
-                             int kW, float threshold, float weightScale, void* workspace, cbStream_t stream);
+ * cbinfer_split_forward.  No bias; fixed summation order.  pooled != 0: `input` is the tensor in front of a
+ * 2x2/stride-2 max pool [C,pH,pW] (CBPoolMax2d folded into the detection; H x W the pooled size). */
+int cbinfer_split_forward_fg(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared, int C,
+                             int H, int W, int K, int kH, int kW, float threshold, float weightScale, void* workspace,
+                             cbStream_t stream);
 /* The layer + the fused 1x1 tail behind it (sceneLabeling/modelLoader.py:45-47: the dense conv1x1 -> ReLU -> conv1x1
  * the experiments keep; cbinfer_tail1x1 evaluates it at the changed pixels) with the tail folded into the second
  * launch of a deep contraction: the launch that finishes the layer's outputs -- summing the partial tiles of a split

@@ -1840,8 +1840,28 @@ def test_fg_with_change_based_pools_fullsize_threshold_zero(pkg):
     pkg.fuseTail1x1(fg)
     assert sum(1 for m in fg.modules() if type(m) is pkg.CBPoolMax2d) == 2
     vid = workloads.SyntheticVideo(H=320, W=480, ratio=0.1, block=16, seed=5)
+    frames = vid.frames(10)
     worst = 0.0
     with torch.no_grad():
-        for f in vid.frames(10):
+        for f in frames:
             worst = max(worst, (fg(f) - base(f)).abs().max().item())
     assert worst <= FP32_TOL, worst
+    # ... and with the pools folded into the fine-grained detections (cbinfer_split_forward_fg, pooled form): no pool
+    # launch, the pooled maps only in the layers' states
+    _, fz = workloads.sceneLabelingModels(experimentIdx=7, threshold=0.0)
+    for m in fz.modules():
+        if type(m) is pkg.CBConv2d:
+            m.fgInPlace = True
+    pkg.insertCBPooling(fz, cloneOutput=False)
+    pkg.fuseTail1x1(fz)
+    pkg.fusePoolingIntoDetection(fz)
+    pools = [m for m in fz.modules() if type(m) is pkg.CBPoolMax2d]
+    assert len(pools) == 2 and all(p.lazy for p in pools)
+    worst = 0.0
+    with torch.no_grad():
+        for f in frames:
+            worst = max(worst, (fz(f) - base(f)).abs().max().item())
+    assert worst <= FP32_TOL, worst
+    convs = [m for m in fz.modules() if type(m) is pkg.CBConv2d]
+    assert all(m._plan is not None and m._plan.get('fgSplit') and m._plan['pooled'] for m in convs[1:])
+    assert all(p.outputState.numel() == 0 for p in pools)      # (the pooled maps were never materialised)

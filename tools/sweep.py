@@ -88,6 +88,7 @@ def main():
                     m.fgInPlace = True
             pycbinfer.insertCBPooling(fp, cloneOutput=False)
             pycbinfer.fuseTail1x1(fp)
+            pycbinfer.fusePoolingIntoDetection(fp)      # (the pools in the fine-grained detections: no launch of their own)
             ffp = max(measure(fp, frames, args.steps, args.warmup, m) for m in ("graph", "eager"))
             _, fa = workloads.sceneLabelingModels(experimentIdx=7, threshold=0.05)
             for m in fa.modules():

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Profiling target for the fine-grained path (BASELINE config 3): experiment 7 at 480x320, 10 % of the pixels
-re-drawn per frame in 16x16 blocks, in-place execution form, eager launches (every kernel its own dispatch).
-Prints frames/s and the per-layer touched-pixel counts."""
+"""Profiling target for the fine-grained path (BASELINE config 3, "fine-grained + CBPoolMax2d"): experiment 7 at
+480x320 with its two pools change-based (pycbinfer.insertCBPooling) and folded into the fine-grained detections
+(fusePoolingIntoDetection), 10 % of the pixels re-drawn per frame in 16x16 blocks, in-place execution form, eager
+launches (every kernel its own dispatch).  Prints frames/s and the per-layer touched-pixel counts.
+FG_DENSE_POOLS=1: the experiment as the reference's loader builds it (nn.MaxPool2d)."""
 import os
 import sys
 import time
@@ -20,7 +22,10 @@ def main():
     cbs = [m for m in test.modules() if type(m) is pycbinfer.CBConv2d]
     for m in cbs:
         m.fgInPlace = True
+    if os.environ.get("FG_DENSE_POOLS", "0") != "1":
+        pycbinfer.insertCBPooling(test, cloneOutput=False)
     pycbinfer.fuseTail1x1(test)
+    pycbinfer.fusePoolingIntoDetection(test)
     vid = workloads.SyntheticVideo(H=320, W=480, ratio=ratio, block=16, seed=7)
     frames = vid.frames(64)
     with torch.no_grad():
@@ -33,7 +38,8 @@ def main():
             test(frames[8 + (j if j < 56 else 110 - j)])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    print("fine-grained experiment 7, in-place form, %.0f %% change: %.0f frames/s" % (100 * vid.ratio, steps / dt))
+    print("fine-grained experiment 7 + CBPoolMax2d (folded), in-place form, %.0f %% change: %.0f frames/s"
+          % (100 * vid.ratio, steps / dt))
     for m in cbs:
         K, C, kH, kW = m.weight.shape
         # (a mask-driven fine-grained frame leaves the mask of touched output pixels; its list and count are made

@@ -160,7 +160,10 @@ def fusePoolingIntoDetection(rootModule, enabled=True):
                 #  takes the pool's input as it is, cbinfer_split_forward_fg; other fine-grained frames pool first)
                 pool.lazy = bool(enabled and type(consumer) == CBConv2d and not pool.propChangeIndexes and
                                  ((consumer.feedbackLoop and not consumer.finegrained) or
-                                  (consumer.finegrained and consumer.fgInPlace)))
+                                  (consumer.finegrained and consumer.fgInPlace) or
+                                  # (a layer that keeps a copy of its input: the copy-all detection of the split-state
+                                  #  kernels takes the pool; where those do not take the layer it pools densely)
+                                  (consumer.copyInput and not consumer.feedbackLoop and not consumer.finegrained)))
     return rootModule
 
 

@@ -893,6 +893,12 @@ class CBConv2d(nn.Module):
                     not self.gatherComputationStats and inp.source.dtype == self.weight.dtype):
                 pooled = inp
                 return self._forward_pooled(pooled)
+            # (round 4: a layer WITHOUT feedback loop that keeps a copy of its input, on the split-state kernels -- the
+            #  detection's copy-all form takes the 2x2 max on the fly and the pooled map lives in prevInput)
+            if (self.copyInput and not self.feedbackLoop and not self.syncIndexes and not self.saveChangeMap and
+                    not self.gatherComputationStats and inp.source.dtype == self.weight.dtype and
+                    inp.source.is_cuda and self._split_ok(inp.source.dtype, inp.outSize[-2], inp.outSize[-1])):
+                return self._forward_pooled(inp)
             inp = inp.tensor()           # any other configuration: pool densely, then as usual
         src = inp[1] if type(inp) == tuple else inp
         # a producer that hands out its in-place-updated state (CBPoolMax2d.cloneOutput=False) tags it
@@ -974,6 +980,8 @@ class CBConv2d(nn.Module):
         K, Cin, kH, kW = self.weight.size()
         if self._split_ok(src.dtype, H, W):
             return self._forward_split(src, lazy, work)
+        if not self.feedbackLoop:      # (the other pooled frames refresh the state at the changed pixels only)
+            return self.forward_normal(lazy.tensor())
         path = self._rows_path(src.dtype, H, W)
         if path:
             rows = self._rows_workspace(work, H, W, src.device)

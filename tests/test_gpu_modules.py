@@ -1865,3 +1865,37 @@ def test_fg_with_change_based_pools_fullsize_threshold_zero(pkg):
     convs = [m for m in fz.modules() if type(m) is pkg.CBConv2d]
     assert all(m._plan is not None and m._plan.get('fgSplit') and m._plan['pooled'] for m in convs[1:])
     assert all(p.outputState.numel() == 0 for p in pools)      # (the pooled maps were never materialised)
+
+
+@pytest.mark.gpu
+def test_pools_fold_into_the_detection_of_layers_without_feedback(pkg):
+    """What convert() makes (experiment 2: feedbackLoop=False, copyInput=True) with its pools change-based
+    (insertCBPooling): fusePoolingIntoDetection folds them into the copy-all detections of the split-state layers
+    (round 4) -- an execution-level fusion: the same frames with and without it give bit-identical outputs, layer
+    states and change lists; with threshold 0 the network tracks the dense one; and the pooled maps are never
+    materialised."""
+    from cbinfer_amd import workloads
+    vid = workloads.SyntheticVideo(H=320, W=480, ratio=0.1, block=16, seed=9)
+    frames = vid.frames(9)
+    for th in (0.05, 0.0):
+        nets = []
+        for fuse in (True, False):
+            base, net = workloads.sceneLabelingModels(experimentIdx=2, threshold=th)
+            pkg.insertCBPooling(net, cloneOutput=False)
+            pkg.fusePoolingIntoDetection(net, enabled=fuse)
+            nets.append(net)
+        pools = [m for m in nets[0].modules() if type(m) is pkg.CBPoolMax2d]
+        assert len(pools) == 2 and all(p.lazy for p in pools)
+        with torch.no_grad():
+            for t, f in enumerate(frames):
+                a, b = nets[0](f), nets[1](f)
+                assert torch.equal(a, b), (th, t)
+                for ma, mb in zip([m for m in nets[0].modules() if type(m) is pkg.CBConv2d],
+                                  [m for m in nets[1].modules() if type(m) is pkg.CBConv2d]):
+                    assert torch.equal(ma.prevInput, mb.prevInput), (th, t)
+                    assert torch.equal(ma.lastChangeIndexes().tensor(), mb.lastChangeIndexes().tensor()), (th, t)
+                if th == 0.0:
+                    assert (a - base(f)).abs().max().item() <= FP32_TOL, t
+        convs = [m for m in nets[0].modules() if type(m) is pkg.CBConv2d]
+        assert all(m._plan is not None and m._plan.get('split') and m._plan['pooled'] for m in convs[1:3])
+        assert all(p.outputState.numel() == 0 for p in pools)

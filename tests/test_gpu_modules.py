@@ -574,7 +574,11 @@ def test_fuzz_shapes_track_dense(pkg, dtype):
     rng = np.random.default_rng(17)
     shapes = [(1, 1, 1, 1, 5, 9), (3, 7, 3, 3, 17, 63), (2, 33, 3, 3, 9, 64), (5, 32, 5, 5, 11, 65),
               (4, 65, 7, 7, 23, 129), (20, 100, 3, 1, 13, 200), (3, 8, 1, 5, 31, 37), (16, 64, 7, 7, 40, 96),
-              (7, 3, 3, 3, 64, 64), (1, 16, 7, 7, 8, 300)]
+              (7, 3, 3, 3, 64, 64), (1, 16, 7, 7, 8, 300),
+              # (round 4: shapes the split-state kernels take -- fp32: 16/32/64 input channels, with and without feedback
+              #  loop; fp16: multiples of 64 -- odd maps, non-square filters, K off the tile sizes, shallow and deep)
+              (32, 40, 3, 5, 21, 70), (64, 17, 5, 3, 19, 131), (16, 130, 3, 3, 33, 65), (64, 64, 1, 7, 12, 190),
+              (128, 70, 3, 3, 27, 66), (192, 33, 1, 3, 15, 129), (64, 200, 5, 5, 18, 64), (256, 64, 3, 1, 9, 77)]
     tol = 1e-4 if dtype == torch.float32 else None
     for (C, K, kH, kW, H, W) in shapes:
         conv = torch.nn.Conv2d(C, K, (kH, kW), padding=(kH // 2, kW // 2)).cuda().to(dtype)

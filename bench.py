@@ -759,6 +759,7 @@ def secondary_configs(args):
     # dense, so this is an option beside the configuration, not the configuration)
     cbp = workloads.convertOpenPose(workloads.OpenPoseModel(T=2).cuda().half(), threshold=0.02)
     pycbinfer.insertCBPooling(cbp, cloneOutput=False)
+    pycbinfer.fusePoolingIntoDetection(cbp)      # (the pools in the consumers' detections, cbinfer_hsplit_forward's pooled form)
     cbpool = max(measure(cbp, frames, m, psteps, 3) for m in ("graph", "eager"))
     del cbp
     pose_ops = workloads.openPoseDenseOps(2, Hp, Wp)

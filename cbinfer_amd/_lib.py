@@ -158,8 +158,8 @@ _SIGNATURES = {
     "cbinfer_hsplit_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cbinfer_hsplit_state_init": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "cbinfer_hsplit_state_rebuild": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "cbinfer_hsplit_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f,
-                                    _i, _i, _vp, _vp]),
+    "cbinfer_hsplit_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
+                                    _i, _i, _i, _f, _i, _i, _vp, _vp]),
     "cbinfer_split_forward_tail": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _i,
                                         _stp, _vp]),
     "cbinfer_split_tail_supported": (_i, [_i, _i, _i, _i, _i, _i]),

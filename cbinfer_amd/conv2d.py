@@ -425,11 +425,12 @@ class CBConv2d(nn.Module):
                 and C.cbinfer_mask_words(H, W) <= C.cbinfer_hsplit_max_mask_words(K)
                 and C.cbinfer_hsplit_state_bytes(Cin, H, W, kH, kW) < (1 << 31) and H * W * W < (1 << 32))
 
-    def _forward_hsplit(self, input, work):
+    def _forward_hsplit(self, input, work, lazy=None):
         """One fp16 frame on the split-state machinery: detection + refresh of prevInput and of its pixel-major copy,
-        then the LDS-DMA contraction."""
+        then the LDS-DMA contraction.  `lazy`: the layer sits behind a CBPoolMax2d folded into its detection -- `input`
+        is the pool's INPUT, the layer runs at the pooled size."""
         K, Cin, kH, kW = self.weight.size()
-        H, W = input.size(-2), input.size(-1)
+        H, W = (lazy.outSize[-2], lazy.outSize[-1]) if lazy is not None else (input.size(-2), input.size(-1))
         dev = input.device
         hs = work.get('hsplit')
         if hs is None:
@@ -452,12 +453,22 @@ class CBConv2d(nn.Module):
         if not prev.is_contiguous():
             prev = self.prevInput = prev.contiguous()
         stateKey = (prev.data_ptr(), prev._version)
-        if hs['stateKey'] != stateKey:
+        rebuilt = hs['stateKey'] != stateKey
+        if rebuilt:
             # first frame on this path, or prevInput was (re)allocated or written by somebody else: the pixel-major
             # copy is made again from it
             check(C.cbinfer_hsplit_state_rebuild(ptr(prev), ptr(hs['S']), Cin, H, W, kH, kW, stream_ptr(input)))
             hs['stateKey'] = stateKey
-        args = (None, ptr(input), ptr(prev), ptr(hs['S']), ptr(hs['bits']), ptr(self.prevOutput), ptr(work['idx']),
+        pmask = None
+        if lazy is not None:
+            # (the producer-mask shortcut assumes the skipped segments compared below THIS threshold last frame and a
+            #  state that has seen every pixel: not on a fresh or restored state, not after a change of the threshold)
+            sameTh = self.__dict__.get('_pmaskThreshold') == float(self.threshold)
+            self.__dict__['_pmaskThreshold'] = float(self.threshold)
+            pmask = None if (rebuilt or not sameTh) else lazy.producerMask()
+        pooled = lazy is not None
+        args = (None, ptr(input), int(pooled), input.size(-2) if pooled else 0, input.size(-1) if pooled else 0,
+                ptr(pmask), ptr(prev), ptr(hs['S']), ptr(hs['bits']), ptr(self.prevOutput), ptr(work['idx']),
                 ptr(work['count']), ptr(hs['copy']), ptr(wp), ptr(self.bias.detach()), Cin, H, W, K, kH, kW,
                 float(self.threshold), int(bool(self.feedbackLoop)), int(bool(self.withReLU)), ptr(hs['ws']),
                 stream_ptr(input))
@@ -465,9 +476,9 @@ class CBConv2d(nn.Module):
         self.__dict__['_ranSplit'] = True      # (a frame on any OTHER path invalidates hs['stateKey'], see forward)
         self._publish_count(work['count'])
         if not self._inputIsLiveState:
-            self._make_plan(False, input, C.cbinfer_hsplit_forward, args, 1)
+            self._make_plan(pooled, input, C.cbinfer_hsplit_forward, args, 1, pmask=ptr(pmask))
             if self._plan is not None:
-                self._plan.update(chain=True, stateVersion=prev._version)
+                self._plan.update(chain=True, stateVersion=prev._version, checkPmask=pooled)
         result = MaskChangeIndexes(hs['copy'], (H, W), work['idx'], work['count'], made=True)
         if self._plan is not None:
             self._plan['indexes'] = result
@@ -897,7 +908,8 @@ class CBConv2d(nn.Module):
             #  detection's copy-all form takes the 2x2 max on the fly and the pooled map lives in prevInput)
             if (self.copyInput and not self.feedbackLoop and not self.syncIndexes and not self.saveChangeMap and
                     not self.gatherComputationStats and inp.source.dtype == self.weight.dtype and
-                    inp.source.is_cuda and self._split_ok(inp.source.dtype, inp.outSize[-2], inp.outSize[-1])):
+                    inp.source.is_cuda and (self._split_ok(inp.source.dtype, inp.outSize[-2], inp.outSize[-1]) or
+                                            self._hsplit_ok(inp.source.dtype, inp.outSize[-2], inp.outSize[-1]))):
                 return self._forward_pooled(inp)
             inp = inp.tensor()           # any other configuration: pool densely, then as usual
         src = inp[1] if type(inp) == tuple else inp
@@ -980,6 +992,11 @@ class CBConv2d(nn.Module):
         K, Cin, kH, kW = self.weight.size()
         if self._split_ok(src.dtype, H, W):
             return self._forward_split(src, lazy, work)
+        if self._hsplit_ok(src.dtype, H, W):
+            self._lastIndexes = self._forward_hsplit(src, work, lazy)
+            if self.propChangeIndexes:
+                return 'changeIndexes', self.prevOutput, self._lastIndexes
+            return self.prevOutput
         if not self.feedbackLoop:      # (the other pooled frames refresh the state at the changed pixels only)
             return self.forward_normal(lazy.tensor())
         path = self._rows_path(src.dtype, H, W)
@@ -1196,7 +1213,7 @@ class CBConv2d(nn.Module):
             if type(inp) is not LazyPool:
                 return None
             src = inp.source
-            if plan['rows']:      # the producer's mask is baked into the call: it must still be the one offered
+            if plan['rows'] or plan.get('checkPmask'):      # the producer's mask is baked into the call: it must still be the one offered
                 pm = inp.producerMask()
                 if (pm.data_ptr() if pm is not None else None) != plan['pmask']:
                     return None

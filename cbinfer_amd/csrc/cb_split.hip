@@ -1677,13 +1677,32 @@ struct CbhDetArgs {
     float th;
     int copyAll;
     const int* upstream;      // optional: the producing layer's change count of this frame (0: nothing to look at)
+    int pH, pW;               // POOL: `in` is the tensor in front of a 2x2/stride-2 max pool, [C,pH,pW]
+    const unsigned long long* prodMask;      // POOL, optional: the producing layer's change mask of this frame
 };
+// POOL: the value compared with (and written to) the states is the 2x2 max of `in`, computed on the fly with clamped
+// window coordinates (cb_detect_kernel<T, BITS, POOL>); a segment none of whose window pixels the producer rewrote is
+// not looked at (its pooled values are last frame's: nothing above the threshold, nothing to copy).
+template <bool POOL>
 __global__ __launch_bounds__(512) void cbh_detect_kernel(CbhDetArgs a) {
     if (a.upstream && *a.upstream == 0) return;
     cb_touch_kernarg<sizeof(CbhDetArgs)>();
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, t = threadIdx.x;
     const int tx = blockIdx.x, y = blockIdx.y;
     const int W = a.W, H = a.H, C = a.C;
+    if (POOL && a.prodMask) {
+        const int pwpr = (a.pW + 63) >> 6;
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int yy = 2 * y + j, ww = 2 * tx + i;
+                const unsigned long long v = a.prodMask[(long)min(yy, a.pH - 1) * pwpr + min(ww, pwpr - 1)];
+                any |= (yy < a.pH && ww < pwpr) ? v : 0ull;
+            }
+        if (__builtin_amdgcn_readfirstlane((int)(any != 0ull)) == 0) return;
+    }
     const int x = tx * 64 + lane;
     const bool valid = x < W;
     const long HW = (long)H * W;
@@ -1691,6 +1710,14 @@ __global__ __launch_bounds__(512) void cbh_detect_kernel(CbhDetArgs a) {
     const _Float16* __restrict__ in = a.in;
     _Float16* state = a.state;
     const cb_half th = cb_threshold(a.th, (cb_half*)nullptr);
+    const long pHW = (long)a.pH * a.pW;
+    const int py0 = 2 * y, px0 = 2 * x;
+    const int px1 = POOL ? min(px0 + 1, a.pW - 1) - px0 : 0, py1 = POOL ? (min(py0 + 1, a.pH - 1) - py0) * a.pW : 0;
+    auto ldin = [&](int c) -> _Float16 {
+        if (!POOL) return in[(long)c * HW + p];
+        const _Float16* q = in + (long)c * pHW + (long)py0 * a.pW + px0;
+        return cb_max(cb_max(q[0], q[px1]), cb_max(q[py1], q[py1 + px1]));
+    };
     __shared__ unsigned long long sm[8];
     __shared__ _Float16 T[64][66];
     const unsigned long long vm = cbs_valid_mask(W, tx);
@@ -1709,7 +1736,7 @@ __global__ __launch_bounds__(512) void cbh_detect_kernel(CbhDetArgs a) {
         for (int i = 0; i < 8; ++i) xv[i] = (_Float16)0;
         if (valid) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xv[i] = in[(long)(c0 + i) * HW + p];
+            for (int i = 0; i < 8; ++i) xv[i] = ldin(c0 + i);
             if (compare) {
                 _Float16 sv[8];
 #pragma unroll
@@ -1844,12 +1871,17 @@ int cbinfer_hsplit_state_rebuild(const void* state, void* pixelState, int C, int
 // One frame of an fp16 CBConv2d (conv2d.py:178-259 on the half backend): detection + refresh of prevInput and of its
 // pixel-major copy (feedbackLoop: at the changed pixels; else every value -- the layer keeps a copy of its input),
 // then the LDS-DMA contraction (+ the reduce launch of a deep one).  All tensors f16; frameMasks / idxOut / countOut /
-// maskCopy as for cbinfer_split_forward; upstreamCount (optional) as for cbinfer_cbconv2d_forward_after.
-int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, void* state, void* pixelState, uint64_t* frameMasks, void* output,
-                           int32_t* idxOut, int32_t* countOut, uint64_t* maskCopy, const void* prepared,
+// maskCopy as for cbinfer_split_forward; upstreamCount (optional) as for cbinfer_cbconv2d_forward_after.  pooled != 0:
+// `input` is the tensor in FRONT of a 2x2/stride-2 max pool [C,pH,pW] (a CBPoolMax2d folded into the detection),
+// producerMask (optional) the change mask the layer that produced it left this frame (cbinfer_mask_words(pH,pW) words):
+// segments whose windows it did not touch are skipped.
+int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int pooled, int pH, int pW,
+                           const uint64_t* producerMask, void* state, void* pixelState, uint64_t* frameMasks,
+                           void* output, int32_t* idxOut, int32_t* countOut, uint64_t* maskCopy, const void* prepared,
                            const void* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
                            int feedbackLoop, int relu, void* workspace, cbStream_t stream) {
     CB_REQUIRE(input && state && pixelState && frameMasks && output && idxOut && countOut && prepared && H > 0 && W > 0);
+    if (pooled) CB_REQUIRE((H == pH / 2 || H == (pH + 1) / 2) && (W == pW / 2 || W == (pW + 1) / 2));
     if (!cbh_supported(C, K, kH, kW) || H > 65535) return CB_ERR_UNSUPPORTED;
     const CbsGeom g = cbh_geom(C, H, W, kH, kW);
     const int KP = cbs_kp(K);
@@ -1878,7 +1910,11 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, void
     a.W = W, a.H = H, a.C = C, a.kHH = (kH - 1) / 2, a.kWH = (kW - 1) / 2, a.wpr = cbinfer_mask_words_per_row(W);
     a.Wp = g.Wp, a.rec = g.rec, a.padY = g.padY, a.padXL = g.padXL, a.th = threshold, a.copyAll = feedbackLoop ? 0 : 1;
     a.upstream = upstreamCount;
-    hipLaunchKernelGGL(cbh_detect_kernel, dim3(a.wpr, H, a.copyAll ? C / 64 : 1), dim3(512), 0, s, a);
+    a.pH = pH, a.pW = pW, a.prodMask = pooled ? (const unsigned long long*)producerMask : nullptr;
+    if (pooled)
+        hipLaunchKernelGGL(cbh_detect_kernel<true>, dim3(a.wpr, H, a.copyAll ? C / 64 : 1), dim3(512), 0, s, a);
+    else
+        hipLaunchKernelGGL(cbh_detect_kernel<false>, dim3(a.wpr, H, a.copyAll ? C / 64 : 1), dim3(512), 0, s, a);
     int st = cb_launch_status();
     if (st != CB_OK) return st;
 

@@ -516,7 +516,9 @@ int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int mode, int p
  * pixels' values (.cu:74-80 of the half backend); 0: every value of the frame (the layer keeps a copy of its input,
  * conv2d.py:234-236).  frameMasks: cbinfer_frame_mask_bytes(H,W) bytes, zero once; workspace:
  * cbinfer_hsplit_workspace_bytes (0 for fewer than 48 k-stages), zero once; upstreamCount: optional, as for
- * cbinfer_cbconv2d_forward_after.  idxOut / countOut / maskCopy as for cbinfer_split_forward. */
+ * cbinfer_cbconv2d_forward_after.  idxOut / countOut / maskCopy as for cbinfer_split_forward.  pooled != 0: `input`
+ * is the tensor in front of a 2x2/stride-2 max pool [C,pH,pW] (CBPoolMax2d folded into the detection; H x W the
+ * pooled size), producerMask as for cbinfer_change_detection_bits_pooled. */
 int cbinfer_hsplit_supported(int C, int K, int kH, int kW);
 long cbinfer_hsplit_max_mask_words(int K);
 long cbinfer_hsplit_state_bytes(int C, int H, int W, int kH, int kW);
@@ -527,10 +529,11 @@ int cbinfer_hsplit_prep_weights(const void* weight, void* prepared, int K, int C
 int cbinfer_hsplit_state_init(void* pixelState, int C, int H, int W, int kH, int kW, cbStream_t stream);
 int cbinfer_hsplit_state_rebuild(const void* state, void* pixelState, int C, int H, int W, int kH, int kW,
                                  cbStream_t stream);
-int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, void* state, void* pixelState,
-                           uint64_t* frameMasks, void* output, int32_t* idxOut, int32_t* countOut, uint64_t* maskCopy,
-                           const void* prepared, const void* bias, int C, int H, int W, int K, int kH, int kW,
-                           float threshold, int feedbackLoop, int relu, void* workspace, cbStream_t stream);
+int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int pooled, int pH, int pW,
+                           const uint64_t* producerMask, void* state, void* pixelState, uint64_t* frameMasks,
+                           void* output, int32_t* idxOut, int32_t* countOut, uint64_t* maskCopy, const void* prepared,
+                           const void* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
+                           int feedbackLoop, int relu, void* workspace, cbStream_t stream);
 
 /* ---- a5..a8 fused for a layer of few channels, ROW-PAIR form, with the NEXT layer's pooled change detection folded
  * in (round 4).  Replaces, per frame, the launcher sequence genXMatrix -> matmul -> updateOutput

@@ -1903,3 +1903,51 @@ def test_pools_fold_into_the_detection_of_layers_without_feedback(pkg):
         convs = [m for m in nets[0].modules() if type(m) is pkg.CBConv2d]
         assert all(m._plan is not None and m._plan.get('split') and m._plan['pooled'] for m in convs[1:3])
         assert all(p.outputState.numel() == 0 for p in pools)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("feedback", [False, True])
+@pytest.mark.parametrize("size", [(46, 82), (45, 67)])
+def test_pools_fold_into_the_fp16_split_state_detection(pkg, feedback, size):
+    """An fp16 chain conv -> CBPoolMax2d -> conv -> CBPoolMax2d -> conv (64/128/256 channels: the split-state fp16
+    kernels) with the pools folded into the consumers' detections (cbinfer_hsplit_forward, pooled form; the producer's
+    mask tells it which segments to look at) and with pool launches of their own: outputs, layer states and change
+    lists bit-identical in every frame; even and odd maps (floor pooling of an odd size)."""
+    H, W = size
+    nets = []
+    for fuse in (True, False):
+        torch.manual_seed(21)
+        convs = [nn.Conv2d(64, 64, 3, padding=1), nn.Conv2d(64, 128, 3, padding=1), nn.Conv2d(128, 256, 3, padding=1)]
+        mods = []
+        for i, c in enumerate(convs):
+            m = pkg.CBConv2d(c.cuda().half().eval(), 0.05)
+            m.withReLU, m.feedbackLoop = True, feedback
+            mods.append(m)
+            if i < 2:
+                mods.append(nn.MaxPool2d(2, 2))
+        net = nn.Sequential(*mods)
+        pkg.insertCBPooling(net, cloneOutput=False)
+        pkg.fusePoolingIntoDetection(net, enabled=fuse)
+        nets.append(net)
+    pools = [m for m in nets[0] if type(m) is pkg.CBPoolMax2d]
+    assert len(pools) == 2 and all(p.lazy for p in pools)
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((1, 64, H, W)).astype(np.float16)
+    with torch.no_grad():
+        for t in range(8):
+            x = x.copy()
+            if t not in (4,):
+                y0, x0 = rng.integers(0, H - 8), rng.integers(0, W - 8)
+                x[0, :, y0:y0 + 8, x0:x0 + 8] = rng.standard_normal((64, 8, 8)).astype(np.float16)
+            f = torch.from_numpy(x).cuda()
+            a, b = nets[0](f), nets[1](f)
+            assert torch.equal(a, b), t
+            for ma, mb in zip([m for m in nets[0] if type(m) is pkg.CBConv2d],
+                              [m for m in nets[1] if type(m) is pkg.CBConv2d]):
+                assert torch.equal(ma.prevInput, mb.prevInput), t
+                assert torch.equal(ma.lastChangeIndexes().tensor(), mb.lastChangeIndexes().tensor()), t
+    convs0 = [m for m in nets[0] if type(m) is pkg.CBConv2d]
+    from cbinfer_amd import _lib
+    assert all(m._plan is not None and m._plan['fn'] is _lib.C.cbinfer_hsplit_forward and m._plan['pooled']
+               for m in convs0[1:])
+    assert all(p.outputState.numel() == 0 for p in pools)

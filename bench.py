@@ -1181,6 +1181,26 @@ def main():
                 fe, ne = time_batches([(sb, None, bfr[:Sb])])
                 fg, ng = time_graph(sb, bfr[:Sb])
                 batched[str(Sb)] = {"value": max(fe, fg), "eager": fe, "graph": fg, "steps": ne if fe >= fg else ng}
+                if Sb == 8:
+                    # where a step of eight sequences goes (in-process kernel trace) and what the 64->256 contraction
+                    # reaches with all CUs filled: f32-equivalent flops over the f16-pair ceiling
+                    def bstep8(i, sb=sb):
+                        with torch.no_grad():
+                            sb([f[2 + pingpong(i, len(f) - 2)] for f in bfr[:8]])
+                    got8 = traced_kernel_durations(bstep8, 24)
+                    if got8[0] is not None:
+                        ks = sorted(got8[0].items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches_per_frame"])
+                        multi_result["step_of_8_kernels_us"] = {n.split("(")[0].replace("void ", "")[:72]: round(v["avg_us"] * v["launches_per_frame"], 2)
+                                                                for n, v in ks[:6]}
+                        multi_result["step_of_8_busy_us"] = got8[1]
+                        c3 = [v["avg_us"] for n, v in got8[0].items() if "cbs_conv_kernel<128" in n.replace(" ", "")]
+                        if c3:
+                            # (flops: 2 N C k K of the 64->256 layer with N = the mean change-list length of one sequence
+                            #  of this workload, x 8 -- the sequences differ by a few percent)
+                            multi_result["contraction_64_256_us_at_8"] = c3[0]
+                            multi_result["contraction_64_256_flops_note"] = (
+                                "frac_of_f16x2_ceiling_at_8 = 8 x the single sequence's 2 N C k K (layers[]) / this "
+                                "launch / 833 TFLOP/s; filled in below once the single-sequence layers are measured")
                 del sb, bnet
                 torch.cuda.synchronize()
             grouped = {}
@@ -1502,6 +1522,10 @@ def main():
                                                    "trace -- detect_GBps / conv_TFLOPs are computed from these where "
                                                    "present")
             best = max((r for r in test_rows if "conv_ms" in r), key=lambda r: r["conv_ms"], default=None)
+            ms = result.get("multi_sequence")
+            if best is not None and ms and ms.get("contraction_64_256_us_at_8") and "64->256" in best["layer"]:
+                ms["contraction_64_256_frac_of_f16x2_ceiling_at_8"] = (
+                    8.0 * best["conv_flops"] / (ms["contraction_64_256_us_at_8"] * 1e-6) / 1e12 / F16X2_CEILING_TFLOPS)
             if best is not None:
                 r = best
                 split = "split-state" in r["conv_kernel"]

@@ -1190,7 +1190,7 @@ def main():
                     got8 = traced_kernel_durations(bstep8, 24)
                     if got8[0] is not None:
                         ks = sorted(got8[0].items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches_per_frame"])
-                        multi_result["step_of_8_kernels_us"] = {n.split("(")[0].replace("void ", "")[:72]: round(v["avg_us"] * v["launches_per_frame"], 2)
+                        multi_result["step_of_8_kernels_us"] = {n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:72]: round(v["avg_us"] * v["launches_per_frame"], 2)
                                                                 for n, v in ks[:6]}
                         multi_result["step_of_8_busy_us"] = got8[1]
                         c3 = [v["avg_us"] for n, v in got8[0].items() if "cbs_conv_kernel<128" in n.replace(" ", "")]

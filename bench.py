@@ -10,9 +10,10 @@ feedback loop + CBPoolMax2d for the three 7x7 layers, dense 1x1 tail; sceneLabel
 Every rank owns one independent sequence (weak scaling); the only collective is the final
 MAX(elapsed) reduction.  Frames are resident in HBM before the timed region starts.
 
-Rank 0 prints ONE JSON line (see the keys below).  `roofline` is measured live with HIP events on the
-launch stream for the dominant kernel; `cpu_baseline` times the oracle port (test infrastructure) of the
-same path on the host cores over a bounded sample.
+Rank 0's FINAL stdout line is the record the driver parses: one JSON object below 4 KB (compact_line) with the
+metric, `roofline` (measured live on the launch stream for the dominant kernel) and `cpu_baseline` (the oracle
+port -- test infrastructure -- of the same path timed on the host cores over a bounded sample).  Everything else
+the run measures goes to gpurun_out/bench_details.json and is printed as one {"bench_details": ...} line before it.
 """
 import argparse
 import contextlib
@@ -97,6 +98,78 @@ def parse():
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------
+# What goes where.  The driver keeps the TAIL of the output and parses the final stdout line, so that line is
+# small and fixed (compact_line: < 4 KB, enforced by tests/test_host_logic.py); everything else this run measures
+# -- per-layer tables, kernel trace, isolated layers, sequences per GPU, the config-3/4 samples, all prose -- is the
+# DETAILS object: written to a side file (gpurun_out/bench_details.json, or ./bench_details.json) and printed as
+# one line {"bench_details": ...} BEFORE the final line.
+# ---------------------------------------------------------------------------------------------------
+COMPACT_LIMIT = 4096
+
+
+def _num(v, digits=4):
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (digits + 2, v))
+    return v
+
+
+def compact_line(result):
+    """The final stdout line: BASELINE.json's metric on its configuration + `roofline` + `cpu_baseline`, values
+    only.  `result` is the full dict of main()."""
+    cfg = result.get("config", {})
+    line = {k: _num(result.get(k)) for k in (
+        "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "timed_region_s",
+        "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "sequences_per_gpu", "launch", "dist_backend")}
+    for k in ("speedup_vs_dense", "dense_fps", "effective_gflops"):
+        if k in result:
+            line[k] = _num(result[k])
+    rf = result.get("roofline")
+    if isinstance(rf, dict):
+        line["roofline"] = {k: (_num(rf.get(k)) if not isinstance(rf.get(k), str) else rf[k][:160])
+                            for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                      "avg_duration_us", "units_per_launch") if k in rf}
+    cb = result.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {k: (_num(cb.get(k)) if not isinstance(cb.get(k), str) else cb[k][:200])
+                                for k in ("value", "unit", "cores", "kind", "dense_cpu_fps", "sample") if k in cb}
+    var = result.get("variants")
+    if isinstance(var, dict):
+        line["variants"] = {k: _num(v["value"]) for k, v in var.items()
+                            if isinstance(v, dict) and isinstance(v.get("value"), (int, float))}
+    if result.get("details_file"):
+        line["details_file"] = result["details_file"]
+    return line
+
+
+def emit(result):
+    """Side file + details line, then the final (compact) line."""
+    details = {k: v for k, v in result.items()}
+    path = None
+    for d in (os.path.join(REPO, "gpurun_out"), REPO, os.getcwd()):
+        try:
+            os.makedirs(d, exist_ok=True)
+            cand = os.path.join(d, "bench_details.json")
+            with open(cand, "w") as f:
+                json.dump(details, f, indent=1)
+            path = os.path.relpath(cand, REPO) if cand.startswith(REPO) else cand
+            break
+        except OSError:
+            continue
+    result["details_file"] = path
+    line = compact_line(result)
+    text = json.dumps(line)
+    if len(text) >= COMPACT_LIMIT:      # (never let prose push the record out of the driver's window again)
+        line.pop("variants", None)
+        line["roofline"] = {k: v for k, v in line.get("roofline", {}).items() if k != "kernel"}
+        text = json.dumps(line)
+    print(json.dumps({"bench_details": details}), flush=True)
+    print(text, flush=True)
 
 
 class PipelinedRunner(object):
@@ -1596,7 +1669,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(args)
 
-    print(json.dumps(result), flush=True)
+    emit(result)
     shard.finish()
 
 

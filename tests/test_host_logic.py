@@ -246,3 +246,29 @@ def test_fused_tail_link_survives_pickle_and_deepcopy():
         assert type(kids[-1]) is pycbinfer.CBTail1x1 and head.__dict__["_fusedTail"] is kids[-1]
         assert not any(type(m) is pycbinfer.CBTail1x1 for m in head.modules())
     assert [n for n, _ in net.named_modules()] == names[:len(names) - 2]
+
+
+def test_bench_final_line_stays_small():
+    """The driver parses the FINAL stdout line of bench.py out of a tail of a few KB (round 4 lost its record to a
+    20 KB line): bench.compact_line of a realistic full result -- the largest one a round has produced, with every
+    optional section present -- stays below 4 KB and carries the record's required objects."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(REPO, "profiles", "r04_bench.json")))
+    assert len(json.dumps(full)) > 15000          # (the realistic input: the line that was cut off)
+    full["details_file"] = "gpurun_out/bench_details.json"
+    # prose growing in the full result must not reach the line
+    full["roofline"]["kernel"] = full["roofline"]["kernel"] * 8
+    full["cpu_baseline"]["sample"] = full["cpu_baseline"]["sample"] * 8
+    full["variants"]["exact_f32"]["arithmetic"] = "x" * 5000
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < bench.COMPACT_LIMIT == 4096, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert line["config"]["workload"] and "model" not in line["config"]
+    assert json.loads(text)["value"] == pytest.approx(full["value"], rel=1e-4)
+    assert all(isinstance(v, (int, float)) for v in line["variants"].values())

@@ -48,7 +48,7 @@ _stp = ctypes.POINTER(SplitTail)
 class NextDetect(ctypes.Structure):
     """cbNextDetect of include/cbinfer_hip.h: the next layer's detection state for the row-pair kernel."""
     _fields_ = [("state", _vp), ("splitState", _vp), ("frameMasks", _vp), ("rangeFlag", _vp), ("H", _i), ("W", _i),
-                ("kH", _i), ("kW", _i), ("threshold", _f)]
+                ("kH", _i), ("kW", _i), ("threshold", _f), ("arith", _i)]
 
 
 _ndp = ctypes.POINTER(NextDetect)
@@ -146,6 +146,11 @@ _SIGNATURES = {
     "cbinfer_split_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "cbinfer_split_state_init": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "cbinfer_split_state_rebuild": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "cbinfer_split3_state_bytes": (_l, [_i, _i, _i, _i, _i]),
+    "cbinfer_split3_prepared_bytes": (_l, [_i, _i, _i, _i]),
+    "cbinfer_split3_prep_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "cbinfer_split3_state_init": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "cbinfer_split3_state_rebuild": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cbinfer_split_detect": (_i, [_sp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "cbinfer_split_conv": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp]),
     "cbinfer_split_forward": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _vp]),
@@ -186,7 +191,7 @@ def _load():
         fn = getattr(lib, name)     # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.cbinfer_abi_version() != 7:
+    if lib.cbinfer_abi_version() != 8:
         raise ImportError("cbinfer_amd: libcbinfer_hip.so ABI version mismatch")
     return lib
 

@@ -124,7 +124,8 @@ class SequenceBatch(object):
                 L['kind'] = 'split'
                 wp, scale = m._split_weights(h, w)
                 L['wp'], L['scale'] = wp, scale
-                nbytes = C.cbinfer_split_state_bytes(Cin, h, w, kH, kW)
+                x3 = L['x3'] = scale == 0.0      # (bf16 triples -- CBConv2d._split_arith, the modules' own choice)
+                nbytes = (C.cbinfer_split3_state_bytes if x3 else C.cbinfer_split_state_bytes)(Cin, h, w, kH, kW)
                 L['S'] = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(S)]
                 L['masks'] = [torch.zeros(C.cbinfer_frame_mask_bytes(h, w) // 8, dtype=torch.int64, device=dev)
                               for _ in range(S)]
@@ -134,6 +135,11 @@ class SequenceBatch(object):
                 wsBytes = C.cbinfer_split_workspace_bytes(S, Cin, h, w, K, kH, kW)
                 L['ws'] = torch.zeros(wsBytes, dtype=torch.uint8, device=dev) if wsBytes > 0 else None
                 for q in range(S):
+                    if x3:
+                        check(C.cbinfer_split3_state_init(ptr(L['S'][q]), Cin, h, w, kH, kW, stream_ptr(frame)))
+                        check(C.cbinfer_split3_state_rebuild(ptr(L['prevInput'][q]), ptr(L['S'][q]), Cin, h, w, kH, kW,
+                                                             stream_ptr(frame)))
+                        continue
                     check(C.cbinfer_split_state_init(ptr(L['S'][q]), Cin, h, w, kH, kW, stream_ptr(frame)))
                     check(C.cbinfer_split_state_rebuild(ptr(L['prevInput'][q]), ptr(L['S'][q]), Cin, h, w, kH, kW,
                                                         ptr(L['flag']), stream_ptr(frame)))
@@ -187,6 +193,7 @@ class SequenceBatch(object):
                 P = layers[li - 1]
                 nd = _lib.NextDetect()
                 nd.H, nd.W, nd.kH, nd.kW = L['H'], L['W'], L['kH'], L['kW']
+                nd.arith = 1 if L['x3'] else 0
                 for q in range(S):
                     P['pseq'][q].nextState = L['prevInput'][q].data_ptr()
                     P['pseq'][q].nextSplitState = L['S'][q].data_ptr()
@@ -209,6 +216,9 @@ class SequenceBatch(object):
         m = L['m']
         if L['kind'] == 'split':
             L['wp'], L['scale'] = m._split_weights(L['H'], L['W'])
+            if (L['scale'] == 0.0) != L['x3']:
+                raise CBinferError("SequenceBatch: CBINFER_ARITH changed since the batch was built (its split states "
+                                   "hold the other arithmetic's records)")
         elif L['kind'] == 'rows':
             L['wp'] = m._masked_call('rows')[1]
         if L['kind'] == 'tail' or L.get('tail') is not None:

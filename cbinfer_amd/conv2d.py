@@ -323,10 +323,11 @@ class CBConv2d(nn.Module):
         th = float(self.threshold)
         if self.__dict__.get('_pmaskThreshold') != th or self.__dict__.get('_rangeFallback'):
             return None
-        return (id(self), prev.data_ptr(), sp['S'].data_ptr(), sp['bits'].data_ptr(), th)
+        return (id(self), prev.data_ptr(), sp['S'].data_ptr(), sp['bits'].data_ptr(), th, sp['arith'])
 
     def _detect_token_with(self, sp, prev):
-        return (id(self), prev.data_ptr(), sp['S'].data_ptr(), sp['bits'].data_ptr(), float(self.threshold))
+        return (id(self), prev.data_ptr(), sp['S'].data_ptr(), sp['bits'].data_ptr(), float(self.threshold),
+                sp['arith'])
 
     def _next_detect(self, H, W):
         """(cbNextDetect, token) if this layer's row-pair launch can also be the pooled change detection of the layer
@@ -355,6 +356,7 @@ class CBConv2d(nn.Module):
             st.state, st.splitState, st.frameMasks = prev2.data_ptr(), sp['S'].data_ptr(), sp['bits'].data_ptr()
             st.rangeFlag, st.H, st.W = sp['flag'].data_ptr(), H2, W2
             st.kH, st.kW, st.threshold = cons.weight.size(2), cons.weight.size(3), float(cons.threshold)
+            st.arith = 1 if sp['arith'] == 'x3' else 0
             nd = self.__dict__['_nextStruct'] = (tok, st)
         return nd[1], tok
 
@@ -365,6 +367,16 @@ class CBConv2d(nn.Module):
                                 arrive=torch.zeros(words, dtype=torch.int32, device=dev),
                                 copy=torch.zeros(words, dtype=torch.int64, device=dev))
         return work['rows']
+
+    @staticmethod
+    def _split_arith():
+        """Arithmetic of the split-state kernels for fp32 layers (CBINFER_ARITH): 'x3' (default, round 5) -- bf16
+        TRIPLES: every f32 operand exactly, six term products, f32 accumulation: f32-equivalent, what
+        conv2d_cg.py:342-349's sgemm multiplies --, or 'f16x2' -- f16 PAIRS, 22-23 significant bits per operand, three
+        products (rounds 3-4's default, narrower than f32).  Any other value ('bf16x3') keeps the layer on rounds 1-2's
+        list / patch-staged kernels.  Returns 'x3', 'f16x2' or None."""
+        a = os.environ.get('CBINFER_ARITH', 'x3')
+        return a if a in ('x3', 'f16x2') else None
 
     def _arith_code(self, dtype):
         if dtype == torch.float16:
@@ -399,10 +411,10 @@ class CBConv2d(nn.Module):
         return (dtype == torch.float32 and (self.feedbackLoop or self.copyInput)
                 and not self.syncIndexes and not self.saveChangeMap
                 and not self.finegrained and self._arith_code(dtype) == _lib.CB_F32S
-                and not self.__dict__.get('_rangeFallback')
+                and (not self.__dict__.get('_rangeFallback') or self._split_arith() == 'x3')
                 and os.environ.get('CBINFER_NO_SPLIT', '0') != '1'
                 and int(os.environ.get('CBINFER_SPLIT_MINK', '0')) <= K <= int(os.environ.get('CBINFER_SPLIT_MAXK', '100000'))
-                and os.environ.get('CBINFER_ARITH', 'f16x2') == 'f16x2'
+                and self._split_arith() is not None
                 and os.environ.get('CBINFER_NO_SELFCOMPACT', '0') != '1'
                 and bool(C.cbinfer_split_supported(Cin, K, kH, kW))
                 and C.cbinfer_mask_words(H, W) <= C.cbinfer_split_max_mask_words(K)
@@ -489,41 +501,55 @@ class CBConv2d(nn.Module):
         As _split_ok, for a layer in fine-grained mode."""
         K, Cin, kH, kW = self.weight.size()
         return (dtype == torch.float32 and self._arith_code(dtype) == _lib.CB_F32S
-                and not self.__dict__.get('_rangeFallback')
+                and (not self.__dict__.get('_rangeFallback') or self._split_arith() == 'x3')
                 and os.environ.get('CBINFER_NO_SPLIT', '0') != '1' and os.environ.get('CBINFER_NO_SPLIT_FG', '0') != '1'
-                and os.environ.get('CBINFER_ARITH', 'f16x2') == 'f16x2'
+                and self._split_arith() is not None
                 and bool(C.cbinfer_split_supported(Cin, K, kH, kW))
                 and C.cbinfer_mask_words(H, W) <= C.cbinfer_split_max_mask_words(K)
                 and H * W * W < (1 << 32))
 
     def _split_weights(self, H, W):
-        """(prepared buffer, power-of-two weight scale): max |w| * scale in [2^13, 2^14)."""
+        """(prepared buffer, weight scale).  f16 pairs: a power of two with max |w| * scale in [2^13, 2^14); bf16
+        triples ('x3'): the weights as they are -- scale 0.0, which is also what tells the library's frame functions
+        which form the buffers hold (include/cbinfer_hip.h)."""
         w = self.weight
-        key = ('split', w.data_ptr(), w._version, w.device, H, W)
+        arith = self._split_arith()
+        key = ('split', w.data_ptr(), w._version, w.device, H, W, arith)
         if self._wrows is None or self._wrows[0] != key:
             K, Cin, kH, kW = w.size()
-            wmax = float(w.detach().abs().max())          # (one host sync when the weights change)
-            scale = 2.0 ** (13 - math.floor(math.log2(wmax))) if wmax > 0 and math.isfinite(wmax) else 1.0
-            wp = torch.empty(C.cbinfer_split_prepared_bytes(Cin, K, kH, kW), dtype=torch.uint8, device=w.device)
-            check(C.cbinfer_split_prep_weights(ptr(w.detach().contiguous()), ptr(wp), K, Cin, kH, kW, H, W,
-                                               scale, stream_ptr(w)))
+            if arith == 'x3':
+                scale = 0.0
+                wp = torch.empty(C.cbinfer_split3_prepared_bytes(Cin, K, kH, kW), dtype=torch.uint8, device=w.device)
+                check(C.cbinfer_split3_prep_weights(ptr(w.detach().contiguous()), ptr(wp), K, Cin, kH, kW, H, W,
+                                                    stream_ptr(w)))
+            else:
+                wmax = float(w.detach().abs().max())          # (one host sync when the weights change)
+                scale = 2.0 ** (13 - math.floor(math.log2(wmax))) if wmax > 0 and math.isfinite(wmax) else 1.0
+                wp = torch.empty(C.cbinfer_split_prepared_bytes(Cin, K, kH, kW), dtype=torch.uint8, device=w.device)
+                check(C.cbinfer_split_prep_weights(ptr(w.detach().contiguous()), ptr(wp), K, Cin, kH, kW, H, W,
+                                                   scale, stream_ptr(w)))
             self._wrows = (key, wp, scale)
         return self._wrows[1], self._wrows[2]
 
     def _split_workspace(self, work, H, W, dev):
         sp = work.get('split')
-        if sp is None:
+        arith = self._split_arith()
+        if sp is None or sp['arith'] != arith:      # (the records of the two arithmetics differ in size and content)
             K, Cin, kH, kW = self.weight.size()
             words = C.cbinfer_mask_words(H, W)
-            S = torch.empty(C.cbinfer_split_state_bytes(Cin, H, W, kH, kW), dtype=torch.uint8, device=dev)
-            check(C.cbinfer_split_state_init(ptr(S), Cin, H, W, kH, kW, stream_ptr(S)))
+            if arith == 'x3':
+                S = torch.empty(C.cbinfer_split3_state_bytes(Cin, H, W, kH, kW), dtype=torch.uint8, device=dev)
+                check(C.cbinfer_split3_state_init(ptr(S), Cin, H, W, kH, kW, stream_ptr(S)))
+            else:
+                S = torch.empty(C.cbinfer_split_state_bytes(Cin, H, W, kH, kW), dtype=torch.uint8, device=dev)
+                check(C.cbinfer_split_state_init(ptr(S), Cin, H, W, kH, kW, stream_ptr(S)))
             # (slabs only for deep contractions -- 48 k-stages and more: 0 bytes otherwise)
             wsBytes = C.cbinfer_split_workspace_bytes(1, Cin, H, W, K, kH, kW)
             ws = torch.zeros(wsBytes, dtype=torch.uint8, device=dev) if wsBytes > 0 else None
             # (a frame mask of its own: the list kernels' protocol -- two masks alternating by a device-side parity --
             #  and the split-state kernels' -- one mask, an arrival counter behind it -- must never meet in one
             #  buffer when a module changes paths in mid-sequence; ADVICE round 3)
-            sp = work['split'] = dict(S=S, flag=torch.zeros(1, dtype=torch.int32, device=dev),
+            sp = work['split'] = dict(S=S, arith=arith, flag=torch.zeros(1, dtype=torch.int32, device=dev),
                                       bits=torch.zeros(C.cbinfer_frame_mask_bytes(H, W) // 8, dtype=torch.int64,
                                                        device=dev),
                                       copy=torch.zeros(words, dtype=torch.int64, device=dev), ws=ws,
@@ -570,6 +596,8 @@ class CBConv2d(nn.Module):
         at what the previous copy brought (no sync, no wait).  A tripped flag moves the layer to the bf16x3 kernels for
         good (`_rangeFallback`; clearMemory resets it): the in-kernel exact path that kept the frames since the trip
         right is orders of magnitude slower than either."""
+        if sp['arith'] == 'x3':      # (bf16 triples have f32's range: the flag is never set)
+            return
         n = sp['poll'] = sp.get('poll', 0) + 1
         if n & 63 or torch.cuda.is_current_stream_capturing():
             return
@@ -598,8 +626,11 @@ class CBConv2d(nn.Module):
         if rebuilt:
             # first frame, or prevInput was (re)allocated or written by somebody else (restored states,
             # eval03.py:88-95): the pre-split copy is made again from it
-            check(C.cbinfer_split_state_rebuild(ptr(prev), ptr(sp['S']), Cin, H, W, kH, kW, ptr(sp['flag']),
-                                                stream_ptr(src)))
+            if sp['arith'] == 'x3':
+                check(C.cbinfer_split3_state_rebuild(ptr(prev), ptr(sp['S']), Cin, H, W, kH, kW, stream_ptr(src)))
+            else:
+                check(C.cbinfer_split_state_rebuild(ptr(prev), ptr(sp['S']), Cin, H, W, kH, kW, ptr(sp['flag']),
+                                                    stream_ptr(src)))
             sp['stateKey'] = stateKey
         pmask = None
         if lazy is not None:
@@ -643,14 +674,15 @@ class CBConv2d(nn.Module):
         if (w is not None and b is not None and not self.gatherComputationStats and
                 os.environ.get('CBINFER_NO_FASTPATH', '0') != '1'):
             self._plan = dict(
-                split=True, pooled=lazy is not None, shape=tuple(src.shape), dtype=src.dtype, device=dev,
+                split=True, arith=sp['arith'], pooled=lazy is not None, shape=tuple(src.shape), dtype=src.dtype,
+                device=dev,
                 flags=self._flags(), w=(w.data_ptr(), w._version), b=(b.data_ptr(), b._version),
                 state=(self._buffers['prevInput'].data_ptr(), self._buffers['prevOutput'].data_ptr()),
                 stateVersion=prev._version, stream=args[-1], work=work, args=args, seq=q, pmask=ptr(pmask),
                 indexes=self._lastIndexes, fn=fn, tail=tail, tailKey=tail._fold_key() if tail is not None else None,
                 convFn=cfn, convArgs=cargs, tailBlocked=bool(self.__dict__.get('_noTailFold')),
                 detectToken=(id(self), prev.data_ptr(), sp['S'].data_ptr(), sp['bits'].data_ptr(),
-                             float(self.threshold)))
+                             float(self.threshold), sp['arith']))
         if self.propChangeIndexes:
             return 'changeIndexes', self.prevOutput, self._lastIndexes
         return self.prevOutput
@@ -675,7 +707,8 @@ class CBConv2d(nn.Module):
                 (w.data_ptr(), w._version) != plan['w'] or (b.data_ptr(), b._version) != plan['b'] or
                 (prev.data_ptr(), bufs['prevOutput'].data_ptr()) != plan['state'] or
                 prev._version != plan['stateVersion'] or
-                self._work is not plan['work'] or raw_stream(src.device.index) != plan['stream']):
+                self._work is not plan['work'] or raw_stream(src.device.index) != plan['stream'] or
+                plan['arith'] != os.environ.get('CBINFER_ARITH', 'x3')):
             return None
         if plan['tailBlocked'] != bool(self.__dict__.get('_noTailFold')):
             return None      # (a FramePipeline took the tail's folding away, or gave it back)
@@ -776,7 +809,7 @@ class CBConv2d(nn.Module):
             result = ('changeIndexes', result, self._lastIndexes)
         self._make_plan(pooled, src, C.cbinfer_split_forward_fg, args, None, result=result)
         if self._plan is not None:
-            self._plan.update(fgSplit=True, seq=q, wsplit=(wp, scale), relu=relu)
+            self._plan.update(fgSplit=True, arith=sp['arith'], seq=q, wsplit=(wp, scale), relu=relu)
         return result
 
     def forward_fg(self, inp):
@@ -1237,6 +1270,8 @@ class CBConv2d(nn.Module):
                 return None
         args = plan['args']
         if plan.get('fgSplit'):
+            if plan['arith'] != os.environ.get('CBINFER_ARITH', 'x3'):
+                return None
             plan['seq'].input = src.data_ptr()
         else:
             args[plan['srcSlot']] = src.data_ptr()

@@ -46,6 +46,7 @@ using cbs::halfx8;
 struct PairNext {                   // geometry of the next layer's detection (fold != 0)
     int fold, H2, W2, wpr2, kHH, kWH, Wp, rec, padY, padXL;
     float th;
+    int planes;                     // its records: 2 = f16 pairs, 3 = bf16 triples (cb_split_common.h)
 };
 struct PairSeq {                    // the tensors of ONE sequence (several sequences per launch: cbPairSeq)
     const float* state;             // prevInput [C,H,W]: what the gather reads (conv2d.py:242)
@@ -405,21 +406,15 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
         if (t < 64) {
             const int pl2 = t >> 1, half = t & 1;
             if ((m32 >> pl2) & 1u) {
-                halfx8 hi, lo;
-                bool over = false;
+                float v8[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int c = half * 8 + j;
-                    const float v = (c < p.K ? s_P[c * 33 + pl2] : 0.f) * CBS_XSCALE;
-                    over |= !(fabsf(v) <= CBS_F16_MAX);
-                    _Float16 h, l;
-                    cbs::cbs_split(v, h, l);
-                    hi[j] = h, lo[j] = l;
+                    v8[j] = c < p.K ? s_P[c * 33 + pl2] : 0.f;
                 }
                 char* rec = sq.nS + CBS_SPAD +
-                            ((long)(yo + p.next.padY) * p.next.Wp + (tx * 32 + pl2 + p.next.padXL)) * p.next.rec + half * 16;
-                *(halfx8*)rec = hi;
-                *(halfx8*)(rec + 32) = lo;
+                            ((long)(yo + p.next.padY) * p.next.Wp + (tx * 32 + pl2 + p.next.padXL)) * p.next.rec;
+                const bool over = cbs::cbs_store_part(rec, 0, half, p.next.planes, v8);
                 if (over && sq.nflag) *sq.nflag = 1;
             }
         }
@@ -507,14 +502,16 @@ static int cbp_launch(const cbPairSeq* seqs, int nSeq, const void* prepared, con
     p.C = C, p.H = H, p.W = W, p.K = K, p.relu = relu, p.nSeq = nSeq;
     p.wpr = cbinfer_mask_words_per_row(W), p.MW = (int)cbinfer_mask_words(H, W);
     p.units = ((H + 1) / 2) * p.wpr;
-    p.next.fold = 0;
+    p.next.fold = 0, p.next.planes = 2;
     const bool fold = next != nullptr && next->H > 0 && seqs[0].nextState != nullptr;
     if (fold) {
         // the layer behind the 2x2/stride-2 pool: K channels at (H/2 or (H+1)/2) x (W/2 or (W+1)/2), split-state form
         CB_REQUIRE((next->H == H / 2 || next->H == (H + 1) / 2) && (next->W == W / 2 || next->W == (W + 1) / 2));
         if (K != 16 || !cbs::cbs_supported(K, 1, next->kH, next->kW)) return CB_ERR_UNSUPPORTED;
-        const cbs::CbsGeom g = cbs::cbs_geom(K, next->H, next->W, next->kH, next->kW);
+        CB_REQUIRE(next->arith == 0 || next->arith == 1);
+        const cbs::CbsGeom g = cbs::cbs_geom(K, next->H, next->W, next->kH, next->kW, next->arith ? 3 : 2);
         p.next.fold = 1;
+        p.next.planes = g.planes;
         p.next.H2 = next->H, p.next.W2 = next->W, p.next.wpr2 = cbinfer_mask_words_per_row(next->W);
         p.next.kHH = (next->kH - 1) / 2, p.next.kWH = (next->kW - 1) / 2;
         p.next.Wp = g.Wp, p.next.rec = g.rec, p.next.padY = g.padY, p.next.padXL = g.padXL;
@@ -528,7 +525,8 @@ static int cbp_launch(const cbPairSeq* seqs, int nSeq, const void* prepared, con
         if (fold) {
             CB_REQUIRE(seqs[q].nextState && seqs[q].nextSplitState && seqs[q].nextFrameMasks);
             p.seq[q].nstate = seqs[q].nextState, p.seq[q].nS = (char*)seqs[q].nextSplitState;
-            p.seq[q].nmasks = (unsigned long long*)seqs[q].nextFrameMasks, p.seq[q].nflag = seqs[q].nextRangeFlag;
+            p.seq[q].nmasks = (unsigned long long*)seqs[q].nextFrameMasks;
+            p.seq[q].nflag = next->arith ? nullptr : seqs[q].nextRangeFlag;      // (bf16 triples have f32's range)
         }
     }
     const long total = (long)p.units * nSeq;

@@ -66,8 +66,10 @@ __global__ __launch_bounds__(256) void cbs_prep_kernel(const float* __restrict__
                                                       CbsGeom g, int K, int KP, float wscale) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     // (the plain f32 filter bank, as it came, behind the stage table: what the exact path of a layer whose state left
-    //  the f16 pair's range multiplies with -- cbs_exact_tile)
-    for (long i = idx; i < (long)K * g.C * g.kH * g.kW; i += (long)gridDim.x * blockDim.x) wPlain[i] = w[i];
+    //  the f16 pair's range multiplies with -- cbs_exact_tile; the bf16-triple form has f32's range and no such path)
+    if (wPlain)
+        for (long i = idx; i < (long)K * g.C * g.kH * g.kW; i += (long)gridDim.x * blockDim.x) wPlain[i] = w[i];
+    const int PL = g.planes;      // 2: f16 pairs, 3: bf16 triples -- blocks [stage][row tile][k-step][plane], 1 KB each
     if (idx < g.nStages) {
         const int s = (int)idx;
         int off;
@@ -75,17 +77,17 @@ __global__ __launch_bounds__(256) void cbs_prep_kernel(const float* __restrict__
             off = ((s / g.kWs) * g.Wp + 2 * (s % g.kWs)) * g.rec;
         } else {
             const int tap = s / (g.G / 2), sub = s % (g.G / 2);
-            off = ((tap / g.kW) * g.Wp + tap % g.kW) * g.rec + sub * 128;
+            off = ((tap / g.kW) * g.Wp + tap % g.kW) * g.rec + sub * 64 * PL;
         }
         stageOff[s] = off;
     }
     const int RT = KP / 32;
-    const long total = (long)g.nStages * RT * 4 * 64;
+    const long total = (long)g.nStages * RT * 2 * PL * 64;
     if (idx >= total) return;
     const int lane = (int)(idx & 63);
     const long blk = idx >> 6;
-    const int plane = (int)(blk & 1), ks = (int)((blk >> 1) & 1);
-    const int rt = (int)((blk >> 2) % RT), stage = (int)((blk >> 2) / RT);
+    const int plane = (int)(blk % PL), ks = (int)((blk / PL) & 1);
+    const int rt = (int)((blk / (2 * PL)) % RT), stage = (int)((blk / (2 * PL)) / RT);
     const int m = rt * 32 + (lane & 31);
     halfx8 o;
 #pragma unroll
@@ -100,6 +102,12 @@ __global__ __launch_bounds__(256) void cbs_prep_kernel(const float* __restrict__
         }
         float v = 0.f;
         if (m < K && kx < g.kW) v = w[(((long)m * g.C + c) * g.kH + ky) * g.kW + kx] * wscale;
+        if (PL == 3) {      // (wscale is 1: the triple carries the weight as it is)
+            __bf16 t[3];
+            cbs_split3(v, t[0], t[1], t[2]);
+            o[j] = __builtin_bit_cast(_Float16, t[plane]);
+            continue;
+        }
         _Float16 hi, lo;
         cbs_split(v, hi, lo);
         o[j] = plane ? lo : hi;
@@ -115,11 +123,11 @@ __global__ __launch_bounds__(256) void cbs_state_init_kernel(uint4* __restrict__
     S += CBS_SPAD / 16;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long)gridDim.x * blockDim.x) {
         const long pix = i / (g.rec / 16);
-        const int q = (int)(i % (g.rec / 16));        // chunk within the record: [group][plane][half]
+        const int q = (int)(i % (g.rec / 16));        // chunk within the record: [group][plane (2 or 3)][half]
         const int py = (int)(pix / g.Wp), px = (int)(pix % g.Wp);
         const bool inside = py >= g.padY && py < g.padY + g.H && px >= g.padXL && px < g.padXL + g.W;
-        const bool hiPlane = ((q >> 1) & 1) == 0;
-        const unsigned v = (inside && hiPlane) ? 0x7c007c00u : 0u;
+        const bool hiPlane = ((q >> 1) % g.planes) == 0;
+        const unsigned v = (inside && hiPlane) ? (g.planes == 3 ? 0x7f807f80u : 0x7c007c00u) : 0u;      // f16 / bf16 +inf
         S[i] = make_uint4(v, v, v, v);
     }
 }
@@ -135,6 +143,13 @@ __global__ __launch_bounds__(256) void cbs_state_rebuild_kernel(const float* __r
         const long pix = i % HW;                       // (consecutive threads: consecutive pixels of one channel)
         const int y = (int)(pix / g.W), x = (int)(pix % g.W);
         const int grp = part >> 1, half = part & 1;
+        if (g.planes == 3) {
+            float v8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v8[j] = state[(long)(grp * 16 + half * 8 + j) * HW + pix];
+            cbs_store_part(S + CBS_SPAD + ((long)(y + g.padY) * g.Wp + (x + g.padXL)) * g.rec, grp, half, 3, v8);
+            continue;
+        }
         halfx8 hi, lo;
         bool over = false;
 #pragma unroll
@@ -170,6 +185,7 @@ struct CbsDetArgs {
     int W, H, C, kHH, kWH, wpr, pH, pW, Wp, rec, padY, padXL;
     long words;
     float th;
+    int planes;       // 2: the records are f16 pairs, 3: bf16 triples (cb_split_common.h)
     int copyAll;      // the layer is NOT in feedback mode and keeps a copy of its input (conv2d.py:234-236): both
                       // states take EVERY value of the frame, not only those of the changed pixels (round 4)
     int fg;           // fine-grained frame (conv2d.py:160-176, cbconv2d_fg_backend.cu:7-23; implies copyAll): prevInput
@@ -294,20 +310,11 @@ __global__ __launch_bounds__(1024) void cbs_detect_kernel(CbsDetArgs a) {
             const int pl = t / parts, part = t % parts;
             if (((upd >> pl) & 1ull) != 0ull) {
                 const int grp = part >> 1, half = part & 1;
-                halfx8 hi, lo;
-                bool over = false;
+                float v8[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float v = T[grp * 16 + half * 8 + j][pl] * CBS_XSCALE;
-                    over |= !(fabsf(v) <= CBS_F16_MAX);
-                    _Float16 h, l;
-                    cbs_split(v, h, l);
-                    hi[j] = h, lo[j] = l;
-                }
-                char* rec = sq.S + CBS_SPAD + ((long)(y + a.padY) * a.Wp + (tx * 64 + pl + a.padXL)) * a.rec + grp * 64 +
-                            half * 16;
-                *(halfx8*)rec = hi;
-                *(halfx8*)(rec + 32) = lo;
+                for (int j = 0; j < 8; ++j) v8[j] = T[grp * 16 + half * 8 + j][pl];
+                char* rec = sq.S + CBS_SPAD + ((long)(y + a.padY) * a.Wp + (tx * 64 + pl + a.padXL)) * a.rec;
+                const bool over = cbs_store_part(rec, grp, half, a.planes, v8);
                 if (over && sq.rangeFlag) *sq.rangeFlag = 1;
             }
         }
@@ -430,8 +437,22 @@ __device__ __forceinline__ int cbs_div(int x, unsigned long long magic) {
 // come -- ONE plane, a stage is 64 k = the same 128 bytes of a pixel's record and the same 4 KB weight block per row
 // tile, so DMA, ring, swizzle and fragment addresses are the f16-pair form's; what differs is the matrix work of a
 // stage (four k-steps of one product instead of two of three), no scale, and f16 outputs.
-template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING, bool HALF = false>
+//
+// AR = 2, bf16 TRIPLES ("x3", round 5): the f32-EQUIVALENT form.  Every f32 operand is three bf16 terms, exactly
+// (cbs_split3); a product is the six term products above 2^-24: b0 w0 into the main accumulator, b0 w1 + b1 w0 + b1 w1
+// + b0 w2 + b2 w0 into a second one (its roundings are relative to a sum 2^-8 of the main one's), summed at the end.
+// What is dropped (b1 w2 + b2 w1 + b2 w2) is below 2^-25 |x w| per product; the arithmetic error left is the f32
+// accumulation of one 16-k block sum per MFMA -- fewer roundings than the f32 fma chain of conv2d_cg.py:342-349's
+// sgemm.  No scale, no range flag: bf16 has f32's exponent range.  A stage is still 32 k, now 192 bytes of a
+// pixel's record ([k-step][plane][k-half] pieces of 16 bytes) and 6 KB of weights per 32-row tile; the pixel image of a
+// stage in LDS is [16-pixel block][quad of pieces][pixel][piece ^ swizzle] -- four consecutive DMA lanes fetch 64
+// contiguous bytes of one pixel, and the ds_read_b128 lane groups of a fragment read touch all 64 banks once --; the
+// stage loop works in UNITS of one k-step (the fragment registers of a whole stage would not fit beside two
+// accumulator sets): unit (s, 0) is multiplied while (s, 1) is read, then the barrier of the stage, then (s, 1) is
+// multiplied while (s + 1, 0) is read.
+template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING, int AR = 0>
 __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
+    constexpr bool HALF = AR == 1, X3 = AR == 2;
     // (before anything else -- the burst over the kilobyte of arguments included: an idle frame is this one load)
     if (HALF && p.upstream && *p.upstream == 0) {      // (the detection in front returned the same way: the mask is empty)
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -444,11 +465,12 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TN = BN / WN / 32;
     static_assert(BM == 32 * WM, "one 32-row tile per wave");
-    constexpr int ABLK = BM / 8, BBLK = BN / 8;          // 1-KB DMA blocks per stage
+    constexpr int PB = X3 ? 192 : 128;                   // bytes of one pixel's (one weight row's) stage
+    constexpr int ABLK = BM * PB / 1024, BBLK = BN * PB / 1024;      // 1-KB DMA blocks per stage
     constexpr int APW = ABLK / NW, BPW = BBLK / NW;      // ... per wave
     static_assert(APW * NW == ABLK && BPW * NW == BBLK && APW >= 1 && BPW >= 1, "DMA blocks must deal evenly");
     constexpr int DPW = APW + BPW;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = BM * PB, B_BYTES = BN * PB, STAGE = A_BYTES + B_BYTES;
     constexpr int TILE = BM * BN;
     // static LDS (a workgroup may declare up to 160 KB without any opt-in): RING stages, then the popcount
     // prefix over the mask words of ALL sequences of the launch (one scan) and -- MASK_LDS -- the words themselves.
@@ -612,18 +634,25 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     //   weight block b = (row tile, k-step, plane) -> (b / APW) * 4096 + (b % APW) * 1024
     //   pixel n: block c = n / 8                  -> (c / BPW) * 4096 + (APW + c % BPW) * 1024 + (n % 8) * 128,
     //            chunk (k-step ks, plane pl, k-half h) at slot (ks * 4 + pl * 2 + h) ^ ((n >> 1) & 7)
-    static_assert(APW == 2 && BPW == 2, "four DMA instructions per wave and stage");
-    int aRead[4];      // this lane's A fragment of (row tile wm; e = ks * 2 + plane)
+    // x3: every wave owns 6 KB -- its three weight blocks, then ONE block of 16 pixels x 192 B laid out as
+    //   [quad cq = piece / 4][pixel i][piece % 4 ^ (i >> 2)] x 16 B,  piece = (k-step * 3 + plane) * 2 + k-half
+    // (two M0 values per stage: the instruction's immediate offset ends at 4095)
+    //   weight block a = (row tile) * 6 + (k-step * 3 + plane) -> (a / 3) * 6144 + (a % 3) * 1024
+    static_assert(APW == (X3 ? 3 : 2) && BPW == APW, "four (x3: six) DMA instructions per wave and stage");
+    int aRead[4];      // this lane's A fragment of (row tile wm; e = ks * 2 + plane); x3: [0] + immediates
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int b = wm * 4 + e;
-        aRead[e] = (b / APW) * 4096 + (b % APW) * 1024 + lane * 16;
+        aRead[e] = X3 ? (2 * wm) * 6144 + lane * 16 : (b / APW) * 4096 + (b % APW) * 1024 + lane * 16;
     }
-    int bRead[TN];
+    int bRead[TN];     // x3: the pixel's slot base (piece parity 0; the other parity = ^ 32), + (piece / 4) KB immediates
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = (wn * TN + j) * 32 + l31, c = n >> 3;
-        bRead[j] = (c / BPW) * 4096 + (APW + c % BPW) * 1024 + (n & 7) * 128 + ((h ^ ((n >> 1) & 7)) << 4);
+        if (X3)
+            bRead[j] = (n >> 4) * 6144 + 3072 + (n & 15) * 64 + ((h ^ ((n >> 2) & 3)) << 4);
+        else
+            bRead[j] = (c / BPW) * 4096 + (APW + c % BPW) * 1024 + (n & 7) * 128 + ((h ^ ((n >> 1) & 7)) << 4);
     }
 
     for (int it = blockIdx.x; it < items; it += gridDim.x) {
@@ -688,7 +717,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
                                 ? (HALF ? (float)((const _Float16*)p.bias)[m0 + t] : p.bias[m0 + t]) : 0.f;
         __syncthreads();
         CBS_STAMP_AT(10);
-        if (!HALF && __builtin_expect(__builtin_amdgcn_readfirstlane(s_exact[q]) != 0, 0)) {
+        if (AR == 0 && __builtin_expect(__builtin_amdgcn_readfirstlane(s_exact[q]) != 0, 0)) {
             // The sequence's state left the range of the f16 pairs (|x| >= 2^20, cbs_detect_kernel): its split state is
             // not usable.  The tile is computed from prevInput and the plain filter bank instead, one f32 fma chain per
             // output in (channel, ky, kx) order like conv2d_cg.py:342-349's sgemm -- orders of magnitude slower, and
@@ -745,14 +774,19 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         int bVoff[BPW];
 #pragma unroll
         for (int i = 0; i < BPW; ++i) {
-            const int nl = (wave * BPW + i) * 8 + (lane >> 3);
+            // x3: ONE pixel per lane for its three DMAs -- pixel lane / 4 of the wave's block of 16, quad i of its 12
+            // pieces, piece (lane & 3) ^ swizzle of the quad (the B DMAs' LDS base is mine + 3 KB: immediates 0, 1, 2 KB)
+            const int nl = X3 ? wave * 16 + (lane >> 2) : (wave * BPW + i) * 8 + (lane >> 3);
             const int pos = s_tilePix[nl];
             const int py = cbs_div(max(pos, 0), p.magicW);
             const int base = (pos < 0 || CBS_DBGBIT(1)) ? p.dummyBase : (py * p.Wp + (pos - py * p.W)) * p.rec;
-            bVoff[i] = CBS_SPAD + base + (((lane & 7) ^ ((nl >> 1) & 7)) << 4) - (APW + i) * 1024;
+            if (X3)
+                bVoff[i] = CBS_SPAD + base + ((i * 4 + ((lane & 3) ^ ((lane >> 4) & 3))) << 4) - i * 1024;
+            else
+                bVoff[i] = CBS_SPAD + base + (((lane & 7) ^ ((nl >> 1) & 7)) << 4) - (APW + i) * 1024;
         }
-        const int aItem = (m0 / 32) * 4096;            // row tiles of this m-tile inside a stage
-        const int aStageBytes = (p.KP / 32) * 4096;
+        const int aItem = (m0 / 32) * (PB * 32);            // row tiles of this m-tile inside a stage
+        const int aStageBytes = (p.KP / 32) * (PB * 32);
 
         // (the pixel operand's stage offset comes from the table by a scalar load: requested one stage early)
         CBS_STAMP_AT(11);
@@ -772,17 +806,40 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, live ? aRecords : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)Sq, 0, live ? bRecords : 0, 0x00020000);
             char* mine = dst + wave * (DPW * 1024);      // ONE LDS base (M0) for the four
-            cbs_dma16<0>(ar, mine, aVoff, aS);
-            cbs_dma16<1024>(ar, mine, aVoff, aS);
-            cbs_dma16<2048>(br, mine, bVoff[0], bS);
-            cbs_dma16<3072>(br, mine, bVoff[1], bS);
+            if constexpr (X3) {
+                cbs_dma16<0>(ar, mine, aVoff, aS);
+                cbs_dma16<1024>(ar, mine, aVoff, aS);
+                cbs_dma16<2048>(ar, mine, aVoff, aS);
+                cbs_dma16<0>(br, mine + 3072, bVoff[0], bS);
+                cbs_dma16<1024>(br, mine + 3072, bVoff[BPW > 1 ? 1 : 0], bS);
+                cbs_dma16<2048>(br, mine + 3072, bVoff[BPW > 2 ? 2 : 0], bS);
+            } else {
+                cbs_dma16<0>(ar, mine, aVoff, aS);
+                cbs_dma16<1024>(ar, mine, aVoff, aS);
+                cbs_dma16<2048>(br, mine, bVoff[0], bS);
+                cbs_dma16<3072>(br, mine, bVoff[1], bS);
+            }
         };
 
-        floatx16 acc1[TN], acc2[TN];
+        // x3, one column tile per wave: the main products of the two k-steps of a stage go to accumulators of their own
+        // (acc1 / acc3) -- an accumulation chain rounds once per matrix instruction, at the magnitude of what it holds;
+        // two chains of half the length hold the large terms half as long (the registers are there: 16 per lane)
+        constexpr bool DUALM = X3 && TN == 1;
+        floatx16 acc1[TN], acc2[TN], acc3[DUALM ? TN : 1];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc1[j][i] = 0.f, acc2[j][i] = 0.f;
+            for (int i = 0; i < 16; ++i) {
+                acc1[j][i] = 0.f, acc2[j][i] = 0.f;
+                if (DUALM) acc3[j][i] = 0.f;
+            }
+        // what the accumulators hold, as one number
+        auto comb = [&](int j, int i) -> float {
+            if (HALF) return acc1[j][i];
+            if (DUALM) return (acc1[j][i] + acc3[j][i]) + acc2[j][i];
+            if (X3) return acc1[j][i] + acc2[j][i];
+            return acc1[j][i] + acc2[j][i] * lo2;
+        };
         // Chunk boundary of an unsplit deep item: running sum = (first ? 0 : running sum) + (acc1 + acc2 / 2^11),
         // accumulators from zero again.  The running sum is kept in REGISTERS (16 TN per lane): with one step body the
         // stage loop has them to spare (round 3's first form, with its peeled loop tails, did not -- it kept the sum
@@ -800,32 +857,35 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
                 for (int i = 0; i < 16; ++i) {
                     // (the first chunk's sum is taken as it is: 0 + x would turn a -0 into +0 where the split form,
                     //  which adds the second slab to the first, keeps it)
-                    const float c = HALF ? acc1[j][i] : acc1[j][i] + acc2[j][i] * lo2;
+                    const float c = comb(j, i);
                     run[j][i] = folds > 0 ? run[j][i] + c : c;
                     acc1[j][i] = 0.f, acc2[j][i] = 0.f;
+                    if (DUALM) acc3[j][i] = 0.f;
                 }
             ++folds;
         };
 
         // the fragments of one stage in registers: two sets, the reads of stage s+1 run under the MFMAs of stage s
+        constexpr int FN = X3 ? 3 : 4;      // fragments per operand tile and register set (x3: one k-step's planes)
         struct Frags {
-            halfx8 a[4];          // [ks * 2 + plane]
-            halfx8 b[TN * 4];     // [j * 4 + ks * 2 + plane]
+            halfx8 a[FN];          // [ks * 2 + plane]; x3: [plane] of the unit's k-step (bf16 bits)
+            halfx8 b[TN * FN];     // [j * 4 + ks * 2 + plane]; x3: [j * 3 + plane]
         };
         const unsigned ringBase = (unsigned)(size_t)(cb_lds_ptr)ring;
         unsigned bAddr[TN * 4];   // LDS byte address (slot 0) of this lane's B chunk [j][ks * 2 + plane]
-#pragma unroll
+#pragma unroll                    // (x3: [j * 4 + parity of the piece pair k-step * 3 + plane], the quad by immediates)
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                bAddr[j * 4 + e] = ringBase + (bRead[j] ^ (((e >> 1) * 4 + (e & 1) * 2) << 4));
+                bAddr[j * 4 + e] = X3 ? ringBase + (bRead[j] ^ ((e & 1) << 5))
+                                      : ringBase + (bRead[j] ^ (((e >> 1) * 4 + (e & 1) * 2) << 4));
         unsigned aAddr[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) aAddr[e] = ringBase + aRead[e];
         auto readA = [&](int s, Frags& f) {
             const unsigned slot = (s % RING) * STAGE;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < FN; ++e) {
                 if (CBS_DBGBIT(16))
                     f.a[e] = halfx8{1, 1, 1, 1, 1, 1, 1, 1};
                 else
@@ -835,7 +895,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         auto readB = [&](int s, Frags& f, int j) {
             const unsigned slot = (s % RING) * STAGE;
 #pragma unroll
-            for (int e = 4 * j; e < 4 * j + 4; ++e) {
+            for (int e = FN * j; e < FN * j + FN; ++e) {
                 if (CBS_DBGBIT(8))
                     f.b[e] = halfx8{1, 1, 1, 1, 1, 1, 1, 1};
                 else
@@ -846,6 +906,43 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             readA(s, f);
 #pragma unroll
             for (int j = 0; j < TN; ++j) readB(s, f, j);
+        };
+        // x3: the fragments of UNIT (stage s, k-step KS): plane pl = piece pair e = 3 KS + pl -- weight block e of the
+        // row tile (immediate), pixel quad e / 2 (immediate), parity e & 1 (address register)
+        auto readA3 = [&](auto ksTag, int s, Frags& f) {
+            constexpr int KS = decltype(ksTag)::value;
+            const unsigned a0 = aAddr[0] + (s % RING) * STAGE;
+            constexpr int E0 = 3 * KS, E1 = 3 * KS + 1, E2 = 3 * KS + 2;
+            f.a[0] = cbs_lds_read16<(E0 / 3) * 6144 + (E0 % 3) * 1024>(a0);
+            f.a[1] = cbs_lds_read16<(E1 / 3) * 6144 + (E1 % 3) * 1024>(a0);
+            f.a[2] = cbs_lds_read16<(E2 / 3) * 6144 + (E2 % 3) * 1024>(a0);
+        };
+        auto readB3 = [&](auto ksTag, int s, Frags& f, int j) {
+            constexpr int KS = decltype(ksTag)::value;
+            const unsigned slot = (s % RING) * STAGE;
+            constexpr int E0 = 3 * KS, E1 = 3 * KS + 1, E2 = 3 * KS + 2;
+            f.b[j * 3 + 0] = cbs_lds_read16<(E0 / 2) * 1024>(bAddr[j * 4 + (E0 & 1)] + slot);
+            f.b[j * 3 + 1] = cbs_lds_read16<(E1 / 2) * 1024>(bAddr[j * 4 + (E1 & 1)] + slot);
+            f.b[j * 3 + 2] = cbs_lds_read16<(E2 / 2) * 1024>(bAddr[j * 4 + (E2 & 1)] + slot);
+        };
+        // x3: the 6 TN matrix instructions of a unit, i = j * 6 + term: the five small products into acc2, b0 w0 into acc1
+        constexpr int NM3 = 6 * TN;
+        auto mma3 = [&](auto ksTag, const Frags& f, int i0, int i1) {
+            constexpr int KS = decltype(ksTag)::value;
+            if (CBS_DBGBIT(2)) return;
+#pragma unroll
+            for (int i = i0; i < (i1 < NM3 ? i1 : NM3); ++i) {
+                const int j = i / 6, term = i % 6;
+                const int wa = term == 0 ? 2 : (term == 1 ? 0 : (term == 2 ? 1 : (term == 3 ? 1 : 0)));
+                const int xb = term == 0 ? 0 : (term == 1 ? 2 : (term == 2 ? 1 : (term == 3 ? 0 : (term == 4 ? 1 : 0))));
+                const bf16x8 av = __builtin_bit_cast(bf16x8, f.a[wa]), bv = __builtin_bit_cast(bf16x8, f.b[j * 3 + xb]);
+                if (term == 5 && DUALM && KS == 1)
+                    acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc3[j], 0, 0, 0);
+                else if (term == 5)
+                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc1[j], 0, 0, 0);
+                else
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc2[j], 0, 0, 0);
+            }
         };
         // the 6 TN matrix instructions of a stage, numbered i = (ks * TN + j) * 3 + term
         // (HALF: 4 TN, i = ks * TN + j, one product each, fragment e = k-step ks of the stage's four)
@@ -860,6 +957,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
                 }
                 return;
             }
+            if constexpr (!X3)
 #pragma unroll
             for (int i = i0; i < i1; ++i) {
                 const int ks = i / (3 * TN), j = (i / 3) % TN, term = i % 3;
@@ -874,7 +972,18 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         // s_waitcnt lgkmcnt(0) that NAMES the fragment registers it makes valid (in/out operands): nothing that
         // consumes them can be scheduled in front of it
         auto waitFrags = [&](Frags& f) {
-            if constexpr (TN == 2)
+            if constexpr (X3 && TN == 2)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]),
+                               "+v"(f.b[3]), "+v"(f.b[4]), "+v"(f.b[5])
+                             :
+                             : "memory");
+            else if constexpr (X3)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2])
+                             :
+                             : "memory");
+            else if constexpr (TN == 2)
                 asm volatile("s_waitcnt lgkmcnt(0)"
                              : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]),
                                "+v"(f.b[2]), "+v"(f.b[3]), "+v"(f.b[4]), "+v"(f.b[5]), "+v"(f.b[6]), "+v"(f.b[7])
@@ -926,6 +1035,55 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             waitFrags(FNEXT);                                                              \
         } while (0)
 
+        // x3: a stage is two UNITS (k-steps); F0 holds k-step 0, F1 k-step 1.  Half-step A multiplies (s, 0) while
+        // (s, 1) is read -- stage s is in LDS, nothing is aimed at its slot yet.  Half-step B starts with the stage's
+        // wait and barrier (stage s + 1 has landed for everybody, everybody's reads of stage s are behind their
+        // waits), issues stage s + RING into the slot of stage s, and multiplies (s, 1) while (s + 1, 0) is read.
+        typedef std::integral_constant<int, 0> KS0;
+        typedef std::integral_constant<int, 1> KS1;
+#define CBS_STEP3A(S, FCUR, FNEXT)                                                         \
+        do {                                                                               \
+            CBS_SB();                                                                      \
+            mma3(KS0(), FCUR, 0, 2);                                                              \
+            CBS_SB();                                                                      \
+            readA3(KS1(), (S), FNEXT);                                                     \
+            CBS_SB();                                                                      \
+            mma3(KS0(), FCUR, 2, 3);                                                              \
+            CBS_SB();                                                                      \
+            readB3(KS1(), (S), FNEXT, 0);                                                  \
+            CBS_SB();                                                                      \
+            mma3(KS0(), FCUR, 3, 4);                                                              \
+            CBS_SB();                                                                      \
+            if (TN > 1) readB3(KS1(), (S), FNEXT, TN - 1);                                 \
+            CBS_SB();                                                                      \
+            mma3(KS0(), FCUR, 4, NM3);                                                            \
+            waitFrags(FNEXT);                                                              \
+        } while (0)
+#define CBS_STEP3B(WAITN, S, FCUR, FNEXT)                                                  \
+        do {                                                                               \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");                  \
+            __builtin_amdgcn_s_barrier();                                                  \
+            CBS_SB();                                                                      \
+            mma3(KS1(), FCUR, 0, 2);                                                              \
+            CBS_SB();                                                                      \
+            issue((S) + RING);                                                             \
+            CBS_SB();                                                                      \
+            mma3(KS1(), FCUR, 2, 3);                                                              \
+            CBS_SB();                                                                      \
+            readA3(KS0(), (S) + 1, FNEXT);                                                 \
+            CBS_SB();                                                                      \
+            mma3(KS1(), FCUR, 3, 4);                                                              \
+            CBS_SB();                                                                      \
+            readB3(KS0(), (S) + 1, FNEXT, 0);                                              \
+            CBS_SB();                                                                      \
+            mma3(KS1(), FCUR, 4, 5);                                                              \
+            CBS_SB();                                                                      \
+            if (TN > 1) readB3(KS0(), (S) + 1, FNEXT, TN - 1);                             \
+            CBS_SB();                                                                      \
+            mma3(KS1(), FCUR, 5, NM3);                                                            \
+            waitFrags(FNEXT);                                                              \
+        } while (0)
+
         Frags F0, F1;
         CBS_STAMP_AT(2);
 #pragma unroll
@@ -933,25 +1091,45 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 1) * DPW) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        readFrags(sBeg, F0);
+        if constexpr (X3) {
+            readA3(KS0(), sBeg, F0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) readB3(KS0(), sBeg, F0, j);
+        } else {
+            readFrags(sBeg, F0);
+        }
         waitFrags(F0);
         if (t < BM) s_bias[t] = biasv;      // (read in the epilogue, many barriers later)
         CBS_STAMP_AT(3);
         int s = sBeg;
+        if constexpr (X3) {
+            for (int c = c0; c < c1; ++c) {
+                const int cEnd = chunkBeg(c + 1);
+                for (; s < cEnd; ++s) {
+                    CBS_STEP3A(s, F0, F1);
+                    CBS_STEP3B((RING - 2) * DPW, s, F1, F0);
+                }
+                if (c + 1 < c1) fold();
+            }
+        }
         // Chunks before the last one (an unsplit deep item) are whole pairs of steps and end in a fold; the last
         // chunk may end in a single step.  The last steps of the item issue dead DMAs and read a stage that does
         // not exist (a ring slot with old bytes) into the fragment set nobody multiplies.
-        for (int c = c0; c < c1; ++c) {
-            const int cEnd = chunkBeg(c + 1);
-            for (; s + 1 < cEnd; s += 2) {
-                CBS_STEP((RING - 2) * DPW, true, s, F0, F1);
-                CBS_STEP((RING - 2) * DPW, true, s + 1, F1, F0);
+        if constexpr (!X3) {
+            for (int c = c0; c < c1; ++c) {
+                const int cEnd = chunkBeg(c + 1);
+                for (; s + 1 < cEnd; s += 2) {
+                    CBS_STEP((RING - 2) * DPW, true, s, F0, F1);
+                    CBS_STEP((RING - 2) * DPW, true, s + 1, F1, F0);
+                }
+                if (c + 1 < c1) fold();
             }
-            if (c + 1 < c1) fold();
+            if (s < sEnd) CBS_STEP((RING - 2) * DPW, true, s, F0, F1);
         }
-        if (s < sEnd) CBS_STEP((RING - 2) * DPW, true, s, F0, F1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (no dead DMA lands in the ring of the next item)
 #undef CBS_STEP
+#undef CBS_STEP3A
+#undef CBS_STEP3B
 #undef CBS_SB
         __builtin_amdgcn_sched_barrier(0);      // (nothing of the epilogue -- its loads, its addresses -- up into the steps)
         CBS_STAMP_AT(4);
@@ -981,14 +1159,8 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int mq = wm * 8 + 2 * r4 + h;
-                    if (HALF)
-                        slab[mq * BN + nl] = make_float4(acc1[j][4 * r4], acc1[j][4 * r4 + 1], acc1[j][4 * r4 + 2],
-                                                         acc1[j][4 * r4 + 3]);
-                    else
-                        slab[mq * BN + nl] = make_float4(acc1[j][4 * r4] + acc2[j][4 * r4] * lo2,
-                                                         acc1[j][4 * r4 + 1] + acc2[j][4 * r4 + 1] * lo2,
-                                                         acc1[j][4 * r4 + 2] + acc2[j][4 * r4 + 2] * lo2,
-                                                         acc1[j][4 * r4 + 3] + acc2[j][4 * r4 + 3] * lo2);
+                    slab[mq * BN + nl] = make_float4(comb(j, 4 * r4), comb(j, 4 * r4 + 1), comb(j, 4 * r4 + 2),
+                                                     comb(j, 4 * r4 + 3));
                 }
             }
             CBS_STAMP_AT(5);
@@ -1004,7 +1176,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, m = m0 + ml;
-                float v = HALF ? acc1[j][r] : acc1[j][r] + acc2[j][r] * lo2;
+                float v = comb(j, r);
                 if (folds > 0) v = run[j][r] + v;        // (the last chunk joins the running sum)
                 v = fmaf(v, p.outScale, s_bias[ml]);      // (an explicit fma here, in the reduce launch and in the
                 if (p.relu) v = v <= 0.f ? 0.f : v;        //  fused tail: one rounding at all three sites)
@@ -1265,13 +1437,13 @@ int cbs_num_cus() {
     return cus;
 }
 
-template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING, bool HALF = false>
+template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING, int AR = 0>
 int cbs_launch_conv(const CbsParams& p, int perCU, const CbsTailArgs* tail, hipStream_t s) {
     if ((long)p.nSeq * p.maskWords > PRE_CAP) return CB_ERR_UNSUPPORTED;
     const bool second = p.slabs && (p.nStages >= 48 || p.forceSK > 0);
     if (tail && !second) return CB_ERR_UNSUPPORTED;      // (the fused tail reads the launch info of a deep contraction)
     dim3 grid((unsigned)(perCU * cbs_num_cus())), block(64 * WM * WN);
-    hipLaunchKernelGGL((cbs_conv_kernel<BM, BN, WM, WN, PRE_CAP, MASK_LDS, RING, HALF>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((cbs_conv_kernel<BM, BN, WM, WN, PRE_CAP, MASK_LDS, RING, AR>), grid, block, 0, s, p);
     int st = cb_launch_status();
     if (st != CB_OK) return st;
     if (tail) {
@@ -1311,12 +1483,21 @@ long cbinfer_split_state_bytes(int C, int H, int W, int kH, int kW) {
     const CbsGeom g = cbs_geom(C, H, W, kH, kW);
     return CBS_SPAD + (long)g.Hp * g.Wp * g.rec;
 }
+long cbinfer_split3_state_bytes(int C, int H, int W, int kH, int kW) {
+    const CbsGeom g = cbs_geom(C, H, W, kH, kW, 3);
+    return CBS_SPAD + (long)g.Hp * g.Wp * g.rec;
+}
 
 // prepared weights: [A fragments | stage table | pad to 16 B | plain f32 filter bank]
 static long cbs_plain_offset(long aBytes, int nStages) { return (aBytes + (long)nStages * 4 + 15) / 16 * 16; }
 long cbinfer_split_prepared_bytes(int C, int K, int kH, int kW) {
     const CbsGeom g = cbs_geom(C, 64, 64, kH, kW);
     return cbs_plain_offset((long)g.nStages * (cbs_kp(K) / 32) * 4096, g.nStages) + (long)K * C * kH * kW * 4;
+}
+// bf16-triple form: [A fragments, 6 KB per stage and 32-row tile | stage table | pad to 16 B] (no plain filter bank: no exact path)
+long cbinfer_split3_prepared_bytes(int C, int K, int kH, int kW) {
+    const CbsGeom g = cbs_geom(C, 64, 64, kH, kW, 3);
+    return cbs_plain_offset((long)g.nStages * (cbs_kp(K) / 32) * 6144, g.nStages);
 }
 
 // Workspace of a deep contraction (>= 48 stages; 0 bytes otherwise): 64 ints of launch info + one BM x BN partial
@@ -1350,13 +1531,33 @@ int cbinfer_split_prep_weights(const float* weight, void* prepared, int K, int C
                        (halfx8*)prepared, stageOff, wPlain, g, K, KP, weightScale);
     return cb_launch_status();
 }
+int cbinfer_split3_prep_weights(const float* weight, void* prepared, int K, int C, int kH, int kW, int H, int W,
+                                cbStream_t stream) {
+    CB_REQUIRE(weight && prepared && H > 0 && W > 0);
+    if (!cbs_supported(C, K, kH, kW)) return CB_ERR_UNSUPPORTED;
+    const CbsGeom g = cbs_geom(C, H, W, kH, kW, 3);
+    if ((long)g.Hp * g.Wp * g.rec >= (1l << 31)) return CB_ERR_UNSUPPORTED;
+    const int KP = cbs_kp(K);
+    const long total = (long)g.nStages * (KP / 32) * 6 * 64;
+    const long aBytes = (long)g.nStages * (KP / 32) * 6144;
+    int* stageOff = (int*)((char*)prepared + aBytes);
+    hipLaunchKernelGGL(cbs_prep_kernel, dim3(cb_div_up(total > g.nStages ? total : g.nStages, 256)), dim3(256), 0,
+                       (hipStream_t)stream, weight, (halfx8*)prepared, stageOff, (float*)nullptr, g, K, KP, 1.0f);
+    return cb_launch_status();
+}
 
-int cbinfer_split_state_init(void* splitState, int C, int H, int W, int kH, int kW, cbStream_t stream) {
+static int cbs_state_init(void* splitState, int C, int H, int W, int kH, int kW, int planes, cbStream_t stream) {
     CB_REQUIRE(splitState && H > 0 && W > 0);
     if (!cbs_supported(C, 1, kH, kW)) return CB_ERR_UNSUPPORTED;
-    const CbsGeom g = cbs_geom(C, H, W, kH, kW);
+    const CbsGeom g = cbs_geom(C, H, W, kH, kW, planes);
     hipLaunchKernelGGL(cbs_state_init_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (uint4*)splitState, g);
     return cb_launch_status();
+}
+int cbinfer_split_state_init(void* splitState, int C, int H, int W, int kH, int kW, cbStream_t stream) {
+    return cbs_state_init(splitState, C, H, W, kH, kW, 2, stream);
+}
+int cbinfer_split3_state_init(void* splitState, int C, int H, int W, int kH, int kW, cbStream_t stream) {
+    return cbs_state_init(splitState, C, H, W, kH, kW, 3, stream);
 }
 
 // splitState <- split(state): for a state the caller wrote itself (restored states); the zero border must exist
@@ -1370,18 +1571,29 @@ int cbinfer_split_state_rebuild(const float* state, void* splitState, int C, int
                        (char*)splitState, g, rangeFlag);
     return cb_launch_status();
 }
+int cbinfer_split3_state_rebuild(const float* state, void* splitState, int C, int H, int W, int kH, int kW,
+                                 cbStream_t stream) {
+    CB_REQUIRE(state && splitState && H > 0 && W > 0);
+    if (!cbs_supported(C, 1, kH, kW)) return CB_ERR_UNSUPPORTED;
+    const CbsGeom g = cbs_geom(C, H, W, kH, kW, 3);
+    hipLaunchKernelGGL(cbs_state_rebuild_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, state,
+                       (char*)splitState, g, (int*)nullptr);
+    return cb_launch_status();
+}
 
 // Detection of up to CBS_MAXSEQ sequences in one launch (see cbSplitSeq in the header).  pooled != 0: `input` is
 // the tensor in front of a 2x2/stride-2 max pool, [C,pH,pW].
 int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, int C, int H, int W,
                          int kH, int kW, float threshold, cbStream_t stream) {
-    CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && H > 0 && W > 0 && mode >= 0 && mode <= 7);
+    CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && H > 0 && W > 0 && mode >= 0 && mode <= 15);
+    const int x3 = (mode >> 3) & 1;   // bit 3 (CBINFER_SPLIT_X3): the records are bf16 triples (cbinfer_split3_state_bytes)
     const int pooled = mode & 1;      // bit 1 (CBINFER_SPLIT_COPY_ALL): not in feedback mode, every value goes to the states
     const int fg = (mode >> 2) & 1;   // bit 2 (CBINFER_SPLIT_FG): fine-grained frame, the pre-split copy takes the differences
     if (!cbs_supported(C, 1, kH, kW) || H > 65535) return CB_ERR_UNSUPPORTED;
     if (pooled) CB_REQUIRE((H == pH / 2 || H == (pH + 1) / 2) && (W == pW / 2 || W == (pW + 1) / 2));
-    const CbsGeom g = cbs_geom(C, H, W, kH, kW);
+    const CbsGeom g = cbs_geom(C, H, W, kH, kW, x3 ? 3 : 2);
     CbsDetArgs a;
+    a.planes = g.planes;
     for (int q = 0; q < nSeq; ++q) {
         CB_REQUIRE(seqs[q].input && seqs[q].state && seqs[q].splitState && seqs[q].frameMasks);
         a.seq[q].in = seqs[q].input;
@@ -1391,7 +1603,7 @@ int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int
         // (fine-grained: every record is rewritten every frame -- a segment the producer did not touch holds last frame's
         //  differences and must be zeroed: no producer-mask shortcut)
         a.seq[q].prodMask = (pooled && !fg) ? (const unsigned long long*)seqs[q].producerMask : nullptr;
-        a.seq[q].rangeFlag = seqs[q].rangeFlag;
+        a.seq[q].rangeFlag = x3 ? nullptr : seqs[q].rangeFlag;      // (bf16 triples have f32's range)
         a.seq[q].delta = seqs[q].delta;
         if (fg) CB_REQUIRE(seqs[q].delta != nullptr);
     }
@@ -1412,14 +1624,17 @@ int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int
 
 // The contraction of up to CBS_MAXSEQ sequences in one launch (+ the reduce launch of a split contraction).
 // outScale = 1 / (weightScale * 2^-4).  forceSplit > 0 overrides the k-split decision (tests, tuning).
+// weightScale == 0 selects the bf16-TRIPLE form (x3: prepared weights of cbinfer_split3_prep_weights, split states of
+// cbinfer_split3_state_bytes; no scale anywhere, outScale = 1, no range flag).
 static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
                           int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
                           const CbsTailArgs* tail, cbStream_t stream, int accumulate = 0) {
     if (workspace == nullptr && cbs_supported(C, K, kH, kW) && cbs_geom(C, H, W, kH, kW).nStages >= 48)
         return CB_ERR_BADARG;      // a deep contraction needs its workspace (cbinfer_split_workspace_bytes)
-    CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && prepared && H > 0 && W > 0 && weightScale > 0.f);
+    CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && prepared && H > 0 && W > 0 && weightScale >= 0.f);
     if (!cbs_supported(C, K, kH, kW)) return CB_ERR_UNSUPPORTED;
-    const CbsGeom g = cbs_geom(C, H, W, kH, kW);
+    const bool x3 = weightScale == 0.f;
+    const CbsGeom g = cbs_geom(C, H, W, kH, kW, x3 ? 3 : 2);
     const int KP = cbs_kp(K), BM = cbs_bm(K);
     const long MW = cbinfer_mask_words(H, W);
     if ((long)nSeq * MW > (BM >= 128 ? CBS_PRE_BIG : CBS_PRE_MID) || (long)g.Hp * g.Wp * g.rec >= (1l << 31) ||
@@ -1432,7 +1647,7 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
         // (what the exact path contracts in plain f32: the layer state -- or, fine-grained, the delta tensor)
         p.seq[q].state = accumulate ? seqs[q].delta : seqs[q].state;
         p.seq[q].reluOut = accumulate ? seqs[q].reluOut : nullptr;
-        p.seq[q].rangeFlag = p.seq[q].state ? seqs[q].rangeFlag : nullptr;      // (no f32 operand handed in: no exact path)
+        p.seq[q].rangeFlag = (p.seq[q].state && !x3) ? seqs[q].rangeFlag : nullptr;      // (no f32 operand handed in: no exact path)
         p.seq[q].out = seqs[q].output;
         p.seq[q].masks = (unsigned long long*)seqs[q].frameMasks;
         p.seq[q].listOut = seqs[q].idxOut;
@@ -1440,17 +1655,17 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
         p.seq[q].maskCopy = (unsigned long long*)seqs[q].maskCopy;
     }
     p.nSeq = nSeq;
-    p.aBytes = (long)g.nStages * (KP / 32) * 4096;
+    p.aBytes = (long)g.nStages * (KP / 32) * (x3 ? 6144 : 4096);
     p.A = (const char*)prepared;
     p.stageOff = (const int*)((const char*)prepared + p.aBytes);
-    p.wPlain = (const float*)((const char*)prepared + cbs_plain_offset(p.aBytes, g.nStages));
+    p.wPlain = x3 ? nullptr : (const float*)((const char*)prepared + cbs_plain_offset(p.aBytes, g.nStages));
     p.bias = bias;
     p.info = workspace ? (int*)workspace : nullptr;
     p.slabs = workspace ? (float*)((char*)workspace + 256) : nullptr;
     p.K = K, p.KP = KP, p.H = H, p.W = W, p.Wp = g.Wp, p.rec = g.rec, p.nStages = g.nStages, p.kH = kH, p.kW = kW;
     p.maskWords = (int)MW, p.wpr = cbinfer_mask_words_per_row(W), p.relu = relu, p.dummyBase = g.dummyBase;
     p.stateBytes = (long)g.Hp * g.Wp * g.rec;
-    p.outScale = 1.0f / (weightScale * CBS_XSCALE);
+    p.outScale = x3 ? 1.0f : 1.0f / (weightScale * CBS_XSCALE);
     p.magicMW = (1ull << 32) / (unsigned long long)MW + 1ull;
     p.magicWpr = (1ull << 32) / (unsigned long long)p.wpr + 1ull;
     p.magicW = (1ull << 32) / (unsigned long long)W + 1ull;
@@ -1477,6 +1692,18 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
     // itself (items <= grid <= 2 CUs) always fits, a forced one (forceSplit: tests, tuning) is refused beyond it
     const long cap = cbs_slab_capacity(nSeq, H, W, K);
     p.slabCap = (int)(cap > 0x7fffffffl ? 0x7fffffffl : cap);
+    if (x3) {
+        // bf16 triples: 48 KB stages (128-row tile, three in the ring, the mask words in LDS while they and their prefix
+        // fit beside it: six 80x120 sequences) / 24 KB stages (64-row tile: five alone on a CU, three when two
+        // workgroups share one)
+        if (BM == 128) {
+            if ((long)nSeq * MW <= CBS_PRE_X3) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_X3, true, 3, 2>(p, 1, tail, s);
+            return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG, false, 3, 2>(p, 1, tail, s);
+        }
+        if (nSeq == 1 && MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 5, 2>(p, 1, tail, s);
+        if ((long)nSeq * MW <= CBS_PRE_SMALL) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, false, 3, 2>(p, 2, tail, s);
+        return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 5, 2>(p, 1, tail, s);
+    }
     if (BM == 128) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG, true, 4>(p, 1, tail, s);
     // The 64-row tile moves 16 KB per stage, and what bounds its stage rate is the DMA in flight on the CU (bytes in
     // flight / latency): one sequence rarely has more tiles than there are CUs, so it runs one workgroup per CU with
@@ -1541,6 +1768,7 @@ int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int mode, int p
                                cbStream_t stream) {
     CB_REQUIRE(tail);
     if (!cbinfer_split_tail_supported(C, K, kH, kW, tail->C1, tail->C2)) return CB_ERR_UNSUPPORTED;
+    mode = (mode & ~CBINFER_SPLIT_X3) | (weightScale == 0.f ? CBINFER_SPLIT_X3 : 0);
     const int st = cbinfer_split_detect(seqs, nSeq, mode, pH, pW, C, H, W, kH, kW, threshold, stream);
     if (st != CB_OK) return st;
     return cbinfer_split_conv_tail(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace,
@@ -1557,7 +1785,8 @@ int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int mode, int p
 int cbinfer_split_forward_fg(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared, int C,
                              int H, int W, int K, int kH, int kW, float threshold, float weightScale, void* workspace,
                              cbStream_t stream) {
-    const int st = cbinfer_split_detect(seqs, nSeq, CBINFER_SPLIT_FG | (pooled ? CBINFER_SPLIT_POOLED : 0), pH, pW, C, H, W,
+    const int st = cbinfer_split_detect(seqs, nSeq, CBINFER_SPLIT_FG | (pooled ? CBINFER_SPLIT_POOLED : 0) |
+                                        (weightScale == 0.f ? CBINFER_SPLIT_X3 : 0), pH, pW, C, H, W,
                                         kH, kW, threshold, stream);
     if (st != CB_OK) return st;
     return cbs_split_conv(seqs, nSeq, prepared, nullptr, C, H, W, K, kH, kW, weightScale, 0, workspace, 0, nullptr,
@@ -1569,6 +1798,7 @@ int cbinfer_split_forward_fg(const cbSplitSeq* seqs, int nSeq, int pooled, int p
 int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, const void* prepared,
                           const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
                           float weightScale, int relu, void* workspace, cbStream_t stream) {
+    mode = (mode & ~CBINFER_SPLIT_X3) | (weightScale == 0.f ? CBINFER_SPLIT_X3 : 0);
     const int st = cbinfer_split_detect(seqs, nSeq, mode, pH, pW, C, H, W, kH, kW, threshold, stream);
     if (st != CB_OK) return st;
     return cbs_split_conv(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace, 0, nullptr,
@@ -1948,8 +2178,8 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int 
     const long cap = cbs_slab_capacity(1, H, W, K);
     p.slabCap = (int)(cap > 0x7fffffffl ? 0x7fffffffl : cap);
     if (BM == 128) {
-        if (MW <= CBS_PRE_BIG) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG, true, 4, true>(p, 1, nullptr, s);
-        return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_MID, false, 4, true>(p, 1, nullptr, s);
+        if (MW <= CBS_PRE_BIG) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG, true, 4, 1>(p, 1, nullptr, s);
+        return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_MID, false, 4, 1>(p, 1, nullptr, s);
     }
     if (MW <= CBS_PRE_SMALL) {
         // (two workgroups per CU with four-stage rings: these contractions are shallow -- 9 to 36 stages -- and a layer
@@ -1959,8 +2189,8 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int 
             const char* e = getenv("CBINFER_HSPLIT_TWO_PER_CU");
             two = e ? atoi(e) : 1;
         }
-        if (two) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 4, true>(p, 2, nullptr, s);
-        return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 8, true>(p, 1, nullptr, s);
+        if (two) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 4, 1>(p, 2, nullptr, s);
+        return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 8, 1>(p, 1, nullptr, s);
     }
     // (a large map -- OpenPose's 64-channel 368x654 layer: 541 tiles of nine stages at 14 % change -- has more tiles than
     //  CUs and little depth: two workgroups per CU with three-stage rings (68 KB each beside the 20 KB prefix))
@@ -1969,8 +2199,8 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int 
         const char* e = getenv("CBINFER_HSPLIT_BIG2");
         big2 = e ? atoi(e) : 1;
     }
-    if (big2) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 3, true>(p, 2, nullptr, s);
-    return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 8, true>(p, 1, nullptr, s);
+    if (big2) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 3, 1>(p, 2, nullptr, s);
+    return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 8, 1>(p, 1, nullptr, s);
 }
 
 }  // extern "C"

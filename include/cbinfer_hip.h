@@ -54,8 +54,10 @@ typedef void* cbStream_t; /* hipStream_t */
  * (cbinfer_cbconv2d_forward_fg_masked and its parts).  4: split-state frame (cbinfer_split_*, several sequences
  * per launch), cbinfer_tail1x1_supported.  5: cbinfer_split_forward_tail (the 1x1 tail in the contraction's second
  * launch), cbinfer_split_tail_supported.  6: row-pair frame (cbinfer_*rowpairs*), cbinfer_dilate_change_indexes,
- * updateInputState = 2.  7: chained layers (cbinfer_*_after: the producer's change count ends an idle frame). */
-#define CBINFER_ABI_VERSION 7
+ * updateInputState = 2.  7: chained layers (cbinfer_*_after: the producer's change count ends an idle frame).
+ * 8: the f32-EQUIVALENT (bf16-triple) form of the split-state frame: cbinfer_split3_*, CBINFER_SPLIT_X3,
+ * weightScale == 0, cbNextDetect.arith. */
+#define CBINFER_ABI_VERSION 8
 
 int cbinfer_abi_version(void);
 const char* cbinfer_status_string(int status);
@@ -414,11 +416,22 @@ int cbinfer_tail1x1(const float* input, const int32_t* changeList, int numChange
  * mode and keeps a copy of its input (feedbackLoop=False, copyInput=True: what convert() makes, conv2d.py:234-236,
  * `prevInput.copy_(input)`): the detection writes EVERY value of the frame into prevInput and into the pre-split
  * copy, not only those of the changed pixels -- the gather then reads this frame's input everywhere, as the
- * reference's does. */
+ * reference's does.
+ *
+ * The f32-EQUIVALENT form (round 5, "x3"): the same frame with every f32 operand kept as THREE bf16 terms, exactly
+ * (x = b0 + b1 + b2, 8 significant bits each; bf16 has f32's exponent range: no scale, no range flag), and a product
+ * made of the six term products above 2^-24 of it on the bf16 MFMA -- b0 w0 in one f32 accumulator, the five small
+ * ones in a second, summed at the end: operands of 24 bits as conv2d_cg.py:342-349's sgemm has them, with FEWER
+ * accumulation roundings than its fma chain (one per 16 k).  Records are 96 bytes per 16 channels, weights 6 KB per
+ * stage and 32-row tile.  Selected by: the cbinfer_split3_* functions for the buffers (state bytes / init / rebuild,
+ * prepared bytes / prep_weights), mode bit 3 (CBINFER_SPLIT_X3) of cbinfer_split_detect, and weightScale == 0 wherever
+ * a frame function takes a weightScale (the triple form has none; cbinfer_split_forward[_tail,_fg] derive the
+ * detection's mode bit from it).  rangeFlag is not used.  Workspace as for the pair form. */
 #define CBINFER_SPLIT_MAX_SEQUENCES 8
 #define CBINFER_SPLIT_POOLED 1
 #define CBINFER_SPLIT_COPY_ALL 2
 #define CBINFER_SPLIT_FG 4        /* cbinfer_split_detect only: the fine-grained frame's detection (cbinfer_split_forward_fg) */
+#define CBINFER_SPLIT_X3 8        /* the split state holds bf16 triples (cbinfer_split3_state_bytes) */
 typedef struct {
     const float* input;           /* this frame's layer input (or the pool's input) */
     float* state;                 /* prevInput [C,H,W] */
@@ -446,6 +459,13 @@ int cbinfer_split_prep_weights(const float* weight, void* prepared, int K, int C
 int cbinfer_split_state_init(void* splitState, int C, int H, int W, int kH, int kW, cbStream_t stream);
 int cbinfer_split_state_rebuild(const float* state, void* splitState, int C, int H, int W, int kH, int kW,
                                 int32_t* rangeFlag, cbStream_t stream);
+long cbinfer_split3_state_bytes(int C, int H, int W, int kH, int kW);
+long cbinfer_split3_prepared_bytes(int C, int K, int kH, int kW);
+int cbinfer_split3_prep_weights(const float* weight, void* prepared, int K, int C, int kH, int kW, int H, int W,
+                                cbStream_t stream);
+int cbinfer_split3_state_init(void* splitState, int C, int H, int W, int kH, int kW, cbStream_t stream);
+int cbinfer_split3_state_rebuild(const float* state, void* splitState, int C, int H, int W, int kH, int kW,
+                                 cbStream_t stream);
 int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, int C, int H, int W,
                          int kH, int kW, float threshold, cbStream_t stream);
 int cbinfer_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
@@ -553,11 +573,12 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int 
  *   next            : may be NULL (or next->state NULL): no folding */
 typedef struct {
     float* state;             /* the next layer's prevInput [K, H, W] */
-    void* splitState;         /* its cbinfer_split_state_bytes(K, H, W, kH, kW) buffer */
+    void* splitState;         /* its cbinfer_split_state_bytes(K, H, W, kH, kW) buffer (arith 1: cbinfer_split3_state_bytes) */
     uint64_t* frameMasks;     /* its frame mask (cbSplitSeq.frameMasks) */
     int32_t* rangeFlag;       /* may be NULL */
     int H, W, kH, kW;         /* the next layer's map size (behind the pool) and filter */
     float threshold;
+    int arith;                /* 0: its split state holds f16 pairs, 1: bf16 triples (cbinfer_split3_*) */
 } cbNextDetect;
 typedef struct {                /* ONE sequence's tensors for the batched form (own state each, shared weights) */
     const float* state;         /* prevInput [C,H,W] */

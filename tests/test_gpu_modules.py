@@ -1315,11 +1315,14 @@ def test_module_leaves_and_reenters_the_split_path(pkg, oracle):
     assert ran == [True, True, True, False, False, True, True, False, False, False, True, False, True, True], ran
 
 
-def test_module_range_flag_falls_back(pkg, oracle):
-    """VERDICT round 3, 1(c) at module level: one state value >= 2^20.  The frame that brings it is already right
-    (the contraction launch computes the layer from prevInput in plain f32 once the detection has raised the flag),
-    the module reports it (rangeExceeded), and within a few polls (no sync) it moves the layer to the bf16x3 kernels
-    for good; every frame against the oracle."""
+@pytest.mark.parametrize("arith", ["f16x2", "x3"])
+def test_module_range_flag_falls_back(pkg, oracle, monkeypatch, arith):
+    """VERDICT round 3, 1(c) at module level: one state value >= 2^20.  f16 pairs (CBINFER_ARITH=f16x2): the frame that
+    brings it is already right (the contraction launch computes the layer from prevInput in plain f32 once the detection
+    has raised the flag), the module reports it (rangeExceeded), and within a few polls (no sync) it moves the layer to
+    the bf16x3 kernels for good.  bf16 triples (the default): f32's range -- nothing trips, the layer stays on the
+    split-state kernels.  Every frame against the oracle."""
+    monkeypatch.setenv("CBINFER_ARITH", arith)
     rng = np.random.default_rng(43)
     C, K, H, W = 16, 64, 40, 64
     conv = nn.Conv2d(C, K, 7, padding=3).cuda().eval()
@@ -1349,8 +1352,11 @@ def test_module_range_flag_falls_back(pkg, oracle):
                 o.forward(x)
             if t == 2:
                 assert not m.rangeExceeded()
-            if t == 3:
+            if t == 3 and arith == "f16x2":
                 assert m.rangeExceeded() and not m.__dict__.get('_rangeFallback')
+    if arith == "x3":
+        assert not m.rangeExceeded() and m._split_ok(torch.float32, H, W) and m._plan.get('split')
+        return
     assert m.__dict__.get('_rangeFallback') and m.rangeExceeded()
     assert not m._split_ok(torch.float32, H, W)
     pkg.clearMemory(m)

@@ -86,11 +86,13 @@ def test_rowpairs_contraction_vs_oracle(lib, oracle, C, K, k, H, W):
     assert np.array_equal(out.cpu().numpy(), got) and int(copy.abs().sum().item()) == 0
 
 
+@pytest.mark.parametrize("x3", [True, False])
 @pytest.mark.parametrize("H,W,ceil,k2", [(64, 96, False, 7), (45, 67, False, 7), (45, 67, True, 3), (90, 200, False, 5)])
-def test_rowpairs_folded_detection_equals_separate_launch(lib, oracle, H, W, ceil, k2):
+def test_rowpairs_folded_detection_equals_separate_launch(lib, oracle, H, W, ceil, k2, x3):
     """The next layer's pooled change detection inside the row-pair launch against cbinfer_split_detect (pooled, with
     the producer's mask) fed the same outputs: the next layer's f32 state, its pre-split copy, its frame mask and its
-    range flag bit-identical over a sequence of frames; floor and ceil pooling of odd maps."""
+    range flag bit-identical over a sequence of frames; floor and ceil pooling of odd maps; the next layer's records as
+    bf16 triples (x3: no range flag) and as f16 pairs."""
     C_ = lib.C
     rng = np.random.default_rng(H + W)
     C, K, k = 3, 16, 7
@@ -110,17 +112,26 @@ def test_rowpairs_folded_detection_equals_separate_launch(lib, oracle, H, W, cei
             self.ctl = torch.zeros(words, dtype=torch.int32, device="cuda")
             self.copy = torch.zeros(words, dtype=torch.int64, device="cuda")
             self.state2 = torch.full((1, K, H2, W2), float("inf"), device="cuda")
-            self.S2 = torch.empty(C_.cbinfer_split_state_bytes(K, H2, W2, k2, k2), dtype=torch.uint8, device="cuda")
-            lib.check(C_.cbinfer_split_state_init(self.S2.data_ptr(), K, H2, W2, k2, k2, None))
             self.flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-            lib.check(C_.cbinfer_split_state_rebuild(self.state2.data_ptr(), self.S2.data_ptr(), K, H2, W2, k2, k2,
-                                                     self.flag.data_ptr(), None))
+            if x3:
+                self.S2 = torch.empty(C_.cbinfer_split3_state_bytes(K, H2, W2, k2, k2), dtype=torch.uint8,
+                                      device="cuda")
+                lib.check(C_.cbinfer_split3_state_init(self.S2.data_ptr(), K, H2, W2, k2, k2, None))
+                lib.check(C_.cbinfer_split3_state_rebuild(self.state2.data_ptr(), self.S2.data_ptr(), K, H2, W2, k2,
+                                                          k2, None))
+            else:
+                self.S2 = torch.empty(C_.cbinfer_split_state_bytes(K, H2, W2, k2, k2), dtype=torch.uint8,
+                                      device="cuda")
+                lib.check(C_.cbinfer_split_state_init(self.S2.data_ptr(), K, H2, W2, k2, k2, None))
+                lib.check(C_.cbinfer_split_state_rebuild(self.state2.data_ptr(), self.S2.data_ptr(), K, H2, W2, k2,
+                                                         k2, self.flag.data_ptr(), None))
             self.mask2 = torch.zeros(C_.cbinfer_frame_mask_bytes(H2, W2) // 8, dtype=torch.int64, device="cuda")
 
     fo, se = Side(), Side()
     nd = lib.NextDetect()
     nd.state, nd.splitState, nd.frameMasks = fo.state2.data_ptr(), fo.S2.data_ptr(), fo.mask2.data_ptr()
     nd.rangeFlag, nd.H, nd.W, nd.kH, nd.kW, nd.threshold = fo.flag.data_ptr(), H2, W2, k2, k2, 0.07
+    nd.arith = 1 if x3 else 0
     seq = (lib.SplitSeq * 1)()
     x = rng.standard_normal((1, C, H, W)).astype(np.float32)
     total2 = 0
@@ -147,13 +158,13 @@ def test_rowpairs_folded_detection_equals_separate_launch(lib, oracle, H, W, cei
         s.input, s.state, s.splitState = se.out.data_ptr(), se.state2.data_ptr(), se.S2.data_ptr()
         s.frameMasks, s.rangeFlag = se.mask2.data_ptr(), se.flag.data_ptr()
         s.producerMask = se.copy.data_ptr() if t > 0 else None
-        lib.check(C_.cbinfer_split_detect(seq, 1, 1, H, W, K, H2, W2, k2, k2, 0.07, None))
+        lib.check(C_.cbinfer_split_detect(seq, 1, 1 | (8 if x3 else 0), H, W, K, H2, W2, k2, k2, 0.07, None))
         torch.cuda.synchronize()
         assert torch.equal(fo.out, se.out) and torch.equal(fo.state, se.state) and torch.equal(fo.copy, se.copy), t
         assert torch.equal(fo.state2, se.state2), t
         assert torch.equal(fo.mask2, se.mask2), t
         assert torch.equal(fo.S2, se.S2), t
-        assert int(fo.flag.item()) == int(se.flag.item()) == (1 if t >= 4 else 0), t
+        assert int(fo.flag.item()) == int(se.flag.item()) == (1 if t >= 4 and not x3 else 0), t
         # ... and against the oracle: pooled outputs vs the refreshed state, strict >, dilation
         n2 = int(torch.count_nonzero(fo.mask2[:words2]).item())
         total2 += n2

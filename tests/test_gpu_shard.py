@@ -35,8 +35,9 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     out = subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, lines                    # rank 0 alone prints, one line
-    r = json.loads(lines[0])
+    # rank 0 alone prints: the details object, then -- the FINAL line, what the driver parses -- the compact record
+    assert len(lines) == 2 and lines[0].startswith('{"bench_details"') and len(lines[1]) < 4096, lines
+    r = json.loads(lines[-1])
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 0
     assert r["steps"] % 20 == 0 and r["steps"] >= 20   # the agreed repeat count times the requested steps
     assert r["config"]["launch"] in ("graph", "eager")
@@ -69,7 +70,7 @@ def test_bench_control_flow_over_rccl_with_one_rank():
     out = subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, lines
-    r = json.loads(lines[0])
+    assert len(lines) == 2 and lines[0].startswith('{"bench_details"') and len(lines[1]) < 4096, lines
+    r = json.loads(lines[-1])
     assert r["config"]["dist_backend"] == "nccl" and r["n_gpus"] == 1 and r["value"] > 0
     assert r["steps"] % 20 == 0 and r["config"]["launch"] in ("graph", "eager")

@@ -1,5 +1,7 @@
 """-m gpu tests of the split-state kernels (cb_split.hip) through the C ABI: detection + refresh of both states,
-the LDS-DMA contraction in f16-pair arithmetic, the k-split and its invariance, several sequences per launch.
+the LDS-DMA contraction in BOTH arithmetics -- bf16 triples ("x3": f32-equivalent, the default since round 5) and f16
+pairs (every test below runs once per arithmetic unless it says otherwise) --, the k-split and its invariance,
+several sequences per launch.
 Reference behaviour: cbconv2d_cg_backend.cu:40-81 (detection, feedback refresh), :138-197 + conv2d_cg.py:342-349
 (gather, contraction, scatter) as restated by the oracle."""
 import math
@@ -24,20 +26,38 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+ARITH = "x3"
+
+
+@pytest.fixture(scope="module", autouse=True, params=["x3", "f16x2"])
+def arith(request):
+    """Every test of this module once per arithmetic of the split-state kernels (Layer picks it up)."""
+    global ARITH
+    ARITH = request.param
+    yield request.param
+    ARITH = "x3"
+
+
 class Layer(object):
     """Buffers of one layer for nSeq sequences + the calls, as CBConv2d._forward_split makes them."""
 
-    def __init__(self, lib, w, b, H, W, nSeq=1, pooled=None):
+    def __init__(self, lib, w, b, H, W, nSeq=1, pooled=None, arith=None):
         C_ = lib.C
         self.lib, self.nSeq, self.H, self.W = lib, nSeq, H, W
         self.K, self.C, self.kH, self.kW = w.shape
         self.w, self.b = dev(w), dev(b)
-        wmax = float(np.abs(w).max())
-        self.scale = 2.0 ** (13 - math.floor(math.log2(wmax)))
+        self.x3 = x3 = (arith or ARITH) == "x3"
         K, Cc, kH, kW = w.shape
-        self.wp = torch.empty(C_.cbinfer_split_prepared_bytes(Cc, K, kH, kW), dtype=torch.uint8, device="cuda")
-        lib.check(C_.cbinfer_split_prep_weights(self.w.data_ptr(), self.wp.data_ptr(), K, Cc, kH, kW, H, W,
-                                                 self.scale, None))
+        if x3:      # bf16 triples: no scale (0.0 tells the frame functions which form the buffers hold)
+            self.scale = 0.0
+            self.wp = torch.empty(C_.cbinfer_split3_prepared_bytes(Cc, K, kH, kW), dtype=torch.uint8, device="cuda")
+            lib.check(C_.cbinfer_split3_prep_weights(self.w.data_ptr(), self.wp.data_ptr(), K, Cc, kH, kW, H, W, None))
+        else:
+            wmax = float(np.abs(w).max())
+            self.scale = 2.0 ** (13 - math.floor(math.log2(wmax)))
+            self.wp = torch.empty(C_.cbinfer_split_prepared_bytes(Cc, K, kH, kW), dtype=torch.uint8, device="cuda")
+            lib.check(C_.cbinfer_split_prep_weights(self.w.data_ptr(), self.wp.data_ptr(), K, Cc, kH, kW, H, W,
+                                                     self.scale, None))
         words = C_.cbinfer_mask_words(H, W)
         wsb = C_.cbinfer_split_workspace_bytes(nSeq, Cc, H, W, K, kH, kW)
         self.ws = torch.zeros(wsb, dtype=torch.uint8, device="cuda") if wsb else None
@@ -47,11 +67,14 @@ class Layer(object):
         self.pooled = pooled
         for q in range(nSeq):
             self.state.append(torch.full((1, Cc, H, W), float("inf"), device="cuda"))
-            S = torch.empty(C_.cbinfer_split_state_bytes(Cc, H, W, kH, kW), dtype=torch.uint8, device="cuda")
-            lib.check(C_.cbinfer_split_state_init(S.data_ptr(), Cc, H, W, kH, kW, None))
-            lib.check(C_.cbinfer_split_state_rebuild(self.state[q].data_ptr(), S.data_ptr(), Cc, H, W, kH, kW,
-                                                     self.flag.data_ptr(), None))
+            if x3:
+                S = torch.empty(C_.cbinfer_split3_state_bytes(Cc, H, W, kH, kW), dtype=torch.uint8, device="cuda")
+                lib.check(C_.cbinfer_split3_state_init(S.data_ptr(), Cc, H, W, kH, kW, None))
+            else:
+                S = torch.empty(C_.cbinfer_split_state_bytes(Cc, H, W, kH, kW), dtype=torch.uint8, device="cuda")
+                lib.check(C_.cbinfer_split_state_init(S.data_ptr(), Cc, H, W, kH, kW, None))
             self.S.append(S)
+            self.rebuild(q)
             self.masks.append(torch.zeros(C_.cbinfer_frame_mask_bytes(H, W) // 8, dtype=torch.int64, device="cuda"))
             self.out.append(torch.full((1, K, H, W), float("inf"), device="cuda"))
             self.idx.append(torch.zeros(H * W, dtype=torch.int32, device="cuda"))
@@ -62,14 +85,23 @@ class Layer(object):
             s.output, s.idxOut, s.countOut = self.out[q].data_ptr(), self.idx[q].data_ptr(), self.cnt[q].data_ptr()
             s.rangeFlag, s.maskCopy = self.flag.data_ptr(), self.copy[q].data_ptr()
 
+    def rebuild(self, q=0):
+        """The split state of sequence q made again from its f32 state."""
+        C_, a = self.lib.C, (self.C, self.H, self.W, self.kH, self.kW)
+        if self.x3:
+            self.lib.check(C_.cbinfer_split3_state_rebuild(self.state[q].data_ptr(), self.S[q].data_ptr(), *a, None))
+        else:
+            self.lib.check(C_.cbinfer_split_state_rebuild(self.state[q].data_ptr(), self.S[q].data_ptr(), *a,
+                                                          self.flag.data_ptr(), None))
+
     def frame(self, inputs, th, relu=False, force=0, prodMasks=None):
         C_ = self.lib.C
         for q, x in enumerate(inputs):
             self.seqs[q].input = x.data_ptr()
             self.seqs[q].producerMask = prodMasks[q].data_ptr() if prodMasks else None
         pH, pW = (inputs[0].shape[-2], inputs[0].shape[-1]) if self.pooled else (0, 0)
-        self.lib.check(C_.cbinfer_split_detect(self.seqs, self.nSeq, int(bool(self.pooled)), pH, pW, self.C, self.H,
-                                               self.W, self.kH, self.kW, th, None))
+        self.lib.check(C_.cbinfer_split_detect(self.seqs, self.nSeq, int(bool(self.pooled)) | (8 if self.x3 else 0),
+                                               pH, pW, self.C, self.H, self.W, self.kH, self.kW, th, None))
         self.lib.check(C_.cbinfer_split_conv(self.seqs, self.nSeq, self.wp.data_ptr(), self.b.data_ptr(), self.C,
                                              self.H, self.W, self.K, self.kH, self.kW, self.scale, int(relu),
                                              self.ws.data_ptr() if self.ws is not None else None, force, None))
@@ -144,9 +176,11 @@ def test_split_arithmetic_accuracy(lib, oracle, C, K, H, W):
     mag = (np.abs(X).astype(np.float64) @ np.abs(w.reshape(K, -1)).astype(np.float64).T).T.reshape(1, K, H, W)
     err = np.abs(L.out[0].cpu().numpy().astype(np.float64) - Y)
     rel = (err / (mag + 1e-30)).max()
-    print("C%d K%d: max |err| %.3g, relative to sum|a||b| %.3g (2^%.1f)" % (C, K, err.max(), rel, np.log2(rel)))
+    print("%s C%d K%d: max |err| %.3g, relative to sum|a||b| %.3g (2^%.1f)" % (ARITH, C, K, err.max(), rel, np.log2(rel)))
     assert np.all(err <= 64 * 2.0 ** -24 * mag + 1e-30)
     assert rel <= 8 * 2.0 ** -22
+    if L.x3:      # exact operands; what is left is one rounding per 16-k block sum + the dropped terms (< 2^-25 each)
+        assert rel <= 2.0 ** -21
 
 
 def test_split_is_invariant_under_the_k_split(lib, oracle):
@@ -238,8 +272,7 @@ def test_split_state_rebuild_and_range_flag(lib, oracle):
     # overwrite the state with another frame, re-split, and present a frame that differs in a few pixels only
     y = dev(rng.standard_normal((1, C, H, W)).astype(np.float32))
     L.state[0].copy_(y)
-    lib.check(lib.C.cbinfer_split_state_rebuild(L.state[0].data_ptr(), L.S[0].data_ptr(), C, H, W, 7, 7,
-                                                L.flag.data_ptr(), None))
+    L.rebuild(0)
     y2 = y.clone()
     y2[0, :, 5:9, 7:12] += 1.0
     L.frame([y2], 0.1)
@@ -255,7 +288,17 @@ def test_split_state_rebuild_and_range_flag(lib, oracle):
     y3 = y2.clone()
     y3[0, 3, 0, 0] = 3e6
     L.frame([y3], 0.1)
-    assert int(L.flag.item()) == 1
+    if not L.x3:
+        assert int(L.flag.item()) == 1
+        return
+    # bf16 triples have f32's range: no flag, and the huge value is simply an operand
+    assert int(L.flag.item()) == 0
+    got = o.forward(y3.cpu().numpy())
+    n = got[2]
+    assert np.array_equal(L.list(), n)
+    out = L.out[0].cpu().numpy().reshape(K, -1)[:, n].astype(np.float64)
+    mag = _sum_abs(oracle, o.prevInput, w, n, 7, 7).T + np.abs(b)[:, None]
+    assert np.all(np.abs(out - o.prevOutput.reshape(K, -1)[:, n]) <= 64 * 2.0 ** -24 * mag)
 
 
 def test_split_module_reports_range_and_survives_state_restore(lib):
@@ -359,6 +402,9 @@ def test_split_range_flag_acts(lib, oracle, C, K, H, W, nSeq, tail):
     f32 chain's bound, in that frame and in the frames behind it (the flag is sticky), for one sequence and for two in
     one launch, with and without the fused 1x1 tail in the second launch (the unsplit form of that launch)."""
     import ctypes
+    if ARITH == "x3":
+        pytest.skip("the range flag belongs to the f16-pair form (bf16 triples have f32's range: "
+                    "test_split_state_rebuild_and_range_flag covers a huge operand there)")
     C_ = lib.C
     rng = np.random.default_rng(C + K + nSeq)
     w = (rng.standard_normal((K, C, 7, 7)) / np.sqrt(C * 49)).astype(np.float32)
@@ -447,13 +493,16 @@ def test_split_forced_k_split_respects_the_workspace(lib, oracle):
 
 @pytest.mark.parametrize("C,K,H,W", [(64, 256, 80, 120), (16, 64, 160, 240)])
 def test_split_hostile_data_accuracy_fullsize(lib, oracle, C, K, H, W, capsys):
-    """the two split-state layers of the bench network at FULL size on hostile data --
-    activations spanning 2^-20 ... 2^19 with ReLU-like sparsity, heavy-tailed weights -- against the double-accumulated
-    oracle, the f16-pair kernel and the library's exact-f32 MFMA kernel (CB_F32) and bf16x3 kernel (CB_F32S) side by
-    side, every pixel changed.  Reported: max |err| / sum|a||b| of each.  Asserted: the f16-pair form within
-    4 * 2^-22 * sum|a||b| + 2^-20 * sum|b| (the relative bound of 22-23 significant bits per operand plus the absolute
-    floor of terms dropped below the f16 normal range: activations below 2^-10 keep 11 bits), and no worse than 16x the
-    exact f32 chain's own error."""
+    """the two split-state layers of the bench network at FULL size on hostile
+    data -- activations spanning 2^-20 ... 2^19 with ReLU-like sparsity, heavy-tailed weights -- against the
+    double-accumulated oracle: the bf16-TRIPLE split-state kernel (the default, f32-equivalent), the f16-pair one, and
+    the library's exact-f32 MFMA kernel (CB_F32: the f32 fma chain, what conv2d_cg.py:342-349's sgemm does) and
+    rounds 1-2's bf16x3 kernel (CB_F32S) side by side, every pixel changed.  Reported: max |err| / sum|a||b| of each.
+    Asserted: the triple form's error is NO LARGER than the exact f32 chain's on both layers (its operands are exact
+    and it rounds once per 16-k block sum where the chain rounds once per product); the f16-pair form within
+    4 * 2^-22 * sum|a||b| (22-23 significant bits per operand) and no worse than 16x the chain's."""
+    if ARITH != "x3":
+        pytest.skip("one run compares all arithmetics")
     from cbinfer_amd import conv2d_cg, _lib as L_
     rng = np.random.default_rng(C * 7 + K)
     mag_x = np.exp2(rng.uniform(-20, 19, (1, C, H, W)))
@@ -462,11 +511,14 @@ def test_split_hostile_data_accuracy_fullsize(lib, oracle, C, K, H, W, capsys):
     x = np.minimum(x, np.float32(2.0 ** 19.9))
     w = (rng.standard_t(2.5, (K, C, 7, 7)) / np.sqrt(C * 49)).astype(np.float32)           # heavy tails
     b = rng.standard_normal(K).astype(np.float32)
-    Ly = Layer(lib, w, b, H, W)
+    Ly = Layer(lib, w, b, H, W, arith="f16x2")
     Ly.frame([dev(x)], 0.0)
     assert int(Ly.flag.item()) == 0
     idx = np.arange(H * W, dtype=np.int32)
     assert np.array_equal(Ly.list(), idx)
+    L3 = Layer(lib, w, b, H, W, arith="x3")
+    L3.frame([dev(x)], 0.0)
+    assert np.array_equal(L3.list(), idx)
     X = oracle.genXMatrix(x, idx, (7, 7)).astype(np.float64)
     wm = w.reshape(K, -1).astype(np.float64)
     Y = (X @ wm.T + b[None, :].astype(np.float64)).T.reshape(K, H * W)
@@ -474,6 +526,7 @@ def test_split_hostile_data_accuracy_fullsize(lib, oracle, C, K, H, W, capsys):
     sumw = np.abs(wm).sum(axis=1)[:, None]
     del X
     res = {}
+    res["x3 split-state (bf16 triples)"] = np.abs(L3.out[0].cpu().numpy().reshape(K, -1).astype(np.float64) - Y)
     res["f16x2 split-state"] = np.abs(Ly.out[0].cpu().numpy().reshape(K, -1).astype(np.float64) - Y)
     xd, wd, bd = dev(x), dev(w), dev(b)
     idxd = torch.arange(H * W, dtype=torch.int32, device="cuda")
@@ -497,3 +550,6 @@ def test_split_hostile_data_accuracy_fullsize(lib, oracle, C, K, H, W, capsys):
     split = res["f16x2 split-state"]
     assert np.all(split <= 4 * 2.0 ** -22 * mag + 1e-30)
     assert rel["f16x2 split-state"] <= 16 * max(rel["exact f32 MFMA"], 2.0 ** -24)
+    # the f32-equivalent form: no worse than the f32 fma chain itself
+    assert rel["x3 split-state (bf16 triples)"] <= rel["exact f32 MFMA"], rel
+    assert res["x3 split-state (bf16 triples)"].max() <= res["exact f32 MFMA"].max() * 1.05 + 1e-30

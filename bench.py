@@ -41,6 +41,25 @@ BF16X3_CEILING_TFLOPS = F16_MFMA_PEAK_TFLOPS / 6     # ... on bf16 triples: six
 HBM_PEAK_GBS = 8000.0
 
 
+def split_arith():
+    """Arithmetic of the fp32 split-state kernels in this process: 'x3' (bf16 triples, f32-equivalent; the default),
+    'f16x2' (f16 pairs) or None (CBINFER_ARITH names rounds 1-2's kernels)."""
+    a = os.environ.get("CBINFER_ARITH", "x3")
+    return a if a in ("x3", "f16x2") else None
+
+
+def split_ceiling():
+    return BF16X3_CEILING_TFLOPS if split_arith() == "x3" else F16X2_CEILING_TFLOPS
+
+
+ARITH_TEXT = {
+    "x3": ("f32-equivalent: f32 tensors, every operand as three bf16 terms (24 bits, exact), six products on the bf16 MFMA, "
+           "f32 accumulate"),
+    "f16x2": "f32 tensors, f16x2 split multiply (22-23 significant bits per operand), f32 accumulate",
+    None: "f32 tensors, bf16x3 split multiply on rounds 1-2's kernels (24-bit operands), f32 accumulate",
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -404,7 +423,8 @@ def inframe_layer_times(test, frames, start, reps=40):
                         int(bool(m.withReLU)), ptr(sp['ws']), 0, st)))
                 ci = MaskChangeIndexes(sp['copy'], (Hh, Ww), work['idx'], work['count'], made=True)
                 ci.tailDone = tail
-                kern = "cbs_conv_kernel (split-state, LDS-DMA, f16-pair products)" + \
+                kern = "cbs_conv_kernel (split-state, LDS-DMA, %s)" % (
+                    "bf16-triple products: f32-equivalent" if sp['arith'] == 'x3' else "f16-pair products") + \
                     (" + cbs_reduce_tail_kernel (second launch: sums the k-slices' partial tiles AND evaluates the "
                      "1x1 tail)" if tail is not None else " + cbs_reduce_kernel" if sp['ws'] is not None else "")
             else:
@@ -622,7 +642,7 @@ def isolated_layers(test, ratio=0.10, reps=40):
         row["conv_TFLOPs"] = row["conv_flops"] / (row["conv_us"] * 1e-6) / 1e12
         row["conv_GBps_algorithmic"] = row["conv_bytes"] / (row["conv_us"] * 1e-6) / 1e9
         split = "cbs_conv" in row["kernels"]
-        row["conv_ceiling_TFLOPs"] = F16X2_CEILING_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+        row["conv_ceiling_TFLOPs"] = split_ceiling() if split else FP32_MFMA_PEAK_TFLOPS
         row["conv_frac_of_ceiling"] = row["conv_TFLOPs"] / row["conv_ceiling_TFLOPs"]
         out.append({k: (round(v, 4) if isinstance(v, float) else v) for k, v in row.items()})
     return out
@@ -1272,8 +1292,8 @@ def main():
                             #  of this workload, x 8 -- the sequences differ by a few percent)
                             multi_result["contraction_64_256_us_at_8"] = c3[0]
                             multi_result["contraction_64_256_flops_note"] = (
-                                "frac_of_f16x2_ceiling_at_8 = 8 x the single sequence's 2 N C k K (layers[]) / this "
-                                "launch / 833 TFLOP/s; filled in below once the single-sequence layers are measured")
+                                "frac_of_ceiling_at_8 = 8 x the single sequence's 2 N C k K (layers[]) / this "
+                                "launch / the arithmetic's ceiling; filled in below once the single-sequence layers are measured")
                 del sb, bnet
                 torch.cuda.synchronize()
             grouped = {}
@@ -1349,20 +1369,19 @@ def main():
         "ms_per_step": 1e3 * elapsed / steps_timed, "timed_region_s": elapsed,
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 tensors, f16x2 split multiply (22-23 significant bits per operand), f32 accumulate",
+        "dtype": ARITH_TEXT[split_arith()],
         "data": "synthetic",
-        "arithmetic": "`value` is measured on the DEFAULT arithmetic: f32 tensors and f32 accumulation; the 7x7 "
-                      "contractions of the 16- and 64-channel layers multiply f16 PAIRS (each operand = hi + lo * 2^-11 "
-                      "in f16: 22-23 significant bits against f32's 24; products hi.hi + hi.lo + lo.hi, lo.lo dropped) on "
-                      "the 16-bit MFMA; terms below the f16 normal range are dropped, so activations below 2^-10 keep 11 "
-                      "bits (an absolute floor of 2^-21 per activation); the 3->16 layer and the 1x1 tail run on the exact "
-                      "f32 MFMA.  That is NARROWER than the reference's sgemm (conv2d_cg.py:342-349); it passes the "
-                      "1e-4 parity bar, and tests/test_gpu_split.py::test_split_hostile_data_accuracy_fullsize reports "
-                      "its error beside the exact f32 chain's.  The f32-EQUIVALENT figures are variants.exact_f32 "
-                      "(exact f32 MFMA fma chain, CBINFER_EXACT_F32=1) and variants.bf16x3 (three bf16 terms per operand "
-                      "= 24 bits, six products; CBINFER_ARITH=bf16x3), measured by this same run.  A state value "
-                      "beyond the f16 pair's range (|x| >= 2^20) switches the layer to plain f32 arithmetic inside "
-                      "the same launch (tests: test_split_range_flag_acts)",
+        "arithmetic": "`value` is measured on the DEFAULT arithmetic (CBINFER_ARITH=x3): f32 tensors, f32 accumulation, "
+                      "and f32-EQUIVALENT products -- the 7x7 contractions of the 16- and 64-channel layers keep every "
+                      "f32 operand as THREE bf16 terms (x = b0 + b1 + b2 exactly: 24 bits, f32's exponent range, no scale "
+                      "and no range limit) and multiply them as the six term products above 2^-24 on the bf16 MFMA (b0 w0 "
+                      "in one accumulator, the five small ones in a second); the 3->16 layer and the 1x1 tail run on the "
+                      "exact f32 MFMA.  Operands as wide as the reference's sgemm (conv2d_cg.py:342-349) with fewer "
+                      "accumulation roundings than its fma chain: tests/test_gpu_split.py::"
+                      "test_split_hostile_data_accuracy_fullsize asserts that its error is no larger than the exact f32 "
+                      "chain's on both layers.  variants.f16x2 is rounds 3-4's narrower form (f16 pairs, 22-23 bits per "
+                      "operand, three products; CBINFER_ARITH=f16x2), variants.exact_f32 the f32 fma chain itself "
+                      "(CBINFER_EXACT_F32=1) and variants.bf16x3 rounds 1-2's bf16-triple kernels, all measured by this run",
         "config": {"workload": "sceneLabeling CBConv2d coarse-grained fp32, synthetic 480x320 seq @%g%% "
                                "change (%s), experiment %d, %s per GPU"
                                % (100 * vid.ratio, ("%dx%d re-drawn blocks" % (args.block, args.block))
@@ -1417,7 +1436,8 @@ def main():
     # (sceneLabeling/modelLoader.py:62-78 as is) -- and (b) the video as ONE moving rectangle of the same area
     if world == 1 and S == 1 and not args.no_variants:
         result["variants"] = {}
-        for name, var in (("exact_f32", dict(env=dict(CBINFER_EXACT_F32="1"))),
+        for name, var in (("f16x2", dict(env=dict(CBINFER_ARITH="f16x2"))),
+                          ("exact_f32", dict(env=dict(CBINFER_EXACT_F32="1"))),
                           ("bf16x3", dict(env=dict(CBINFER_ARITH="bf16x3"))),
                           ("reference_structured", dict(fuse_tail=False, fuse_pool=False, pool_clone=True)),
                           ("no_feedback_experiment2", dict(experiment=2, fuse_tail=False, fuse_pool=False)),
@@ -1455,7 +1475,11 @@ def main():
             if name == "bf16x3":
                 result["variants"][name]["arithmetic"] = (
                     "f32 operands as three bf16 terms (24 bits), the six products above 2^-24, f32 accumulation: "
-                    "f32-equivalent; rounds 1-2's patch-staged and list kernels (the split-state kernels are f16x2 only)")
+                    "f32-equivalent; rounds 1-2's patch-staged and list kernels")
+            if name == "f16x2":
+                result["variants"][name]["arithmetic"] = (
+                    "f16 PAIRS on the split-state kernels (rounds 3-4's default): 22-23 significant bits per operand, "
+                    "three products -- NARROWER than f32, reported for comparison only")
 
     # dense network on the same GPU, timed the same way (eval01.py:68)
     if not args.no_dense and world == 1:
@@ -1597,8 +1621,8 @@ def main():
             best = max((r for r in test_rows if "conv_ms" in r), key=lambda r: r["conv_ms"], default=None)
             ms = result.get("multi_sequence")
             if best is not None and ms and ms.get("contraction_64_256_us_at_8") and "64->256" in best["layer"]:
-                ms["contraction_64_256_frac_of_f16x2_ceiling_at_8"] = (
-                    8.0 * best["conv_flops"] / (ms["contraction_64_256_us_at_8"] * 1e-6) / 1e12 / F16X2_CEILING_TFLOPS)
+                ms["contraction_64_256_frac_of_ceiling_at_8"] = (
+                    8.0 * best["conv_flops"] / (ms["contraction_64_256_us_at_8"] * 1e-6) / 1e12 / split_ceiling())
             if best is not None:
                 r = best
                 split = "split-state" in r["conv_kernel"]
@@ -1615,7 +1639,7 @@ def main():
                         firsts = [d["avg_us"] for n, d in ktrace.items() if "cbs_conv_kernel<128" in n.replace(" ", "")]
                         first_us = firsts[0] if firsts else None
                 ach = r["conv_flops"] / (dur_us * 1e-6) / 1e12
-                ceiling = F16X2_CEILING_TFLOPS if split else (FP32_MFMA_PEAK_TFLOPS if exact else BF16X3_CEILING_TFLOPS)
+                ceiling = split_ceiling() if split else (FP32_MFMA_PEAK_TFLOPS if exact else BF16X3_CEILING_TFLOPS)
                 traffic, traffic_src = measured_traffic("conv", r["layer"])
                 result["roofline"] = {
                     "kernel": r["conv_kernel"] + " (fused gather->MFMA->scatter), " + r["layer"],
@@ -1625,7 +1649,9 @@ def main():
                                  "in-frame duration; `peak` = the ceiling of the unit that executes them: %s.  The ratio "
                                  "to the f32 MFMA peak (the tensors' dtype) is kept as frac_of_f32_mfma_peak -- it can "
                                  "exceed what that unit could do, because that unit does none of the work"
-                                 % ("%.1f TFLOP/s = 2.5 PFLOP/s of f16 MFMA / 3 products per multiply (f16 pairs)"
+                                 % (("%.1f TFLOP/s = 2.5 PFLOP/s of bf16 MFMA / 6 products per multiply (bf16 triples)"
+                                     % BF16X3_CEILING_TFLOPS) if (split and split_arith() == "x3") else
+                                    "%.1f TFLOP/s = 2.5 PFLOP/s of f16 MFMA / 3 products per multiply (f16 pairs)"
                                     % F16X2_CEILING_TFLOPS if split else
                                     "157.3 TFLOP/s exact f32 MFMA" if exact else
                                     "%.1f TFLOP/s = 2.5 PFLOP/s of bf16 MFMA / 6 products per multiply (bf16x3)"

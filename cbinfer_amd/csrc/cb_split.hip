@@ -382,10 +382,12 @@ struct CbsParams {
     const int* upstream;              // optional (one sequence): the producing layer's change count of this frame; 0 ends
                                       // the launch at once (cbinfer_cbconv2d_forward_after's contract)
     int dbg;                          // diagnostic ablations (builds with -DCBS_DBG only; CBINFER_SPLIT_DBG)
+    int stagger;                      // x3, eight waves: waves 4-7 issue their DMAs half a stage behind waves 0-3
 };
 // diagnostic ablations are a build option (make EXTRA=-DCBS_DBG; tools/split_dbg_run.sh): 1 every pixel-operand
 // DMA reads the dummy pixel, 2 no fragment reads / MFMAs, 4 no DMA at all, 8 no pixel-operand fragment reads,
-// 16 no weight fragment reads, 32 no epilogue stores
+// 16 no weight fragment reads, 32 no epilogue stores, 64 every DMA issued dead (no memory traffic), 128 / 256 the weight /
+// pixel DMAs dead
 #ifdef CBS_STAMP
 // diagnostic build only (make EXTRA=-DCBS_STAMP; tools/split_stamps.py): per-workgroup phase stamps of its FIRST item,
 // 100 MHz constant clock: 0 entry, 1 list lengths known, 2 item set up, 3 ring primed, 4 stage loop done, 5 epilogue
@@ -803,8 +805,10 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             const int bS = bNext;
             bNext = stageOff[min(s + 1, sEnd - 1)];
             if (CBS_DBGBIT(4)) return;
-            const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, live ? aRecords : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)Sq, 0, live ? bRecords : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)p.A, 0, (live && !CBS_DBGBIT(64 | 128)) ? aRecords : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)Sq, 0, (live && !CBS_DBGBIT(64 | 256)) ? bRecords : 0, 0x00020000);
             char* mine = dst + wave * (DPW * 1024);      // ONE LDS base (M0) for the four
             if constexpr (X3) {
                 cbs_dma16<0>(ar, mine, aVoff, aS);
@@ -1039,12 +1043,21 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         // (s, 1) is read -- stage s is in LDS, nothing is aimed at its slot yet.  Half-step B starts with the stage's
         // wait and barrier (stage s + 1 has landed for everybody, everybody's reads of stage s are behind their
         // waits), issues stage s + RING into the slot of stage s, and multiplies (s, 1) while (s + 1, 0) is read.
+        // The two waves of a SIMD (w and w + NW/2 of an eight-wave workgroup) run the same program between the same
+        // barriers: left alone both issue their six DMA instructions -- some hundred cycles each -- at the same point
+        // of the stage, and the SIMD's matrix pipe idles meanwhile.  The second half of the waves issues the DMAs of
+        // stage s + RING half a stage later (head of half-step A of stage s + 1: still behind the barrier of stage s,
+        // the same number in flight at every wait), beside its partner's matrix instructions (MI355X_MICROARCH.md,
+        // "Two waves per SIMD", item 9).
         typedef std::integral_constant<int, 0> KS0;
         typedef std::integral_constant<int, 1> KS1;
+        const bool lateIssue = X3 && NW == 8 && p.stagger && wave >= NW / 2;
 #define CBS_STEP3A(S, FCUR, FNEXT)                                                         \
         do {                                                                               \
             CBS_SB();                                                                      \
             mma3(KS0(), FCUR, 0, 2);                                                              \
+            CBS_SB();                                                                      \
+            if (lateIssue && (S) > sBeg) issue((S) - 1 + RING);                            \
             CBS_SB();                                                                      \
             readA3(KS1(), (S), FNEXT);                                                     \
             CBS_SB();                                                                      \
@@ -1066,7 +1079,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             CBS_SB();                                                                      \
             mma3(KS1(), FCUR, 0, 2);                                                              \
             CBS_SB();                                                                      \
-            issue((S) + RING);                                                             \
+            if (!lateIssue) issue((S) + RING);                                             \
             CBS_SB();                                                                      \
             mma3(KS1(), FCUR, 2, 3);                                                              \
             CBS_SB();                                                                      \
@@ -1684,6 +1697,14 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
     }
     p.arriveShards = (int)(MW / 16 < 8 ? MW / 16 : 8);
     p.dbg = 0;
+    {
+        static int stag = -1;      // CBINFER_SPLIT_STAGGER (A/B aid; default 1)
+        if (stag < 0) {
+            const char* e = getenv("CBINFER_SPLIT_STAGGER");
+            stag = e ? atoi(e) : 1;
+        }
+        p.stagger = stag;
+    }
 #ifdef CBS_DBG
     if (const char* e = getenv("CBINFER_SPLIT_DBG")) p.dbg = atoi(e);
 #endif
@@ -2172,7 +2193,7 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int 
     p.magicWpr = (1ull << 32) / (unsigned long long)p.wpr + 1ull;
     p.magicW = (1ull << 32) / (unsigned long long)W + 1ull;
     p.magicMT = (1ull << 32) / (unsigned long long)(KP / BM) + 1ull;
-    p.forceSK = 0, p.accumulate = 0, p.halfOut = 1, p.splitRounds = 2, p.dbg = 0;
+    p.forceSK = 0, p.accumulate = 0, p.halfOut = 1, p.splitRounds = 2, p.dbg = 0, p.stagger = 0;
     p.upstream = upstreamCount;
     p.arriveShards = (int)(MW / 16 < 8 ? MW / 16 : 8);
     const long cap = cbs_slab_capacity(1, H, W, K);

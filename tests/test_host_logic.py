@@ -272,3 +272,16 @@ def test_bench_final_line_stays_small():
     assert line["config"]["workload"] and "model" not in line["config"]
     assert json.loads(text)["value"] == pytest.approx(full["value"], rel=1e-4)
     assert all(isinstance(v, (int, float)) for v in line["variants"].values())
+
+
+def test_no_store_between_a_load_and_its_hand_counted_wait():
+    """over every kernel of the library, no store / atomic sits among the N youngest operations of a
+    hand-counted `s_waitcnt vmcnt(N)` that covers a load or an LDS-DMA (tools/lint_vmcnt.py, on the generated ISA)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "lint_vmcnt.py")], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=900)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-3000:]
+    m = re.search(r"(\d+) kernel\(s\), (\d+) hand-counted wait\(s\), 0 finding\(s\)", text)
+    assert m and int(m.group(1)) >= 100 and int(m.group(2)) >= 100, text[-1000:]

@@ -3,6 +3,7 @@
 the change pattern of the bench (blocks, dilated), one or several sequences per launch.  The kernel consumes
 its frame mask (two alternating masks + parity), so both halves are refilled before every launch; the refill
 is timed alone and subtracted.  CBINFER_SPLIT_DBG ablations need a -DCBS_DBG build (tools/split_dbg_run.sh).
+CBINFER_ARITH=f16x2 times the f16-pair form (default: x3, bf16 triples).
 usage: bench_split.py [nSeq] [forceSplit]"""
 import os
 import sys
@@ -19,23 +20,34 @@ from tools.bench_rows import ev  # noqa: E402
 def main():
     nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     force = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    x3 = os.environ.get("CBINFER_ARITH", "x3") == "x3"
     gen = torch.Generator().manual_seed(0)
     for (C, K, k, H, W, blk, ratio) in [(16, 64, 7, 160, 240, 16, 0.10), (64, 256, 7, 80, 120, 8, 0.10)]:
         w = torch.randn(K, C, k, k, device="cuda") / (C * k * k) ** 0.5
         b = torch.randn(K, device="cuda")
         import math
-        scale = 2.0 ** (13 - math.floor(math.log2(float(w.abs().max()))))
-        wp = torch.empty(lib.cbinfer_split_prepared_bytes(C, K, k, k), dtype=torch.uint8, device="cuda")
-        check(lib.cbinfer_split_prep_weights(ptr(w), ptr(wp), K, C, k, k, H, W, scale, None))
+        if x3:
+            scale = 0.0
+            wp = torch.empty(lib.cbinfer_split3_prepared_bytes(C, K, k, k), dtype=torch.uint8, device="cuda")
+            check(lib.cbinfer_split3_prep_weights(ptr(w), ptr(wp), K, C, k, k, H, W, None))
+        else:
+            scale = 2.0 ** (13 - math.floor(math.log2(float(w.abs().max()))))
+            wp = torch.empty(lib.cbinfer_split_prepared_bytes(C, K, k, k), dtype=torch.uint8, device="cuda")
+            check(lib.cbinfer_split_prep_weights(ptr(w), ptr(wp), K, C, k, k, H, W, scale, None))
         words = lib.cbinfer_mask_words(H, W)
         seqs = (_lib.SplitSeq * nseq)()
         keep, fills, Ns = [], [], []
         for q in range(nseq):
             x = torch.randn(1, C, H, W, device="cuda")
-            S = torch.empty(lib.cbinfer_split_state_bytes(C, H, W, k, k), dtype=torch.uint8, device="cuda")
-            check(lib.cbinfer_split_state_init(ptr(S), C, H, W, k, k, None))
             flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-            check(lib.cbinfer_split_state_rebuild(ptr(x), ptr(S), C, H, W, k, k, ptr(flag), None))
+            if x3:
+                S = torch.empty(lib.cbinfer_split3_state_bytes(C, H, W, k, k), dtype=torch.uint8, device="cuda")
+                check(lib.cbinfer_split3_state_init(ptr(S), C, H, W, k, k, None))
+                check(lib.cbinfer_split3_state_rebuild(ptr(x), ptr(S), C, H, W, k, k, None))
+            else:
+                S = torch.empty(lib.cbinfer_split_state_bytes(C, H, W, k, k), dtype=torch.uint8, device="cuda")
+                check(lib.cbinfer_split_state_init(ptr(S), C, H, W, k, k, None))
+                check(lib.cbinfer_split_state_rebuild(ptr(x), ptr(S), C, H, W, k, k, ptr(flag), None))
             cm = torch.zeros(H, W, dtype=torch.int8)
             gy, gx = H // blk, W // blk
             cells = torch.randperm(gy * gx, generator=gen)[:max(1, int(round(ratio * gy * gx)))]
@@ -74,8 +86,9 @@ def main():
         t_fill = ev(fill)
         t = max(ev(run) - t_fill, 1e-6)
         N = sum(Ns)
-        print("%d->%d k%d @%dx%d  %d seq, N=%d (%.0f%%): %.1f us  = %.1f TFLOP/s f32-equivalent | dbg=%s force=%d"
-              % (C, K, k, H, W, nseq, N, 100.0 * N / (H * W * nseq), t, 2.0 * N * C * k * k * K / t / 1e6,
+        print("%s %d->%d k%d @%dx%d  %d seq, N=%d (%.0f%%): %.1f us  = %.1f TFLOP/s f32-equivalent | dbg=%s force=%d"
+              % ("x3" if x3 else "f16x2", C, K, k, H, W, nseq, N, 100.0 * N / (H * W * nseq), t,
+                 2.0 * N * C * k * k * K / t / 1e6,
                  os.environ.get("CBINFER_SPLIT_DBG", "0"), force), flush=True)
 
 

@@ -193,7 +193,11 @@ class OpenPoseModel(nn.Module):
     `model{t}_2` (19 confidence maps); stages t >= 2 see cat(branch1, branch2, features) = 185
     channels (PoseModel.py:122-137)."""
 
-    def __init__(self, T=2, seed=0, concurrentBranches=False):
+    def __init__(self, T=2, seed=0, concurrentBranches=False, init='default'):
+        """init='default': nn.Conv2d's own initialisation (kaiming_uniform with a = sqrt(5): activations shrink by ~0.4
+        per layer, so on random weights a change dies out behind the fifth conv).  init='kaiming': variance-preserving
+        kaiming_normal_(nonlinearity='relu') and zero biases -- activations keep their scale through all 36 layers, so
+        a change at the input reaches every layer, as with trained weights (the LIVE network of bench.py / tools/)."""
         super(OpenPoseModel, self).__init__()
         # the two branches of a stage are independent: with concurrentBranches they are enqueued on two
         # HIP streams (fork/join per stage), so that their per-launch fixed costs overlap
@@ -205,6 +209,13 @@ class OpenPoseModel(nn.Module):
         for t in range(1, T + 1):
             setattr(self, 'model%d_1' % t, _seq(_openpose_stage(t, 38), relu_after_last=False))
             setattr(self, 'model%d_2' % t, _seq(_openpose_stage(t, 19), relu_after_last=False))
+        if init == 'kaiming':
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    nn.init.kaiming_normal_(m.weight, nonlinearity='relu')
+                    nn.init.zeros_(m.bias)
+        elif init != 'default':
+            raise ValueError("OpenPoseModel: init must be 'default' or 'kaiming'")
         torch.random.set_rng_state(state)
         self.eval()
 
@@ -246,6 +257,67 @@ def convertOpenPose(model, threshold=1e-2, feedbackLoop=False):
             if type(m) is CBConv2d:
                 m.feedbackLoop = True
     return model
+
+
+def calibrateChangeRatio(converted, nextFrame, target=0.10, pairs=4, settle=8, finalSettle=24):
+    """Per-layer thresholds that give every CBConv2d of the CONVERTED network a post-dilation change ratio of `target` on
+    the video `nextFrame()` yields, found layer by layer in execution order IN the change-based network itself (a
+    layer's threshold decides what the layers behind it see): layer L's threshold is bisected on the recorded
+    |input - prevInput| maps of `pairs` consecutive frames, with the layers in front of it at their calibrated
+    thresholds -- after `settle` frames: a change-based layer's outputs keep drifting for many frames after its
+    threshold was raised (the longer a pixel was not recomputed, the larger its jump when it is, so the layer behind
+    sees more) -- and itself and the layers behind it at threshold 0 (exact: they recompute every pixel whose input
+    differs at all, so nothing is stale when their turn comes).  `finalSettle` more frames bring the whole network to
+    its steady state.  A WORKLOAD generator for measurements (BASELINE.md budgets config 4 at 10 % of the dense work,
+    SURVEY 8(d): "r = 10 % at every layer"), not the reference's accuracy-driven tuner
+    (pycbinfer.tuneThresholdParameters).  Returns the thresholds; the network is left warm: continue the same video."""
+    from . import CBConv2d
+    convs = [m for m in converted.modules() if type(m) is CBConv2d]
+    for m in convs:
+        m.threshold = 0.0
+    with torch.no_grad():
+        converted(nextFrame())
+        for m in convs:
+            for _ in range(settle):
+                converted(nextFrame())
+            diffs = []
+
+            def hook(mod, inp, diffs=diffs):
+                x = inp[0]
+                x = x[1] if isinstance(x, tuple) else x
+                prev = mod.prevInput
+                if torch.is_tensor(x) and torch.is_tensor(prev) and prev.shape == x.shape:
+                    d = torch.nan_to_num((x.detach().float() - prev.float()).abs(), nan=0.0, posinf=3e38)
+                    diffs.append(d.amax(dim=1, keepdim=True))
+            h = m.register_forward_pre_hook(hook)
+            try:
+                for _ in range(pairs):
+                    converted(nextFrame())
+            finally:
+                h.remove()
+            D = torch.cat(diffs)
+            k = m.kernel_size[0]
+
+            def cover(th, D=D, k=k):
+                chg = (D > th).float()
+                if k > 1:
+                    chg = torch.nn.functional.max_pool2d(chg, k, 1, k // 2)
+                return float(chg.mean())
+            fin = D[D < 1e38]
+            lo, hi = 0.0, (float(fin.max()) + 1e-6) if fin.numel() else 1.0
+            if cover(0.0) <= target:
+                m.threshold = 0.0
+            else:
+                for _ in range(24):
+                    mid = 0.5 * (lo + hi)
+                    if cover(mid) > target:
+                        lo = mid
+                    else:
+                        hi = mid
+                m.threshold = hi
+        for _ in range(finalSettle):
+            converted(nextFrame())
+    return [float(m.threshold) for m in convs]
 
 
 def openPoseDenseOps(T, H, W):

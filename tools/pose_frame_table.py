@@ -10,7 +10,8 @@ import sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 det = [i for i, r in enumerate(rows) if "detect" in r["Kernel_Name"]]
-frame = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+# (default: a frame of the timed walk -- 25 frames before the last one; the threshold calibration runs in front of it)
+frame = int(sys.argv[2]) if len(sys.argv) > 2 else len(det) // 36 - 25
 a, b = det[frame * 36], det[(frame + 1) * 36]
 t0 = int(rows[a]["Start_Timestamp"])
 agg = collections.defaultdict(lambda: [0, 0.0])

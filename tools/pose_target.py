@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Profiling target for BASELINE config 4: OpenPose T=2, 368x654, fp16 (cg_half path), all 36 convs converted, 10 % of
 the input re-drawn per frame in 16x16 blocks, eager launches (every kernel its own dispatch).  Prints frames/s of the
-change-based and the dense network and the per-layer change ratios.  usage: pose_target.py [feedback]"""
+change-based and the dense network and the per-layer change ratios.
+LIVE network (default since round 5): variance-preserving random weights (workloads.OpenPoseModel(init='kaiming')) and
+per-layer thresholds that give every layer a post-dilation change ratio of 10 % on this video
+(workloads.calibrateChangeRatio) -- all 36 layers recompute; POSE_INIT=default POSE_TH=0.02 is rounds 1-4's artefact
+(nn.Conv2d's default init, one threshold: the change dies behind the fifth conv).
+usage: pose_target.py [feedback]"""
 import os
 import sys
 import time
@@ -17,9 +22,18 @@ def main():
     feedback = len(sys.argv) > 1 and sys.argv[1] == "feedback"
     H, W = 368, 654
     vid = workloads.SyntheticVideo(H=H, W=672, ratio=0.10, block=16, seed=3)
-    frames = [(f[:, :, :, :W] * (255.0 / 256.0) - 0.5).half().contiguous() for f in vid.frames(40)]
-    test = workloads.convertOpenPose(workloads.OpenPoseModel(T=2).cuda().half(), threshold=0.02, feedbackLoop=feedback)
-    base = workloads.OpenPoseModel(T=2).cuda().half()
+
+    def prep(f):        # PoseDetector.py:72: x * 255/256 - 0.5, fp16
+        return (f[:, :, :, :W] * (255.0 / 256.0) - 0.5).half().contiguous()
+    init = os.environ.get("POSE_INIT", "kaiming")
+    test = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, init=init).cuda().half(),
+                                     threshold=float(os.environ.get("POSE_TH", "0.02")), feedbackLoop=feedback)
+    base = workloads.OpenPoseModel(T=2, init=init).cuda().half()
+    if "POSE_TH" not in os.environ:
+        # (calibrated on the running video; the timed walk continues it, so the network is in its steady state)
+        workloads.calibrateChangeRatio(test, lambda: prep(vid.next()), target=float(os.environ.get("POSE_TARGET", "0.10")))
+    frames = [prep(vid.frame)] + [prep(vid.next()) for _ in range(49)]
+    frames, fresh = frames[:40], frames[40:]      # (the last ten: for the per-layer ratios, behind the timed walk)
     with torch.no_grad():
         for f in frames[:6]:
             test(f)
@@ -40,16 +54,29 @@ def main():
     n = len(frames) - 6
     print("OpenPose T=2 %dx%d fp16%s: change-based %.0f frames/s (%.1f us per frame), dense %.0f frames/s, eager"
           % (H, W, ", feedback mode" if feedback else "", n / dt, 1e6 * dt / n, n / dd))
-    rs = []
-    for m in test.modules():
-        if type(m) is pycbinfer.CBConv2d and m.lastChangeIndexes() is not None:
+    # per-layer change ratios: the mean over ten more frames of the walk (untimed: reading a list length is a sync)
+    convs = [m for m in test.modules() if type(m) is pycbinfer.CBConv2d]
+    counts = [0.0] * len(convs)
+    with torch.no_grad():
+        # (FRESH frames, forward: walking back over the stored ones under-states the change behind thresholded layers
+        #  -- a pixel that was refreshed one frame ago jumps less than one that has been stale for ten)
+        for f in fresh:
+            test(f)
+            for i, m in enumerate(convs):
+                counts[i] += m.lastChangeIndexes().numel() / 10.0
+    rs, flops = [], []
+    for m, n in zip(convs, counts):
+        if m.lastChangeIndexes() is not None:
             ci = m.lastChangeIndexes()
             K, C, kH, kW = m.weight.shape
-            r = ci.numel() / float(ci.size[0] * ci.size[1])
+            r = n / float(ci.size[0] * ci.size[1])
             rs.append(r)
-            print("  conv %3d->%3d k%d @%dx%d: %5.1f %% of the pixels recomputed, %.1f MFLOP"
-                  % (C, K, kH, ci.size[0], ci.size[1], 100 * r, 2e-6 * ci.numel() * C * kH * kW * K))
-    print("mean post-dilation ratio over %d layers: %.1f %%" % (len(rs), 100 * sum(rs) / max(1, len(rs))))
+            flops.append(2.0 * n * C * kH * kW * K)
+            print("  conv %3d->%3d k%d @%dx%d: %5.1f %% of the pixels recomputed, %.1f MFLOP, threshold %.4g%s"
+                  % (C, K, kH, ci.size[0], ci.size[1], 100 * r, 1e-6 * flops[-1], float(m.threshold),
+                     (", " + m._plan['fn'].__name__) if getattr(m, '_plan', None) and m._plan.get('fn') is not None else ""))
+    print("mean post-dilation ratio over %d layers: %.1f %%; recomputed work %.2f GFLOP per frame of %.1f dense"
+          % (len(rs), 100 * sum(rs) / max(1, len(rs)), 1e-9 * sum(flops), 1e-9 * workloads.openPoseDenseOps(2, H, W)))
 
 
 if __name__ == "__main__":

@@ -728,13 +728,155 @@ def _chk(status):
 
 
 
+def openpose_config(args, measure):
+    """BASELINE.json configs[3]: OpenPose T=2 (poseDetection/openPose/PoseModel.py:34-68, :122-137), 368x654, fp16
+    (cg_half path), all 36 convs converted per sub-model as poseDetection/modelConverter.py:20-24 does, 10 % of the input
+    re-drawn per frame in 16x16 blocks -- on a LIVE network (round 5): variance-preserving random weights
+    (workloads.OpenPoseModel(init='kaiming')) and per-layer thresholds that give every layer a post-dilation change ratio
+    of ~10 % in the running change-based network (workloads.calibrateChangeRatio), so that all 36 layers recompute and
+    the frame carries the ~22 GFLOP BASELINE.md budgets.  Frames are FRESH and consecutive (no walk back and forth: a
+    pixel refreshed one frame ago jumps less than one that has been stale for ten, so a ping-pong walk under-states the
+    change behind thresholded layers)."""
+    import pycbinfer
+    from cbinfer_amd import workloads
+    Hp, Wp = 368, 654
+    vid = workloads.SyntheticVideo(H=Hp, W=672, ratio=0.10, block=16, seed=3)
+
+    def prep(f):        # PoseDetector.py:72
+        return (f[:, :, :, :Wp] * (255.0 / 256.0) - 0.5).half().contiguous()
+
+    def live():
+        return workloads.OpenPoseModel(T=2, init='kaiming').cuda().half()
+    psteps, pwarm = 30, 30
+    base = live()
+    test = workloads.convertOpenPose(live(), threshold=0.02)
+    ths = workloads.calibrateChangeRatio(test, lambda: prep(vid.next()), target=0.10)
+    convs = [m for m in test.modules() if type(m) is pycbinfer.CBConv2d]
+    frames = [prep(vid.frame)] + [prep(vid.next()) for _ in range(2 + pwarm + psteps + 22)]
+    fresh, frames = frames[-22:], frames[:-22]
+
+    def with_thresholds(model):
+        for m, th in zip([m for m in model.modules() if type(m) is pycbinfer.CBConv2d], ths):
+            m.threshold = th
+        return model
+    dense = max(measure(base, frames, m, psteps, 3) for m in ("graph", "eager"))
+    cb_modes = {m: measure(test, frames, m, psteps, pwarm) for m in ("eager", "graph")}
+    cb = max(cb_modes.values())
+    # per-layer change ratios and recomputed work: the mean over ten fresh frames behind the timed ones
+    counts = [0.0] * len(convs)
+    with torch.no_grad():
+        test(frames[-1])
+        for f in fresh[:10]:
+            test(f)
+            for i, m in enumerate(convs):
+                counts[i] += m.lastChangeIndexes().numel() / 10.0
+    rs, flops, byts = [], 0.0, 0.0
+    layer_rows = []
+    for m, n in zip(convs, counts):
+        K, Cc, kh, kw = m.weight.shape
+        hw = float(m.prevInput.size(-1) * m.prevInput.size(-2))
+        rs.append(n / hw)
+        flops += 2.0 * n * Cc * kh * kw * K
+        byts += 2.0 * Cc * hw * 2 + hw / 8      # SURVEY 8(d): input + state read (f16), the mask
+        layer_rows.append({"layer": "%d->%d k%d @%dx%d" % (Cc, K, kh, m.prevInput.size(-2), m.prevInput.size(-1)),
+                           "ratio": round(n / hw, 4), "threshold": round(float(m.threshold), 4),
+                           "path": m._plan['fn'].__name__ if getattr(m, '_plan', None) and m._plan.get('fn') else None})
+    # roofline of the frame's launches (kernel durations: in-process kernel trace of eager frames of the same walk)
+    pose_roofline = None
+    try:
+        walk = fresh[10:]      # (consecutive frames, each used once: traced_kernel_durations runs 3 untraced + 8 traced steps)
+
+        def pstep(i):
+            with torch.no_grad():
+                test(walk[min(i, len(walk) - 1)])
+        got = traced_kernel_durations(pstep, 8)
+        if got[0] is not None:
+            k = got[0]
+            conv_us = sum(v["launches_per_frame"] * v["avg_us"] for n, v in k.items()
+                          if "conv_kernel" in n or "cb_mfma" in n or "reduce" in n)
+            det_us = sum(v["launches_per_frame"] * v["avg_us"] for n, v in k.items() if "detect" in n)
+            pose_roofline = {
+                "contractions": {"bound": "mfma", "flops_per_frame": flops, "us_per_frame": conv_us,
+                                 "achieved": flops / conv_us / 1e6, "peak": 2500.0, "unit": "TFLOP/s",
+                                 "frac": flops / conv_us / 1e6 / 2500.0,
+                                 "note": "f16 MFMA flops of the recomputed pixels (2 N C k K summed over the 36 layers, mean "
+                                         "of ten frames) over the summed durations of the contraction launches of a frame "
+                                         "(all 36 layers are busy on the live network); peak = dense f16 MFMA"},
+                "detections": {"bound": "hbm", "bytes_per_frame": byts, "us_per_frame": det_us,
+                               "achieved": byts / det_us / 1e3, "peak": 8000.0, "unit": "GB/s",
+                               "frac": byts / det_us / 1e3 / 8000.0,
+                               "note": "SURVEY 8(d) bytes (input + state read, mask) of the 36 detections over the summed "
+                                       "durations of the detection launches of the frame"},
+                "kernels": {n[:60]: v for n, v in sorted(k.items(), key=lambda x: -x[1]["avg_us"] * x[1]["launches_per_frame"])[:8]},
+                "busy_us_per_frame": got[1]}
+    except Exception as e:      # (an add-on: never at the expense of the line)
+        pose_roofline = {"error": repr(e)}
+    # the reference's "recursive mode" (modelConverter.py:84-86): feedback loop -- thresholds calibrated in that mode (a
+    # state that is refreshed at the changed pixels only drifts differently: the copy mode's thresholds let the change die
+    # out behind the fourth layer there), on the video's next frames
+    testf = workloads.convertOpenPose(live(), threshold=0.02, feedbackLoop=True)
+    workloads.calibrateChangeRatio(testf, lambda: prep(vid.next()), target=0.10)
+    fframes = [prep(vid.frame)] + [prep(vid.next()) for _ in range(2 + 3 + psteps + 10)]
+    ffresh, fframes = fframes[-10:], fframes[:-10]
+    cbf = max(measure(testf, fframes, m, psteps, 3) for m in ("eager",))
+    fconvs = [m for m in testf.modules() if type(m) is pycbinfer.CBConv2d]
+    fcount = [0.0] * len(fconvs)
+    with torch.no_grad():
+        for f in ffresh:
+            testf(f)
+            for i, m in enumerate(fconvs):
+                fcount[i] += m.lastChangeIndexes().numel() / 10.0
+    fratio = [n / float(m.prevInput.size(-1) * m.prevInput.size(-2)) for m, n in zip(fconvs, fcount)]
+    fflops = sum(2.0 * n * m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3] * m.weight.shape[0]
+                 for m, n in zip(fconvs, fcount))
+    del testf
+    # every layer scanning its whole input as the reference's layers do (conv2d.py:228-233): what the chained entry
+    # (cbinfer_cbconv2d_forward_after) contributes -- nothing to speak of on a network whose layers all change
+    from cbinfer_amd import conv2d as _c2
+    _c2._NO_CHAIN = True
+    try:
+        plain = with_thresholds(workloads.convertOpenPose(live(), threshold=0.02))
+        cbu = max(measure(plain, frames, m, psteps, pwarm) for m in ("graph", "eager"))
+        del plain
+    finally:
+        _c2._NO_CHAIN = os.environ.get("CBINFER_NO_CHAIN", "0") == "1"
+    # the three VGG pools change-based as well and folded into their consumers' detections (pycbinfer.insertCBPooling +
+    # fusePoolingIntoDetection: what sceneLabeling/modelLoader.py:62-78 does by hand; the pose converter of the
+    # reference leaves the pools dense, so this is an option beside the configuration)
+    cbp = with_thresholds(workloads.convertOpenPose(live(), threshold=0.02))
+    pycbinfer.insertCBPooling(cbp, cloneOutput=False)
+    pycbinfer.fusePoolingIntoDetection(cbp)
+    cbpool = max(measure(cbp, frames, m, psteps, pwarm) for m in ("graph", "eager"))
+    del cbp
+    pose_ops = workloads.openPoseDenseOps(2, Hp, Wp)
+    return {
+        "dense_fps": dense, "cb_fps": cb, "cb_launch": max(cb_modes, key=cb_modes.get), "speedup": cb / dense,
+        "cb_feedback_mode_fps": cbf, "feedback_speedup": cbf / dense,
+        "feedback_mode_mean_ratio": sum(fratio) / max(1, len(fratio)), "feedback_mode_recomputed_gflop": fflops / 1e9,
+        "feedback_mode_ratios": [round(r, 3) for r in fratio], "cb_unchained_fps": cbu,
+        "unchained_speedup": cbu / dense, "cb_with_change_based_pools_fps": cbpool,
+        "change_based_pools_speedup": cbpool / dense,
+        "effective_gflops": cb * pose_ops / 1e9, "dense_ops_per_frame": pose_ops,
+        "recomputed_gflop_per_frame": flops / 1e9,
+        "mean_post_dilation_ratio": sum(rs) / max(1, len(rs)), "min_ratio": min(rs), "max_ratio": max(rs),
+        "layers": len(rs), "layers_without_change": sum(1 for r in rs if r == 0.0),
+        "per_layer": layer_rows, "roofline": pose_roofline,
+        "note": "LIVE network: 36 converted convs, fp16 (cg_half path, f16 MFMA / f32 accumulation), variance-preserving "
+                "random weights, per-layer thresholds calibrated to a post-dilation change ratio of ~10 % in the running "
+                "network (per_layer[]), fresh consecutive frames.  Layers of >= 64 input channels on the fp16 split-state "
+                "kernels (deep ones in 4-16 k-chunks + a reduce launch, 185 channels padded to 192), the 3-channel "
+                "first layer and the 1x1 layers behind a propagating producer on rounds 1-2's list kernels.  Rounds "
+                "1-4 measured this configuration on nn.Conv2d's default initialisation, where the change dies out "
+                "behind the fifth conv (31 idle layers): 5.5-5.9x then was launches returning early, not work"}
+
+
 def secondary_configs(args):
     """BASELINE.json configs[2] (fine-grained + CBPoolMax2d, sweep of the change ratio) and configs[3] (OpenPose T=2,
     368x654, coarse-grained fp16) in the driver line -- bounded samples of what tools/sweep.py measures in full:
     three ratios of the sweep (1 / 10 / 50 % of the pixels re-drawn per frame in 16x16 blocks) for the coarse-grained
     experiment 6 network of the headline and the fine-grained experiment 7 network (in-place form), and the OpenPose
-    network (random weights, 10 % of the input re-drawn per frame) in the reference's two modes, each beside the dense
-    network on the same GPU, the better of eager / graph-replayed launches for every network."""
+    network (LIVE: openpose_config) in the reference's two modes, each beside the dense network on the same GPU, the
+    better of eager / graph-replayed launches for every network."""
     import pycbinfer
     from cbinfer_amd import workloads
     steps, warm = 40, 5
@@ -785,93 +927,7 @@ def secondary_configs(args):
                                      "fg_touched_ratio_per_layer": ratios(fg)})
         del base, cg, fg, frames
         torch.cuda.synchronize()
-    Hp, Wp = 368, 654
-    vid = workloads.SyntheticVideo(H=Hp, W=672, ratio=0.10, block=16, seed=3)
-    psteps = 20
-    frames = [(f[:, :, :, :Wp] * (255.0 / 256.0) - 0.5).half().contiguous() for f in vid.frames(2 + 3 + psteps)]
-    base = workloads.OpenPoseModel(T=2).cuda().half()
-    test = workloads.convertOpenPose(workloads.OpenPoseModel(T=2).cuda().half(), threshold=0.02)
-    testf = workloads.convertOpenPose(workloads.OpenPoseModel(T=2).cuda().half(), threshold=0.02, feedbackLoop=True)
-    dense = max(measure(base, frames, m, psteps, 3) for m in ("graph", "eager"))
-    cb = max(measure(test, frames, m, psteps, 3) for m in ("graph", "eager"))
-    cbf = max(measure(testf, frames, m, psteps, 3) for m in ("graph", "eager"))
-    rs = ratios(test)
-    # a roofline entry for config 4: the contraction launches of a frame as ONE figure -- f16 MFMA
-    # flops of the recomputed pixels over the time of every contraction launch of the frame, the idle ones included --
-    # and the detection launches as bytes over time (kernel durations: in-process kernel trace of eager frames)
-    pose_roofline = None
-    try:
-        convs = [m for m in test.modules() if type(m) is pycbinfer.CBConv2d]
-        flops = byts = 0.0
-        for m in convs:
-            ci = m.lastChangeIndexes()
-            n = float(ci.numel()) if ci is not None else 0.0
-            K, Cc, kh, kw = m.weight.shape
-            hw = float(m.prevInput.size(-1) * m.prevInput.size(-2))
-            flops += 2.0 * n * Cc * kh * kw * K
-            byts += 2.0 * Cc * hw * 2 + hw / 8      # input + state read (f16), the mask
-        walk = frames[5:]
-
-        def pstep(i):
-            with torch.no_grad():
-                test(walk[pingpong(i, len(walk))])
-        got = traced_kernel_durations(pstep, 12)
-        if got[0] is not None:
-            k = got[0]
-            conv_us = sum(v["launches_per_frame"] * v["avg_us"] for n, v in k.items()
-                          if "conv_kernel" in n or "cb_mfma" in n or "reduce" in n)
-            det_us = sum(v["launches_per_frame"] * v["avg_us"] for n, v in k.items() if "detect" in n)
-            pose_roofline = {
-                "contractions": {"bound": "mfma", "flops_per_frame": flops, "us_per_frame": conv_us,
-                                 "achieved": flops / conv_us / 1e6, "peak": 2500.0, "unit": "TFLOP/s",
-                                 "frac": flops / conv_us / 1e6 / 2500.0,
-                                 "note": "f16 MFMA flops of the recomputed pixels (2 N C k K summed over the 36 layers, "
-                                         "one frame) over the summed durations of ALL contraction launches of the frame "
-                                         "-- 31 of them find nothing to do and are launch floor; peak = dense f16 MFMA"},
-                "detections": {"bound": "hbm", "bytes_per_frame": byts, "us_per_frame": det_us,
-                               "achieved": byts / det_us / 1e3, "peak": 8000.0, "unit": "GB/s",
-                               "frac": byts / det_us / 1e3 / 8000.0,
-                               "note": "SURVEY 8(d) bytes (input + state read, mask) of ALL 36 detections over the "
-                                       "summed durations of the detection launches of the frame; chained idle layers "
-                                       "read one word and return, so this counts bytes they never move -- an upper bound"},
-                "kernels": {n[:60]: v for n, v in sorted(k.items(), key=lambda x: -x[1]["avg_us"] * x[1]["launches_per_frame"])[:8]}}
-    except Exception as e:      # (an add-on: never at the expense of the line)
-        pose_roofline = {"error": repr(e)}
-    # the same network with every layer scanning its whole input, as the reference's layers do (conv2d.py:228-233):
-    # what the chained entry (cbinfer_cbconv2d_forward_after) contributes on this data
-    from cbinfer_amd import conv2d as _c2
-    _c2._NO_CHAIN = True
-    try:
-        plain = workloads.convertOpenPose(workloads.OpenPoseModel(T=2).cuda().half(), threshold=0.02)
-        cbu = max(measure(plain, frames, m, psteps, 3) for m in ("graph", "eager"))
-        del plain
-    finally:
-        _c2._NO_CHAIN = os.environ.get("CBINFER_NO_CHAIN", "0") == "1"
-    # ... and with the three VGG pools change-based as well (pycbinfer.insertCBPooling: what sceneLabeling/modelLoader.py:
-    # 62-78 does by hand for the scene-labeling experiments 5/6 -- the pose converter of the reference leaves the pools
-    # dense, so this is an option beside the configuration, not the configuration)
-    cbp = workloads.convertOpenPose(workloads.OpenPoseModel(T=2).cuda().half(), threshold=0.02)
-    pycbinfer.insertCBPooling(cbp, cloneOutput=False)
-    pycbinfer.fusePoolingIntoDetection(cbp)      # (the pools in the consumers' detections, cbinfer_hsplit_forward's pooled form)
-    cbpool = max(measure(cbp, frames, m, psteps, 3) for m in ("graph", "eager"))
-    del cbp
-    pose_ops = workloads.openPoseDenseOps(2, Hp, Wp)
-    out["config4_openpose_fp16"] = {
-        "dense_fps": dense, "cb_fps": cb, "speedup": cb / dense, "cb_feedback_mode_fps": cbf,
-        "feedback_speedup": cbf / dense, "cb_unchained_fps": cbu, "unchained_speedup": cbu / dense,
-        "cb_with_change_based_pools_fps": cbpool, "change_based_pools_speedup": cbpool / dense,
-        "effective_gflops": cb * pose_ops / 1e9, "dense_ops_per_frame": pose_ops,
-        "mean_post_dilation_ratio": sum(rs) / max(1, len(rs)), "layers": len(rs),
-        "layers_without_change": sum(1 for r in rs if r == 0.0),
-        "roofline": pose_roofline,
-        "note": "36 converted convs, fp16 (cg_half path, f16 MFMA / f32 accumulation: layers of 64 n input channels and fewer "
-                "than 48 k-stages on the fp16 split-state kernels of round 4, the others on rounds 1-2's list kernels), RANDOM "
-                "weights: the change dies out behind the fifth conv (layers_without_change of the 36 recompute nothing "
-                "in any frame), so most of the frame is launches that find nothing to do.  cb_fps: a layer fed "
-                "another layer's output buffer reads that layer's change count and returns at once when it is zero "
-                "(exact: the buffer is what it compared last frame); cb_unchained_fps: every layer scans its whole "
-                "input as the reference does.  The path at full size, not a representative speed-up -- trained "
-                "weights carry change deeper into the network"}
+    out["config4_openpose_fp16"] = openpose_config(args, measure)
     return out
 
 

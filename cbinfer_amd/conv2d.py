@@ -430,10 +430,13 @@ class CBConv2d(nn.Module):
                 and os.environ.get('CBINFER_NO_SPLIT', '0') != '1' and os.environ.get('CBINFER_NO_HSPLIT', '0') != '1'
                 and os.environ.get('CBINFER_NO_SELFCOMPACT', '0') != '1'
                 and bool(C.cbinfer_hsplit_supported(Cin, K, kH, kW))
-                # (a deep contraction -- 48 k-stages and more: 7x7 on 128 channels, 3x3 on 512 -- brings a second launch
-                #  that also runs, and costs its 2.5 us, in frames in which the layer has nothing to do: OpenPose's
-                #  eleven such layers lost more there than the four busy ones gained; CBINFER_HSPLIT_DEEP=1 takes them)
-                and (kH * kW * (Cin // 64) < 48 or os.environ.get('CBINFER_HSPLIT_DEEP', '0') == '1')
+                # (deep contractions -- 48 k-stages and more: 7x7 on 128 channels, 3x3 on 512 -- are taken since round 5:
+                #  on a network whose deep layers do change they are the bulk of the work, and with few tiles the kernel
+                #  cuts their depth into 8 or 16 chunks; rounds 4's artefact of random weights -- 31 idle layers, where the
+                #  second launch of a deep contraction only cost -- had kept them off: CBINFER_HSPLIT_DEEP=0 does that again.
+                #  Channels that are not a multiple of 64 are padded (OpenPose's 185 -> 192); up to a quarter of padding.)
+                and (kH * kW * ((Cin + 63) // 64) < 48 or os.environ.get('CBINFER_HSPLIT_DEEP', '1') == '1')
+                and 4 * ((Cin + 63) // 64 * 64 - Cin) <= (Cin + 63) // 64 * 64
                 and C.cbinfer_mask_words(H, W) <= C.cbinfer_hsplit_max_mask_words(K)
                 and C.cbinfer_hsplit_state_bytes(Cin, H, W, kH, kW) < (1 << 31) and H * W * W < (1 << 32))
 

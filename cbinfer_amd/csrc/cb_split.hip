@@ -383,6 +383,7 @@ struct CbsParams {
                                       // the launch at once (cbinfer_cbconv2d_forward_after's contract)
     int dbg;                          // diagnostic ablations (builds with -DCBS_DBG only; CBINFER_SPLIT_DBG)
     int stagger;                      // x3, eight waves: waves 4-7 issue their DMAs half a stage behind waves 0-3
+    int maxChunks;                    // k-chunks of a deep contraction: CBS_CHUNKS; fp16 layers: up to 16 (chosen on the device)
 };
 // diagnostic ablations are a build option (make EXTRA=-DCBS_DBG; tools/split_dbg_run.sh): 1 every pixel-operand
 // DMA reads the dummy pixel, 2 no fragment reads / MFMAs, 4 no DMA at all, 8 no pixel-operand fragment reads,
@@ -601,7 +602,15 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     // item of its own and the reduce launch adds the slabs in chunk order; unsplit, one workgroup walks the whole
     // depth and folds its accumulators into a running sum at the chunk boundaries: the same additions in the
     // same order, so a sequence gets the same bits whether it runs alone (split) or beside others (unsplit).
-    const int CH = (p.nStages >= 48 && p.slabs) ? CBS_CHUNKS : 1;      // (the host refuses a deep layer without slabs)
+    // fp16 layers (HALF; one sequence per launch, so no batch invariance to keep): with few tiles the depth is cut into
+    // 8 or 16 chunks instead -- OpenPose's 7x7 layers on 128 channels at 46x81 recompute some 400 pixels, i.e. 14 tiles of
+    // 98 stages: 56 work items where there are 256 CUs (round 5).  p.maxChunks: 4, or up to 16 for HALF.
+    int CH = (p.nStages >= 48 && p.slabs) ? CBS_CHUNKS : 1;      // (the host refuses a deep layer without slabs)
+    if (HALF && CH > 1)
+        while (2 * CH <= p.maxChunks && TP * MT * 2 * CH <= (int)gridDim.x && TP * MT * 2 * CH <= p.slabCap &&
+               p.nStages >= 8 * CH)      // (at least four stages per chunk)
+            CH *= 2;
+    const int chShift = CH >= 16 ? 4 : (CH >= 8 ? 3 : 2);
     int anyExact = 0;
     for (int q = 0; q < p.nSeq; ++q) anyExact |= s_exact[q];
     anyExact = __builtin_amdgcn_readfirstlane(anyExact);
@@ -661,7 +670,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         // it = (ptg * SK + slice) * MT + mt -- MT by its magic, SK (1 or CBS_CHUNKS, powers of two) by shifts: no
         // integer division by a run-time value on the way to the first DMA
         const int d = cbs_div(it, p.magicMT), mt = it - d * MT;
-        const int slice = d & (SK - 1), ptg = SK == 1 ? d : d / CBS_CHUNKS;
+        const int slice = d & (SK - 1), ptg = SK == 1 ? d : d >> chShift;
         int q = 0, N = totAll, rb = 0, tile0 = 0;
         if (p.nSeq > 1) {      // (one sequence: all of it known without LDS)
             for (int u = 1; u < p.nSeq; ++u)
@@ -677,7 +686,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         // which keeps the two fragment register sets in step with the loop below.
         const int P2 = p.nStages >> 1;
         static_assert(CBS_CHUNKS == 4, "chunk boundaries by shifts");
-        auto chunkBeg = [&](int c) { return c >= CH ? p.nStages : (CH == 1 ? 0 : 2 * ((P2 * c) >> 2)); };
+        auto chunkBeg = [&](int c) { return c >= CH ? p.nStages : (CH == 1 ? 0 : 2 * ((P2 * c) >> chShift)); };
         const int c0 = SK == 1 ? 0 : slice, c1 = SK == 1 ? CH : slice + 1;
         const int sBeg = chunkBeg(c0), sEnd = chunkBeg(c1);
 
@@ -1705,6 +1714,7 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
         }
         p.stagger = stag;
     }
+    p.maxChunks = CBS_CHUNKS;
 #ifdef CBS_DBG
     if (const char* e = getenv("CBINFER_SPLIT_DBG")) p.dbg = atoi(e);
 #endif
@@ -1839,8 +1849,14 @@ int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int mode, int pH, in
 // ===================================================================================================
 namespace cbs {
 
-__host__ __device__ inline CbsGeom cbh_geom(int C, int H, int W, int kH, int kW) {
+// Input channels that are not a multiple of 64 (OpenPose's 185 = 38 + 19 + 128 concatenated maps, PoseModel.py:122-137)
+// are PADDED to the next one in the pixel-major copy and in the prepared weights -- zero records, zero weights (round 5);
+// the [C,H,W] tensors keep their C.  g.C is the padded count.
+__host__ __device__ inline int cbh_cpad(int C) { return (C + 63) / 64 * 64; }
+__host__ __device__ inline CbsGeom cbh_geom(int Cin, int H, int W, int kH, int kW) {
     CbsGeom g;
+    const int C = cbh_cpad(Cin);
+    g.planes = 1;
     g.C = C, g.G = C / 64, g.H = H, g.W = W, g.kH = kH, g.kW = kW;      // (G: stages per tap)
     g.padY = kH / 2, g.padXL = kW / 2, g.padXR = kW / 2;
     g.pair = 0, g.kWs = kW;
@@ -1852,14 +1868,14 @@ __host__ __device__ inline CbsGeom cbh_geom(int C, int H, int W, int kH, int kW)
     return g;
 }
 inline bool cbh_supported(int C, int K, int kH, int kW) {
-    return C >= 64 && C <= 1024 && C % 64 == 0 && K >= 1 && K <= 1024 && (kH & 1) && (kW & 1) && kH <= 15 && kW <= 15 &&
+    return C >= 64 && C <= 1024 && K >= 1 && K <= 1024 && (kH & 1) && (kW & 1) && kH <= 15 && kW <= 15 &&
            cbh_geom(C, 64, 64, kH, kW).nStages >= 4;
 }
 
 // weights [K,C,kH,kW] f16 -> [stage][row tile of 32][k-step 0..3][lane][8 f16] (the A-fragment order of the f16-pair
 // form with the (k-step, plane) index read as the k-step of four) + the stage table
 __global__ __launch_bounds__(256) void cbh_prep_kernel(const _Float16* __restrict__ w, halfx8* __restrict__ A,
-                                                      int* __restrict__ stageOff, CbsGeom g, int K, int KP) {
+                                                      int* __restrict__ stageOff, CbsGeom g, int K, int KP, int Cin) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < g.nStages) {
         const int s = (int)idx, tap = s / g.G, sub = s % g.G;
@@ -1878,28 +1894,32 @@ __global__ __launch_bounds__(256) void cbh_prep_kernel(const _Float16* __restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = sub * 64 + ks * 16 + 8 * (lane >> 5) + j;
-        o[j] = m < K ? w[(((long)m * g.C + c) * g.kH + ky) * g.kW + kx] : (_Float16)0;
+        o[j] = (m < K && c < Cin) ? w[(((long)m * Cin + c) * g.kH + ky) * g.kW + kx] : (_Float16)0;
     }
     A[idx] = o;
 }
 
 // pixel-major state: zero everywhere, +inf at the image pixels (the f16 state starts as +inf, conv2d.py:192-199)
-__global__ __launch_bounds__(256) void cbh_state_init_kernel(uint4* __restrict__ S, CbsGeom g) {
+__global__ __launch_bounds__(256) void cbh_state_init_kernel(uint4* __restrict__ S, CbsGeom g, int Cin) {
     const long chunks = (long)g.Hp * g.Wp * (g.rec / 16);
     if (blockIdx.x == 0) S[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);     // the CBS_SPAD bytes in front (256 x 16)
     S += CBS_SPAD / 16;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long)gridDim.x * blockDim.x) {
         const long pix = i / (g.rec / 16);
+        const int c0 = (int)(i % (g.rec / 16)) * 8;      // first channel of this 16-byte piece
         const int py = (int)(pix / g.Wp), px = (int)(pix % g.Wp);
         const bool inside = py >= g.padY && py < g.padY + g.H && px >= g.padXL && px < g.padXL + g.W;
-        const unsigned v = inside ? 0x7c007c00u : 0u;
-        S[i] = make_uint4(v, v, v, v);
+        unsigned v[4];      // (the padding channels behind Cin stay zero: their weights are zero, and inf * 0 is NaN)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            v[j] = !inside ? 0u : ((c0 + 2 * j < Cin ? 0x7c00u : 0u) | (c0 + 2 * j + 1 < Cin ? 0x7c000000u : 0u));
+        S[i] = make_uint4(v[0], v[1], v[2], v[3]);
     }
 }
 
 // the pixel-major copy made again from the [C,H,W] state (restored states; the border is left alone)
 __global__ __launch_bounds__(256) void cbh_state_rebuild_kernel(const _Float16* __restrict__ state,
-                                                               char* __restrict__ S, CbsGeom g) {
+                                                               char* __restrict__ S, CbsGeom g, int Cin) {
     const long HW = (long)g.H * g.W;
     const int parts = g.C / 8;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW * parts; i += (long)gridDim.x * blockDim.x) {
@@ -1908,7 +1928,7 @@ __global__ __launch_bounds__(256) void cbh_state_rebuild_kernel(const _Float16* 
         const int y = (int)(pix / g.W), x = (int)(pix % g.W);
         halfx8 v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = state[(long)(part * 8 + j) * HW + pix];
+        for (int j = 0; j < 8; ++j) v[j] = part * 8 + j < Cin ? state[(long)(part * 8 + j) * HW + pix] : (_Float16)0;
         *(halfx8*)(S + CBS_SPAD + ((long)(y + g.padY) * g.Wp + (x + g.padXL)) * g.rec + part * 16) = v;
     }
 }
@@ -1964,7 +1984,8 @@ __global__ __launch_bounds__(512) void cbh_detect_kernel(CbhDetArgs a) {
     const long pHW = (long)a.pH * a.pW;
     const int py0 = 2 * y, px0 = 2 * x;
     const int px1 = POOL ? min(px0 + 1, a.pW - 1) - px0 : 0, py1 = POOL ? (min(py0 + 1, a.pH - 1) - py0) * a.pW : 0;
-    auto ldin = [&](int c) -> _Float16 {
+    auto ldin = [&](int c) -> _Float16 {      // (a channel beyond C -- the padding of the last group -- reads channel C-1:
+        c = min(c, C - 1);                    //  never used, see `real` below)
         if (!POOL) return in[(long)c * HW + p];
         const _Float16* q = in + (long)c * pHW + (long)py0 * a.pW + px0;
         return cb_max(cb_max(q[0], q[px1]), cb_max(q[py1], q[py1 + px1]));
@@ -1985,21 +2006,27 @@ __global__ __launch_bounds__(512) void cbh_detect_kernel(CbhDetArgs a) {
         unsigned diffBits = 0;      // bit i: channel c0 + i of this lane's pixel differs from the state
 #pragma unroll
         for (int i = 0; i < 8; ++i) xv[i] = (_Float16)0;
+        // which of this wave's eight channels exist (all of them unless the group is the padded tail of C)
+        const unsigned real = c0 + 8 <= C ? 0xffu : (c0 >= C ? 0u : (1u << (C - c0)) - 1u);
         if (valid) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) xv[i] = ldin(c0 + i);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (!((real >> i) & 1u)) xv[i] = (_Float16)0;      // (padding: zero records, never changed)
             if (compare) {
                 _Float16 sv[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) sv[i] = state[(long)(c0 + i) * HW + p];
+                for (int i = 0; i < 8; ++i) sv[i] = state[(long)min(c0 + i, C - 1) * HW + p];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
+                    if (!((real >> i) & 1u)) continue;
                     chg |= cb_changed(sv[i], xv[i], th);
                     diffBits |= (__builtin_bit_cast(unsigned short, sv[i]) != __builtin_bit_cast(unsigned short, xv[i]))
                                 << i;
                 }
             } else {
-                diffBits = 0xffu;
+                diffBits = real;
             }
         }
         if (!write) return;
@@ -2031,7 +2058,7 @@ __global__ __launch_bounds__(512) void cbh_detect_kernel(CbhDetArgs a) {
 
     // (copy-all form: the channel groups are independent -- each compares, copies and ORs its own finds into the mask
     //  -- and go to workgroups of their own, blockIdx.z: a 512-channel 46x81 layer took eight dependent rounds, 15 us)
-    const int NG = C >> 6;
+    const int NG = (C + 63) >> 6;
     const int cgBeg = a.copyAll ? (int)blockIdx.z : 0, cgEnd = a.copyAll ? cgBeg + 1 : NG;
     bool chg = false;
     for (int cg = cgBeg; cg < cgEnd; ++cg) group(cg, true, a.copyAll != 0, vm, chg);
@@ -2100,14 +2127,14 @@ int cbinfer_hsplit_prep_weights(const void* weight, void* prepared, int K, int C
     const long aBytes = (long)g.nStages * (KP / 32) * 4096;
     hipLaunchKernelGGL(cbh_prep_kernel, dim3(cb_div_up(total > g.nStages ? total : g.nStages, 256)), dim3(256), 0,
                        (hipStream_t)stream, (const _Float16*)weight, (halfx8*)prepared,
-                       (int*)((char*)prepared + aBytes), g, K, KP);
+                       (int*)((char*)prepared + aBytes), g, K, KP, C);
     return cb_launch_status();
 }
 int cbinfer_hsplit_state_init(void* pixelState, int C, int H, int W, int kH, int kW, cbStream_t stream) {
     CB_REQUIRE(pixelState && H > 0 && W > 0);
     if (!cbh_supported(C, 1, kH, kW)) return CB_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(cbh_state_init_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (uint4*)pixelState,
-                       cbh_geom(C, H, W, kH, kW));
+                       cbh_geom(C, H, W, kH, kW), C);
     return cb_launch_status();
 }
 int cbinfer_hsplit_state_rebuild(const void* state, void* pixelState, int C, int H, int W, int kH, int kW,
@@ -2115,7 +2142,7 @@ int cbinfer_hsplit_state_rebuild(const void* state, void* pixelState, int C, int
     CB_REQUIRE(state && pixelState && H > 0 && W > 0);
     if (!cbh_supported(C, 1, kH, kW)) return CB_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(cbh_state_rebuild_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream,
-                       (const _Float16*)state, (char*)pixelState, cbh_geom(C, H, W, kH, kW));
+                       (const _Float16*)state, (char*)pixelState, cbh_geom(C, H, W, kH, kW), C);
     return cb_launch_status();
 }
 
@@ -2163,9 +2190,9 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int 
     a.upstream = upstreamCount;
     a.pH = pH, a.pW = pW, a.prodMask = pooled ? (const unsigned long long*)producerMask : nullptr;
     if (pooled)
-        hipLaunchKernelGGL(cbh_detect_kernel<true>, dim3(a.wpr, H, a.copyAll ? C / 64 : 1), dim3(512), 0, s, a);
+        hipLaunchKernelGGL(cbh_detect_kernel<true>, dim3(a.wpr, H, a.copyAll ? g.C / 64 : 1), dim3(512), 0, s, a);
     else
-        hipLaunchKernelGGL(cbh_detect_kernel<false>, dim3(a.wpr, H, a.copyAll ? C / 64 : 1), dim3(512), 0, s, a);
+        hipLaunchKernelGGL(cbh_detect_kernel<false>, dim3(a.wpr, H, a.copyAll ? g.C / 64 : 1), dim3(512), 0, s, a);
     int st = cb_launch_status();
     if (st != CB_OK) return st;
 
@@ -2194,6 +2221,14 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int 
     p.magicW = (1ull << 32) / (unsigned long long)W + 1ull;
     p.magicMT = (1ull << 32) / (unsigned long long)(KP / BM) + 1ull;
     p.forceSK = 0, p.accumulate = 0, p.halfOut = 1, p.splitRounds = 2, p.dbg = 0, p.stagger = 0;
+    {
+        static int mc = -1;      // CBINFER_HSPLIT_MAXCHUNKS (A/B aid; default 16: the device picks 4, 8 or 16 by the tile count)
+        if (mc < 0) {
+            const char* e = getenv("CBINFER_HSPLIT_MAXCHUNKS");
+            mc = e && atoi(e) >= 4 ? atoi(e) : 16;
+        }
+        p.maxChunks = mc;
+    }
     p.upstream = upstreamCount;
     p.arriveShards = (int)(MW / 16 < 8 ? MW / 16 : 8);
     const long cap = cbs_slab_capacity(1, H, W, K);

@@ -1703,10 +1703,14 @@ def test_chain_tags_do_not_travel_with_copies(pkg):
 @pytest.mark.gpu
 @pytest.mark.parametrize("feedback", [False, True])
 @pytest.mark.parametrize("shape", [(64, 64, 3, 46, 81), (128, 128, 3, 45, 67), (128, 38, 3, 30, 44), (512, 64, 1, 33, 50),
-                                   (128, 128, 7, 30, 44), (192, 160, 3, 24, 40)])
+                                   (128, 128, 7, 30, 44), (192, 160, 3, 24, 40),
+                                   # round 5: OpenPose's deep layers at their size -- 7x7 on 185 channels (padded to 192:
+                                   # 147 k-stages), 7x7 on 128 (98), 3x3 on 512 (72): the depth in 4, 8 or 16 chunks --
+                                   # and a padded shallow one
+                                   (185, 128, 7, 46, 81), (128, 128, 7, 46, 81), (512, 512, 3, 46, 81), (100, 64, 3, 31, 45)])
 def test_half_layers_on_the_split_state_machinery(pkg, oracle, shape, feedback, monkeypatch):
-    """Round 4: fp16 layers whose input channels are a multiple of 64 keep a pixel-major f16
-    copy of their state and contract by LDS-DMA (cbinfer_hsplit_forward; cbconv2d_cg_half_backend.cu:10-88, :146-197).
+    """Round 4: fp16 layers of 64 and more input channels (padded to a multiple of 64, round 5)
+    keep a pixel-major f16 copy of their state and contract by LDS-DMA (cbinfer_hsplit_forward; cbconv2d_cg_half_backend.cu:10-88, :146-197).
     Every frame against the oracle's half state machine: change list bit-exact, prevInput bit-exact (the whole frame
     without feedback loop, the changed pixels with it), outputs within 2 fp16 ulp of the layer's largest output
     (DESIGN section 6's fp16 bar); the same frames on rounds 1-2's list kernel agree to the same bar; shallow and deep
@@ -1718,7 +1722,6 @@ def test_half_layers_on_the_split_state_machinery(pkg, oracle, shape, feedback, 
 
     def run(hsplit):
         monkeypatch.setenv("CBINFER_NO_HSPLIT", "0" if hsplit else "1")
-        monkeypatch.setenv("CBINFER_HSPLIT_DEEP", "1")      # (the module leaves deep contractions to the list kernel by default)
         m = pkg.CBConv2d(conv, 0.1)
         m.withReLU, m.feedbackLoop = True, feedback
         o = oracle.OracleCBConv2dHalf(conv.weight.detach().cpu().numpy(), conv.bias.detach().cpu().numpy(), 0.1,
@@ -1957,3 +1960,79 @@ def test_pools_fold_into_the_fp16_split_state_detection(pkg, feedback, size):
     assert all(m._plan is not None and m._plan['fn'] is _lib.C.cbinfer_hsplit_forward and m._plan['pooled']
                for m in convs0[1:])
     assert all(p.outputState.numel() == 0 for p in pools)
+
+
+@pytest.mark.gpu
+def test_openpose_live_network_fullsize(pkg, oracle):
+    """BASELINE config 4 on the LIVE network the bench measures (round 5: workloads.OpenPoseModel(init='kaiming'),
+    per-layer thresholds from workloads.calibrateChangeRatio), full size 368x654, fp16.
+    (1) threshold-0 property: with every threshold 0 the change-based network recomputes exactly the pixels whose
+        input differs (strict >, cbconv2d_cg_half_backend.cu:27-28), so its two heat-map outputs track the dense
+        network's on the same weights -- every layer busy, the 185-channel layers padded to 192, the deep contractions
+        split 4..16 ways -- within the fp16 bar of 36 chained layers;
+    (2) at the calibrated thresholds every layer recomputes (no dead tail as on nn.Conv2d's default initialisation), and
+        three deep layers -- 3x3 on 512 channels (72 k-stages), 7x7 on 185 channels (padded, 147 k-stages), 7x7 on 128
+        (98) -- are TEACHER-FORCED against the oracle's half state machine on the inputs the running network hands
+        them: change lists bit-exact, prevInput bit-exact, outputs within 2 fp16 ulp of the layer's largest output."""
+    from cbinfer_amd import workloads, _lib
+    H, W = 368, 654
+    vid = workloads.SyntheticVideo(H=H, W=672, ratio=0.10, block=16, seed=11)
+
+    def prep(f):
+        return (f[:, :, :, :W] * (255.0 / 256.0) - 0.5).half().contiguous()
+
+    def live():
+        return workloads.OpenPoseModel(T=2, init='kaiming').cuda().half()
+    dense = live()
+    # (1) threshold 0
+    net0 = workloads.convertOpenPose(live(), threshold=0.0)
+    with torch.no_grad():
+        for t in range(4):
+            f = prep(vid.next())
+            a, b = net0(f), dense(f)
+            for u, v in zip(a, b):
+                ref = v.float()
+                tol = 0.03 * float(ref.abs().max())
+                err = float((u.float() - ref).abs().max())
+                assert err <= tol, (t, err, tol)
+    convs0 = [m for m in net0.modules() if type(m) is pkg.CBConv2d]
+    assert all(m.lastChangeIndexes().numel() > 0 for m in convs0)
+    paths = [m._plan['fn'] for m in convs0 if m._plan is not None and m._plan.get('fn') is not None]
+    assert sum(1 for p in paths if p is _lib.C.cbinfer_hsplit_forward) >= 28      # (all but the 3-channel layer and 1x1s)
+    del net0
+    # (2) calibrated thresholds, teacher-forced deep layers
+    net = workloads.convertOpenPose(live(), threshold=0.02)
+    ths = workloads.calibrateChangeRatio(net, lambda: prep(vid.next()), target=0.10, pairs=3, settle=6, finalSettle=12)
+    convs = [m for m in net.modules() if type(m) is pkg.CBConv2d]
+    assert len(ths) == 36 and all(th >= 0 for th in ths)
+    deep = [m for m in convs if tuple(m.weight.shape[1:]) in ((512, 3, 3), (185, 7, 7), (128, 7, 7))]
+    picks = [next(m for m in deep if m.weight.shape[1] == 512 and m.weight.shape[0] == 512),
+             next(m for m in deep if m.weight.shape[1] == 185),
+             next(m for m in deep if m.weight.shape[1] == 128 and m.weight.shape[2] == 7)]
+    twins, captured = {}, {}
+    for m in picks:
+        twins[m] = oracle.OracleCBConv2dHalf(m.weight.detach().cpu().numpy(), m.bias.detach().cpu().numpy(),
+                                             float(m.threshold), withReLU=bool(m.withReLU), feedbackLoop=False,
+                                             propChangeIndexes=True)
+        # the twin starts from the layer's present state
+        twins[m].prevInput = m.prevInput.cpu().numpy().copy()
+        twins[m].prevOutput = m.prevOutput.cpu().numpy().copy()
+        m.register_forward_pre_hook(lambda mod, inp: captured.__setitem__(mod, inp[0].detach().cpu().numpy().copy()))
+    counts = np.zeros(len(convs))
+    with torch.no_grad():
+        for t in range(4):
+            net(prep(vid.next()))
+            counts += [m.lastChangeIndexes().numel() for m in convs]
+            for m in picks:
+                o = twins[m]
+                got = o.forward(captured[m])
+                assert m._plan is not None and m._plan.get('fn') is _lib.C.cbinfer_hsplit_forward
+                assert np.array_equal(m.lastChangeIndexes().tensor().cpu().numpy(), got[2]), (t, m.weight.shape)
+                assert got[2].size > 0
+                assert np.array_equal(m.prevInput.cpu().numpy(), o.prevInput), (t, m.weight.shape)
+                ref = o.prevOutput.astype(np.float32)
+                tol = 2 * 2.0 ** -10 * max(1.0, float(np.abs(ref[np.isfinite(ref)]).max()))
+                err = np.abs(m.prevOutput.float().cpu().numpy() - ref).max()
+                assert err <= tol, (t, m.weight.shape, err, tol)
+    ratios = counts / 4.0 / np.array([m.prevInput.size(-1) * m.prevInput.size(-2) for m in convs], dtype=np.float64)
+    assert ratios.min() > 0.01 and 0.04 < ratios.mean() < 0.25, ratios      # every layer alive, ~10 % on average

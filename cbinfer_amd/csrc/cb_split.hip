@@ -1064,21 +1064,23 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
 #define CBS_STEP3A(S, FCUR, FNEXT)                                                         \
         do {                                                                               \
             CBS_SB();                                                                      \
-            mma3(KS0(), FCUR, 0, 2);                                                              \
-            CBS_SB();                                                                      \
-            if (lateIssue && (S) > sBeg) issue((S) - 1 + RING);                            \
+            mma3(KS0(), FCUR, 0, 1);                                                       \
             CBS_SB();                                                                      \
             readA3(KS1(), (S), FNEXT);                                                     \
             CBS_SB();                                                                      \
-            mma3(KS0(), FCUR, 2, 3);                                                              \
+            mma3(KS0(), FCUR, 1, 2);                                                       \
             CBS_SB();                                                                      \
             readB3(KS1(), (S), FNEXT, 0);                                                  \
             CBS_SB();                                                                      \
-            mma3(KS0(), FCUR, 3, 4);                                                              \
+            mma3(KS0(), FCUR, 2, 3);                                                       \
             CBS_SB();                                                                      \
             if (TN > 1) readB3(KS1(), (S), FNEXT, TN - 1);                                 \
             CBS_SB();                                                                      \
-            mma3(KS0(), FCUR, 4, NM3);                                                            \
+            mma3(KS0(), FCUR, 3, 4);                                                       \
+            CBS_SB();                                                                      \
+            if (lateIssue && (S) > sBeg) issue((S) - 1 + RING);                            \
+            CBS_SB();                                                                      \
+            mma3(KS0(), FCUR, 4, NM3);                                                     \
             waitFrags(FNEXT);                                                              \
         } while (0)
 #define CBS_STEP3B(WAITN, S, FCUR, FNEXT)                                                  \
@@ -1086,23 +1088,23 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");                  \
             __builtin_amdgcn_s_barrier();                                                  \
             CBS_SB();                                                                      \
-            mma3(KS1(), FCUR, 0, 2);                                                              \
-            CBS_SB();                                                                      \
-            if (!lateIssue) issue((S) + RING);                                             \
-            CBS_SB();                                                                      \
-            mma3(KS1(), FCUR, 2, 3);                                                              \
+            mma3(KS1(), FCUR, 0, 1);                                                       \
             CBS_SB();                                                                      \
             readA3(KS0(), (S) + 1, FNEXT);                                                 \
             CBS_SB();                                                                      \
-            mma3(KS1(), FCUR, 3, 4);                                                              \
+            mma3(KS1(), FCUR, 1, 2);                                                       \
             CBS_SB();                                                                      \
             readB3(KS0(), (S) + 1, FNEXT, 0);                                              \
             CBS_SB();                                                                      \
-            mma3(KS1(), FCUR, 4, 5);                                                              \
+            mma3(KS1(), FCUR, 2, 3);                                                       \
             CBS_SB();                                                                      \
             if (TN > 1) readB3(KS0(), (S) + 1, FNEXT, TN - 1);                             \
             CBS_SB();                                                                      \
-            mma3(KS1(), FCUR, 5, NM3);                                                            \
+            mma3(KS1(), FCUR, 3, 4);                                                       \
+            CBS_SB();                                                                      \
+            if (!lateIssue) issue((S) + RING);                                             \
+            CBS_SB();                                                                      \
+            mma3(KS1(), FCUR, 4, NM3);                                                     \
             waitFrags(FNEXT);                                                              \
         } while (0)
 

@@ -129,11 +129,13 @@ def log(*a):
 COMPACT_LIMIT = 4096
 
 
-def _num(v, digits=4):
+def _num(v, digits=10):
+    """Floats at 10 significant digits (value, steps and timed_region_s must stay consistent with each other to the
+    driver's tolerance); non-finite -> null."""
     if isinstance(v, float):
         if v != v or v in (float("inf"), float("-inf")):
             return None
-        return float("%.*g" % (digits + 2, v))
+        return float("%.*g" % (digits, v))
     return v
 
 

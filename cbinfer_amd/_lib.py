@@ -167,6 +167,7 @@ _SIGNATURES = {
                                     _i, _i, _i, _f, _i, _i, _vp, _vp]),
     "cbinfer_split_forward_tail": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _i,
                                         _stp, _vp]),
+    "cbinfer_split_forward_fg_tail": (_i, [_sp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _stp, _vp]),
     "cbinfer_split_tail_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "cbinfer_split_conv_tail": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _stp, _vp]),
     "cbinfer_rowpairs_supported": (_i, [_i, _i, _i, _i, _i, _i]),

@@ -583,6 +583,15 @@ class CBConv2d(nn.Module):
         st.output[0] = out.data_ptr()
         return t
 
+    def _fusedTailCandidate(self):
+        """The fused tail this layer would fold into its second launch right now (cheap form of _folded_tail's test,
+        for the call plans), or None."""
+        t = self.__dict__.get('_fusedTail')
+        if (t is None or not self.propChangeIndexes or self.__dict__.get('_noTailFold') or
+                os.environ.get('CBINFER_NO_TAILFOLD', '0') == '1'):
+            return None
+        return t
+
     def rangeExceeded(self):
         """True if a state value of this layer ever left the range of the f16-pair arithmetic (|x| >= 2^20, or a
         non-finite input) since the state was cleared (one host sync unless the module has noticed already).  The
@@ -802,17 +811,29 @@ class CBConv2d(nn.Module):
         sp['stateKey'] = None      # (the records hold differences now: a coarse-grained frame re-splits the state)
         pooled = lazy is not None
         args = [sp['seq'], 1, int(pooled), src.size(-2) if pooled else 0, src.size(-1) if pooled else 0, ptr(wp),
-                Cin, H, W, K, kH, kW, float(self.threshold), float(scale), ptr(sp['ws']), stream_ptr(src)]
-        check(C.cbinfer_split_forward_fg(*args))
+                Cin, H, W, K, kH, kW, float(self.threshold), float(scale), ptr(sp['ws'])]
+        # the fused 1x1 tail behind this layer rides in the contraction's second launch, as in coarse-grained mode
+        # (round 5: cbinfer_split_forward_fg_tail); it reads the relu'd copy when the layer has one
+        tail = self._folded_tail(sp, H, W, src.device)
+        if tail is not None and (not self.withReLU or relu is not None):
+            fn = C.cbinfer_split_forward_fg_tail
+            args += [ctypes.pointer(sp['tail']), stream_ptr(src)]
+        else:
+            tail, fn = None, C.cbinfer_split_forward_fg
+            args += [stream_ptr(src)]
+        check(fn(*args))
         self._poll_range(sp)
         self.__dict__['_ranSplit'] = True
         result = relu if self.withReLU else self.prevOutput
         self._lastIndexes = MaskChangeIndexes(sp['copy'], (H, W), work['idx'], work['count'], made=True)
+        self._lastIndexes.tailDone = tail
         if self.propChangeIndexes:
             result = ('changeIndexes', result, self._lastIndexes)
-        self._make_plan(pooled, src, C.cbinfer_split_forward_fg, args, None, result=result)
+        self._make_plan(pooled, src, fn, args, None, result=result)
         if self._plan is not None:
-            self._plan.update(fgSplit=True, arith=sp['arith'], seq=q, wsplit=(wp, scale), relu=relu)
+            self._plan.update(fgSplit=True, arith=sp['arith'], seq=q, wsplit=(wp, scale), relu=relu,
+                              tail=tail, tailKey=tail._fold_key() if tail is not None else None,
+                              tailCand=self._fusedTailCandidate())
         return result
 
     def forward_fg(self, inp):
@@ -1274,6 +1295,10 @@ class CBConv2d(nn.Module):
         args = plan['args']
         if plan.get('fgSplit'):
             if plan['arith'] != os.environ.get('CBINFER_ARITH', 'x3'):
+                return None
+            t = plan.get('tail')
+            if self._fusedTailCandidate() is not plan['tailCand'] or (
+                    t is not None and t._fold_key() != plan['tailKey']):
                 return None
             plan['seq'].input = src.data_ptr()
         else:

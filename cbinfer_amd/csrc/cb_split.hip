@@ -1370,6 +1370,10 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cbs_reduce_tail_kernel(CbsP
         const int N = p.info[CBS_INFO_TP + CBS_MAXSEQ + q];
         if (n0 >= N) continue;      // (uniform: a tile's last groups may be empty)
         float* outq = p.seq[q].out;
+        // fine-grained frame (accumulate: out += W * delta, cbconv2d_fg_backend.cu:37-66): the sum of the slabs JOINS
+        // what the output holds, the relu'd copy (reluOut, if the layer has one) is kept beside it, and the tail's input
+        // is that copy -- what the next module of the network is handed (conv2d.py:169-173)
+        float* relq = p.accumulate ? p.seq[q].reluOut : nullptr;
         int pixMine = -1;           // (thread px of every 16: the same 16 indices, no LDS hop before the scatter)
         if (n0 + px < N) pixMine = p.seq[q].listOut[n0 + px];
         // (everything below that depends only on the thread index is the same in every round of this loop, and the
@@ -1415,8 +1419,19 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cbs_reduce_tail_kernel(CbsP
                         float r = fmaf(sv[e], p.outScale, hasBias ? bv[e] : 0.f);
                         if (p.relu) r = r <= 0.f ? 0.f : r;
                         if (cq < QN) {
-                            if (pixMine >= 0 && m < p.K) outq[(long)m * HW + pixMine] = r;
-                            L.Xs[m * CB_TAIL_PX + px] = m < p.K ? r : 0.f;
+                            if (p.accumulate) {      // (uniform; the old outputs: one more round trip, as cbs_reduce_kernel's)
+                                if (pixMine >= 0 && m < p.K) {
+                                    r += outq[(long)m * HW + pixMine];
+                                    outq[(long)m * HW + pixMine] = r;
+                                    if (relq) {
+                                        r = r <= 0.f ? 0.f : r;
+                                        relq[(long)m * HW + pixMine] = r;
+                                    }
+                                }
+                            } else if (pixMine >= 0 && m < p.K) {
+                                outq[(long)m * HW + pixMine] = r;
+                            }
+                            L.Xs[m * CB_TAIL_PX + px] = (m < p.K && pixMine >= 0) ? r : 0.f;
                         }
                     }
                 }
@@ -1425,10 +1440,11 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cbs_reduce_tail_kernel(CbsP
             // unsplit: the contraction's epilogue has written prevOutput; gather as the tail kernel does
             __syncthreads();
             if (t < CB_TAIL_PX) s_pix[t] = pixMine;
+            const float* gsrc = relq ? relq : outq;      // (fine-grained with a relu'd copy: the tail reads the copy)
             for (int c0 = tq; c0 < C0P; c0 += 16 * cstep) {
                 float v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = outq[(long)min(c0 + u * cstep, C0 - 1) * HW + pixLd];
+                for (int u = 0; u < 16; ++u) v[u] = gsrc[(long)min(c0 + u * cstep, C0 - 1) * HW + pixLd];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const int c = c0 + u * cstep;
@@ -1823,6 +1839,31 @@ int cbinfer_split_forward_fg(const cbSplitSeq* seqs, int nSeq, int pooled, int p
                                         kH, kW, threshold, stream);
     if (st != CB_OK) return st;
     return cbs_split_conv(seqs, nSeq, prepared, nullptr, C, H, W, K, kH, kW, weightScale, 0, workspace, 0, nullptr,
+                          stream, 1);
+}
+
+// cbinfer_split_forward_fg with the fused 1x1 tail behind the layer evaluated by the contraction's second launch
+// (cbinfer_split_forward_tail's arrangement for the fine-grained frame, round 5): that launch adds the slabs' sum to
+// `output`, keeps `reluOut` and runs conv1x1 -> [relu1] -> conv1x1 on the finished columns -- on relu(output) when the
+// layer has a relu'd copy (reluOut != NULL: what the network hands the next module), else on output.
+int cbinfer_split_forward_fg_tail(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared,
+                                  int C, int H, int W, int K, int kH, int kW, float threshold, float weightScale,
+                                  void* workspace, const cbSplitTail* tail, cbStream_t stream) {
+    CB_REQUIRE(tail && tail->w1Prepared && tail->b1 && tail->w2 && tail->b2 && nSeq >= 1 && nSeq <= CBS_MAXSEQ);
+    CB_REQUIRE(((size_t)tail->b1 & 15) == 0);
+    if (!cbinfer_split_tail_supported(C, K, kH, kW, tail->C1, tail->C2)) return CB_ERR_UNSUPPORTED;
+    CbsTailArgs ta;
+    ta.w1p = tail->w1Prepared, ta.b1 = tail->b1, ta.w2 = tail->w2, ta.b2 = tail->b2;
+    ta.C1 = tail->C1, ta.C2 = tail->C2, ta.relu1 = tail->relu1, ta.relu2 = tail->relu2;
+    for (int q = 0; q < CBS_MAXSEQ; ++q) {
+        if (q < nSeq) CB_REQUIRE(tail->output[q]);
+        ta.out[q] = q < nSeq ? tail->output[q] : nullptr;
+    }
+    const int st = cbinfer_split_detect(seqs, nSeq, CBINFER_SPLIT_FG | (pooled ? CBINFER_SPLIT_POOLED : 0) |
+                                        (weightScale == 0.f ? CBINFER_SPLIT_X3 : 0), pH, pW, C, H, W,
+                                        kH, kW, threshold, stream);
+    if (st != CB_OK) return st;
+    return cbs_split_conv(seqs, nSeq, prepared, nullptr, C, H, W, K, kH, kW, weightScale, 0, workspace, 0, &ta,
                           stream, 1);
 }
 

@@ -525,6 +525,13 @@ int cbinfer_split_forward_tail(const cbSplitSeq* seqs, int nSeq, int mode, int p
                                const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
                                float weightScale, int relu, void* workspace, int forceSplit, const cbSplitTail* tail,
                                cbStream_t stream);
+/* cbinfer_split_forward_fg with the fused 1x1 tail in the contraction's second launch (round 5): that launch adds the
+ * partial tiles' sum to `output`, keeps `reluOut`, and evaluates the tail on relu(output) when reluOut is given (what
+ * the network hands the next module, conv2d.py:169-173), else on output.  Same bits as cbinfer_split_forward_fg
+ * followed by cbinfer_tail1x1. */
+int cbinfer_split_forward_fg_tail(const cbSplitSeq* seqs, int nSeq, int pooled, int pH, int pW, const void* prepared,
+                                  int C, int H, int W, int K, int kH, int kW, float threshold, float weightScale,
+                                  void* workspace, const cbSplitTail* tail, cbStream_t stream);
 
 /* ---- fp16 layers on the split-state machinery (round 4): the frame of a CBConv2d in half precision
  * (cbconv2d_cg_half_backend.cu:10-88 change detection, :146-197 genXMatrix / updateOutput around an fp16 matmul;

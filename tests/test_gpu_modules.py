@@ -2036,3 +2036,48 @@ def test_openpose_live_network_fullsize(pkg, oracle):
                 assert err <= tol, (t, m.weight.shape, err, tol)
     ratios = counts / 4.0 / np.array([m.prevInput.size(-1) * m.prevInput.size(-2) for m in convs], dtype=np.float64)
     assert ratios.min() > 0.01 and 0.04 < ratios.mean() < 0.25, ratios      # every layer alive, ~10 % on average
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pools", [False, True])
+def test_fine_grained_tail_rides_in_the_second_launch(pkg, monkeypatch, pools):
+    """Round 5: the fine-grained experiment 7 network in its in-place form with the fused 1x1 tail
+    evaluated by the 64->256 contraction's second launch (cbinfer_split_forward_fg_tail: that launch adds the partial
+    tiles' sum to prevOutput, keeps the relu'd copy and runs the tail on it) against the same network with the tail's
+    own launch (CBINFER_NO_TAILFOLD=1): network outputs, layer outputs and relu'd copies bit-identical over a walk with
+    idle frames, at 480x320, with nn.MaxPool2d and with change-based pools folded into the fine-grained detections; and
+    the fold really runs."""
+    from cbinfer_amd import workloads, _lib
+
+    def build(fold):
+        monkeypatch.setenv("CBINFER_NO_TAILFOLD", "0" if fold else "1")
+        _, net = workloads.sceneLabelingModels(experimentIdx=7, threshold=0.05)
+        for m in net.modules():
+            if type(m) is pkg.CBConv2d:
+                m.fgInPlace = True
+        if pools:
+            pkg.insertCBPooling(net, cloneOutput=False)
+        pkg.fuseTail1x1(net)
+        if pools:
+            pkg.fusePoolingIntoDetection(net)
+        return net
+    vid = workloads.SyntheticVideo(H=320, W=480, ratio=0.10, block=16, seed=5)
+    frames = vid.frames(7)
+    frames = frames[:3] + [frames[2], frames[2]] + frames[3:]        # (two idle frames)
+    outs = {}
+    for fold in (True, False):
+        net = build(fold)      # (the switch is read when a frame is dispatched: keep it set while this network runs)
+        got = []
+        with torch.no_grad():
+            for f in frames:
+                y = net(f)
+                head = [m for m in net.children() if type(m) is pkg.CBConv2d][-1]
+                got.append((y.clone(), head.prevOutput.clone()))
+        if fold:
+            assert head._plan is not None and head._plan.get('fn') is _lib.C.cbinfer_split_forward_fg_tail
+        else:
+            assert head._plan is None or head._plan.get('fn') is not _lib.C.cbinfer_split_forward_fg_tail
+        outs[fold] = got
+    for t, (a, b) in enumerate(zip(outs[True], outs[False])):
+        assert torch.equal(a[0], b[0]), t
+        assert torch.equal(a[1], b[1]), t

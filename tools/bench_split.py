@@ -14,7 +14,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cbinfer_amd import conv2d_cg as cg  # noqa: E402
 from cbinfer_amd import _lib  # noqa: E402
 from cbinfer_amd._lib import C as lib, check, ptr  # noqa: E402
-from tools.bench_rows import ev  # noqa: E402
+
+
+def ev(fn, reps=60):
+    """Mean duration of fn() in microseconds over `reps` back-to-back calls (HIP events on the current stream)."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / reps
 
 
 def main():

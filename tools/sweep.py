@@ -46,7 +46,8 @@ def main():
     args = ap.parse_args()
     n = 2 + args.warmup + args.steps
 
-    print("## scene labeling 480x320 fp32, 16x16 re-drawn blocks (config 3 sweep)\n")
+    print("## scene labeling 480x320 fp32, 16x16 re-drawn blocks (config 3 sweep); arithmetic of the split-state "
+          "kernels: %s\n" % bench.ARITH_TEXT[bench.split_arith()])
     print("| change | dense f/s | CG exp6 f/s | speed-up | post-dilation ratio per CB layer | "
           "FG exp7 f/s (default: fresh tensors, eager) | FG exp7 in-place f/s (best of graph/eager) | "
           "FG in-place speed-up | FG in-place + CBPoolMax2d f/s | FG exp7 atomic scatter f/s (eager) |")
@@ -100,37 +101,33 @@ def main():
               (100 * vid.ratio, dense, fcg, fcg / dense, ratios, ffg, ffd, ffd / dense, ffp, ffa), flush=True)
 
     if not args.skip_pose:
-        print("\n## OpenPose T=2 368x654 fp16, coarse-grained (config 4), 10 % change in 46x... blocks\n")
-        H, W = 368, 654
-        # synthetic video at the preprocess range x*255/256-0.5 (PoseDetector.py:72); blocks of 46x... do
-        # not tile 654, so use a padded generator and crop
-        vid = workloads.SyntheticVideo(H=368, W=672, ratio=0.10, block=16, seed=3)
-        frames = [(f[:, :, :, :W] * (255.0 / 256.0) - 0.5).half().contiguous() for f in vid.frames(n)]
-        base = workloads.OpenPoseModel(T=2).cuda().half()
-        test = workloads.convertOpenPose(workloads.OpenPoseModel(T=2).cuda().half(), threshold=0.02)
-        # best of the two launch forms for both networks (as bench.py --mode auto does)
-        dense = max(measure(base, frames, min(args.steps, 20), 3, m) for m in ("graph", "eager"))
-        cbm = {m: measure(test, frames, min(args.steps, 20), 3, m) for m in ("graph", "eager")}
-        cb = max(cbm.values())
-        print("CB launch forms:", cbm)
-        # the two branches of every stage on two streams (eager; applied to the dense network as well)
-        based = workloads.OpenPoseModel(T=2, concurrentBranches=True).cuda().half()
-        testd = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, concurrentBranches=True).cuda().half(),
-                                          threshold=0.02)
-        print("concurrent branches (eager): dense %.1f f/s, CB %.1f f/s" % (
-            measure(based, frames, min(args.steps, 20), 3, "eager"),
-            measure(testd, frames, min(args.steps, 20), 3, "eager")))
-        # the reference's experiments 10/11: feedback ("recursive") mode, no per-frame copy of the layer inputs
-        testf = workloads.convertOpenPose(workloads.OpenPoseModel(T=2).cuda().half(), threshold=0.02,
-                                          feedbackLoop=True)
-        cbf = max(measure(testf, frames, min(args.steps, 20), 3, m) for m in ("graph", "eager"))
-        print("feedback mode (modelConverter.py:84-86): CB %.1f f/s = %.2fx dense; mean post-dilation ratio %.0f%%"
-              % (cbf, cbf / dense, 100 * sum(layer_ratios(testf)) / max(1, len(layer_ratios(testf)))))
-        rs = layer_ratios(test)
-        print("| dense f/s | CB f/s | speed-up | mean post-dilation ratio over 36 layers |")
-        print("|---|---|---|---|")
-        print("| %.1f | %.1f | %.2fx | %.0f%% |" % (dense, cb, cb / dense, 100 * sum(rs) / max(1, len(rs))))
+        print("\n## OpenPose T=2 368x654 fp16, coarse-grained (config 4), 10 % of the input re-drawn per frame in 16x16 "
+              "blocks -- LIVE network (bench.openpose_config: variance-preserving random weights, per-layer thresholds "
+              "calibrated to ~10 % post-dilation change in the running network, fresh consecutive frames)\n")
 
+        def pmeasure(model, frames, mode, steps=30, warm=5):
+            return measure(model, frames, steps, warm, mode)
+        c = bench.openpose_config(args, pmeasure)
+        print("| dense f/s | CB f/s (%s) | speed-up | every layer scanning its input | feedback mode (own thresholds; mean "
+              "ratio) | + change-based pools folded into the detections | mean / min / max post-dilation ratio over 36 "
+              "layers | recomputed GFLOP per frame (dense %.1f) |" % (c["cb_launch"], c["dense_ops_per_frame"] / 1e9))
+        print("|---|---|---|---|---|---|---|---|")
+        print("| %.1f | %.1f | %.2fx | %.1f (%.2fx) | %.1f (%.2fx; %.0f %%) | %.1f (%.2fx) | %.1f / %.1f / %.1f %% | %.1f |"
+              % (c["dense_fps"], c["cb_fps"], c["speedup"], c["cb_unchained_fps"], c["unchained_speedup"],
+                 c["cb_feedback_mode_fps"], c["feedback_speedup"], 100 * c["feedback_mode_mean_ratio"],
+                 c["cb_with_change_based_pools_fps"], c["change_based_pools_speedup"],
+                 100 * c["mean_post_dilation_ratio"], 100 * c["min_ratio"], 100 * c["max_ratio"],
+                 c["recomputed_gflop_per_frame"]))
+        print("\nper layer (ratio, threshold, library call):")
+        for r in c["per_layer"]:
+            print("  %-22s %5.1f %%  th %.4g  %s" % (r["layer"], 100 * r["ratio"], r["threshold"], r["path"]))
+        rf = c.get("roofline") or {}
+        if "contractions" in rf:
+            print("\ncontraction launches: %.1f GFLOP in %.0f us = %.1f TFLOP/s = %.3f of the dense f16 MFMA peak; "
+                  "detections: %.0f MB in %.0f us = %.0f GB/s = %.2f of HBM"
+                  % (rf["contractions"]["flops_per_frame"] / 1e9, rf["contractions"]["us_per_frame"],
+                     rf["contractions"]["achieved"], rf["contractions"]["frac"], rf["detections"]["bytes_per_frame"] / 1e6,
+                     rf["detections"]["us_per_frame"], rf["detections"]["achieved"], rf["detections"]["frac"]))
 
 if __name__ == "__main__":
     main()

@@ -535,7 +535,9 @@ int cbinfer_split_forward_fg_tail(const cbSplitSeq* seqs, int nSeq, int pooled, 
 
 /* ---- fp16 layers on the split-state machinery (round 4): the frame of a CBConv2d in half precision
  * (cbconv2d_cg_half_backend.cu:10-88 change detection, :146-197 genXMatrix / updateOutput around an fp16 matmul;
- * conv2d.py:178-259) whose input channels are a multiple of 64.  Beside prevInput [C,H,W] f16 the layer keeps a
+ * conv2d.py:178-259) of 64 and more input channels (round 5: a count that is not a multiple of 64 -- OpenPose's 185 --
+ * is padded to the next one in the pixel-major copy and the prepared weights: zero records, zero weights; the tensors
+ * keep their C).  Beside prevInput [C,H,W] f16 the layer keeps a
  * pixel-major copy [Hp][Wp][C] f16 with a zero border (cbinfer_hsplit_state_bytes; no split -- the values are f16
  * already), so that a pixel's 64 channels of one tap are 128 contiguous bytes and both operands of the contraction go
  * global -> LDS by LDS-DMA; v_mfma_f32_32x32x16_f16, f32 accumulation, outputs rounded to f16 once (the arithmetic

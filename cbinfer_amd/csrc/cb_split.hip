@@ -388,7 +388,7 @@ struct CbsParams {
 // diagnostic ablations are a build option (make EXTRA=-DCBS_DBG; tools/split_dbg_run.sh): 1 every pixel-operand
 // DMA reads the dummy pixel, 2 no fragment reads / MFMAs, 4 no DMA at all, 8 no pixel-operand fragment reads,
 // 16 no weight fragment reads, 32 no epilogue stores, 64 every DMA issued dead (no memory traffic), 128 / 256 the weight /
-// pixel DMAs dead
+// pixel DMAs dead, 512 (x3) the second column tile's fragments are not read (a third of the LDS read volume less)
 #ifdef CBS_STAMP
 // diagnostic build only (make EXTRA=-DCBS_STAMP; tools/split_stamps.py): per-workgroup phase stamps of its FIRST item,
 // 100 MHz constant clock: 0 entry, 1 list lengths known, 2 item set up, 3 ring primed, 4 stage loop done, 5 epilogue
@@ -935,6 +935,10 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             constexpr int KS = decltype(ksTag)::value;
             const unsigned slot = (s % RING) * STAGE;
             constexpr int E0 = 3 * KS, E1 = 3 * KS + 1, E2 = 3 * KS + 2;
+            if (CBS_DBGBIT(512) && j > 0) {      // (ablation: a third fewer fragment reads -- what 64x64 wave tiles would read)
+                f.b[j * 3 + 0] = f.b[0], f.b[j * 3 + 1] = f.b[1], f.b[j * 3 + 2] = f.b[2];
+                return;
+            }
             f.b[j * 3 + 0] = cbs_lds_read16<(E0 / 2) * 1024>(bAddr[j * 4 + (E0 & 1)] + slot);
             f.b[j * 3 + 1] = cbs_lds_read16<(E1 / 2) * 1024>(bAddr[j * 4 + (E1 & 1)] + slot);
             f.b[j * 3 + 2] = cbs_lds_read16<(E2 / 2) * 1024>(bAddr[j * 4 + (E2 & 1)] + slot);
@@ -1340,7 +1344,7 @@ struct CbsTailArgs {
 };
 template <int BM, int BN>
 __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cbs_reduce_tail_kernel(CbsParams p, CbsTailArgs ta) {
-    extern __shared__ float cbs_tail_sm[];
+    extern __shared__ __attribute__((aligned(16))) float cbs_tail_sm[];
     cb_touch_kernarg<sizeof(CbsParams) + sizeof(CbsTailArgs)>();
     const int C0 = p.K, C0P = (C0 + 15) / 16 * 16, C1 = ta.C1, C2 = ta.C2, HW = p.H * p.W;
     const int t = threadIdx.x, NT = blockDim.x;
@@ -1362,7 +1366,7 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cbs_reduce_tail_kernel(CbsP
     __shared__ int s_pix[CB_TAIL_PX];
     // W1 (prepared: [wave][16-channel group][lane][4 floats]) -> LDS, every wave its own C0P / 16 KB, no registers, no wait
     // here: the barrier in front of the first layer's MFMAs waits for it (the compiler counts LDS-DMA as an LDS write)
-    float* W1s = cbs_tail_sm + cb_tail_lds_bytes(C0, C1, C2) / 4;
+    float* W1s = cbs_tail_sm + (cb_tail_lds_bytes(C0, C1, C2) + 15) / 16 * 4;      // (16-byte aligned: ds_read_b128, LDS-DMA)
     if (ta.w1Lds) {
         const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, groups16 = C0P / 16;
         if (16 * wave < C1) {
@@ -1521,7 +1525,7 @@ int cbs_launch_conv(const CbsParams& p, int perCU, const CbsTailArgs* tail, hipS
     if (tail) {
         const int waves = (tail->C1 + 15) / 16;
         CbsTailArgs ta = *tail;
-        const size_t base = cb_tail_lds_bytes(p.K, tail->C1, tail->C2);
+        const size_t base = (cb_tail_lds_bytes(p.K, tail->C1, tail->C2) + 15) / 16 * 16;
         const size_t w1 = (size_t)tail->C1 * ((p.K + 15) / 16 * 16) * 4;
         static int w1lds = -1;      // CBINFER_TAIL_W1_LDS (A/B aid; default 1)
         if (w1lds < 0) {

@@ -474,13 +474,15 @@ class CBConv2d(nn.Module):
             # copy is made again from it
             check(C.cbinfer_hsplit_state_rebuild(ptr(prev), ptr(hs['S']), Cin, H, W, kH, kW, stream_ptr(input)))
             hs['stateKey'] = stateKey
+        # (the producer-mask shortcut assumes the skipped segments compared below THIS threshold last frame and a
+        #  state that has seen every pixel: not on a fresh or restored state, not after a change of the threshold)
+        sameTh = self.__dict__.get('_pmaskThreshold') == float(self.threshold)
+        self.__dict__['_pmaskThreshold'] = float(self.threshold)
         pmask = None
         if lazy is not None:
-            # (the producer-mask shortcut assumes the skipped segments compared below THIS threshold last frame and a
-            #  state that has seen every pixel: not on a fresh or restored state, not after a change of the threshold)
-            sameTh = self.__dict__.get('_pmaskThreshold') == float(self.threshold)
-            self.__dict__['_pmaskThreshold'] = float(self.threshold)
             pmask = None if (rebuilt or not sameTh) else lazy.producerMask()
+        elif not rebuilt and sameTh:
+            pmask = self._chain_mask(H, W)      # (round 5: a chained layer skips the segments its producer left alone)
         pooled = lazy is not None
         args = (None, ptr(input), int(pooled), input.size(-2) if pooled else 0, input.size(-1) if pooled else 0,
                 ptr(pmask), ptr(prev), ptr(hs['S']), ptr(hs['bits']), ptr(self.prevOutput), ptr(work['idx']),
@@ -493,7 +495,8 @@ class CBConv2d(nn.Module):
         if not self._inputIsLiveState:
             self._make_plan(pooled, input, C.cbinfer_hsplit_forward, args, 1, pmask=ptr(pmask))
             if self._plan is not None:
-                self._plan.update(chain=True, stateVersion=prev._version, checkPmask=pooled)
+                self._plan.update(chain=True, stateVersion=prev._version, checkPmask=pooled,
+                                  chainMask=None if pooled else (5, H, W))
         result = MaskChangeIndexes(hs['copy'], (H, W), work['idx'], work['count'], made=True)
         if self._plan is not None:
             self._plan['indexes'] = result
@@ -1307,6 +1310,10 @@ class CBConv2d(nn.Module):
         if chain:
             up = self.__dict__.get('_upNow')
             args[0] = up.data_ptr() if up is not None else None
+            cm = plan.get('chainMask')
+            if cm is not None:      # (the producer's mask of this frame, under the chain's own conditions)
+                pm = self._chain_mask(cm[1], cm[2])
+                args[cm[0]] = pm.data_ptr() if pm is not None else None
         status = plan['fn'](*args)
         if status != 0:
             check(status)
@@ -1347,6 +1354,19 @@ class CBConv2d(nn.Module):
     def _publish_count(self, count):
         out = self._buffers['prevOutput']
         out._cbProduced = _Produced(self, self.__dict__.get('_serial', 0), out._version, count)
+
+    def _chain_mask(self, H, W):
+        """The change mask the PRODUCING layer of a chain left this frame (its MaskChangeIndexes' mask copy, H x W) while
+        the chain's conditions hold (_note_upstream: the input is that layer's output buffer of its latest frame, this
+        layer consumed its previous one from the same buffer into the same state) -- else None.  CBINFER_NO_CHAINMASK=1
+        switches it off."""
+        d = self.__dict__
+        if d.get('_upNow') is None or os.environ.get('CBINFER_NO_CHAINMASK', '0') == '1':
+            return None
+        ix = getattr(d['_upSeen'][0], '_lastIndexes', None)
+        if isinstance(ix, MaskChangeIndexes) and tuple(ix.size) == (H, W) and ix._mask is not None:
+            return ix._mask
+        return None
 
     def _note_upstream(self, inp):
         d = self.__dict__

@@ -2075,6 +2075,13 @@ __global__ __launch_bounds__(512) void cbh_detect_kernel(CbhDetArgs a) {
             }
         if (__builtin_amdgcn_readfirstlane((int)(any != 0ull)) == 0) return;
     }
+    if (!POOL && a.prodMask) {
+        // round 5: the layer is handed the OUTPUT BUFFER of another change-based layer of the same resolution (a chain,
+        // CBConv2d._note_upstream) and that layer's change mask of this frame: a 64-pixel segment none of whose pixels
+        // the producer rewrote holds bit for bit what this layer compared last frame -- nothing to detect, nothing to
+        // copy -- and is not even read (the pooled form's shortcut, for the layers between the pools)
+        if (__builtin_amdgcn_readfirstlane((int)(a.prodMask[(long)y * a.wpr + tx] != 0ull)) == 0) return;
+    }
     const int x = tx * 64 + lane;
     const bool valid = x < W;
     const long HW = (long)H * W;
@@ -2289,7 +2296,7 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int 
     a.W = W, a.H = H, a.C = C, a.kHH = (kH - 1) / 2, a.kWH = (kW - 1) / 2, a.wpr = cbinfer_mask_words_per_row(W);
     a.Wp = g.Wp, a.rec = g.rec, a.padY = g.padY, a.padXL = g.padXL, a.th = threshold, a.copyAll = feedbackLoop ? 0 : 1;
     a.upstream = upstreamCount;
-    a.pH = pH, a.pW = pW, a.prodMask = pooled ? (const unsigned long long*)producerMask : nullptr;
+    a.pH = pH, a.pW = pW, a.prodMask = (const unsigned long long*)producerMask;      // (pooled: at pH x pW; else at H x W)
     if (pooled)
         hipLaunchKernelGGL(cbh_detect_kernel<true>, dim3(a.wpr, H, a.copyAll ? g.C / 64 : 1), dim3(512), 0, s, a);
     else

@@ -547,7 +547,11 @@ int cbinfer_split_forward_fg_tail(const cbSplitSeq* seqs, int nSeq, int pooled, 
  * cbinfer_hsplit_workspace_bytes (0 for fewer than 48 k-stages), zero once; upstreamCount: optional, as for
  * cbinfer_cbconv2d_forward_after.  idxOut / countOut / maskCopy as for cbinfer_split_forward.  pooled != 0: `input`
  * is the tensor in front of a 2x2/stride-2 max pool [C,pH,pW] (CBPoolMax2d folded into the detection; H x W the
- * pooled size), producerMask as for cbinfer_change_detection_bits_pooled. */
+ * pooled size), producerMask as for cbinfer_change_detection_bits_pooled.  pooled == 0 with a producerMask (round
+ * 5): `input` is the output buffer of another change-based layer of the SAME resolution and producerMask that layer's
+ * change mask of this frame (cbinfer_mask_words(H,W) words): 64-pixel segments it did not rewrite are skipped.  Valid
+ * under the conditions of upstreamCount (the buffer is what this layer compared last frame wherever the producer
+ * rewrote nothing; state not fresh or restored, threshold unchanged since the last frame). */
 int cbinfer_hsplit_supported(int C, int K, int kH, int kW);
 long cbinfer_hsplit_max_mask_words(int K);
 long cbinfer_hsplit_state_bytes(int C, int H, int W, int kH, int kW);

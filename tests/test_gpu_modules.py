@@ -2081,3 +2081,43 @@ def test_fine_grained_tail_rides_in_the_second_launch(pkg, monkeypatch, pools):
     for t, (a, b) in enumerate(zip(outs[True], outs[False])):
         assert torch.equal(a[0], b[0]), t
         assert torch.equal(a[1], b[1]), t
+
+
+@pytest.mark.gpu
+def test_chained_fp16_layers_skip_what_their_producer_left_alone(pkg, monkeypatch):
+    """Round 5: an fp16 split-state layer that is handed another change-based layer's output buffer (a chain) also
+    gets that layer's change mask of the frame, and its detection skips the 64-pixel segments the producer did not
+    rewrite (cbh_detect_kernel, non-pooled producer-mask shortcut).  The live OpenPose network at full size with
+    calibrated thresholds, 12 frames: the two heat-map outputs, every layer's prevInput / prevOutput and change list
+    bit-identical with the shortcut on and off (CBINFER_NO_CHAINMASK=1) -- and the shortcut really is offered."""
+    from cbinfer_amd import workloads
+    H, W = 368, 654
+
+    def prep(f):
+        return (f[:, :, :, :W] * (255.0 / 256.0) - 0.5).half().contiguous()
+    vid = workloads.SyntheticVideo(H=H, W=672, ratio=0.10, block=16, seed=21)
+    net = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, init='kaiming').cuda().half(), threshold=0.02)
+    ths = workloads.calibrateChangeRatio(net, lambda: prep(vid.next()), target=0.10, pairs=2, settle=4, finalSettle=4)
+    frames = [prep(vid.next()) for _ in range(12)]
+    frames[5] = frames[4]                      # (an exact repeat: every count is zero, the chain skips whole layers)
+    runs = {}
+    for off in ("0", "1"):
+        monkeypatch.setenv("CBINFER_NO_CHAINMASK", off)
+        m = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, init='kaiming').cuda().half(), threshold=0.02)
+        convs = [c for c in m.modules() if type(c) is pkg.CBConv2d]
+        for c, th in zip(convs, ths):
+            c.threshold = th
+        got, offered = [], 0
+        with torch.no_grad():
+            for f in frames:
+                y = m(f)
+                offered += sum(1 for c in convs if c._chain_mask(c.prevInput.size(-2), c.prevInput.size(-1)) is not None)
+                got.append(([t.clone() for t in y], [c.prevInput.clone() for c in convs],
+                            [c.prevOutput.clone() for c in convs],
+                            [c.lastChangeIndexes().tensor().clone() for c in convs]))
+        runs[off] = (got, offered)
+    assert runs["0"][1] >= 15 * 8 and runs["1"][1] == 0, (runs["0"][1], runs["1"][1])
+    for t, (a, b) in enumerate(zip(runs["0"][0], runs["1"][0])):
+        for part in range(4):
+            for u, v in zip(a[part], b[part]):
+                assert torch.equal(u, v), (t, part)

@@ -850,6 +850,14 @@ def openpose_config(args, measure):
     pycbinfer.fusePoolingIntoDetection(cbp)
     cbpool = max(measure(cbp, frames, m, psteps, pwarm) for m in ("graph", "eager"))
     del cbp
+    # the two branches of every stage (PoseModel.py:122-137: independent until the concat) on two HIP streams, fork / join
+    # per stage -- an execution option of the MODEL, applied to the dense network as well
+    cbc = with_thresholds(workloads.convertOpenPose(
+        workloads.OpenPoseModel(T=2, init='kaiming', concurrentBranches=True).cuda().half(), threshold=0.02))
+    cbconc = measure(cbc, frames, "eager", psteps, pwarm)
+    del cbc
+    densec = measure(workloads.OpenPoseModel(T=2, init='kaiming', concurrentBranches=True).cuda().half(), frames, "eager",
+                     psteps, 3)
     pose_ops = workloads.openPoseDenseOps(2, Hp, Wp)
     return {
         "dense_fps": dense, "cb_fps": cb, "cb_launch": max(cb_modes, key=cb_modes.get), "speedup": cb / dense,
@@ -858,6 +866,8 @@ def openpose_config(args, measure):
         "feedback_mode_ratios": [round(r, 3) for r in fratio], "cb_unchained_fps": cbu,
         "unchained_speedup": cbu / dense, "cb_with_change_based_pools_fps": cbpool,
         "change_based_pools_speedup": cbpool / dense,
+        "concurrent_branches": {"cb_fps": cbconc, "dense_fps": densec, "speedup": cbconc / densec,
+                                "what": "the two branches of every stage on two HIP streams (eager), both networks"},
         "effective_gflops": cb * pose_ops / 1e9, "dense_ops_per_frame": pose_ops,
         "recomputed_gflop_per_frame": flops / 1e9,
         "mean_post_dilation_ratio": sum(rs) / max(1, len(rs)), "min_ratio": min(rs), "max_ratio": max(rs),

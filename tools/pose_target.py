@@ -26,9 +26,10 @@ def main():
     def prep(f):        # PoseDetector.py:72: x * 255/256 - 0.5, fp16
         return (f[:, :, :, :W] * (255.0 / 256.0) - 0.5).half().contiguous()
     init = os.environ.get("POSE_INIT", "kaiming")
-    test = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, init=init).cuda().half(),
+    conc = os.environ.get("POSE_CONCURRENT", "0") == "1"      # the two branches of every stage on two HIP streams
+    test = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, init=init, concurrentBranches=conc).cuda().half(),
                                      threshold=float(os.environ.get("POSE_TH", "0.02")), feedbackLoop=feedback)
-    base = workloads.OpenPoseModel(T=2, init=init).cuda().half()
+    base = workloads.OpenPoseModel(T=2, init=init, concurrentBranches=conc).cuda().half()
     if "POSE_TH" not in os.environ:
         # (calibrated on the running video; the timed walk continues it, so the network is in its steady state)
         workloads.calibrateChangeRatio(test, lambda: prep(vid.next()), target=float(os.environ.get("POSE_TARGET", "0.10")))

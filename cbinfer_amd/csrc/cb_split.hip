@@ -1338,21 +1338,16 @@ struct CbsTailArgs {
     const float* b2;
     float* out[CBS_MAXSEQ];
     int C1, C2, relu1, relu2;
-    int w1Lds;      // != 0: the first layer's prepared matrix is copied to LDS by LDS-DMA at kernel entry (C1 * C0P floats
-                    // behind the tail's own LDS) and its fragments are read from there: the round trip of the W1 request
-                    // runs beside the slabs' instead of behind their sums (round 5)
 };
 template <int BM, int BN>
 __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cbs_reduce_tail_kernel(CbsParams p, CbsTailArgs ta) {
-    extern __shared__ __attribute__((aligned(16))) float cbs_tail_sm[];
+    extern __shared__ float cbs_tail_sm[];
     cb_touch_kernarg<sizeof(CbsParams) + sizeof(CbsTailArgs)>();
     const int C0 = p.K, C0P = (C0 + 15) / 16 * 16, C1 = ta.C1, C2 = ta.C2, HW = p.H * p.W;
     const int t = threadIdx.x, NT = blockDim.x;
-    // Round trips to memory are what this launch consists of.  First: the launch info of the contraction.  Second (per
-    // group): the slabs of the group's 16 pixel columns -- their address needs no pixel index --, the 16 pixel indices,
-    // the layer's biases and (first group) the second layer's matrix, ALL requested before the first of them is used
-    // (round 5: the matrix copy and the index check used to be round trips of their own in front of the slabs: 3.3 us
-    // from "launch info known" to "slab columns arrived" where one round trip is 1.1).  Third: this wave's rows of W1.
+    // Round trips to memory are what this launch consists of.  First: the launch info of the contraction, the
+    // layer's biases, the second layer's matrix.  Second (per group): the slabs of the group's 16 pixel columns --
+    // their address needs no pixel index -- and the 16 pixel indices.  Third: this wave's rows of W1.
     CB_TAIL_STAMP(0);
     const int SK = p.info[CBS_INFO_SK], MT = p.info[CBS_INFO_MT], CMB = MT * SK, TILE4 = BM * BN / 4;
     int tilesBefore[CBS_MAXSEQ + 1];
@@ -1364,24 +1359,8 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cbs_reduce_tail_kernel(CbsP
     CB_TAIL_STAMP(1);
     const CbTailLds L = cb_tail_lds(cbs_tail_sm, C0P, C1, C2, NT);
     __shared__ int s_pix[CB_TAIL_PX];
-    // W1 (prepared: [wave][16-channel group][lane][4 floats]) -> LDS, every wave its own C0P / 16 KB, no registers, no wait
-    // here: the barrier in front of the first layer's MFMAs waits for it (the compiler counts LDS-DMA as an LDS write)
-    float* W1s = cbs_tail_sm + (cb_tail_lds_bytes(C0, C1, C2) + 15) / 16 * 4;      // (16-byte aligned: ds_read_b128, LDS-DMA)
-    if (ta.w1Lds) {
-        const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, groups16 = C0P / 16;
-        if (16 * wave < C1) {
-            const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)ta.w1p, 0, C1 * C0P * 4, 0x00020000);
-            char* dst = (char*)(W1s + (long)wave * groups16 * 256);
-            for (int i = 0; i < groups16; ++i)
-                cbs_dma16<0>(wr, dst + i * 1024, lane * 16, (wave * groups16 + i) * 1024);
-        }
-    }
-    bool w2Pending = true;      // (the second layer's matrix goes to LDS behind the first group's slab requests)
-    auto copyW2 = [&]() {
-        for (int i = t; i < C2 * C1; i += NT) L.W2s[i] = ta.w2[i];
-        for (int i = t; i < C2; i += NT) L.b2s[i] = ta.b2[i];
-        w2Pending = false;
-    };
+    for (int i = t; i < C2 * C1; i += NT) L.W2s[i] = ta.w2[i];
+    for (int i = t; i < C2; i += NT) L.b2s[i] = ta.b2[i];
     const float4* __restrict__ slabs = (const float4*)p.slabs;
     const bool hasBias = p.bias != nullptr;
     const float* biasp = hasBias ? p.bias : ta.b1;      // (no bias: any readable address, the values are not used)
@@ -1400,14 +1379,17 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cbs_reduce_tail_kernel(CbsP
         // what the output holds, the relu'd copy (reluOut, if the layer has one) is kept beside it, and the tail's input
         // is that copy -- what the next module of the network is handed (conv2d.py:169-173)
         float* relq = p.accumulate ? p.seq[q].reluOut : nullptr;
-        // (thread px of every 16: the same 16 indices, no LDS hop before the scatter; requested here with a clamped
-        //  address, looked at behind the slab requests)
-        int pixMine = p.seq[q].listOut[min(n0 + px, N - 1)];
+        int pixMine = -1;           // (thread px of every 16: the same 16 indices, no LDS hop before the scatter)
+        if (n0 + px < N) pixMine = p.seq[q].listOut[n0 + px];
         // (everything below that depends only on the thread index is the same in every round of this loop, and the
         //  compiler would keep it all -- some eighty registers of addresses -- alive across the loop: an opaque copy
         //  of the index makes it recompute them, a few integer instructions per use)
         int tq = t >> 4;
         asm volatile("" : "+v"(tq));
+        if ((unsigned)pixMine >= (unsigned)HW) pixMine = -1;
+        const int pixLd = max(pixMine, 0);      // (loads are never predicated -- a predicated load is a branch, and
+                                                //  sixteen branches in a row are sixteen round trips: clamped addresses,
+                                                //  predicated USES)
         if (SK > 1) {
             // X[c][px] from the slabs (SK = CBS_CHUNKS of them): thread -> (px, channel quads t/16 + i NT/16); all loads
             // of a thread in flight.  The same number of rounds for every thread, so that all reach the barrier.
@@ -1425,8 +1407,6 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cbs_reduce_tail_kernel(CbsP
                 }
                 __builtin_amdgcn_sched_barrier(0);      // (all loads requested before anything of the second half)
                 if (rd == 0) {
-                    if (w2Pending) copyW2();
-                    if (n0 + px >= N || (unsigned)pixMine >= (unsigned)HW) pixMine = -1;
                     __syncthreads();   // previous group's Hs / s_pix / Xs reads are done
                     if (t < CB_TAIL_PX) s_pix[t] = pixMine;
                     CB_TAIL_STAMP(2);
@@ -1463,11 +1443,6 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cbs_reduce_tail_kernel(CbsP
             }
         } else {
             // unsplit: the contraction's epilogue has written prevOutput; gather as the tail kernel does
-            if (w2Pending) copyW2();
-            if (n0 + px >= N || (unsigned)pixMine >= (unsigned)HW) pixMine = -1;
-            const int pixLd = max(pixMine, 0);      // (loads are never predicated -- a predicated load is a branch, and
-                                                    //  sixteen branches in a row are sixteen round trips: clamped
-                                                    //  addresses, predicated USES)
             __syncthreads();
             if (t < CB_TAIL_PX) s_pix[t] = pixMine;
             const float* gsrc = relq ? relq : outq;      // (fine-grained with a relu'd copy: the tail reads the copy)
@@ -1487,13 +1462,7 @@ __global__ __launch_bounds__(64 * CB_TAIL_MAXW) void cbs_reduce_tail_kernel(CbsP
         // sums queue behind them), per group -- few workgroups see a second one -- rather than kept across the loop
         asm volatile("" ::: "memory");
         CbTailPre P;
-        if (ta.w1Lds) {      // (its rows of W1 out of LDS -- behind the barrier that completes the X tile, see cb_tail_tile)
-            P.fromLds = (const cb_tail_floatx4*)W1s;
-            cb_tail_preload_bias(P, ta.b1, C1);
-        } else {
-            P.fromLds = nullptr;
-            cb_tail_preload(P, ta.w1p, ta.b1, C0P, C1);
-        }
+        cb_tail_preload(P, ta.w1p, ta.b1, C0P, C1);
         CB_TAIL_STAMP(3);
         cb_tail_tile(L, s_pix, P, ta.w1p, ta.out[q], C0P, C1, C2, HW, ta.relu1, ta.relu2);
         CB_TAIL_STAMP(7);
@@ -1524,30 +1493,8 @@ int cbs_launch_conv(const CbsParams& p, int perCU, const CbsTailArgs* tail, hipS
     if (st != CB_OK) return st;
     if (tail) {
         const int waves = (tail->C1 + 15) / 16;
-        CbsTailArgs ta = *tail;
-        const size_t base = (cb_tail_lds_bytes(p.K, tail->C1, tail->C2) + 15) / 16 * 16;
-        const size_t w1 = (size_t)tail->C1 * ((p.K + 15) / 16 * 16) * 4;
-        static int w1lds = -1;      // CBINFER_TAIL_W1_LDS (A/B aid; default 1)
-        if (w1lds < 0) {
-            const char* e = getenv("CBINFER_TAIL_W1_LDS");
-            w1lds = e ? atoi(e) : 1;
-        }
-        // (one sequence: a group per workgroup, 232 of them on 256 CUs -- the 64 KB cost no occupancy that is used;
-        //  several sequences keep two workgroups per CU and the register form)
-        ta.w1Lds = (w1lds && p.nSeq == 1 && base + w1 <= 150 * 1024 && (tail->C1 % 16) == 0) ? 1 : 0;
-        if (ta.w1Lds) {      // (more than 64 KB of dynamic LDS: the kernel has to be told once)
-            static bool told = false;
-            if (!told) {
-                if (hipFuncSetAttribute((const void*)cbs_reduce_tail_kernel<BM, BN>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
-                    (void)hipGetLastError();
-                    w1lds = 0, ta.w1Lds = 0;
-                }
-                told = true;
-            }
-        }
         hipLaunchKernelGGL((cbs_reduce_tail_kernel<BM, BN>), dim3(2 * cbs_num_cus()), dim3(64 * waves),
-                           base + (ta.w1Lds ? w1 : 0), s, p, ta);
+                           cb_tail_lds_bytes(p.K, tail->C1, tail->C2), s, p, *tail);
         st = cb_launch_status();
     } else if (second) {
         hipLaunchKernelGGL(cbs_reduce_kernel, dim3(4 * cbs_num_cus()), dim3(256), 0, s, p, BM, BN);

@@ -37,17 +37,7 @@ __host__ __device__ inline size_t cb_tail_lds_bytes(int C0, int C1, int C2) {
 struct CbTailPre {
     cb_tail_floatx4 a[16];
     float b1v[4];
-    const cb_tail_floatx4* fromLds;      // != null: the prepared W1 lies in LDS (cbs_reduce_tail_kernel, round 5): a[] is
-                                         // read from there inside cb_tail_tile, behind the barrier that completes the X tile
 };
-__device__ __forceinline__ void cb_tail_preload_bias(CbTailPre& P, const float* __restrict__ b1, int C1) {
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = 16 * wave + 4 * (lane >> 4) + r;
-        P.b1v[r] = m < C1 ? b1[m] : 0.f;
-    }
-}
 __device__ __forceinline__ void cb_tail_preload(CbTailPre& P, const float* __restrict__ w1p,
                                                 const float* __restrict__ b1, int C0P, int C1) {
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -55,13 +45,16 @@ __device__ __forceinline__ void cb_tail_preload(CbTailPre& P, const float* __res
     const cb_tail_floatx4* ap = (const cb_tail_floatx4*)w1p + ((long)wave * groups) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 16; ++i) P.a[i] = ap[(long)min(i, groups - 1) * 64];
-    P.fromLds = nullptr;
-    cb_tail_preload_bias(P, b1, C1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = 16 * wave + 4 * (lane >> 4) + r;
+        P.b1v[r] = m < C1 ? b1[m] : 0.f;
+    }
 }
 
 // Called by every thread of the workgroup once its part of the X tile is WRITTEN to l.Xs (the barrier that makes the
 // tile complete is inside).  s_pix[px]: pixel index or -1.
-__device__ __forceinline__ void cb_tail_tile(const CbTailLds& l, const int* s_pix, CbTailPre& P,
+__device__ __forceinline__ void cb_tail_tile(const CbTailLds& l, const int* s_pix, const CbTailPre& P,
                                              const float* __restrict__ w1p, float* out, int C0P, int C1, int C2, int HW,
                                              int relu1, int relu2) {
     typedef cb_tail_floatx4 floatx4;
@@ -82,12 +75,7 @@ __device__ __forceinline__ void cb_tail_tile(const CbTailLds& l, const int* s_pi
     const floatx4* ap = (const floatx4*)w1p + ((long)wave * (C0P / 16)) * 64 + lane;
     const float* bp = Xs + (lane >> 4) * CB_TAIL_PX + (lane & 15);
     const int groups = C0P / 16;
-    __syncthreads();   // the X tile is complete (and, W1 in LDS: its LDS-DMA has landed -- the barrier's wait covers it)
-    if (P.fromLds) {
-        const floatx4* lp = P.fromLds + ((long)wave * groups) * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) P.a[i] = lp[(long)min(i, groups - 1) * 64];
-    }
+    __syncthreads();   // the X tile is complete
     CB_TAIL_STAMP(4);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {

@@ -15,6 +15,9 @@ for i in $(seq $R); do
 import json
 d=json.load(open("/tmp/l.json"))
 k=json.load(open("gpurun_out/bench_details.json"))["kernel_trace"]["kernels_as_traced"]
+dd=json.load(open("gpurun_out/bench_details.json"))
+ms=dd.get("multi_sequence") or {}
+if ms: print("$v multi", ms.get("sequences_per_gpu"), round(ms.get("value",0)), {k[:40]: v for k,v in (ms.get("step_of_8_kernels_us") or {}).items()}, {k: round(v["value"]) for k,v in (ms.get("batched") or {}).items()})
 print("$v", round(d["value"]), {n.split("(")[0].split("::")[-1][:28]: v["avg_us"] for n,v in k.items()})
 PY
   done

@@ -163,6 +163,13 @@ def compact_line(result):
     if isinstance(var, dict):
         line["variants"] = {k: _num(v["value"]) for k, v in var.items()
                             if isinstance(v, dict) and isinstance(v.get("value"), (int, float))}
+    # (two more figures of the same run, values only: the sequence with frame pipelining -- identical outputs, two
+    #  streams --, and several sequences on the GPU)
+    pl, ms = result.get("pipelined"), result.get("multi_sequence")
+    if isinstance(pl, dict) and isinstance(pl.get("value"), (int, float)):
+        line["pipelined_fps"] = _num(pl["value"], 6)
+    if isinstance(ms, dict) and isinstance(ms.get("value"), (int, float)):
+        line["multi_sequence"] = {"sequences_per_gpu": ms.get("sequences_per_gpu"), "value": _num(ms["value"], 6)}
     if result.get("details_file"):
         line["details_file"] = result["details_file"]
     return line

@@ -163,11 +163,8 @@ def compact_line(result):
     if isinstance(var, dict):
         line["variants"] = {k: _num(v["value"]) for k, v in var.items()
                             if isinstance(v, dict) and isinstance(v.get("value"), (int, float))}
-    # (two more figures of the same run, values only: the sequence with frame pipelining -- identical outputs, two
-    #  streams --, and several sequences on the GPU)
-    pl, ms = result.get("pipelined"), result.get("multi_sequence")
-    if isinstance(pl, dict) and isinstance(pl.get("value"), (int, float)):
-        line["pipelined_fps"] = _num(pl["value"], 6)
+    # (one more figure of the same run, value only: several sequences on the GPU)
+    ms = result.get("multi_sequence")
     if isinstance(ms, dict) and isinstance(ms.get("value"), (int, float)):
         line["multi_sequence"] = {"sequences_per_gpu": ms.get("sequences_per_gpu"), "value": _num(ms["value"], 6)}
     if result.get("details_file"):
@@ -1208,7 +1205,7 @@ def main():
             allframes = vid.frames(2 + nframes)
             if pipelined:     # cut behind the second pool: [conv, pool, conv, pool | conv, tail ...]
                 cut = [i for i, m in enumerate(test.children()) if type(m) is pycbinfer.CBPoolMax2d][-1] + 1
-                runner = PipelinedRunner(test, cut, stream_pool[0])
+                runner = PipelinedRunner(test, cut, None)      # (FramePipeline probes for a stream that overlaps)
             else:
                 runner = FrameRunner(test, allframes[0], mode, stream_pool[q] if S > 1 else None)
             runner.prime(allframes[:2])
@@ -1375,9 +1372,11 @@ def main():
             for Sb in (4, 8):
                 half = Sb // 2
                 groups = []
+                from cbinfer_amd.streams import overlapping_streams
+                gstreams = overlapping_streams(2)      # (two streams that share a hardware queue would take turns)
                 for gi in range(2):
                     _, gnet = build_bench_model(args.experiment, args.threshold, True, True, args.pool_clone)
-                    groups.append((_pk.SequenceBatch(gnet, half), torch.cuda.Stream(), bfr[gi * half:(gi + 1) * half]))
+                    groups.append((_pk.SequenceBatch(gnet, half), gstreams[gi], bfr[gi * half:(gi + 1) * half]))
                 torch.cuda.synchronize()
                 fg2, ng2 = time_batches(groups)
                 grouped[str(Sb)] = {"value": fg2, "steps": ng2,

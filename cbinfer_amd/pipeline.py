@@ -16,6 +16,7 @@ sync per layer, conv2d_cg.py:202).
 import torch
 
 from .conv2d import LazyPool
+from .streams import side_stream
 
 
 class FramePipeline(object):
@@ -87,7 +88,7 @@ class FramePipeline(object):
         """Enqueue one frame; returns the network output, valid once wait() (or a sync) has passed."""
         cur = torch.cuda.current_stream(frame.device)
         if self.side is None:
-            self.side = torch.cuda.Stream(frame.device)
+            self.side = side_stream(frame.device)      # (probed: one that overlaps with the caller's)
         with torch.no_grad():
             h = frame
             for m in self.stage1:

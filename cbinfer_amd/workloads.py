@@ -176,16 +176,11 @@ def _seq(spec, relu_after_last):
     return nn.Sequential(*layers)
 
 
-_side_streams = {}
-
-
 def _side_stream(device):
-    """One side stream per device for the forked branches (kept out of the module: streams do not pickle
-    and belong to a device, not to a model)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device)
-    return _side_streams[key]
+    """The side stream of the forked branches: one that verifiably overlaps with the caller's current stream
+    (cbinfer_amd/streams.py; kept out of the module: streams do not pickle and belong to a device, not to a model)."""
+    from .streams import side_stream
+    return side_stream(device)
 
 
 class OpenPoseModel(nn.Module):

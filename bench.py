@@ -862,8 +862,36 @@ def openpose_config(args, measure):
     del cbc
     densec = measure(workloads.OpenPoseModel(T=2, init='kaiming', concurrentBranches=True).cuda().half(), frames, "eager",
                      psteps, 3)
+    # several sequences per GPU (the serving case: a camera per sequence): S copies of the calibrated network -- own states,
+    # own video --, one captured graph and one stream each (streams probed to overlap: cbinfer_amd/streams.py), frames
+    # fed round-robin; the dense network takes the S frames as ONE batch
+    multi = {}
+    try:
+        from cbinfer_amd.streams import overlapping_streams
+        for S in (2, 4):
+            sstreams = overlapping_streams(S)
+            vids = [workloads.SyntheticVideo(H=Hp, W=672, ratio=0.10, block=16, seed=3 + 101 * (q + 1)) for q in range(S)]
+            fl = [[prep(v.frame)] + [prep(v.next()) for _ in range(2 + pwarm + psteps)] for v in vids]
+            nets = [with_thresholds(workloads.convertOpenPose(live(), threshold=0.02)) for _ in range(S)]
+            runners = [FrameRunner(n, f[0], "graph", st) for n, f, st in zip(nets, fl, sstreams)]
+            for r, f in zip(runners, fl):
+                r.prime(f[:2])
+            for i in range(2, 2 + pwarm):
+                for r, f in zip(runners, fl):
+                    r.step(f[i])
+            dt = timed_loop(runners, [f[2 + pwarm:] for f in fl], psteps, lambda: None)
+            xb = [torch.cat([f[i] for f in fl], 0) for i in range(len(fl[0]))]
+            dS = S * max(measure(base, xb, m, psteps, 3) for m in ("graph", "eager"))
+            multi[str(S)] = {"cb_fps": S * psteps / dt, "dense_fps_batched": dS, "speedup": S * psteps / dt / dS}
+            del runners, nets, fl, xb
+            torch.cuda.synchronize()
+        multi["how"] = ("S sequences: S converted copies with the calibrated thresholds, own video each, one hipGraph and "
+                        "one HIP stream per sequence; dense: the S frames as one batch (better of graph / eager)")
+    except Exception as e:      # (an add-on: never at the expense of the line)
+        multi = {"error": repr(e)}
     pose_ops = workloads.openPoseDenseOps(2, Hp, Wp)
     return {
+        "sequences_per_gpu": multi,
         "dense_fps": dense, "cb_fps": cb, "cb_launch": max(cb_modes, key=cb_modes.get), "speedup": cb / dense,
         "cb_feedback_mode_fps": cbf, "feedback_speedup": cbf / dense,
         "feedback_mode_mean_ratio": sum(fratio) / max(1, len(fratio)), "feedback_mode_recomputed_gflop": fflops / 1e9,

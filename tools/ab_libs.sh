@@ -5,7 +5,7 @@
 set -e
 cd ${GRAFT_REPO_ROOT:-.}
 R=${1:-3}; shift || true
-cp cbinfer_amd/libcbinfer_hip.so tmp_ab/new.so
+mkdir -p tmp_ab; cp cbinfer_amd/libcbinfer_hip.so tmp_ab/new.so
 trap 'cp tmp_ab/new.so cbinfer_amd/libcbinfer_hip.so' EXIT
 for i in $(seq $R); do
   for v in old new; do

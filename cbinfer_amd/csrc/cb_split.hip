@@ -382,7 +382,6 @@ struct CbsParams {
     const int* upstream;              // optional (one sequence): the producing layer's change count of this frame; 0 ends
                                       // the launch at once (cbinfer_cbconv2d_forward_after's contract)
     int dbg;                          // diagnostic ablations (builds with -DCBS_DBG only; CBINFER_SPLIT_DBG)
-    int stagger;                      // x3, eight waves: waves 4-7 issue their DMAs half a stage behind waves 0-3
     int maxChunks;                    // k-chunks of a deep contraction: CBS_CHUNKS; fp16 layers: up to 16 (chosen on the device)
 };
 // diagnostic ablations are a build option (make EXTRA=-DCBS_DBG; tools/split_dbg_run.sh): 1 every pixel-operand
@@ -808,7 +807,16 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         // no memory traffic, zeros into a ring slot nobody reads any more (tools/micro/ldsdma_oob.hip) -- which keeps
         // the number of DMA instructions in flight, and with it the s_waitcnt vmcnt(N) of a step, the same in every
         // step: one step body, no peeled tail.
-        auto issue = [&](int s) {
+        // In the stage loop the instructions of a stage are not issued in one burst: issue(s, true) only sets the stage up
+        // (descriptors, LDS base, offsets) and issuePart<i>() issues its i-th DMA -- one per gap between the first matrix
+        // instructions behind the barrier (round 5, measured on one box against the burst behind the fourth matrix
+        // instruction: 64->256 35.8 -> 33.8 us, 16->64 19.7 -> 18.2 us, eight sequences 244 -> 224 us: a CU takes a DMA
+        // instruction every ~30 cycles, eight waves handing it six each at the same moment queue up behind each other
+        // with their matrix instructions waiting behind the DMAs in program order).
+        __amdgpu_buffer_rsrc_t isA, isB;
+        char* isMine = ring;
+        int isAS = 0, isBS = 0;
+        auto issue = [&](int s, bool setUpOnly = false) {
             char* dst = ring + (s % RING) * STAGE;
             const bool live = s < sEnd;
             const int aS = live ? s * aStageBytes + aItem : 0;
@@ -820,6 +828,10 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)Sq, 0, (live && !CBS_DBGBIT(64 | 256)) ? bRecords : 0, 0x00020000);
             char* mine = dst + wave * (DPW * 1024);      // ONE LDS base (M0) for the four
+            if (setUpOnly) {
+                isA = ar, isB = br, isMine = mine, isAS = aS, isBS = bS;
+                return;
+            }
             if constexpr (X3) {
                 cbs_dma16<0>(ar, mine, aVoff, aS);
                 cbs_dma16<1024>(ar, mine, aVoff, aS);
@@ -834,6 +846,30 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
                 cbs_dma16<3072>(br, mine, bVoff[1], bS);
             }
         };
+
+        auto issuePart = [&](auto partTag) {
+            constexpr int I = decltype(partTag)::value;
+            if (CBS_DBGBIT(4)) return;
+            if constexpr (X3) {
+                if constexpr (I == 0) cbs_dma16<0>(isA, isMine, aVoff, isAS);
+                if constexpr (I == 1) cbs_dma16<1024>(isA, isMine, aVoff, isAS);
+                if constexpr (I == 2) cbs_dma16<2048>(isA, isMine, aVoff, isAS);
+                if constexpr (I == 3) cbs_dma16<0>(isB, isMine + 3072, bVoff[0], isBS);
+                if constexpr (I == 4) cbs_dma16<1024>(isB, isMine + 3072, bVoff[BPW > 1 ? 1 : 0], isBS);
+                if constexpr (I == 5) cbs_dma16<2048>(isB, isMine + 3072, bVoff[BPW > 2 ? 2 : 0], isBS);
+            } else {
+                if constexpr (I == 0) cbs_dma16<0>(isA, isMine, aVoff, isAS);
+                if constexpr (I == 1) cbs_dma16<1024>(isA, isMine, aVoff, isAS);
+                if constexpr (I == 2) cbs_dma16<2048>(isB, isMine, bVoff[0], isBS);
+                if constexpr (I == 3) cbs_dma16<3072>(isB, isMine, bVoff[1], isBS);
+            }
+        };
+        typedef std::integral_constant<int, 0> P0;
+        typedef std::integral_constant<int, 1> P1;
+        typedef std::integral_constant<int, 2> P2t;
+        typedef std::integral_constant<int, 3> P3;
+        typedef std::integral_constant<int, 4> P4;
+        typedef std::integral_constant<int, 5> P5;
 
         // x3, one column tile per wave: the main products of the two k-steps of a stage go to accumulators of their own
         // (acc1 / acc3) -- an accumulation chain rounds once per matrix instruction, at the magnitude of what it holds;
@@ -1033,18 +1069,14 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");                  \
             __builtin_amdgcn_s_barrier();                                                  \
             CBS_SB();                                                                      \
-            mmaRange(FCUR, 0, 2);                                                          \
+            if (ISSUE) issue((S) + RING, true);                                            \
             CBS_SB();                                                                      \
-            if (ISSUE) issue((S) + RING);                                                    \
-            CBS_SB();                                                                      \
-            mmaRange(FCUR, 2, 3);                                                          \
-            CBS_SB();                                                                      \
-            readA((S) + 1, FNEXT);                                                         \
-            CBS_SB();                                                                      \
-            mmaRange(FCUR, 3, 4);                                                          \
-            CBS_SB();                                                                      \
-            readB((S) + 1, FNEXT, 0);                                                      \
-            CBS_SB();                                                                      \
+            mmaRange(FCUR, 0, 1); CBS_SB(); if (ISSUE) issuePart(P0()); CBS_SB();          \
+            mmaRange(FCUR, 1, 2); CBS_SB(); if (ISSUE) issuePart(P1()); CBS_SB();          \
+            mmaRange(FCUR, 2, 3); CBS_SB();                                                \
+            readA((S) + 1, FNEXT); CBS_SB(); if (ISSUE) issuePart(P2t()); CBS_SB();        \
+            mmaRange(FCUR, 3, 4); CBS_SB();                                                \
+            readB((S) + 1, FNEXT, 0); CBS_SB(); if (ISSUE) issuePart(P3()); CBS_SB();      \
             mmaRange(FCUR, 4, 5);                                                          \
             CBS_SB();                                                                      \
             if (TN > 1) readB((S) + 1, FNEXT, TN - 1);                                     \
@@ -1057,15 +1089,10 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         // (s, 1) is read -- stage s is in LDS, nothing is aimed at its slot yet.  Half-step B starts with the stage's
         // wait and barrier (stage s + 1 has landed for everybody, everybody's reads of stage s are behind their
         // waits), issues stage s + RING into the slot of stage s, and multiplies (s, 1) while (s + 1, 0) is read.
-        // The two waves of a SIMD (w and w + NW/2 of an eight-wave workgroup) run the same program between the same
-        // barriers: left alone both issue their six DMA instructions -- some hundred cycles each -- at the same point
-        // of the stage, and the SIMD's matrix pipe idles meanwhile.  The second half of the waves issues the DMAs of
-        // stage s + RING half a stage later (head of half-step A of stage s + 1: still behind the barrier of stage s,
-        // the same number in flight at every wait), beside its partner's matrix instructions (MI355X_MICROARCH.md,
-        // "Two waves per SIMD", item 9).
+        // The stage's six DMA instructions go out one per gap behind the barrier, beside the fragment reads (see issue()).
+        // (An earlier form let the second half of the waves issue theirs half a stage later: superseded.)
         typedef std::integral_constant<int, 0> KS0;
         typedef std::integral_constant<int, 1> KS1;
-        const bool lateIssue = X3 && NW == 8 && p.stagger && wave >= NW / 2;
 #define CBS_STEP3A(S, FCUR, FNEXT)                                                         \
         do {                                                                               \
             CBS_SB();                                                                      \
@@ -1081,11 +1108,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             CBS_SB();                                                                      \
             if (TN > 1) readB3(KS1(), (S), FNEXT, TN - 1);                                 \
             CBS_SB();                                                                      \
-            mma3(KS0(), FCUR, 3, 4);                                                       \
-            CBS_SB();                                                                      \
-            if (lateIssue && (S) > sBeg) issue((S) - 1 + RING);                            \
-            CBS_SB();                                                                      \
-            mma3(KS0(), FCUR, 4, NM3);                                                     \
+            mma3(KS0(), FCUR, 3, NM3);                                                     \
             waitFrags(FNEXT);                                                              \
         } while (0)
 #define CBS_STEP3B(WAITN, S, FCUR, FNEXT)                                                  \
@@ -1093,23 +1116,19 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");                  \
             __builtin_amdgcn_s_barrier();                                                  \
             CBS_SB();                                                                      \
-            mma3(KS1(), FCUR, 0, 1);                                                       \
+            issue((S) + RING, true);                                                       \
             CBS_SB();                                                                      \
-            readA3(KS0(), (S) + 1, FNEXT);                                                 \
-            CBS_SB();                                                                      \
-            mma3(KS1(), FCUR, 1, 2);                                                       \
-            CBS_SB();                                                                      \
-            readB3(KS0(), (S) + 1, FNEXT, 0);                                              \
-            CBS_SB();                                                                      \
-            mma3(KS1(), FCUR, 2, 3);                                                       \
-            CBS_SB();                                                                      \
+            mma3(KS1(), FCUR, 0, 1); CBS_SB();                                             \
+            readA3(KS0(), (S) + 1, FNEXT); CBS_SB(); issuePart(P0()); CBS_SB();            \
+            mma3(KS1(), FCUR, 1, 2); CBS_SB();                                             \
+            readB3(KS0(), (S) + 1, FNEXT, 0); CBS_SB(); issuePart(P1()); CBS_SB();         \
+            mma3(KS1(), FCUR, 2, 3); CBS_SB();                                             \
             if (TN > 1) readB3(KS0(), (S) + 1, FNEXT, TN - 1);                             \
-            CBS_SB();                                                                      \
-            mma3(KS1(), FCUR, 3, 4);                                                       \
-            CBS_SB();                                                                      \
-            if (!lateIssue) issue((S) + RING);                                             \
-            CBS_SB();                                                                      \
-            mma3(KS1(), FCUR, 4, NM3);                                                     \
+            CBS_SB(); issuePart(P2t()); CBS_SB();                                          \
+            mma3(KS1(), FCUR, 3, 4); CBS_SB(); issuePart(P3()); CBS_SB();                  \
+            mma3(KS1(), FCUR, 4, 5); CBS_SB(); issuePart(P4()); CBS_SB();                  \
+            mma3(KS1(), FCUR, 5, 6); CBS_SB(); issuePart(P5()); CBS_SB();                  \
+            mma3(KS1(), FCUR, 6, NM3);                                                     \
             waitFrags(FNEXT);                                                              \
         } while (0)
 
@@ -1729,14 +1748,6 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
     }
     p.arriveShards = (int)(MW / 16 < 8 ? MW / 16 : 8);
     p.dbg = 0;
-    {
-        static int stag = -1;      // CBINFER_SPLIT_STAGGER (A/B aid; default 1)
-        if (stag < 0) {
-            const char* e = getenv("CBINFER_SPLIT_STAGGER");
-            stag = e ? atoi(e) : 1;
-        }
-        p.stagger = stag;
-    }
     p.maxChunks = CBS_CHUNKS;
 #ifdef CBS_DBG
     if (const char* e = getenv("CBINFER_SPLIT_DBG")) p.dbg = atoi(e);
@@ -2275,7 +2286,7 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int 
     p.magicWpr = (1ull << 32) / (unsigned long long)p.wpr + 1ull;
     p.magicW = (1ull << 32) / (unsigned long long)W + 1ull;
     p.magicMT = (1ull << 32) / (unsigned long long)(KP / BM) + 1ull;
-    p.forceSK = 0, p.accumulate = 0, p.halfOut = 1, p.splitRounds = 2, p.dbg = 0, p.stagger = 0;
+    p.forceSK = 0, p.accumulate = 0, p.halfOut = 1, p.splitRounds = 2, p.dbg = 0;
     {
         static int mc = -1;      // CBINFER_HSPLIT_MAXCHUNKS (A/B aid; default 16: the device picks 4, 8 or 16 by the tile count)
         if (mc < 0) {

@@ -979,6 +979,19 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             f.b[j * 3 + 1] = cbs_lds_read16<(E1 / 2) * 1024>(bAddr[j * 4 + (E1 & 1)] + slot);
             f.b[j * 3 + 2] = cbs_lds_read16<(E2 / 2) * 1024>(bAddr[j * 4 + (E2 & 1)] + slot);
         };
+        // (the same reads one by one: R = 0..2 the weight planes, 3..5 / 6..8 the pixel planes of column tile 0 / 1)
+        auto read1 = [&](auto ksTag, auto rTag, int s, Frags& f) {
+            constexpr int KS = decltype(ksTag)::value, R = decltype(rTag)::value;
+            constexpr int E = 3 * KS + (R % 3);
+            if constexpr (R < 3) {
+                const unsigned a0 = aAddr[0] + (s % RING) * STAGE;
+                f.a[R] = cbs_lds_read16<(E / 3) * 6144 + (E % 3) * 1024>(a0);
+            } else if constexpr (R < 3 + 3 * TN) {
+                constexpr int j = (R - 3) / 3;
+                const unsigned slot = (s % RING) * STAGE;
+                f.b[j * 3 + R % 3] = cbs_lds_read16<(E / 2) * 1024>(bAddr[j * 4 + (E & 1)] + slot);
+            }
+        };
         // x3: the 6 TN matrix instructions of a unit, i = j * 6 + term: the five small products into acc2, b0 w0 into acc1
         constexpr int NM3 = 6 * TN;
         auto mma3 = [&](auto ksTag, const Frags& f, int i0, int i1) {
@@ -1093,22 +1106,19 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         // (An earlier form let the second half of the waves issue theirs half a stage later: superseded.)
         typedef std::integral_constant<int, 0> KS0;
         typedef std::integral_constant<int, 1> KS1;
+        typedef std::integral_constant<int, 6> R6;
+        typedef std::integral_constant<int, 7> R7;
+        typedef std::integral_constant<int, 8> R8;
 #define CBS_STEP3A(S, FCUR, FNEXT)                                                         \
         do {                                                                               \
             CBS_SB();                                                                      \
-            mma3(KS0(), FCUR, 0, 1);                                                       \
-            CBS_SB();                                                                      \
-            readA3(KS1(), (S), FNEXT);                                                     \
-            CBS_SB();                                                                      \
-            mma3(KS0(), FCUR, 1, 2);                                                       \
-            CBS_SB();                                                                      \
-            readB3(KS1(), (S), FNEXT, 0);                                                  \
-            CBS_SB();                                                                      \
-            mma3(KS0(), FCUR, 2, 3);                                                       \
-            CBS_SB();                                                                      \
-            if (TN > 1) readB3(KS1(), (S), FNEXT, TN - 1);                                 \
-            CBS_SB();                                                                      \
-            mma3(KS0(), FCUR, 3, NM3);                                                     \
+            mma3(KS0(), FCUR, 0, 1); CBS_SB(); read1(KS1(), P0(), (S), FNEXT); read1(KS1(), P3(), (S), FNEXT); CBS_SB(); \
+            mma3(KS0(), FCUR, 1, 2); CBS_SB(); read1(KS1(), P1(), (S), FNEXT); read1(KS1(), P4(), (S), FNEXT); CBS_SB(); \
+            mma3(KS0(), FCUR, 2, 3); CBS_SB(); read1(KS1(), P2t(), (S), FNEXT); read1(KS1(), P5(), (S), FNEXT); CBS_SB(); \
+            mma3(KS0(), FCUR, 3, 4); CBS_SB(); read1(KS1(), R6(), (S), FNEXT); CBS_SB();   \
+            mma3(KS0(), FCUR, 4, 5); CBS_SB(); read1(KS1(), R7(), (S), FNEXT); CBS_SB();   \
+            mma3(KS0(), FCUR, 5, 6); CBS_SB(); read1(KS1(), R8(), (S), FNEXT); CBS_SB();   \
+            mma3(KS0(), FCUR, 6, NM3);                                                     \
             waitFrags(FNEXT);                                                              \
         } while (0)
 #define CBS_STEP3B(WAITN, S, FCUR, FNEXT)                                                  \
@@ -1119,15 +1129,14 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             issue((S) + RING, true);                                                       \
             CBS_SB();                                                                      \
             mma3(KS1(), FCUR, 0, 1); CBS_SB();                                             \
-            readA3(KS0(), (S) + 1, FNEXT); CBS_SB(); issuePart(P0()); CBS_SB();            \
+            read1(KS0(), P0(), (S) + 1, FNEXT); read1(KS0(), P3(), (S) + 1, FNEXT); CBS_SB(); issuePart(P0()); CBS_SB(); \
             mma3(KS1(), FCUR, 1, 2); CBS_SB();                                             \
-            readB3(KS0(), (S) + 1, FNEXT, 0); CBS_SB(); issuePart(P1()); CBS_SB();         \
+            read1(KS0(), P1(), (S) + 1, FNEXT); read1(KS0(), P4(), (S) + 1, FNEXT); CBS_SB(); issuePart(P1()); CBS_SB(); \
             mma3(KS1(), FCUR, 2, 3); CBS_SB();                                             \
-            if (TN > 1) readB3(KS0(), (S) + 1, FNEXT, TN - 1);                             \
-            CBS_SB(); issuePart(P2t()); CBS_SB();                                          \
-            mma3(KS1(), FCUR, 3, 4); CBS_SB(); issuePart(P3()); CBS_SB();                  \
-            mma3(KS1(), FCUR, 4, 5); CBS_SB(); issuePart(P4()); CBS_SB();                  \
-            mma3(KS1(), FCUR, 5, 6); CBS_SB(); issuePart(P5()); CBS_SB();                  \
+            read1(KS0(), P2t(), (S) + 1, FNEXT); read1(KS0(), P5(), (S) + 1, FNEXT); CBS_SB(); issuePart(P2t()); CBS_SB(); \
+            mma3(KS1(), FCUR, 3, 4); CBS_SB(); read1(KS0(), R6(), (S) + 1, FNEXT); CBS_SB(); issuePart(P3()); CBS_SB(); \
+            mma3(KS1(), FCUR, 4, 5); CBS_SB(); read1(KS0(), R7(), (S) + 1, FNEXT); CBS_SB(); issuePart(P4()); CBS_SB(); \
+            mma3(KS1(), FCUR, 5, 6); CBS_SB(); read1(KS0(), R8(), (S) + 1, FNEXT); CBS_SB(); issuePart(P5()); CBS_SB(); \
             mma3(KS1(), FCUR, 6, NM3);                                                     \
             waitFrags(FNEXT);                                                              \
         } while (0)

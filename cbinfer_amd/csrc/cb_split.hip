@@ -685,7 +685,11 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         // which keeps the two fragment register sets in step with the loop below.
         const int P2 = p.nStages >> 1;
         static_assert(CBS_CHUNKS == 4, "chunk boundaries by shifts");
-        auto chunkBeg = [&](int c) { return c >= CH ? p.nStages : (CH == 1 ? 0 : 2 * ((P2 * c) >> chShift)); };
+        // (bf16 triples: a step is a whole stage -- both register sets per stage --, so the boundaries need not be even:
+        //  98 stages are 24 + 25 + 24 + 25 instead of 24 + 24 + 24 + 26, and the longest slice sets the launch's time)
+        auto chunkBeg = [&](int c) {
+            return c >= CH ? p.nStages : (CH == 1 ? 0 : (X3 ? (p.nStages * c) >> chShift : 2 * ((P2 * c) >> chShift)));
+        };
         const int c0 = SK == 1 ? 0 : slice, c1 = SK == 1 ? CH : slice + 1;
         const int sBeg = chunkBeg(c0), sEnd = chunkBeg(c1);
         // (the first stage's tap offset: a scalar load whose round trip runs beside the pixel lookup below)

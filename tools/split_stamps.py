@@ -87,6 +87,26 @@ def report_one(st):
               % (d.min(), d.mean(), d.max(), ok.sum(), np.median(cyc / np.maximum(tot, 0.01))))
 
 
+def report_by_xcd():
+    """Stage-loop time of the 128-row tile's workgroups by blockIdx % 8 -- for the bench's 64->256 launch that is
+    (k-slice, row tile) and the XCD the workgroup runs on."""
+    torch.cuda.synchronize()
+    buf = np.zeros(4 * 2048 * 16, dtype=np.uint64)
+    raw.cbinfer_debug_split_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(buf.nbytes), 0)
+    st = buf.reshape(4, 2048, 16)[1].astype(np.int64)
+    idx = np.nonzero((st[:, 0] > 0) & (st[:, 4] > st[:, 3]))[0]
+    if len(idx) == 0:
+        return
+    t0 = st[idx, 0].min()
+    for x in range(8):
+        sel = idx[idx % 8 == x]
+        if len(sel):
+            loop = (st[sel, 4] - st[sel, 3]) / 100.0
+            end = (st[sel, 5] - t0) / 100.0
+            print("  blockIdx %% 8 = %d: %3d wgs, loop mean %.2f max %.2f us, done mean %.2f max %.2f us"
+                  % (x, len(sel), loop.mean(), loop.max(), end.mean(), end.max()))
+
+
 _ev = bs.ev
 
 
@@ -114,7 +134,8 @@ if __name__ == "__main__":
             torch.cuda.synchronize()
             raw.cbinfer_debug_split_stamps(None, 0, 1)
             test(frames[-1])
-        report()
+        report(clear=False)
+        report_by_xcd()
     elif len(sys.argv) > 1 and sys.argv[1] == "batch":
         # the same for a SequenceBatch step of S sequences
         import bench

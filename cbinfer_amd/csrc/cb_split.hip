@@ -606,10 +606,10 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     // 98 stages: 56 work items where there are 256 CUs (round 5).  p.maxChunks: 4, or up to 16 for HALF.
     int CH = (p.nStages >= 48 && p.slabs) ? CBS_CHUNKS : 1;      // (the host refuses a deep layer without slabs)
     if (HALF && CH > 1)
-        while (2 * CH <= p.maxChunks && TP * MT * 2 * CH <= (int)gridDim.x && TP * MT * 2 * CH <= p.slabCap &&
+        while (2 * CH <= min(p.maxChunks, 16) && TP * MT * 2 * CH <= (int)gridDim.x && TP * MT * 2 * CH <= p.slabCap &&
                p.nStages >= 8 * CH)      // (at least four stages per chunk)
             CH *= 2;
-    const int chShift = CH >= 16 ? 4 : (CH >= 8 ? 3 : 2);
+    const int chShift = CH >= 16 ? 4 : (CH >= 8 ? 3 : 2);      // (CH is 1, 4, 8 or 16: the host clamps maxChunks to <= 16)
     int anyExact = 0;
     for (int q = 0; q < p.nSeq; ++q) anyExact |= s_exact[q];
     anyExact = __builtin_amdgcn_readfirstlane(anyExact);
@@ -2305,6 +2305,9 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int 
         if (mc < 0) {
             const char* e = getenv("CBINFER_HSPLIT_MAXCHUNKS");
             mc = e && atoi(e) >= 4 ? atoi(e) : 16;
+            // (the device loop doubles CH from 4 while 2 CH <= maxChunks, and decodes items with chShift in {2, 3, 4}:
+            //  4, 8 or 16 chunks -- anything else is rounded down to one of them)
+            mc = mc >= 16 ? 16 : (mc >= 8 ? 8 : 4);
         }
         p.maxChunks = mc;
     }

@@ -73,13 +73,19 @@ __device__ __forceinline__ void cbs_split(float x, _Float16& hi, _Float16& lo) {
 
 // x = b0 + b1 + b2 EXACTLY, bf16 terms rounded to nearest (8 significant bits each: the residual of a round-to-nearest
 // 8-bit head of a 24-bit value has at most 16 bits, that of the second term at most 8).  bf16 has f32's exponent range:
-// no scale, no range flag.  Non-finite x: b0 carries it, the other terms are zero (inf - inf would make them NaN).
+// no scale, no range flag.  A finite |x| above the largest bf16 (3.3895e38 .. FLT_MAX) would round its head to inf: the
+// head is taken by truncation there, the residual (< 2^-7 |x|) is finite and splits as usual.
+// Non-finite x: b0 carries it, the other terms are zero (inf - inf would make them NaN).  The products of such an operand
+// with the residual terms of a weight are inf * 0 = NaN or infinities of both signs: an output that depends on a
+// non-finite state value is NaN where the reference's f32 chain yields +-inf or NaN (either way: not a number to use).
 __device__ __forceinline__ void cbs_split3(float x, __bf16& b0, __bf16& b1, __bf16& b2) {
-    const __bf16 h = (__bf16)x;
+    __bf16 h = (__bf16)x;
+    const bool fin = fabsf(x) < INFINITY;      // (false for NaN too)
+    if (fin && !(fabsf((float)h) < INFINITY))
+        h = __builtin_bit_cast(__bf16, (unsigned short)(__builtin_bit_cast(unsigned, x) >> 16));
     const float r1 = x - (float)h;
     const __bf16 m = (__bf16)r1;
     const float r2 = r1 - (float)m;
-    const bool fin = fabsf(x) < INFINITY;      // (false for NaN too)
     b0 = h;
     b1 = fin ? m : (__bf16)0.f;
     b2 = fin ? (__bf16)r2 : (__bf16)0.f;

@@ -1125,8 +1125,9 @@ def test_tail_fusion_is_refused_beyond_the_kernels_budget(pkg):
 def test_bench_configuration_fullsize_parity(pkg, oracle):
     """THE benchmarked configuration under test at full size (verdict, round 2): bench.build_bench_model() is
     what bench.py times -- experiment 6 (sceneLabeling/modelLoader.py:62-78), fuseTail1x1, pooled detection with
-    the producer-mask shortcut, cloneOutput=False, split-state f16-pair contractions for the 16->64 and 64->256
-    layers with the tail folded into the second launch, row-segment kernel for 3->16, threshold 0.05 -- on bench.bench_video():
+    the producer-mask shortcut, cloneOutput=False, split-state contractions on the DEFAULT arithmetic (bf16 triples,
+    f32-equivalent: CBINFER_ARITH=x3) for the 16->64 and 64->256 layers with the tail folded into the second launch,
+    row-pair kernel (+ the next layer's pooled detection) for 3->16, threshold 0.05 -- on bench.bench_video():
     480x320, 10 % of the pixels re-drawn per frame in 32x32 blocks, the ping-pong walk with both turn-arounds.
     For every frame (a) each layer is teacher-forced against the oracle twin in the REFERENCE's structure
     (oracle/frame_check.py: change lists bit-exact, feedback states bit-exact, outputs <= 1e-4; reference:
@@ -1178,6 +1179,39 @@ def test_bench_configuration_fullsize_parity(pkg, oracle):
     assert all(n[0] < 0.2 * 153600 and n[1] < 0.35 * 38400 and n[2] < 0.6 * 9600 for n in Ns[2:]), Ns
     # end to end the change-based network stays close to the dense one (sub-threshold changes are dropped)
     assert (y - base(walk[order[-1]])).abs().max().item() < 0.5
+
+
+def test_bench_inframe_pass_leaves_the_network_intact(pkg):
+    """bench.inframe_layer_times issues the library's detection and contraction entry points of every layer by hand (to
+    put HIP events around one of them) -- with the arguments the modules themselves would pass: after the pass the
+    network's output and every state tensor equal, bit for bit, those of a twin that ran the same frames through the
+    modules.  (the hand-made detection call had lost the state's arithmetic bit and wrote f16-pair
+    records into a bf16-triple state; nothing noticed.)"""
+    import bench
+    _, a = bench.build_bench_model()
+    _, b = bench.build_bench_model()
+    frames = bench.bench_video(77).frames(2 + 6)
+    walk = frames[2:]
+    with torch.no_grad():
+        for f in frames[:2]:
+            a(f), b(f)
+        for i in range(3):
+            a(walk[bench.pingpong(i, len(walk))]), b(walk[bench.pingpong(i, len(walk))])
+        got = bench.inframe_layer_times(a, walk, 3, reps=4)
+        assert got is not None
+        rows, nxt, pair_us = got
+        assert nxt > 3 and any("conv_ms" in r for r in rows)
+        for i in range(3, nxt):
+            yb = b(walk[bench.pingpong(i, len(walk))])
+        ya = a(walk[bench.pingpong(nxt, len(walk))])
+        yb = b(walk[bench.pingpong(nxt, len(walk))])
+        torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
+    for ta, tb in zip(pkg.getStateTensors(a), pkg.getStateTensors(b)):
+        assert torch.equal(ta, tb)
+    # the isolated-layer pass brackets the same two entry points through the modules' call plans
+    iso = bench.isolated_layers(a, reps=4)
+    assert len(iso) == 3 and all(r["conv_us"] > 0 for r in iso)
 
 
 @pytest.mark.parametrize("name", ["seq_half", "seq_half_k3"])

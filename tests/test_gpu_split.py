@@ -299,6 +299,21 @@ def test_split_state_rebuild_and_range_flag(lib, oracle):
     out = L.out[0].cpu().numpy().reshape(K, -1)[:, n].astype(np.float64)
     mag = _sum_abs(oracle, o.prevInput, w, n, 7, 7).T + np.abs(b)[:, None]
     assert np.all(np.abs(out - o.prevOutput.reshape(K, -1)[:, n]) <= 64 * 2.0 ** -24 * mag)
+    # a finite value above the largest bf16 (FLT_MAX): the head of its triple is taken by truncation, not rounded to
+    # inf -- the outputs stay finite and within the bound
+    y4 = y3.clone()
+    y4[0, 5, 10, 20] = 3.4028234e38
+    y4[0, 6, 11, 21] = -3.39e38
+    L.frame([y4], 0.1)
+    got = o.forward(y4.cpu().numpy())
+    n = got[2]
+    assert np.array_equal(L.list(), n)
+    out = L.out[0].cpu().numpy().reshape(K, -1)[:, n].astype(np.float64)
+    assert np.isfinite(out).all()
+    want = (oracle.genXMatrix(o.prevInput, n, (7, 7)).astype(np.float64) @ w.reshape(K, -1).astype(np.float64).T).T \
+        + b.astype(np.float64)[:, None]
+    mag = _sum_abs(oracle, o.prevInput, w, n, 7, 7).T + np.abs(b)[:, None]
+    assert np.all(np.abs(out - want) <= 64 * 2.0 ** -24 * mag)
 
 
 def test_split_module_reports_range_and_survives_state_restore(lib):

@@ -761,7 +761,13 @@ def openpose_config(args, measure):
         return workloads.OpenPoseModel(T=2, init='kaiming').cuda().half()
     psteps, pwarm = 30, 30
     base = live()
-    test = workloads.convertOpenPose(live(), threshold=0.02)
+
+    def converted(model=None, **kw):
+        """The converted network in the execution form of round 6: every chained layer's change detection inside its
+        producer's launch (workloads.fuseOpenPoseDetections; results bit-identical to the separate launches)."""
+        return workloads.fuseOpenPoseDetections(workloads.convertOpenPose(model if model is not None else live(),
+                                                                          threshold=0.02, **kw))
+    test = converted()
     ths = workloads.calibrateChangeRatio(test, lambda: prep(vid.next()), target=0.10)
     convs = [m for m in test.modules() if type(m) is pycbinfer.CBConv2d]
     frames = [prep(vid.frame)] + [prep(vid.next()) for _ in range(2 + pwarm + psteps + 22)]
@@ -774,6 +780,10 @@ def openpose_config(args, measure):
     dense = max(measure(base, frames, m, psteps, 3) for m in ("graph", "eager"))
     cb_modes = {m: measure(test, frames, m, psteps, pwarm) for m in ("eager", "graph")}
     cb = max(cb_modes.values())
+    # the same network with every layer running its own detection launch (round 5's form: 88 launches per frame)
+    unf = with_thresholds(workloads.convertOpenPose(live(), threshold=0.02))
+    cb_unfolded = max(measure(unf, frames, m, psteps, pwarm) for m in ("graph", "eager"))
+    del unf
     # per-layer change ratios and recomputed work: the mean over ten fresh frames behind the timed ones
     counts = [0.0] * len(convs)
     with torch.no_grad():
@@ -820,13 +830,14 @@ def openpose_config(args, measure):
                                "note": "SURVEY 8(d) bytes (input + state read, mask) of the 36 detections over the summed "
                                        "durations of the detection launches of the frame"},
                 "kernels": {n[:60]: v for n, v in sorted(k.items(), key=lambda x: -x[1]["avg_us"] * x[1]["launches_per_frame"])[:8]},
+                "launches_per_frame": sum(v["launches_per_frame"] for v in k.values()),
                 "busy_us_per_frame": got[1]}
     except Exception as e:      # (an add-on: never at the expense of the line)
         pose_roofline = {"error": repr(e)}
     # the reference's "recursive mode" (modelConverter.py:84-86): feedback loop -- thresholds calibrated in that mode (a
     # state that is refreshed at the changed pixels only drifts differently: the copy mode's thresholds let the change die
     # out behind the fourth layer there), on the video's next frames
-    testf = workloads.convertOpenPose(live(), threshold=0.02, feedbackLoop=True)
+    testf = converted(feedbackLoop=True)
     workloads.calibrateChangeRatio(testf, lambda: prep(vid.next()), target=0.10)
     fframes = [prep(vid.frame)] + [prep(vid.next()) for _ in range(2 + 3 + psteps + 10)]
     ffresh, fframes = fframes[-10:], fframes[:-10]
@@ -847,7 +858,7 @@ def openpose_config(args, measure):
     from cbinfer_amd import conv2d as _c2
     _c2._NO_CHAIN = True
     try:
-        plain = with_thresholds(workloads.convertOpenPose(live(), threshold=0.02))
+        plain = with_thresholds(converted())
         cbu = max(measure(plain, frames, m, psteps, pwarm) for m in ("graph", "eager"))
         del plain
     finally:
@@ -855,15 +866,14 @@ def openpose_config(args, measure):
     # the three VGG pools change-based as well and folded into their consumers' detections (pycbinfer.insertCBPooling +
     # fusePoolingIntoDetection: what sceneLabeling/modelLoader.py:62-78 does by hand; the pose converter of the
     # reference leaves the pools dense, so this is an option beside the configuration)
-    cbp = with_thresholds(workloads.convertOpenPose(live(), threshold=0.02))
+    cbp = with_thresholds(converted())
     pycbinfer.insertCBPooling(cbp, cloneOutput=False)
     pycbinfer.fusePoolingIntoDetection(cbp)
     cbpool = max(measure(cbp, frames, m, psteps, pwarm) for m in ("graph", "eager"))
     del cbp
     # the two branches of every stage (PoseModel.py:122-137: independent until the concat) on two HIP streams, fork / join
     # per stage -- an execution option of the MODEL, applied to the dense network as well
-    cbc = with_thresholds(workloads.convertOpenPose(
-        workloads.OpenPoseModel(T=2, init='kaiming', concurrentBranches=True).cuda().half(), threshold=0.02))
+    cbc = with_thresholds(converted(workloads.OpenPoseModel(T=2, init='kaiming', concurrentBranches=True).cuda().half()))
     cbconc = measure(cbc, frames, "eager", psteps, pwarm)
     del cbc
     densec = measure(workloads.OpenPoseModel(T=2, init='kaiming', concurrentBranches=True).cuda().half(), frames, "eager",
@@ -878,7 +888,7 @@ def openpose_config(args, measure):
             sstreams = overlapping_streams(S)
             vids = [workloads.SyntheticVideo(H=Hp, W=672, ratio=0.10, block=16, seed=3 + 101 * (q + 1)) for q in range(S)]
             fl = [[prep(v.frame)] + [prep(v.next()) for _ in range(2 + pwarm + psteps)] for v in vids]
-            nets = [with_thresholds(workloads.convertOpenPose(live(), threshold=0.02)) for _ in range(S)]
+            nets = [with_thresholds(converted()) for _ in range(S)]
             runners = [FrameRunner(n, f[0], "graph", st) for n, f, st in zip(nets, fl, sstreams)]
             for r, f in zip(runners, fl):
                 r.prime(f[:2])
@@ -899,6 +909,7 @@ def openpose_config(args, measure):
     return {
         "sequences_per_gpu": multi,
         "dense_fps": dense, "cb_fps": cb, "cb_launch": max(cb_modes, key=cb_modes.get), "speedup": cb / dense,
+        "cb_own_detection_launches_fps": cb_unfolded, "own_detection_launches_speedup": cb_unfolded / dense,
         "cb_feedback_mode_fps": cbf, "feedback_speedup": cbf / dense,
         "feedback_mode_mean_ratio": sum(fratio) / max(1, len(fratio)), "feedback_mode_recomputed_gflop": fflops / 1e9,
         "feedback_mode_ratios": [round(r, 3) for r in fratio], "cb_unchained_fps": cbu,

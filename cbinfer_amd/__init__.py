@@ -183,7 +183,28 @@ def fuseDetectionIntoProducer(rootModule, enabled=True):
                     prod.__dict__['_fusedNext'] = (pool, cons)      # (plain references, not children)
                 else:
                     prod.__dict__.pop('_fusedNext', None)
+        # round 6: a CBConv2d directly behind another one (fp16 layers on the split-state machinery, the consumer in copy
+        # mode -- what convert() makes): the producer's contraction launch compares the values it just wrote with the
+        # consumer's state, refreshes that state and ORs the consumer's change mask; the consumer runs its contraction
+        # alone.  Whether a given frame may do so is decided per frame (CBConv2d._fill_consumers / _detected_upstream).
+        for prod, cons in zip(kids[:-1], kids[1:]):
+            if type(prod) == CBConv2d and type(cons) == CBConv2d:
+                linkConsumers(prod, [cons] if enabled else [])
     return rootModule
+
+
+def linkConsumers(producer, consumers):
+    """Name the CBConv2d layers that consume `producer`'s output tensor directly (same resolution) where the module tree
+    does not say so -- e.g. the first layers of the two branches of an OpenPose stage, both fed the feature extractor's
+    last output (poseDetection/openPose/PoseModel.py:122-137).  Their change detection then rides in the producer's
+    launch whenever that is exact (see fuseDetectionIntoProducer); at most two consumers per producer are folded.  An
+    empty list removes the link.  Execution-level only: results do not change."""
+    consumers = [c for c in consumers if type(c) == CBConv2d]
+    if consumers:
+        producer.__dict__['_fusedConsumers'] = list(consumers)      # (plain references, not children)
+    else:
+        producer.__dict__.pop('_fusedConsumers', None)
+    return producer
 
 
 _STATEFUL = (CBConv2d, CBPoolMax2d, CBTail1x1)
@@ -303,6 +324,6 @@ def tuneThresholdParameters(vidSeqReader, evalSequences, numFramesPerSeq, target
 
 __all__ = ['CBConv2d', 'CBPoolMax2d', 'CBTail1x1', 'ChangeIndexes', 'FramePipeline', 'SequenceBatch', 'convert', 'convertRecur', 'subsitute',
            'mergeReLURecur', 'propChangeIndexesOf1x1', 'insertCBPooling', 'fusePoolingIntoDetection',
-           'fuseDetectionIntoProducer', 'fuseTail1x1',
+           'fuseDetectionIntoProducer', 'linkConsumers', 'fuseTail1x1',
            'clearMemory', 'getStateTensors',
            'setSyncIndexes', 'tuneThresholdParameters']

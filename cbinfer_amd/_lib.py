@@ -63,6 +63,25 @@ class PairSeq(ctypes.Structure):
 _psp = ctypes.POINTER(PairSeq)
 _vpp = ctypes.POINTER(ctypes.c_void_p)
 
+HGROUP_MAX, HNEXT_MAX = 2, 2      # CBINFER_HGROUP_MAX, CBINFER_HNEXT_MAX
+
+
+class HalfNext(ctypes.Structure):
+    """cbHalfNext of include/cbinfer_hip.h: a CONSUMER of an fp16 layer's output whose detection rides in its launch."""
+    _fields_ = [("state", _vp), ("pixelState", _vp), ("frameMasks", _vp), ("kH", _i), ("kW", _i), ("threshold", _f),
+                ("reserved", _i)]
+
+
+class HalfLayer(ctypes.Structure):
+    """cbHalfLayer of include/cbinfer_hip.h: one fp16 layer of a cbinfer_hsplit_forward_group call."""
+    _fields_ = [("upstreamCount", _vp), ("input", _vp), ("producerMask", _vp), ("state", _vp), ("pixelState", _vp),
+                ("frameMasks", _vp), ("output", _vp), ("idxOut", _vp), ("countOut", _vp), ("maskCopy", _vp),
+                ("prepared", _vp), ("bias", _vp), ("K", _i), ("threshold", _f), ("relu", _i), ("detect", _i),
+                ("nNext", _i), ("reserved", _i), ("next", HalfNext * HNEXT_MAX)]
+
+
+_hlp = ctypes.POINTER(HalfLayer)
+
 _SIGNATURES = {
     # name: (restype, [argtypes])
     "cbinfer_abi_version": (_i, []),
@@ -165,6 +184,8 @@ _SIGNATURES = {
     "cbinfer_hsplit_state_rebuild": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cbinfer_hsplit_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
                                     _i, _i, _i, _f, _i, _i, _vp, _vp]),
+    "cbinfer_hsplit_group_workspace_bytes": (_l, [_i, _i, _i, _i, _i, _i, _i]),
+    "cbinfer_hsplit_forward_group": (_i, [_hlp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cbinfer_split_forward_tail": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _i,
                                         _stp, _vp]),
     "cbinfer_split_forward_fg_tail": (_i, [_sp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _stp, _vp]),
@@ -192,7 +213,7 @@ def _load():
         fn = getattr(lib, name)     # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.cbinfer_abi_version() != 8:
+    if lib.cbinfer_abi_version() != 9:
         raise ImportError("cbinfer_amd: libcbinfer_hip.so ABI version mismatch")
     return lib
 

@@ -46,10 +46,11 @@ class _Produced(object):
     """What a CBConv2d leaves on its output buffer for the next layer (CBConv2d._note_upstream): who wrote it, in which
     of its frames, the buffer's version counter then, and where the frame's change count is.  Never travels: a pickled
     or deep-copied tensor carries None instead."""
-    __slots__ = ('module', 'serial', 'version', 'count')
+    __slots__ = ('module', 'serial', 'version', 'count', 'tokens')
 
-    def __init__(self, module, serial, version, count):
+    def __init__(self, module, serial, version, count, tokens=()):
         self.module, self.serial, self.version, self.count = module, serial, version, count
+        self.tokens = tokens      # (CBConv2d._half_detect_token of every consumer whose detection rode in the launch)
 
     def __reduce__(self):
         return _no_tag, ()
@@ -442,8 +443,10 @@ class CBConv2d(nn.Module):
 
     def _forward_hsplit(self, input, work, lazy=None):
         """One fp16 frame on the split-state machinery: detection + refresh of prevInput and of its pixel-major copy,
-        then the LDS-DMA contraction.  `lazy`: the layer sits behind a CBPoolMax2d folded into its detection -- `input`
-        is the pool's INPUT, the layer runs at the pooled size."""
+        then the LDS-DMA contraction -- whose launch also runs the change detection of the layers that consume this
+        layer's output (pycbinfer.fuseDetectionIntoProducer; round 6), and whose own detection is skipped when the
+        PRODUCING layer's launch did it.  `lazy`: the layer sits behind a CBPoolMax2d folded into its detection --
+        `input` is the pool's INPUT, the layer runs at the pooled size."""
         K, Cin, kH, kW = self.weight.size()
         H, W = (lazy.outSize[-2], lazy.outSize[-1]) if lazy is not None else (input.size(-2), input.size(-1))
         dev = input.device
@@ -455,15 +458,9 @@ class CBConv2d(nn.Module):
             hs = work['hsplit'] = dict(
                 S=S, bits=torch.zeros(C.cbinfer_frame_mask_bytes(H, W) // 8, dtype=torch.int64, device=dev),
                 copy=torch.zeros(C.cbinfer_mask_words(H, W), dtype=torch.int64, device=dev),
-                ws=torch.zeros(wsBytes, dtype=torch.uint8, device=dev) if wsBytes > 0 else None, stateKey=None)
-        w = self.weight
-        key = ('hsplit', w.data_ptr(), w._version, w.device, H, W)
-        if self._wrows is None or self._wrows[0] != key:
-            wp = torch.empty(C.cbinfer_hsplit_prepared_bytes(Cin, K, kH, kW), dtype=torch.uint8, device=dev)
-            check(C.cbinfer_hsplit_prep_weights(ptr(w.detach().contiguous()), ptr(wp), K, Cin, kH, kW, H, W,
-                                                stream_ptr(w)))
-            self._wrows = (key, wp)
-        wp = self._wrows[1]
+                ws=torch.zeros(wsBytes, dtype=torch.uint8, device=dev) if wsBytes > 0 else None, stateKey=None,
+                layer=(_lib.HalfLayer * 1)())
+        wp = self._hsplit_weights(H, W)
         prev = self.prevInput
         if not prev.is_contiguous():
             prev = self.prevInput = prev.contiguous()
@@ -484,23 +481,107 @@ class CBConv2d(nn.Module):
         elif not rebuilt and sameTh:
             pmask = self._chain_mask(H, W)      # (round 5: a chained layer skips the segments its producer left alone)
         pooled = lazy is not None
-        args = (None, ptr(input), int(pooled), input.size(-2) if pooled else 0, input.size(-1) if pooled else 0,
-                ptr(pmask), ptr(prev), ptr(hs['S']), ptr(hs['bits']), ptr(self.prevOutput), ptr(work['idx']),
-                ptr(work['count']), ptr(hs['copy']), ptr(wp), ptr(self.bias.detach()), Cin, H, W, K, kH, kW,
-                float(self.threshold), int(bool(self.feedbackLoop)), int(bool(self.withReLU)), ptr(hs['ws']),
-                stream_ptr(input))
-        check(C.cbinfer_hsplit_forward(*args))
+        L = hs['layer'][0]
+        L.upstreamCount, L.input, L.producerMask = None, ptr(input), ptr(pmask)
+        L.state, L.pixelState, L.frameMasks = ptr(prev), ptr(hs['S']), ptr(hs['bits'])
+        L.output, L.idxOut, L.countOut = ptr(self.prevOutput), ptr(work['idx']), ptr(work['count'])
+        L.maskCopy, L.prepared, L.bias = ptr(hs['copy']), ptr(wp), ptr(self.bias.detach())
+        L.K, L.threshold, L.relu = K, float(self.threshold), int(bool(self.withReLU))
+        # this layer's own detection: done by the producing layer's launch?  (never on a fresh / restored state, after a
+        # change of the threshold, or behind a pool)
+        mine = None if (rebuilt or not sameTh or pooled) else self._half_token(hs, prev)
+        L.detect = 0 if (mine is not None and self._detected_upstream(mine)) else 1
+        tokens = self._fill_consumers(L, H, W)
+        args = [hs['layer'], 1, int(pooled), input.size(-2) if pooled else 0, input.size(-1) if pooled else 0,
+                Cin, H, W, kH, kW, int(bool(self.feedbackLoop)), ptr(hs['ws']), stream_ptr(input)]
+        check(C.cbinfer_hsplit_forward_group(*args))
         self.__dict__['_ranSplit'] = True      # (a frame on any OTHER path invalidates hs['stateKey'], see forward)
-        self._publish_count(work['count'])
+        self._publish_count(work['count'], tokens)
         if not self._inputIsLiveState:
-            self._make_plan(pooled, input, C.cbinfer_hsplit_forward, args, 1, pmask=ptr(pmask))
+            self._make_plan(pooled, input, C.cbinfer_hsplit_forward_group, args, None, pmask=ptr(pmask))
             if self._plan is not None:
-                self._plan.update(chain=True, stateVersion=prev._version, checkPmask=pooled,
-                                  chainMask=None if pooled else (5, H, W))
+                self._plan.update(hsplit=True, chain=True, stateVersion=prev._version, checkPmask=pooled,
+                                  layer=L, size=(H, W), hs=hs, nextTokens=tokens)
         result = MaskChangeIndexes(hs['copy'], (H, W), work['idx'], work['count'], made=True)
         if self._plan is not None:
             self._plan['indexes'] = result
         return result
+
+    def _hsplit_weights(self, H, W):
+        w = self.weight
+        K, Cin, kH, kW = w.size()
+        key = ('hsplit', w.data_ptr(), w._version, w.device, H, W)
+        if self._wrows is None or self._wrows[0] != key:
+            wp = torch.empty(C.cbinfer_hsplit_prepared_bytes(Cin, K, kH, kW), dtype=torch.uint8, device=w.device)
+            check(C.cbinfer_hsplit_prep_weights(ptr(w.detach().contiguous()), ptr(wp), K, Cin, kH, kW, H, W,
+                                                stream_ptr(w)))
+            self._wrows = (key, wp)
+        return self._wrows[1]
+
+    # ---- the change detection of an fp16 layer inside the launch of the layer that PRODUCES its input (round 6) ----
+    # The reference chains layers through their state tensors: a CBConv2d's input is the prevOutput of the one in front
+    # (conv2d.py:259), and with propChangeIndexes the producer's change list travels along (:180-186, :256-259).  A
+    # consumer in copy mode (feedbackLoop = False, copyInput = True) compares every value of that buffer with its
+    # prevInput -- a copy of last frame's buffer -- so only the pixels the producer just recomputed can trigger, and the
+    # producer's launch can do the whole detection for them (cb_split.hip: the fp16 epilogue / cbh_reduce_kernel).  What
+    # makes that exact is checked on the host every frame, from both sides, with a token that names the consumer's
+    # state buffers and threshold: the PRODUCER folds a consumer in only if that consumer's last frame consumed this
+    # producer's last frame from this very buffer into the state the token names (its _upSeen) on the fp16 split-state
+    # path; the CONSUMER skips its detection launch only if the tag on its input carries its token of this frame.
+    def _half_token(self, hs, prev):
+        return (id(self), prev.data_ptr(), hs['S'].data_ptr(), hs['bits'].data_ptr(), float(self.threshold))
+
+    def _detected_upstream(self, token):
+        d = self.__dict__
+        return (d.get('_upNow') is not None and token in (d.get('_upTokens') or ()) and
+                os.environ.get('CBINFER_NO_NEXTFOLD', '0') != '1')
+
+    def _half_detect_token(self, prod, prodSerial, pout, H, W):
+        """The token under which `prod`'s launch of its NEXT frame may run this layer's change detection, or None."""
+        d = self.__dict__
+        if (self.feedbackLoop or not self.copyInput or self.syncIndexes or self.saveChangeMap or
+                self.gatherComputationStats or self.finegrained or not d.get('_ranSplit')):
+            return None
+        work = self._work
+        hs = work.get('hsplit') if work else None
+        prev = self._buffers.get('prevInput')
+        if (hs is None or prev is None or prev.dtype != torch.float16 or
+                tuple(prev.shape) != (1, prod.out_channels, H, W) or
+                hs['stateKey'] != (prev.data_ptr(), prev._version)):
+            return None
+        seen = d.get('_upSeen')
+        if (seen is None or seen[0] is not prod or seen[1] != prodSerial or seen[2] != pout.data_ptr() or
+                seen[3] != prev.data_ptr() or seen[4] != prev._version):
+            return None
+        if d.get('_pmaskThreshold') != float(self.threshold):
+            return None
+        return self._half_token(hs, prev)
+
+    def _fill_consumers(self, L, H, W):
+        """cbHalfLayer.next[] of this frame: the linked consumers (pycbinfer.fuseDetectionIntoProducer) whose detection
+        this launch may run.  Returns their tokens."""
+        L.nNext = 0
+        links = self.__dict__.get('_fusedConsumers')
+        if not links or os.environ.get('CBINFER_NO_NEXTFOLD', '0') == '1' or self.weight.size(0) < 64:
+            return ()
+        pout = self._buffers['prevOutput']
+        tag = getattr(pout, '_cbProduced', None)      # (still the PREVIOUS frame's)
+        serial = self.__dict__.get('_serial', 0)
+        if tag is None or tag.module is not self or tag.serial != serial - 1 or pout._version != tag.version:
+            return ()
+        tokens = []
+        for cons in links:
+            if len(tokens) == _lib.HNEXT_MAX:
+                break
+            tok = cons._half_detect_token(self, serial - 1, pout, H, W) if type(cons) is CBConv2d else None
+            if tok is None:
+                continue
+            n = L.next[len(tokens)]
+            n.state, n.pixelState, n.frameMasks = tok[1], tok[2], tok[3]
+            n.kH, n.kW, n.threshold = cons.weight.size(2), cons.weight.size(3), tok[4]
+            tokens.append(tok)
+        L.nNext = len(tokens)
+        return tuple(tokens)
 
     def _split_fg_ok(self, dtype, H, W):
         """Does this layer's fine-grained in-place frame run on the split-state kernels (cbinfer_split_forward_fg)?
@@ -1290,6 +1371,8 @@ class CBConv2d(nn.Module):
             return None
         if plan.get('stateVersion') is not None and bufs['prevInput']._version != plan['stateVersion']:
             return None      # (somebody wrote prevInput through torch: its pixel-major copy must be made again)
+        if plan.get('hsplit'):
+            return self._run_hsplit_plan(plan, src, bufs)
         if plan.get('pairs'):
             # the next layer's detection rides in this launch: the plan holds only while that layer's state is the one
             # the plan was made for (and starts to fold as soon as it can)
@@ -1342,6 +1425,30 @@ class CBConv2d(nn.Module):
             return 'changeIndexes', bufs['prevOutput'], self._lastIndexes
         return bufs['prevOutput']
 
+    def _run_hsplit_plan(self, plan, src, bufs):
+        """The per-frame part of an fp16 split-state frame (the plan's invariants hold): input pointer, the chain's
+        count and mask, whose detection rides where."""
+        L, hs = plan['layer'], plan['hs']
+        H, W = plan['size']
+        L.input = src.data_ptr()
+        up = self.__dict__.get('_upNow')
+        L.upstreamCount = up.data_ptr() if up is not None else None
+        if not plan['pooled']:
+            pm = self._chain_mask(H, W)
+            L.producerMask = pm.data_ptr() if pm is not None else None
+            L.detect = 0 if self._detected_upstream(self._half_token(hs, bufs['prevInput'])) else 1
+        tokens = self._fill_consumers(L, H, W) if '_fusedConsumers' in self.__dict__ else ()
+        status = plan['fn'](*plan['args'])
+        if status != 0:
+            check(status)
+        self.__dict__['_ranSplit'] = True
+        self._publish_count(plan['work']['count'], tokens)
+        self._inputIsLiveState = False
+        self._lastIndexes = plan['indexes']
+        if self.propChangeIndexes:
+            return 'changeIndexes', bufs['prevOutput'], self._lastIndexes
+        return bufs['prevOutput']
+
     # ---------------------------------------------------------------- chains of change-based layers
     # A layer whose self-compacting contraction ran leaves its change count on the device (work['count']) and says so
     # on its output buffer: (module, frame serial, buffer version, count).  The next CBConv2d that is handed this
@@ -1351,9 +1458,9 @@ class CBConv2d(nn.Module):
     # wrote to the buffer through torch since (version counter), this layer's previous forward consumed the
     # producer's previous frame from the same buffer, and nobody rewrote this layer's state through torch either.
     # (Threshold and mode are pinned by the plan that carries the call.)  CBINFER_NO_CHAIN=1 switches it off.
-    def _publish_count(self, count):
+    def _publish_count(self, count, tokens=()):
         out = self._buffers['prevOutput']
-        out._cbProduced = _Produced(self, self.__dict__.get('_serial', 0), out._version, count)
+        out._cbProduced = _Produced(self, self.__dict__.get('_serial', 0), out._version, count, tokens)
 
     def _chain_mask(self, H, W):
         """The change mask the PRODUCING layer of a chain left this frame (its MaskChangeIndexes' mask copy, H x W) while
@@ -1373,6 +1480,7 @@ class CBConv2d(nn.Module):
         d['_serial'] = d.get('_serial', 0) + 1
         tag = getattr(inp, '_cbProduced', None) if type(inp) is torch.Tensor else None
         seen, now = None, None
+        d['_upTokens'] = tag.tokens if tag is not None else None
         if tag is not None:
             prod, serial, version, count = tag.module, tag.serial, tag.version, tag.count
             pin = self._buffers.get('prevInput')

@@ -384,6 +384,55 @@ struct CbsParams {
     int dbg;                          // diagnostic ablations (builds with -DCBS_DBG only; CBINFER_SPLIT_DBG)
     int maxChunks;                    // k-chunks of a deep contraction: CBS_CHUNKS; fp16 layers: up to 16 (chosen on the device)
 };
+// fp16 layers only (AR = 1; round 6): what differs between the layers of a GROUP -- the two branches of an OpenPose
+// stage issued as one persistent grid: CbsParams.seq[q] holds layer q's tensors, this its weights, bias, channel count
+// -- and the CONSUMERS of each layer's output whose change detection (copy mode: feedbackLoop = False, copyInput = True,
+// conv2d.py:234-236; predicate cbconv2d_cg_half_backend.cu:24-35) rides in this launch's epilogue.  A second kernel
+// argument of the fp16 instances only: the fp32 instances keep their argument block (and their scalar registers).
+#define CBH_GROUP CBINFER_HGROUP_MAX
+#define CBH_NEXT CBINFER_HNEXT_MAX
+struct CbhNext {
+    _Float16* state;                  // consumer's prevInput [K,H,W]
+    char* S;                          // its pixel-major copy (cbh_geom(K, H, W, kH, kW))
+    unsigned long long* masks;        // its frame mask
+    int kHH, kWH, Wp, rec, padY, padXL;
+    float th;
+    int pad_;
+};
+struct CbhLayer {
+    const char* A;                    // prepared weights of this layer (the stage table behind them depends on the
+                                      // geometry only: the group shares CbsParams.stageOff)
+    const _Float16* bias;
+    int K, relu, nNext, pad_;
+    CbhNext next[CBH_NEXT];
+};
+struct CbhExt {
+    CbhLayer L[CBH_GROUP];
+};
+struct CbsNoExt {};
+template <int AR>
+struct CbsExtOf {
+    typedef CbsNoExt type;
+};
+template <>
+struct CbsExtOf<1> {
+    typedef CbhExt type;
+};
+
+// One pixel of a consumer's dilated change mask: rows y - kHH .. y + kHH, columns x - kWH .. x + kWH, clipped to the map
+// (what cbs_detect_kernel's word shifts produce for a single set bit)
+__device__ __forceinline__ void cbh_or_dilated(unsigned long long* masks, int y, int x, int H, int W, int wpr, int kHH,
+                                               int kWH) {
+    const int lo = max(x - kWH, 0), hi = min(x + kWH, W - 1);
+    const int w0 = lo >> 6, w1 = hi >> 6;
+    const unsigned long long m0 = (~0ull << (lo & 63)) & (w1 == w0 ? (~0ull >> (63 - (hi & 63))) : ~0ull);
+    const unsigned long long m1 = ~0ull >> (63 - (hi & 63));
+    for (int yy = max(y - kHH, 0); yy <= min(y + kHH, H - 1); ++yy) {
+        atomicOr(&masks[(long)yy * wpr + w0], m0);
+        if (w1 != w0) atomicOr(&masks[(long)yy * wpr + w1], m1);
+    }
+}
+
 // diagnostic ablations are a build option (make EXTRA=-DCBS_DBG; tools/split_dbg_run.sh): 1 every pixel-operand
 // DMA reads the dummy pixel, 2 no fragment reads / MFMAs, 4 no DMA at all, 8 no pixel-operand fragment reads,
 // 16 no weight fragment reads, 32 no epilogue stores, 64 every DMA issued dead (no memory traffic), 128 / 256 the weight /
@@ -453,7 +502,7 @@ __device__ __forceinline__ int cbs_div(int x, unsigned long long magic) {
 // accumulator sets): unit (s, 0) is multiplied while (s, 1) is read, then the barrier of the stage, then (s, 1) is
 // multiplied while (s + 1, 0) is read.
 template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING, int AR = 0>
-__global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
+__global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typename CbsExtOf<AR>::type ext) {
     constexpr bool HALF = AR == 1, X3 = AR == 2;
     // (before anything else -- the burst over the kilobyte of arguments included: an idle frame is this one load)
     if (HALF && p.upstream && *p.upstream == 0) {      // (the detection in front returned the same way: the mask is empty)
@@ -463,7 +512,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         }
         return;
     }
-    cb_touch_kernarg<sizeof(CbsParams)>();
+    cb_touch_kernarg<sizeof(CbsParams) + (HALF ? sizeof(CbhExt) : 0)>();
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TN = BN / WN / 32;
     static_assert(BM == 32 * WM, "one 32-row tile per wave");
@@ -485,6 +534,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
     __shared__ int s_wsum[NW];
     __shared__ int s_tilePix[BN];
     __shared__ float s_bias[BM];
+    __shared__ unsigned s_nchg[HALF ? CBH_NEXT * (BN / 32) : 1];      // fp16: a consumer's changed pixels of this tile
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -679,6 +729,14 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             tile0 = __builtin_amdgcn_readfirstlane(s_seqTile[q]);
         }
         const int n0 = (ptg - tile0) * BN, m0 = mt * BM;
+        // (fp16 group: layer q's own weights, bias, channel count and consumers)
+        const char* Aq = p.A;
+        const float* biasq = p.bias;
+        int Kq = p.K, reluq = p.relu, nNext = 0;
+        if constexpr (HALF) {
+            Aq = ext.L[q].A, biasq = (const float*)ext.L[q].bias, Kq = ext.L[q].K, reluq = ext.L[q].relu;
+            nNext = __builtin_amdgcn_readfirstlane(ext.L[q].nNext);
+        }
         // Stages of this item: one chunk (split) or all of them (then the accumulators are folded into the running
         // sum at the chunk boundaries).  Chunk c = stage pairs [P c / CH, P (c+1) / CH) of the P = nStages / 2 pairs
         // (+ the odd last stage in the last chunk): every boundary lies an even number of stages behind the start,
@@ -708,6 +766,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
                 if (a <= R1 && R1 < b) s_wRange[1] = i;
             }
             if (t < BN) s_tilePix[t] = -1;
+            if (HALF && t < CBH_NEXT * (BN / 32)) s_nchg[t] = 0u;
             __syncthreads();
             const int w0 = __builtin_amdgcn_readfirstlane(s_wRange[0]), w1 = __builtin_amdgcn_readfirstlane(s_wRange[1]);
             const bool first = mt == 0 && slice == 0;
@@ -729,8 +788,8 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
         }
         CBS_STAMP_AT(9);
         // (the m-tile's bias for the epilogue: requested now, put into LDS once the ring is primed)
-        const float biasv = (t < BM && p.bias && m0 + t < p.K)
-                                ? (HALF ? (float)((const _Float16*)p.bias)[m0 + t] : p.bias[m0 + t]) : 0.f;
+        const float biasv = (t < BM && biasq && m0 + t < Kq)
+                                ? (HALF ? (float)((const _Float16*)biasq)[m0 + t] : biasq[m0 + t]) : 0.f;
         __syncthreads();
         CBS_STAMP_AT(10);
         if (AR == 0 && __builtin_expect(__builtin_amdgcn_readfirstlane(s_exact[q]) != 0, 0)) {
@@ -828,7 +887,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
             bNext = stageOff[min(s + 1, sEnd - 1)];
             if (CBS_DBGBIT(4)) return;
             const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)p.A, 0, (live && !CBS_DBGBIT(64 | 128)) ? aRecords : 0, 0x00020000);
+                (void*)Aq, 0, (live && !CBS_DBGBIT(64 | 128)) ? aRecords : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)Sq, 0, (live && !CBS_DBGBIT(64 | 256)) ? bRecords : 0, 0x00020000);
             char* mine = dst + wave * (DPW * 1024);      // ONE LDS base (M0) for the four
@@ -1230,6 +1289,25 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
 #endif
             continue;
         }
+        // fp16, one column tile per wave (the 64 x 64 tile: every shallow layer of a pose network), consumers folded in: their
+        // state values are requested HERE, in front of the output arithmetic and stores, and the outputs stay in registers
+        // for the comparison -- the detection then adds no round trip of its own in front of its stores.  (Two column
+        // tiles: the registers are not there -- the values are read back, see below.)
+        constexpr bool NEXT_REGS = HALF && TN == 1;
+        _Float16 hv16[NEXT_REGS ? 16 : 1], sv16[NEXT_REGS ? CBH_NEXT : 1][NEXT_REGS ? 16 : 1];
+        if constexpr (NEXT_REGS) {
+            if (nNext > 0) {      // (uniform)
+                const int pixLd = max(s_tilePix[wn * 32 + l31], 0);
+                const int nx2 = nNext > 1 ? 1 : 0;
+                const int mb0 = m0 + wm * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long o = (long)min(mb0 + 8 * (r >> 2) + (r & 3), Kq - 1) * HW + pixLd;
+                    sv16[0][r] = ext.L[q].next[0].state[o];
+                    if (CBH_NEXT > 1) sv16[CBH_NEXT > 1 ? 1 : 0][r] = ext.L[q].next[nx2].state[o];
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nl = (wn * TN + j) * 32 + l31;
@@ -1240,17 +1318,104 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p) {
                 float v = comb(j, r);
                 if (folds > 0) v = run[j][r] + v;        // (the last chunk joins the running sum)
                 v = fmaf(v, p.outScale, s_bias[ml]);      // (an explicit fma here, in the reduce launch and in the
-                if (p.relu) v = v <= 0.f ? 0.f : v;        //  fused tail: one rounding at all three sites)
+                if (reluq) v = v <= 0.f ? 0.f : v;         //  fused tail: one rounding at all three sites)
                 if (HALF) {
-                    if (pix >= 0 && m < p.K) ((_Float16*)out)[(long)m * HW + pix] = (_Float16)v;
+                    if (NEXT_REGS) hv16[NEXT_REGS ? r : 0] = m < Kq ? (_Float16)v : (_Float16)0;
+                    if (pix >= 0 && m < Kq) ((_Float16*)out)[(long)m * HW + pix] = (_Float16)v;
                     continue;
                 }
-                if (pix >= 0 && m < p.K) {
+                if (pix >= 0 && m < Kq) {
                     if (accum) {      // fine-grained: the sum of the products joins what the output holds
                         v += out[(long)m * HW + pix];
                         if (reluPlane) reluPlane[(long)m * HW + pix] = v <= 0.f ? 0.f : v;
                     }
                     out[(long)m * HW + pix] = v;
+                }
+            }
+        }
+        if constexpr (HALF) {
+            // The change detection of the layers that consume this output (copy mode), on the values just written: a lane
+            // holds 4 x 4 consecutive output channels of its pixels = input channels of the consumer, and reads them back
+            // from prevOutput (its own stores; the accumulators are dead by now -- rolled loops, a few registers).  Per
+            // value: strict > in half precision against the consumer's prevInput (cbconv2d_cg_half_backend.cu:24-35); a
+            // value that differs bit for bit goes into prevInput and -- four channels, 8 bytes -- into the consumer's
+            // pixel-major record.  Pixels this layer did not recompute hold last frame's bits: nothing to do.
+            if (nNext > 0) {      // (uniform)
+                const _Float16* outh = (const _Float16*)out;
+                // (ONE round trip per column tile: the 16 outputs and the 16 state values of every consumer are requested
+                //  together -- clamped addresses, predicated uses: a predicated load is a branch, and a branch per value is
+                //  a round trip per value)
+                const int nx2 = nNext > 1 ? 1 : 0;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int nl = (wn * TN + j) * 32 + l31;
+                    const int pix = s_tilePix[nl];
+                    const int pixLd = max(pix, 0);
+                    const int py = cbs_div(pixLd, p.magicW), px = pixLd - py * p.W;
+                    const int mb0 = m0 + wm * 32 + 4 * h;
+                    _Float16 h16[16], s16[CBH_NEXT][16];
+                    if constexpr (NEXT_REGS) {      // (requested in front of the output stores, outputs from registers)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            h16[r] = hv16[NEXT_REGS ? r : 0];
+                            s16[0][r] = sv16[0][NEXT_REGS ? r : 0];
+                            if (CBH_NEXT > 1) s16[CBH_NEXT > 1 ? 1 : 0][r] = sv16[NEXT_REGS && CBH_NEXT > 1 ? 1 : 0][NEXT_REGS ? r : 0];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const long o = (long)min(mb0 + 8 * (r >> 2) + (r & 3), Kq - 1) * HW + pixLd;
+                            h16[r] = outh[o];
+                            s16[0][r] = ext.L[q].next[0].state[o];
+                            if (CBH_NEXT > 1) s16[CBH_NEXT > 1 ? 1 : 0][r] = ext.L[q].next[nx2].state[o];
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (mb0 + 8 * (r >> 2) + (r & 3) >= Kq) h16[r] = (_Float16)0;   // (the record's padding channels stay zero)
+                    }
+#pragma unroll
+                    for (int c = 0; c < CBH_NEXT; ++c) {
+                        if (c >= nNext || pix < 0) continue;
+                        const CbhNext& nx = ext.L[q].next[c];
+                        _Float16* nst = nx.state;
+                        char* rec = nx.S + CBS_SPAD + ((long)(py + nx.padY) * nx.Wp + (px + nx.padXL)) * nx.rec;
+                        const _Float16 thc = (_Float16)nx.th;
+                        const int cpad = nx.rec >> 1;      // the consumer's padded channel count
+                        bool chg = false;
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const int mb = mb0 + 8 * r4;
+                            unsigned dm = 0u;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (mb + e >= Kq) continue;
+                                chg |= cb_changed(s16[c][4 * r4 + e], h16[4 * r4 + e], thc);
+                                dm |= (unsigned)cb_differs(s16[c][4 * r4 + e], h16[4 * r4 + e]) << e;
+                            }
+                            if (dm) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if ((dm >> e) & 1u) nst[(long)(mb + e) * HW + pix] = h16[4 * r4 + e];
+                                if (mb < cpad) {
+                                    typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
+                                    *(halfx4*)(rec + mb * 2) =
+                                        halfx4{h16[4 * r4], h16[4 * r4 + 1], h16[4 * r4 + 2], h16[4 * r4 + 3]};
+                                }
+                            }
+                        }
+                        if (chg) atomicOr(&s_nchg[c * (BN / 32) + (nl >> 5)], 1u << (nl & 31));
+                    }
+                }
+                // the consumers' masks: every changed pixel of the tile, dilated by their filters
+                __syncthreads();
+#pragma unroll 1
+                for (int c = 0; c < nNext; ++c) {
+                    const CbhNext& nx = ext.L[q].next[c];
+                    if (t < BN && ((s_nchg[c * (BN / 32) + (t >> 5)] >> (t & 31)) & 1u)) {
+                        const int pix = s_tilePix[t];
+                        const int py = cbs_div(pix, p.magicW), px = pix - py * p.W;
+                        cbh_or_dilated(nx.masks, py, px, p.H, p.W, p.wpr, nx.kHH, nx.kWH);
+                    }
                 }
             }
         }
@@ -1354,6 +1519,154 @@ __global__ __launch_bounds__(256) void cbs_reduce_kernel(CbsParams p, int BM, in
                 if (rp) rp[(long)(m + e) * HW + pix] = v <= 0.f ? 0.f : v;
             }
             out[(long)(m + e) * HW + pix] = v;
+        }
+    }
+}
+
+// Second launch of a split fp16 contraction (round 6; cbs_reduce_kernel's work for the fp16 layers): one workgroup per
+// group of 16 changed pixels x ALL output channels -- thread (px = t & 15, channel quad t >> 4 + 16 i) sums the SK slabs
+// of its float4 in slice order, adds the bias, applies the ReLU, rounds to f16 once and scatters -- and then, with every
+// channel of its pixels in one workgroup, the change detection of the layer's CONSUMERS on the values just written (see
+// cbs_conv_kernel's fp16 epilogue: the same per-value steps), their dilated masks ORed by (pixel, row) threads.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void cbh_reduce_kernel(CbsParams p, CbhExt ext) {
+    cb_touch_kernarg<sizeof(CbsParams) + sizeof(CbhExt)>();
+    const int SK = p.info[CBS_INFO_SK];
+    if (SK <= 1) return;
+    const int MT = p.info[CBS_INFO_MT], CMB = MT * SK, TILE4 = BM * BN / 4, HW = p.H * p.W;
+    int tilesBefore[CBH_GROUP + 1];
+    tilesBefore[0] = 0;
+#pragma unroll
+    for (int q = 0; q < CBH_GROUP; ++q) tilesBefore[q + 1] = tilesBefore[q] + p.info[CBS_INFO_TP + q];
+    constexpr int PXG = 16, GP = BN / PXG;
+    const int groups = tilesBefore[CBH_GROUP] * GP;
+    const int t = threadIdx.x, px = t & 15;
+    __shared__ unsigned s_chg[CBH_NEXT];
+    const float4* __restrict__ slabs = (const float4*)p.slabs;
+    for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+        const int ptg = g / GP, gi = g - ptg * GP;
+        int q = 0;
+#pragma unroll
+        for (int u = 1; u < CBH_GROUP; ++u)
+            if (u < p.nSeq && ptg >= tilesBefore[u]) q = u;
+        const int n0 = (ptg - tilesBefore[q]) * BN + gi * PXG;
+        const int N = p.info[CBS_INFO_TP + CBS_MAXSEQ + q];
+        if (n0 >= N) continue;      // (uniform: a tile's last groups may be empty)
+        const CbhLayer& L = ext.L[q];
+        const int Kq = L.K, nNext = L.nNext;
+        int pix = n0 + px < N ? p.seq[q].listOut[n0 + px] : -1;
+        if ((unsigned)pix >= (unsigned)HW) pix = -1;
+        const int pixLd = max(pix, 0);
+        const int py = cbs_div(pixLd, p.magicW), pxx = pixLd - py * p.W;
+        __syncthreads();      // (the previous group's flags have been read)
+        if (t < CBH_NEXT) s_chg[t] = 0u;
+        __syncthreads();
+        _Float16* out = (_Float16*)p.seq[q].out;
+        bool chg[CBH_NEXT];
+#pragma unroll
+        for (int c = 0; c < CBH_NEXT; ++c) chg[c] = false;
+        const float4* sl0 = slabs + (long)ptg * CMB * TILE4 + gi * PXG + px;
+        const int QT = MT * (BM / 4);      // channel quads of a pixel; thread: quads t >> 4, + 16, ... -- two per round
+        const int nx2 = nNext > 1 ? 1 : 0;
+        for (int cq0 = t >> 4; cq0 < QT; cq0 += 32) {
+            // (one round trip per round: up to 2 x 8 slab float4 and the consumers' state values of both quads are
+            //  requested together -- their addresses need the pixel index only; clamped addresses, predicated uses)
+            float4 v[2][8];
+            _Float16 s4[2][CBH_NEXT][4];
+            float acc[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int cq = min(cq0 + 16 * u, QT - 1);
+                const int mt = cq / (BM / 4), mq = cq - mt * (BM / 4), m = mt * BM + 4 * mq;
+                const float4* sl = sl0 + (long)mt * TILE4 + mq * BN;      // slice j: + j * MT * TILE4
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[u][j] = sl[(long)min(j, SK - 1) * MT * TILE4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const long o = (long)min(m + e, Kq - 1) * HW + pixLd;
+                    s4[u][0][e] = nNext > 0 ? L.next[0].state[o] : (_Float16)0;
+                    if (CBH_NEXT > 1) s4[u][CBH_NEXT > 1 ? 1 : 0][e] = nNext > 0 ? L.next[nx2].state[o] : (_Float16)0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < SK) s0 += v[u][j].x, s1 += v[u][j].y, s2 += v[u][j].z, s3 += v[u][j].w;
+                acc[u][0] = s0, acc[u][1] = s1, acc[u][2] = s2, acc[u][3] = s3;
+            }
+            if (SK > 8) {      // (uniform; 16 chunks: the second eight, in slice order behind the first)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int cq = min(cq0 + 16 * u, QT - 1);
+                    const int mt = cq / (BM / 4), mq = cq - mt * (BM / 4);
+                    const float4* sl = sl0 + (long)mt * TILE4 + mq * BN;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[u][j] = sl[(long)min(8 + j, SK - 1) * MT * TILE4];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (8 + j < SK)
+                            acc[u][0] += v[u][j].x, acc[u][1] += v[u][j].y, acc[u][2] += v[u][j].z, acc[u][3] += v[u][j].w;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int cq = cq0 + 16 * u;
+                if (cq >= QT) continue;
+                const int mt = cq / (BM / 4), mq = cq - mt * (BM / 4), m = mt * BM + 4 * mq;
+                if (pix < 0 || m >= Kq) continue;
+                _Float16 hv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float bv = (L.bias && m + e < Kq) ? (float)L.bias[m + e] : 0.f;
+                    float r = fmaf(acc[u][e], p.outScale, bv);
+                    if (L.relu) r = r <= 0.f ? 0.f : r;
+                    hv[e] = m + e < Kq ? (_Float16)r : (_Float16)0;
+                    if (m + e < Kq) out[(long)(m + e) * HW + pix] = hv[e];
+                }
+#pragma unroll
+                for (int c = 0; c < CBH_NEXT; ++c) {
+                    if (c >= nNext) continue;
+                    const CbhNext& nx = L.next[c];
+                    _Float16* nst = nx.state;
+                    const _Float16 thc = (_Float16)nx.th;
+                    unsigned dm = 0u;
+                    bool ch = false;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (m + e >= Kq) continue;
+                        ch |= cb_changed(s4[u][c][e], hv[e], thc);
+                        dm |= (unsigned)cb_differs(s4[u][c][e], hv[e]) << e;
+                    }
+                    chg[c] |= ch;
+                    if (dm) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if ((dm >> e) & 1u) nst[(long)(m + e) * HW + pix] = hv[e];
+                        if (m < (nx.rec >> 1)) {
+                            typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
+                            char* rec = nx.S + CBS_SPAD + ((long)(py + nx.padY) * nx.Wp + (pxx + nx.padXL)) * nx.rec;
+                            *(halfx4*)(rec + m * 2) = halfx4{hv[0], hv[1], hv[2], hv[3]};
+                        }
+                    }
+                }
+            }
+        }
+        if (nNext > 0) {      // (uniform)
+#pragma unroll
+            for (int c = 0; c < CBH_NEXT; ++c)
+                if (c < nNext && chg[c]) atomicOr(&s_chg[c], 1u << px);
+            __syncthreads();
+            // thread (px, row) = (t & 15, t >> 4): one row of one changed pixel's dilated square per thread
+            for (int c = 0; c < nNext; ++c) {
+                const CbhNext& nx = L.next[c];
+                const int dy = (t >> 4) - nx.kHH, yy = py + dy;
+                if (pix >= 0 && ((s_chg[c] >> px) & 1u) && dy <= nx.kHH && yy >= 0 && yy < p.H)
+                    cbh_or_dilated(nx.masks, yy, pxx, p.H, p.W, p.wpr, 0, nx.kWH);
+            }
         }
     }
 }
@@ -1515,14 +1828,22 @@ int cbs_num_cus() {
 }
 
 template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING, int AR = 0>
-int cbs_launch_conv(const CbsParams& p, int perCU, const CbsTailArgs* tail, hipStream_t s) {
+int cbs_launch_conv(const CbsParams& p, int perCU, const CbsTailArgs* tail, hipStream_t s,
+                    const typename CbsExtOf<AR>::type& ext = typename CbsExtOf<AR>::type()) {
     if ((long)p.nSeq * p.maskWords > PRE_CAP) return CB_ERR_UNSUPPORTED;
     const bool second = p.slabs && (p.nStages >= 48 || p.forceSK > 0);
     if (tail && !second) return CB_ERR_UNSUPPORTED;      // (the fused tail reads the launch info of a deep contraction)
     dim3 grid((unsigned)(perCU * cbs_num_cus())), block(64 * WM * WN);
-    hipLaunchKernelGGL((cbs_conv_kernel<BM, BN, WM, WN, PRE_CAP, MASK_LDS, RING, AR>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((cbs_conv_kernel<BM, BN, WM, WN, PRE_CAP, MASK_LDS, RING, AR>), grid, block, 0, s, p, ext);
     int st = cb_launch_status();
     if (st != CB_OK) return st;
+    if constexpr (AR == 1) {
+        if (second) {      // (fp16: the group-aware second launch, which also runs the consumers' detection)
+            hipLaunchKernelGGL((cbh_reduce_kernel<BM, BN>), dim3(2 * cbs_num_cus()), dim3(256), 0, s, p, ext);
+            st = cb_launch_status();
+        }
+        return st;
+    }
     if (tail) {
         const int waves = (tail->C1 + 15) / 16;
         hipLaunchKernelGGL((cbs_reduce_tail_kernel<BM, BN>), dim3(2 * cbs_num_cus()), dim3(64 * waves),
@@ -1940,8 +2261,10 @@ __host__ __device__ inline CbsGeom cbh_geom(int Cin, int H, int W, int kH, int k
     return g;
 }
 inline bool cbh_supported(int C, int K, int kH, int kW) {
+    // (round 6: from a single k-stage up -- the 1x1 layers of OpenPose's stages on 128 and 512 channels; the ring is
+    //  primed with dead stages past the item's last one, and the stage loop has a one-stage tail)
     return C >= 64 && C <= 1024 && K >= 1 && K <= 1024 && (kH & 1) && (kW & 1) && kH <= 15 && kW <= 15 &&
-           cbh_geom(C, 64, 64, kH, kW).nStages >= 4;
+           cbh_geom(C, 64, 64, kH, kW).nStages >= 1;
 }
 
 // weights [K,C,kH,kW] f16 -> [stage][row tile of 32][k-step 0..3][lane][8 f16] (the A-fragment order of the f16-pair
@@ -2225,28 +2548,37 @@ int cbinfer_hsplit_state_rebuild(const void* state, void* pixelState, int C, int
     return cb_launch_status();
 }
 
-// One frame of an fp16 CBConv2d (conv2d.py:178-259 on the half backend): detection + refresh of prevInput and of its
-// pixel-major copy (feedbackLoop: at the changed pixels; else every value -- the layer keeps a copy of its input),
-// then the LDS-DMA contraction (+ the reduce launch of a deep one).  All tensors f16; frameMasks / idxOut / countOut /
-// maskCopy as for cbinfer_split_forward; upstreamCount (optional) as for cbinfer_cbconv2d_forward_after.  pooled != 0:
-// `input` is the tensor in FRONT of a 2x2/stride-2 max pool [C,pH,pW] (a CBPoolMax2d folded into the detection),
-// producerMask (optional) the change mask the layer that produced it left this frame (cbinfer_mask_words(pH,pW) words):
-// segments whose windows it did not touch are skipped.
-int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int pooled, int pH, int pW,
-                           const uint64_t* producerMask, void* state, void* pixelState, uint64_t* frameMasks,
-                           void* output, int32_t* idxOut, int32_t* countOut, uint64_t* maskCopy, const void* prepared,
-                           const void* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
-                           int feedbackLoop, int relu, void* workspace, cbStream_t stream) {
-    CB_REQUIRE(input && state && pixelState && frameMasks && output && idxOut && countOut && prepared && H > 0 && W > 0);
+// One frame of a GROUP of fp16 CBConv2d layers of one geometry (conv2d.py:178-259 on the half backend; the two branches of
+// an OpenPose stage, PoseModel.py:122-137): per layer with detect != 0 the detection launch (refresh of prevInput and
+// of its pixel-major copy; feedbackLoop: at the changed pixels, else every value), then ONE contraction launch for all
+// layers of the group (+ one reduce launch of a deep one), whose epilogue also runs the change detection of every
+// layer's consumers (cbHalfLayer.next[]; copy-mode consumers only).  See include/cbinfer_hip.h.
+int cbinfer_hsplit_forward_group(const cbHalfLayer* layers, int nLayers, int pooled, int pH, int pW, int C, int H, int W,
+                                 int kH, int kW, int feedbackLoop, void* workspace, cbStream_t stream) {
+    CB_REQUIRE(layers && nLayers >= 1 && nLayers <= CBH_GROUP && H > 0 && W > 0);
     if (pooled) CB_REQUIRE((H == pH / 2 || H == (pH + 1) / 2) && (W == pW / 2 || W == (pW + 1) / 2));
-    if (!cbh_supported(C, K, kH, kW) || H > 65535) return CB_ERR_UNSUPPORTED;
+    const int K0 = layers[0].K;
+    if (!cbh_supported(C, K0, kH, kW) || H > 65535) return CB_ERR_UNSUPPORTED;
     const CbsGeom g = cbh_geom(C, H, W, kH, kW);
-    const int KP = cbs_kp(K);
-    int BM = cbs_bm(K);
+    const int KP = cbs_kp(K0);
+    int BM = cbs_bm(K0);
     const long MW = cbinfer_mask_words(H, W);
     if (MW > CBS_PRE_MID || (long)g.Hp * g.Wp * g.rec >= (1l << 31) || (long)H * W * W >= (1l << 32))
         return CB_ERR_UNSUPPORTED;
     if (workspace == nullptr && g.nStages >= 48) return CB_ERR_BADARG;
+    for (int q = 0; q < nLayers; ++q) {
+        const cbHalfLayer& L = layers[q];
+        CB_REQUIRE(L.state && L.pixelState && L.frameMasks && L.output && L.idxOut && L.countOut && L.prepared);
+        CB_REQUIRE(!L.detect || L.input);
+        CB_REQUIRE(L.nNext >= 0 && L.nNext <= CBH_NEXT);
+        // (one tile grid for the group: the padded row count and the tile height must agree)
+        if (!cbh_supported(C, L.K, kH, kW) || cbs_kp(L.K) != KP || cbs_bm(L.K) != BM) return CB_ERR_UNSUPPORTED;
+        for (int c = 0; c < L.nNext; ++c) {
+            const cbHalfNext& n = L.next[c];
+            CB_REQUIRE(n.state && n.pixelState && n.frameMasks && (n.kH & 1) && (n.kW & 1) && n.kH <= 15 && n.kW <= 15);
+            if (L.K < 64) return CB_ERR_UNSUPPORTED;      // (a consumer on this machinery has >= 64 input channels)
+        }
+    }
     // The 128-row tile pays when there are tiles enough for every CU.  A shallow contraction on a map that would give
     // fewer than four 128 x 128 tiles per CU even if EVERY pixel changed -- at the change ratios this path is for it
     // then gives a fraction of one -- runs on 64 x 64 tiles instead (the prepared weights are per 32-row tile: either
@@ -2261,38 +2593,61 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int 
         if (small && BM == 128 && g.nStages < 48 && full128 < 4l * cbs_num_cus()) BM = 64;
     }
     hipStream_t s = (hipStream_t)stream;
-    CbhDetArgs a;
-    a.in = (const _Float16*)input, a.state = (_Float16*)state, a.S = (char*)pixelState;
-    a.masks = (unsigned long long*)frameMasks;
-    a.W = W, a.H = H, a.C = C, a.kHH = (kH - 1) / 2, a.kWH = (kW - 1) / 2, a.wpr = cbinfer_mask_words_per_row(W);
-    a.Wp = g.Wp, a.rec = g.rec, a.padY = g.padY, a.padXL = g.padXL, a.th = threshold, a.copyAll = feedbackLoop ? 0 : 1;
-    a.upstream = upstreamCount;
-    a.pH = pH, a.pW = pW, a.prodMask = (const unsigned long long*)producerMask;      // (pooled: at pH x pW; else at H x W)
-    if (pooled)
-        hipLaunchKernelGGL(cbh_detect_kernel<true>, dim3(a.wpr, H, a.copyAll ? g.C / 64 : 1), dim3(512), 0, s, a);
-    else
-        hipLaunchKernelGGL(cbh_detect_kernel<false>, dim3(a.wpr, H, a.copyAll ? g.C / 64 : 1), dim3(512), 0, s, a);
-    int st = cb_launch_status();
-    if (st != CB_OK) return st;
+    const int wpr = cbinfer_mask_words_per_row(W);
+    for (int q = 0; q < nLayers; ++q) {
+        const cbHalfLayer& L = layers[q];
+        if (!L.detect) continue;
+        CbhDetArgs a;
+        a.in = (const _Float16*)L.input, a.state = (_Float16*)L.state, a.S = (char*)L.pixelState;
+        a.masks = (unsigned long long*)L.frameMasks;
+        a.W = W, a.H = H, a.C = C, a.kHH = (kH - 1) / 2, a.kWH = (kW - 1) / 2, a.wpr = wpr;
+        a.Wp = g.Wp, a.rec = g.rec, a.padY = g.padY, a.padXL = g.padXL, a.th = L.threshold;
+        a.copyAll = feedbackLoop ? 0 : 1;
+        a.upstream = nLayers == 1 ? L.upstreamCount : nullptr;
+        a.pH = pH, a.pW = pW, a.prodMask = (const unsigned long long*)L.producerMask;   // (pooled: at pH x pW; else at H x W)
+        if (pooled)
+            hipLaunchKernelGGL(cbh_detect_kernel<true>, dim3(wpr, H, a.copyAll ? g.C / 64 : 1), dim3(512), 0, s, a);
+        else
+            hipLaunchKernelGGL(cbh_detect_kernel<false>, dim3(wpr, H, a.copyAll ? g.C / 64 : 1), dim3(512), 0, s, a);
+        const int st = cb_launch_status();
+        if (st != CB_OK) return st;
+    }
 
     CbsParams p;
+    CbhExt x;
     for (int q = 0; q < CBS_MAXSEQ; ++q) p.seq[q] = CbsSeq{};
-    p.seq[0].S = (const char*)pixelState;
-    p.seq[0].state = nullptr, p.seq[0].rangeFlag = nullptr, p.seq[0].reluOut = nullptr;
-    p.seq[0].out = (float*)output;
-    p.seq[0].masks = (unsigned long long*)frameMasks;
-    p.seq[0].listOut = idxOut, p.seq[0].countOut = countOut;
-    p.seq[0].maskCopy = (unsigned long long*)maskCopy;
-    p.nSeq = 1;
+    for (int q = 0; q < CBH_GROUP; ++q) {
+        x.L[q] = CbhLayer{};
+        const cbHalfLayer& L = layers[q < nLayers ? q : 0];
+        if (q < nLayers) {
+            p.seq[q].S = (const char*)L.pixelState;
+            p.seq[q].out = (float*)L.output;
+            p.seq[q].masks = (unsigned long long*)L.frameMasks;
+            p.seq[q].listOut = L.idxOut, p.seq[q].countOut = L.countOut;
+            p.seq[q].maskCopy = (unsigned long long*)L.maskCopy;
+        }
+        x.L[q].A = (const char*)L.prepared;
+        x.L[q].bias = (const _Float16*)L.bias;
+        x.L[q].K = L.K, x.L[q].relu = L.relu, x.L[q].nNext = q < nLayers ? L.nNext : 0;
+        for (int c = 0; c < x.L[q].nNext; ++c) {
+            const cbHalfNext& n = L.next[c];
+            const CbsGeom gn = cbh_geom(L.K, H, W, n.kH, n.kW);
+            CbhNext& d = x.L[q].next[c];
+            d.state = (_Float16*)n.state, d.S = (char*)n.pixelState, d.masks = (unsigned long long*)n.frameMasks;
+            d.kHH = (n.kH - 1) / 2, d.kWH = (n.kW - 1) / 2;
+            d.Wp = gn.Wp, d.rec = gn.rec, d.padY = gn.padY, d.padXL = gn.padXL, d.th = n.threshold;
+        }
+    }
+    p.nSeq = nLayers;
     p.aBytes = (long)g.nStages * (KP / 32) * 4096;
-    p.A = (const char*)prepared;
-    p.stageOff = (const int*)((const char*)prepared + p.aBytes);
+    p.A = (const char*)layers[0].prepared;
+    p.stageOff = (const int*)((const char*)layers[0].prepared + p.aBytes);      // (the geometry's: one table for the group)
     p.wPlain = nullptr;
-    p.bias = (const float*)bias;      // (f16 values: cbs_conv_kernel<..., HALF> and the reduce launch read them as such)
+    p.bias = (const float*)layers[0].bias;      // (f16 values; the fp16 kernels read the per-layer pointers of CbhExt)
     p.info = workspace ? (int*)workspace : nullptr;
     p.slabs = workspace ? (float*)((char*)workspace + 256) : nullptr;
-    p.K = K, p.KP = KP, p.H = H, p.W = W, p.Wp = g.Wp, p.rec = g.rec, p.nStages = g.nStages, p.kH = kH, p.kW = kW;
-    p.maskWords = (int)MW, p.wpr = a.wpr, p.relu = relu, p.dummyBase = g.dummyBase;
+    p.K = K0, p.KP = KP, p.H = H, p.W = W, p.Wp = g.Wp, p.rec = g.rec, p.nStages = g.nStages, p.kH = kH, p.kW = kW;
+    p.maskWords = (int)MW, p.wpr = wpr, p.relu = layers[0].relu, p.dummyBase = g.dummyBase;
     p.stateBytes = (long)g.Hp * g.Wp * g.rec;
     p.outScale = 1.0f;
     p.magicMW = (1ull << 32) / (unsigned long long)MW + 1ull;
@@ -2311,15 +2666,16 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int 
         }
         p.maxChunks = mc;
     }
-    p.upstream = upstreamCount;
+    p.upstream = nLayers == 1 ? layers[0].upstreamCount : nullptr;
     p.arriveShards = (int)(MW / 16 < 8 ? MW / 16 : 8);
-    const long cap = cbs_slab_capacity(1, H, W, K);
+    const long cap = cbs_slab_capacity(nLayers, H, W, K0);
     p.slabCap = (int)(cap > 0x7fffffffl ? 0x7fffffffl : cap);
+    const long E = (long)nLayers * MW;
     if (BM == 128) {
-        if (MW <= CBS_PRE_BIG) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG, true, 4, 1>(p, 1, nullptr, s);
-        return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_MID, false, 4, 1>(p, 1, nullptr, s);
+        if (E <= CBS_PRE_BIG) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG, true, 4, 1>(p, 1, nullptr, s, x);
+        return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_MID, false, 4, 1>(p, 1, nullptr, s, x);
     }
-    if (MW <= CBS_PRE_SMALL) {
+    if (E <= CBS_PRE_SMALL) {
         // (two workgroups per CU with four-stage rings: these contractions are shallow -- 9 to 36 stages -- and a layer
         //  sent here from the 128-row tile has two to four times the items)
         static int two = -1;
@@ -2327,8 +2683,8 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int 
             const char* e = getenv("CBINFER_HSPLIT_TWO_PER_CU");
             two = e ? atoi(e) : 1;
         }
-        if (two) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 4, 1>(p, 2, nullptr, s);
-        return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 8, 1>(p, 1, nullptr, s);
+        if (two) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 4, 1>(p, 2, nullptr, s, x);
+        return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 8, 1>(p, 1, nullptr, s, x);
     }
     // (a large map -- OpenPose's 64-channel 368x654 layer: 541 tiles of nine stages at 14 % change -- has more tiles than
     //  CUs and little depth: two workgroups per CU with three-stage rings (68 KB each beside the 20 KB prefix))
@@ -2337,8 +2693,36 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int 
         const char* e = getenv("CBINFER_HSPLIT_BIG2");
         big2 = e ? atoi(e) : 1;
     }
-    if (big2) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 3, 1>(p, 2, nullptr, s);
-    return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 8, 1>(p, 1, nullptr, s);
+    if (E > CBS_PRE_MID) return CB_ERR_UNSUPPORTED;
+    if (big2) return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 3, 1>(p, 2, nullptr, s, x);
+    return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_MID, false, 8, 1>(p, 1, nullptr, s, x);
+}
+
+// One frame of ONE fp16 CBConv2d: cbinfer_hsplit_forward_group with a single layer that runs its own detection and has no
+// consumer folded in.  All tensors f16; frameMasks / idxOut / countOut / maskCopy as for cbinfer_split_forward;
+// upstreamCount (optional) as for cbinfer_cbconv2d_forward_after.  pooled != 0: `input` is the tensor in FRONT of a
+// 2x2/stride-2 max pool [C,pH,pW] (a CBPoolMax2d folded into the detection), producerMask (optional) the change mask the
+// layer that produced it left this frame (cbinfer_mask_words(pH,pW) words): segments whose windows it did not touch are
+// skipped.
+int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int pooled, int pH, int pW,
+                           const uint64_t* producerMask, void* state, void* pixelState, uint64_t* frameMasks,
+                           void* output, int32_t* idxOut, int32_t* countOut, uint64_t* maskCopy, const void* prepared,
+                           const void* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
+                           int feedbackLoop, int relu, void* workspace, cbStream_t stream) {
+    CB_REQUIRE(input);
+    cbHalfLayer L = {};
+    L.upstreamCount = upstreamCount, L.input = input, L.producerMask = producerMask;
+    L.state = state, L.pixelState = pixelState, L.frameMasks = frameMasks, L.output = output;
+    L.idxOut = idxOut, L.countOut = countOut, L.maskCopy = maskCopy, L.prepared = prepared, L.bias = bias;
+    L.K = K, L.threshold = threshold, L.relu = relu, L.detect = 1, L.nNext = 0;
+    return cbinfer_hsplit_forward_group(&L, 1, pooled, pH, pW, C, H, W, kH, kW, feedbackLoop, workspace, stream);
+}
+
+long cbinfer_hsplit_group_workspace_bytes(int nLayers, int C, int H, int W, int K, int kH, int kW) {
+    if (nLayers < 1 || nLayers > CBH_GROUP || !cbh_supported(C, K, kH, kW)) return 0;
+    if (cbh_geom(C, H, W, kH, kW).nStages < 48) return 0;
+    const int bm = cbs_bm(K), bn = bm >= 128 ? 128 : 64;
+    return 256 + cbs_slab_capacity(nLayers, H, W, K) * bm * bn * 4;
 }
 
 }  // extern "C"

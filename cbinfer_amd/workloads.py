@@ -254,6 +254,21 @@ def convertOpenPose(model, threshold=1e-2, feedbackLoop=False):
     return model
 
 
+def fuseOpenPoseDetections(model, enabled=True):
+    """Execution-level (results unchanged): every chained CBConv2d pair inside the sub-models lets the PRODUCER's
+    launch run the consumer's change detection (pycbinfer.fuseDetectionIntoProducer), and the feature extractor's last
+    layer does so for the first layers of BOTH branches of stage 1, which consume its output directly
+    (PoseModel.py:122-137) -- a link the module tree does not show (pycbinfer.linkConsumers)."""
+    from . import CBConv2d, fuseDetectionIntoProducer, linkConsumers
+    for name in model.submodelNames():
+        fuseDetectionIntoProducer(getattr(model, name), enabled)
+    convs = lambda seq: [m for m in seq.children() if type(m) is CBConv2d]
+    last = convs(model.model0)[-1]
+    heads = [convs(getattr(model, 'model1_%d' % b))[0] for b in (1, 2)]
+    linkConsumers(last, heads if enabled else [])
+    return model
+
+
 def calibrateChangeRatio(converted, nextFrame, target=0.10, pairs=4, settle=8, finalSettle=24):
     """Per-layer thresholds that give every CBConv2d of the CONVERTED network a post-dilation change ratio of `target` on
     the video `nextFrame()` yields, found layer by layer in execution order IN the change-based network itself (a
@@ -266,10 +281,26 @@ def calibrateChangeRatio(converted, nextFrame, target=0.10, pairs=4, settle=8, f
     its steady state.  A WORKLOAD generator for measurements (BASELINE.md budgets config 4 at 10 % of the dense work,
     SURVEY 8(d): "r = 10 % at every layer"), not the reference's accuracy-driven tuner
     (pycbinfer.tuneThresholdParameters).  Returns the thresholds; the network is left warm: continue the same video."""
+    import os
     from . import CBConv2d
     convs = [m for m in converted.modules() if type(m) is CBConv2d]
     for m in convs:
         m.threshold = 0.0
+    # (the recorded |input - prevInput| maps need every layer's state as its OWN detection finds it: while a producer's
+    #  launch runs its consumer's detection (pycbinfer.fuseDetectionIntoProducer) that state is refreshed before the
+    #  consumer's forward -- and this hook -- is reached.  The folding is decided per frame: off while calibrating.)
+    saved = os.environ.get('CBINFER_NO_NEXTFOLD')
+    os.environ['CBINFER_NO_NEXTFOLD'] = '1'
+    try:
+        return _calibrate(converted, convs, nextFrame, target, pairs, settle, finalSettle)
+    finally:
+        if saved is None:
+            os.environ.pop('CBINFER_NO_NEXTFOLD', None)
+        else:
+            os.environ['CBINFER_NO_NEXTFOLD'] = saved
+
+
+def _calibrate(converted, convs, nextFrame, target, pairs, settle, finalSettle):
     with torch.no_grad():
         converted(nextFrame())
         for m in convs:

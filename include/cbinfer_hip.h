@@ -56,8 +56,10 @@ typedef void* cbStream_t; /* hipStream_t */
  * launch), cbinfer_split_tail_supported.  6: row-pair frame (cbinfer_*rowpairs*), cbinfer_dilate_change_indexes,
  * updateInputState = 2.  7: chained layers (cbinfer_*_after: the producer's change count ends an idle frame).
  * 8: the f32-EQUIVALENT (bf16-triple) form of the split-state frame: cbinfer_split3_*, CBINFER_SPLIT_X3,
- * weightScale == 0, cbNextDetect.arith. */
-#define CBINFER_ABI_VERSION 8
+ * weightScale == 0, cbNextDetect.arith.  9: cbinfer_hsplit_forward_group (cbHalfLayer / cbHalfNext: two layers of one
+ * geometry per launch, the consumers' change detection in the producing launch); cbinfer_hsplit_* take contractions
+ * of a single k-stage and up (1x1 layers on >= 64 channels). */
+#define CBINFER_ABI_VERSION 9
 
 int cbinfer_abi_version(void);
 const char* cbinfer_status_string(int status);
@@ -567,6 +569,60 @@ int cbinfer_hsplit_forward(const int32_t* upstreamCount, const void* input, int 
                            void* output, int32_t* idxOut, int32_t* countOut, uint64_t* maskCopy, const void* prepared,
                            const void* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
                            int feedbackLoop, int relu, void* workspace, cbStream_t stream);
+
+/* ---- a GROUP of fp16 layers in one set of launches, each doing the change detection of its CONSUMERS (round 6,
+ * ABI 9).  Two things the reference's structure offers and one launch per op hides:
+ *  (1) layers chain through their state tensors -- a CBConv2d's input IS the prevOutput of the CBConv2d in front
+ *      (conv2d.py:259 returns the state tensor itself; ('changeIndexes', out, idx) at :180-186, :256-259 hands the
+ *      producer's change list on) -- so the producing launch knows every value the consumer's changeDetection
+ *      (cbconv2d_cg_half_backend.cu:45-88) could find changed: those of the pixels it just recomputed.  For a consumer
+ *      that keeps a COPY of its input (feedbackLoop = False, copyInput = True: conv2d.py:234-236, what convert() makes)
+ *      the detection decomposes per VALUE -- compare with the consumer's prevInput in half precision (strict >), write
+ *      the value into prevInput and into the consumer's pixel-major copy where it differs bit for bit, OR the dilated
+ *      pixel into the consumer's frame mask -- and rides in the epilogue of the producing contraction (in the reduce
+ *      launch of a contraction that was split along k).  The consumer then runs with detect = 0: its contraction alone.
+ *      Valid exactly where the chained detection's producer-mask shortcut is (cbinfer_hsplit_forward above): the
+ *      consumer compared this very buffer last frame into this very state with this very threshold; the caller falls
+ *      back to detect = 1 for one frame otherwise.  Results are those of the separate launches, bit for bit.
+ *  (2) the two branches of an OpenPose stage (poseDetection/openPose/PoseModel.py:122-137) are independent layers of
+ *      ONE geometry: nLayers = 2 issues both as one persistent grid (items of both layers in one launch; own weights,
+ *      states, masks, lists each; K may differ while the padded tile height agrees -- 38 and 19 outputs both pad to 64).
+ * cbHalfLayer: one layer's tensors (all f16 unless said otherwise); next[]: up to CBINFER_HNEXT_MAX consumers of its
+ * output (same H x W; in_channels = K).  workspace: cbinfer_hsplit_group_workspace_bytes(nLayers, ...), zero once. */
+#define CBINFER_HGROUP_MAX 2
+#define CBINFER_HNEXT_MAX 2
+typedef struct {
+    void* state;              /* the consumer's prevInput [K,H,W] */
+    void* pixelState;         /* its pixel-major copy: cbinfer_hsplit_state_bytes(K, H, W, kH, kW) */
+    uint64_t* frameMasks;     /* its frame mask */
+    int kH, kW;               /* its filter: dilation, and the border geometry of pixelState */
+    float threshold;
+    int reserved;
+} cbHalfNext;
+typedef struct {
+    const int32_t* upstreamCount;   /* optional (nLayers == 1 only), as for cbinfer_hsplit_forward */
+    const void* input;              /* this frame's input (pooled: the pool's input); unused with detect = 0 */
+    const uint64_t* producerMask;   /* optional, as for cbinfer_hsplit_forward */
+    void* state;                    /* prevInput [C,H,W] */
+    void* pixelState;
+    uint64_t* frameMasks;
+    void* output;                   /* prevOutput [K,H,W] */
+    int32_t* idxOut;
+    int32_t* countOut;
+    uint64_t* maskCopy;             /* may be NULL */
+    const void* prepared;           /* cbinfer_hsplit_prep_weights */
+    const void* bias;               /* [K] f16, may be NULL */
+    int K;
+    float threshold;
+    int relu;
+    int detect;                     /* 1: this call runs the layer's change detection; 0: a producer's launch did */
+    int nNext;
+    int reserved;
+    cbHalfNext next[CBINFER_HNEXT_MAX];
+} cbHalfLayer;
+long cbinfer_hsplit_group_workspace_bytes(int nLayers, int C, int H, int W, int K, int kH, int kW);
+int cbinfer_hsplit_forward_group(const cbHalfLayer* layers, int nLayers, int pooled, int pH, int pW, int C, int H, int W,
+                                 int kH, int kW, int feedbackLoop, void* workspace, cbStream_t stream);
 
 /* ---- a5..a8 fused for a layer of few channels, ROW-PAIR form, with the NEXT layer's pooled change detection folded
  * in (round 4).  Replaces, per frame, the launcher sequence genXMatrix -> matmul -> updateOutput

@@ -1,0 +1,134 @@
+"""-m gpu tests of round 6's two forms of an fp16 frame (cb_split.hip: cbinfer_hsplit_forward_group):
+(1) the change detection of a layer's CONSUMERS inside the producing layer's contraction launch -- the reference chains
+    layers through their state tensors (conv2d.py:259: the returned tensor IS prevOutput; :180-186, :256-259), a consumer
+    in copy mode (conv2d.py:234-236) compares that buffer value by value (cbconv2d_cg_half_backend.cu:24-35) --, and
+(2) two layers of one geometry in one launch (the two branches of an OpenPose stage, PoseModel.py:122-137).
+Both are execution forms: every buffer must equal, bit for bit, what the separate launches leave."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import pycbinfer
+    assert torch.cuda.is_available()
+    return pycbinfer
+
+
+def video(rng, C, H, W, n, frac, blk=6):
+    x = rng.standard_normal((1, C, H, W)).astype(np.float16)
+    out = [x.copy()]
+    for t in range(n - 1):
+        x = x.copy()
+        f = frac[t % len(frac)] if isinstance(frac, (list, tuple)) else frac
+        if f >= 1.0:
+            x = rng.standard_normal((1, C, H, W)).astype(np.float16)
+        else:
+            for _ in range(int(round(f * H * W / blk / blk))):
+                y0, x0 = rng.integers(0, H - blk), rng.integers(0, W - blk)
+                x[0, :, y0:y0 + blk, x0:x0 + blk] = rng.standard_normal((C, blk, blk)).astype(np.float16)
+        out.append(x)
+    return out
+
+
+def chain(pkg, spec, seed, threshold=0.05, scale=None):
+    """nn.Sequential of Conv2d(+ReLU) per (C_in, C_out, k), fp16, converted; kaiming weights so that every layer is alive."""
+    torch.manual_seed(seed)
+    layers = []
+    for i, (ci, co, k) in enumerate(spec):
+        conv = nn.Conv2d(ci, co, k, padding=k // 2)
+        nn.init.kaiming_normal_(conv.weight, nonlinearity='relu')
+        nn.init.normal_(conv.bias, std=0.1)
+        layers += [conv, nn.ReLU()] if i < len(spec) - 1 else [conv]
+    return pkg.convert(nn.Sequential(*layers).cuda().half().eval(), threshold=threshold)
+
+
+SPECS = {
+    # shallow producers on 64x64 and 128x128 tiles, a deep one (7x7 on 128: 98 k-stages), output channels off the
+    # 64-channel grid (100 -> the consumer's records are padded to 128), 1x1 layers of two and eight k-stages
+    "mixed": [(64, 128, 3), (128, 128, 7), (128, 100, 3), (100, 128, 3), (128, 512, 1), (512, 38, 1)],
+    # deep producers only (3x3 on 512: 72 stages; 7x7 on 128), a 1x1 consumer behind a deep producer
+    "deep": [(64, 512, 3), (512, 512, 3), (512, 128, 3), (128, 128, 7), (128, 128, 7), (128, 128, 1), (128, 19, 1)],
+}
+
+
+@pytest.mark.parametrize("name,H,W", [("mixed", 46, 81), ("deep", 23, 40), ("mixed", 92, 163)])
+def test_consumer_detection_in_the_producing_launch_is_bit_identical(pkg, name, H, W, monkeypatch):
+    """A chain of fp16 CBConv2d layers with the consumers' detection folded into the producers' launches
+    (pycbinfer.fuseDetectionIntoProducer) against the same chain with every layer running its own detection launch:
+    per frame and layer the change list, prevInput and prevOutput bit-identical -- over frames of 5-15 % change, a frame
+    that changes EVERYTHING (the deep contractions then run unsplit: the detection rides in the contraction's own
+    epilogue), and two idle frames -- and the folding really runs from the third frame on."""
+    spec = SPECS[name]
+    a = chain(pkg, spec, 3)
+    b = chain(pkg, spec, 3)
+    pkg.fuseDetectionIntoProducer(a)
+    rng = np.random.default_rng(H * W)
+    frac = [0.1, 0.05, 0.15, 1.0, 0.1, 0.0, 0.0, 0.08, 0.1]
+    frames = video(rng, spec[0][0], H, W, 12, frac)
+    ca = [m for m in a.modules() if type(m) is pkg.CBConv2d]
+    cb = [m for m in b.modules() if type(m) is pkg.CBConv2d]
+    folded = np.zeros(len(ca), dtype=int)
+    with torch.no_grad():
+        for t, f in enumerate(frames):
+            x = torch.from_numpy(f).cuda()
+            ya, yb = a(x), b(x)
+            torch.cuda.synchronize()
+            for i, (ma, mb) in enumerate(zip(ca, cb)):
+                assert torch.equal(ma.lastChangeIndexes().tensor(), mb.lastChangeIndexes().tensor()), (t, i)
+                assert torch.equal(ma.prevInput, mb.prevInput), (t, i)
+                assert torch.equal(ma.prevOutput, mb.prevOutput), (t, i)
+                hs = ma._work.get('hsplit')
+                if hs is not None and hs['layer'][0].detect == 0:
+                    folded[i] += 1
+            assert torch.equal(ya, yb), t
+    # every layer behind the first one had its detection done by its producer in the steady state
+    assert folded[0] == 0 and all(n >= len(frames) - 3 for n in folded[1:]), folded
+    assert all(m._plan is not None and m._plan.get('hsplit') for m in ca)
+    assert all(m._work['hsplit']['layer'][0].detect == 1 for m in cb)
+    # ... and something was there to detect: the layers are alive
+    assert all(m.lastChangeIndexes().numel() > 0 for m in ca)
+
+
+def test_two_consumers_with_their_own_thresholds(pkg):
+    """One producer, two consumers of its output (the first layers of the two branches of an OpenPose stage,
+    PoseModel.py:122-137) with different thresholds and filter sizes: both detections in the producer's launch
+    (pycbinfer.linkConsumers) equal the consumers' own."""
+    H, W = 46, 81
+
+    def build(link):
+        torch.manual_seed(11)
+        prod = chain(pkg, [(64, 128, 3), (128, 128, 3)], 5)
+        b1 = chain(pkg, [(128, 128, 3), (128, 38, 1)], 6, threshold=0.03)
+        b2 = chain(pkg, [(128, 128, 7), (128, 19, 1)], 7, threshold=0.2)
+        if link:
+            for seq in (prod, b1, b2):
+                pkg.fuseDetectionIntoProducer(seq)
+            last = [m for m in prod.modules() if type(m) is pkg.CBConv2d][-1]
+            pkg.linkConsumers(last, [next(iter(b1.children())), next(iter(b2.children()))])
+        return prod, b1, b2
+    A, B = build(True), build(False)
+    rng = np.random.default_rng(5)
+    frames = video(rng, 64, H, W, 8, 0.1)
+    folded = [0, 0]
+    with torch.no_grad():
+        for t, f in enumerate(frames):
+            x = torch.from_numpy(f).cuda()
+            outs = []
+            for prod, b1, b2 in (A, B):
+                feat = prod(x)
+                outs.append((b1(feat), b2(feat)))
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), t
+            for k in (1, 2):
+                ma, mb = next(iter(A[k].children())), next(iter(B[k].children()))
+                assert torch.equal(ma.prevInput, mb.prevInput) and torch.equal(ma.prevOutput, mb.prevOutput), (t, k)
+                assert torch.equal(ma.lastChangeIndexes().tensor(), mb.lastChangeIndexes().tensor()), (t, k)
+                folded[k - 1] += int(ma._work['hsplit']['layer'][0].detect == 0)
+    assert folded[0] >= 5 and folded[1] >= 5, folded
+    last = [m for m in A[0].modules() if type(m) is pkg.CBConv2d][-1]
+    assert last._work['hsplit']['layer'][0].nNext == 2

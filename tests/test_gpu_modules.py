@@ -1741,7 +1741,10 @@ def test_chain_tags_do_not_travel_with_copies(pkg):
                                    # round 5: OpenPose's deep layers at their size -- 7x7 on 185 channels (padded to 192:
                                    # 147 k-stages), 7x7 on 128 (98), 3x3 on 512 (72): the depth in 4, 8 or 16 chunks --
                                    # and a padded shallow one
-                                   (185, 128, 7, 46, 81), (128, 128, 7, 46, 81), (512, 512, 3, 46, 81), (100, 64, 3, 31, 45)])
+                                   (185, 128, 7, 46, 81), (128, 128, 7, 46, 81), (512, 512, 3, 46, 81), (100, 64, 3, 31, 45),
+                                   # round 6: contractions of one and two k-stages (1x1 on 64 / 128 channels: OpenPose's
+                                   # 128->512, 128->128 and 128->38 layers)
+                                   (128, 512, 1, 46, 81), (64, 96, 1, 33, 50), (128, 38, 1, 46, 81)])
 def test_half_layers_on_the_split_state_machinery(pkg, oracle, shape, feedback, monkeypatch):
     """Round 4: fp16 layers of 64 and more input channels (padded to a multiple of 64, round 5)
     keep a pixel-major f16 copy of their state and contract by LDS-DMA (cbinfer_hsplit_forward; cbconv2d_cg_half_backend.cu:10-88, :146-197).
@@ -1772,7 +1775,7 @@ def test_half_layers_on_the_split_state_machinery(pkg, oracle, shape, feedback, 
                         x[0, :, y0:y0 + 8, x0:x0 + 8] = r.standard_normal((C, 8, 8)).astype(np.float16)
                 xn = (x.astype(np.float32) + r.uniform(-0.03, 0.03, x.shape)).astype(np.float16)
                 out = m(torch.from_numpy(xn).cuda())
-                ran.append(bool(m._plan and m._plan.get('fn') is _lib.C.cbinfer_hsplit_forward))
+                ran.append(bool(m._plan and m._plan.get('fn') is _lib.C.cbinfer_hsplit_forward_group))
                 got = o.forward(xn)
                 assert np.array_equal(m.lastChangeIndexes().tensor().cpu().numpy(), got[2]), (hsplit, t)
                 assert np.array_equal(m.prevInput.cpu().numpy(), o.prevInput), (hsplit, t)
@@ -1991,7 +1994,7 @@ def test_pools_fold_into_the_fp16_split_state_detection(pkg, feedback, size):
                 assert torch.equal(ma.lastChangeIndexes().tensor(), mb.lastChangeIndexes().tensor()), t
     convs0 = [m for m in nets[0] if type(m) is pkg.CBConv2d]
     from cbinfer_amd import _lib
-    assert all(m._plan is not None and m._plan['fn'] is _lib.C.cbinfer_hsplit_forward and m._plan['pooled']
+    assert all(m._plan is not None and m._plan['fn'] is _lib.C.cbinfer_hsplit_forward_group and m._plan['pooled']
                for m in convs0[1:])
     assert all(p.outputState.numel() == 0 for p in pools)
 
@@ -2005,9 +2008,10 @@ def test_openpose_live_network_fullsize(pkg, oracle):
         network's on the same weights -- every layer busy, the 185-channel layers padded to 192, the deep contractions
         split 4..16 ways -- within the fp16 bar of 36 chained layers;
     (2) at the calibrated thresholds every layer recomputes (no dead tail as on nn.Conv2d's default initialisation), and
-        three deep layers -- 3x3 on 512 channels (72 k-stages), 7x7 on 185 channels (padded, 147 k-stages), 7x7 on 128
-        (98) -- are TEACHER-FORCED against the oracle's half state machine on the inputs the running network hands
-        them: change lists bit-exact, prevInput bit-exact, outputs within 2 fp16 ulp of the layer's largest output."""
+        ALL 36 layers (round 6; round 5 forced three) are TEACHER-FORCED against the oracle's half state machine on the
+        inputs the running network hands them -- with the consumers' change detection running inside the producers'
+        launches (29 of the 36 detections): change lists bit-exact, prevInput bit-exact, outputs within 2 fp16 ulp of the
+        layer's largest output."""
     from cbinfer_amd import workloads, _lib
     H, W = 368, 654
     vid = workloads.SyntheticVideo(H=H, W=672, ratio=0.10, block=16, seed=11)
@@ -2032,19 +2036,16 @@ def test_openpose_live_network_fullsize(pkg, oracle):
     convs0 = [m for m in net0.modules() if type(m) is pkg.CBConv2d]
     assert all(m.lastChangeIndexes().numel() > 0 for m in convs0)
     paths = [m._plan['fn'] for m in convs0 if m._plan is not None and m._plan.get('fn') is not None]
-    assert sum(1 for p in paths if p is _lib.C.cbinfer_hsplit_forward) >= 28      # (all but the 3-channel layer and 1x1s)
+    assert sum(1 for p in paths if p is _lib.C.cbinfer_hsplit_forward_group) == 35      # (all but the 3-channel layer)
     del net0
-    # (2) calibrated thresholds, teacher-forced deep layers
-    net = workloads.convertOpenPose(live(), threshold=0.02)
+    # (2) calibrated thresholds, EVERY layer teacher-forced, in the execution form the bench measures: the consumers'
+    #     detection inside the producers' launches (workloads.fuseOpenPoseDetections)
+    net = workloads.fuseOpenPoseDetections(workloads.convertOpenPose(live(), threshold=0.02))
     ths = workloads.calibrateChangeRatio(net, lambda: prep(vid.next()), target=0.10, pairs=3, settle=6, finalSettle=12)
     convs = [m for m in net.modules() if type(m) is pkg.CBConv2d]
     assert len(ths) == 36 and all(th >= 0 for th in ths)
-    deep = [m for m in convs if tuple(m.weight.shape[1:]) in ((512, 3, 3), (185, 7, 7), (128, 7, 7))]
-    picks = [next(m for m in deep if m.weight.shape[1] == 512 and m.weight.shape[0] == 512),
-             next(m for m in deep if m.weight.shape[1] == 185),
-             next(m for m in deep if m.weight.shape[1] == 128 and m.weight.shape[2] == 7)]
     twins, captured = {}, {}
-    for m in picks:
+    for m in convs:
         twins[m] = oracle.OracleCBConv2dHalf(m.weight.detach().cpu().numpy(), m.bias.detach().cpu().numpy(),
                                              float(m.threshold), withReLU=bool(m.withReLU), feedbackLoop=False,
                                              propChangeIndexes=True)
@@ -2053,23 +2054,35 @@ def test_openpose_live_network_fullsize(pkg, oracle):
         twins[m].prevOutput = m.prevOutput.cpu().numpy().copy()
         m.register_forward_pre_hook(lambda mod, inp: captured.__setitem__(mod, inp[0].detach().cpu().numpy().copy()))
     counts = np.zeros(len(convs))
+    folded = np.zeros(len(convs), dtype=int)
+    frames_checked = 3
     with torch.no_grad():
-        for t in range(4):
+        for t in range(frames_checked):
             net(prep(vid.next()))
+            torch.cuda.synchronize()
             counts += [m.lastChangeIndexes().numel() for m in convs]
-            for m in picks:
+            for i, m in enumerate(convs):
                 o = twins[m]
                 got = o.forward(captured[m])
-                assert m._plan is not None and m._plan.get('fn') is _lib.C.cbinfer_hsplit_forward
-                assert np.array_equal(m.lastChangeIndexes().tensor().cpu().numpy(), got[2]), (t, m.weight.shape)
-                assert got[2].size > 0
-                assert np.array_equal(m.prevInput.cpu().numpy(), o.prevInput), (t, m.weight.shape)
+                hs = m._work.get('hsplit')
+                if hs is not None:
+                    assert m._plan is not None and m._plan.get('fn') is _lib.C.cbinfer_hsplit_forward_group
+                    folded[i] += int(hs['layer'][0].detect == 0)
+                assert np.array_equal(m.lastChangeIndexes().tensor().cpu().numpy(), got[2]), (t, i, m.weight.shape)
+                assert got[2].size > 0, (t, i)
+                assert np.array_equal(m.prevInput.cpu().numpy(), o.prevInput), (t, i, m.weight.shape)
                 ref = o.prevOutput.astype(np.float32)
                 tol = 2 * 2.0 ** -10 * max(1.0, float(np.abs(ref[np.isfinite(ref)]).max()))
                 err = np.abs(m.prevOutput.float().cpu().numpy() - ref).max()
-                assert err <= tol, (t, m.weight.shape, err, tol)
-    ratios = counts / 4.0 / np.array([m.prevInput.size(-1) * m.prevInput.size(-2) for m in convs], dtype=np.float64)
+                assert err <= tol, (t, i, m.weight.shape, err, tol)
+    ratios = counts / float(frames_checked) / np.array([m.prevInput.size(-1) * m.prevInput.size(-2) for m in convs],
+                                                       dtype=np.float64)
     assert ratios.min() > 0.01 and 0.04 < ratios.mean() < 0.25, ratios      # every layer alive, ~10 % on average
+    # all layers but the 3-channel one on the split-state machinery (the 1x1 layers too, round 6); the detection of every
+    # layer directly behind another one -- 7 in the feature extractor, 2 x 5 in stage 1 (the heads behind the extractor's
+    # last layer), 2 x 6 in stage 2 -- ran in its producer's launch in every checked frame
+    assert sum(1 for m in convs if m._work.get('hsplit') is not None) == 35
+    assert int((folded == frames_checked).sum()) == 29, folded
 
 
 @pytest.mark.gpu

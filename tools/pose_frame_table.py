@@ -9,10 +9,12 @@ import sys
 
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-det = [i for i, r in enumerate(rows) if "detect" in r["Kernel_Name"]]
+# a frame starts with the detection launch of the 3-channel first layer: the only layer on the list kernels since round 6
+# (cb_detect_kernel; every other layer's detection is cbh_detect_kernel or rides in its producer's launch)
+det = [i for i, r in enumerate(rows) if "cb_detect_kernel" in r["Kernel_Name"]]
 # (default: a frame of the timed walk -- 25 frames before the last one; the threshold calibration runs in front of it)
-frame = int(sys.argv[2]) if len(sys.argv) > 2 else len(det) // 36 - 25
-a, b = det[frame * 36], det[(frame + 1) * 36]
+frame = int(sys.argv[2]) if len(sys.argv) > 2 else len(det) - 25
+a, b = det[frame], det[frame + 1]
 t0 = int(rows[a]["Start_Timestamp"])
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows[a:b]:

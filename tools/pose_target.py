@@ -29,6 +29,11 @@ def main():
     conc = os.environ.get("POSE_CONCURRENT", "0") == "1"      # the two branches of every stage on two HIP streams
     test = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, init=init, concurrentBranches=conc).cuda().half(),
                                      threshold=float(os.environ.get("POSE_TH", "0.02")), feedbackLoop=feedback)
+    if os.environ.get("POSE_NOFOLD", "0") != "1":      # (round 6: the consumers' detection inside the producers' launches)
+        workloads.fuseOpenPoseDetections(test)
+    if os.environ.get("POSE_POOLS", "0") == "1":       # the three VGG pools change-based and folded into the detections
+        pycbinfer.insertCBPooling(test, cloneOutput=False)
+        pycbinfer.fusePoolingIntoDetection(test)
     base = workloads.OpenPoseModel(T=2, init=init, concurrentBranches=conc).cuda().half()
     if "POSE_TH" not in os.environ:
         # (calibrated on the running video; the timed walk continues it, so the network is in its steady state)
@@ -76,6 +81,8 @@ def main():
             print("  conv %3d->%3d k%d @%dx%d: %5.1f %% of the pixels recomputed, %.1f MFLOP, threshold %.4g%s"
                   % (C, K, kH, ci.size[0], ci.size[1], 100 * r, 1e-6 * flops[-1], float(m.threshold),
                      (", " + m._plan['fn'].__name__) if getattr(m, '_plan', None) and m._plan.get('fn') is not None else ""))
+    nf = sum(1 for m in convs if (m._work or {}).get('hsplit') and m._work['hsplit']['layer'][0].detect == 0)
+    print("%d of %d layers had their change detection done by their producer's launch" % (nf, len(convs)))
     print("mean post-dilation ratio over %d layers: %.1f %%; recomputed work %.2f GFLOP per frame of %.1f dense"
           % (len(rs), 100 * sum(rs) / max(1, len(rs)), 1e-9 * sum(flops), 1e-9 * workloads.openPoseDenseOps(2, H, W)))
 

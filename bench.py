@@ -764,9 +764,12 @@ def openpose_config(args, measure):
 
     def converted(model=None, **kw):
         """The converted network in the execution form of round 6: every chained layer's change detection inside its
-        producer's launch (workloads.fuseOpenPoseDetections; results bit-identical to the separate launches)."""
-        return workloads.fuseOpenPoseDetections(workloads.convertOpenPose(model if model is not None else live(),
-                                                                          threshold=0.02, **kw))
+        producer's launch (workloads.fuseOpenPoseDetections) and the two branches of a stage walked in lockstep, one launch
+        per layer pair (OpenPoseModel(groupedBranches=True): pycbinfer.BranchGroup) -- results bit-identical to the
+        separate launches (tests/test_gpu_hgroup.py)."""
+        if model is None:
+            model = workloads.OpenPoseModel(T=2, init='kaiming', groupedBranches=True).cuda().half()
+        return workloads.fuseOpenPoseDetections(workloads.convertOpenPose(model, threshold=0.02, **kw))
     test = converted()
     ths = workloads.calibrateChangeRatio(test, lambda: prep(vid.next()), target=0.10)
     convs = [m for m in test.modules() if type(m) is pycbinfer.CBConv2d]

@@ -16,6 +16,7 @@ from .conv2d import CBTail1x1
 from .conv2d_cg import ChangeIndexes
 from .pipeline import FramePipeline
 from .batch import SequenceBatch
+from .branches import BranchGroup
 
 __version__ = "0.1.0"
 
@@ -322,7 +323,7 @@ def tuneThresholdParameters(vidSeqReader, evalSequences, numFramesPerSeq, target
         anchor = measure()
 
 
-__all__ = ['CBConv2d', 'CBPoolMax2d', 'CBTail1x1', 'ChangeIndexes', 'FramePipeline', 'SequenceBatch', 'convert', 'convertRecur', 'subsitute',
+__all__ = ['CBConv2d', 'CBPoolMax2d', 'CBTail1x1', 'ChangeIndexes', 'FramePipeline', 'SequenceBatch', 'BranchGroup', 'convert', 'convertRecur', 'subsitute',
            'mergeReLURecur', 'propChangeIndexesOf1x1', 'insertCBPooling', 'fusePoolingIntoDetection',
            'fuseDetectionIntoProducer', 'linkConsumers', 'fuseTail1x1',
            'clearMemory', 'getStateTensors',

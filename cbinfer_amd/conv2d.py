@@ -1346,10 +1346,10 @@ class CBConv2d(nn.Module):
             stream=args[-1], work=work, fn=fn, args=list(args), srcSlot=srcSlot, result=result, rows=rows, pmask=pmask,
             indexes=ChangeIndexes(work['idx'], work['count'], work['key'][:2]))
 
-    def _run_plan(self, inp):
+    def _plan_source(self, inp):
+        """The source tensor if the kept call plan (not a split-state fp32 one) applies to `inp` as it stands -- no side
+        effects --, else None."""
         plan = self._plan
-        if plan.get('split'):
-            return self._run_split_plan(inp)
         if plan['pooled']:
             if type(inp) is not LazyPool:
                 return None
@@ -1371,8 +1371,22 @@ class CBConv2d(nn.Module):
             return None
         if plan.get('stateVersion') is not None and bufs['prevInput']._version != plan['stateVersion']:
             return None      # (somebody wrote prevInput through torch: its pixel-major copy must be made again)
+        return src
+
+    def _run_plan(self, inp):
+        plan = self._plan
+        if plan.get('split'):
+            return self._run_split_plan(inp)
+        src = self._plan_source(inp)
+        if src is None:
+            return None
+        bufs = self._buffers
         if plan.get('hsplit'):
-            return self._run_hsplit_plan(plan, src, bufs)
+            tokens = self._prepare_hsplit(plan, src, bufs)
+            status = plan['fn'](*plan['args'])
+            if status != 0:
+                check(status)
+            return self._finish_hsplit(plan, tokens, bufs)
         if plan.get('pairs'):
             # the next layer's detection rides in this launch: the plan holds only while that layer's state is the one
             # the plan was made for (and starts to fold as soon as it can)
@@ -1425,9 +1439,9 @@ class CBConv2d(nn.Module):
             return 'changeIndexes', bufs['prevOutput'], self._lastIndexes
         return bufs['prevOutput']
 
-    def _run_hsplit_plan(self, plan, src, bufs):
-        """The per-frame part of an fp16 split-state frame (the plan's invariants hold): input pointer, the chain's
-        count and mask, whose detection rides where."""
+    def _prepare_hsplit(self, plan, src, bufs):
+        """The per-frame part of an fp16 split-state frame in front of the library call (the plan's invariants hold): input
+        pointer, the chain's count and mask, whose detection rides where.  Returns the consumers' tokens."""
         L, hs = plan['layer'], plan['hs']
         H, W = plan['size']
         L.input = src.data_ptr()
@@ -1437,10 +1451,9 @@ class CBConv2d(nn.Module):
             pm = self._chain_mask(H, W)
             L.producerMask = pm.data_ptr() if pm is not None else None
             L.detect = 0 if self._detected_upstream(self._half_token(hs, bufs['prevInput'])) else 1
-        tokens = self._fill_consumers(L, H, W) if '_fusedConsumers' in self.__dict__ else ()
-        status = plan['fn'](*plan['args'])
-        if status != 0:
-            check(status)
+        return self._fill_consumers(L, H, W) if '_fusedConsumers' in self.__dict__ else ()
+
+    def _finish_hsplit(self, plan, tokens, bufs):
         self.__dict__['_ranSplit'] = True
         self._publish_count(plan['work']['count'], tokens)
         self._inputIsLiveState = False

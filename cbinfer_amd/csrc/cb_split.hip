@@ -408,6 +408,8 @@ struct CbhLayer {
 };
 struct CbhExt {
     CbhLayer L[CBH_GROUP];
+    int slabCap1;                     // partial tiles the workspace of ONE layer alone would hold (the chunk rule's bound)
+    int pad_;
 };
 struct CbsNoExt {};
 template <int AR>
@@ -458,6 +460,7 @@ __device__ __forceinline__ void cbh_or_dilated(unsigned long long* masks, int y,
 #define CBS_INFO_SK 0
 #define CBS_INFO_MT 1
 #define CBS_INFO_TP 4                  // tilesP[q] (pixel tiles of sequence q), then N[q]
+#define CBS_INFO_CH 24                 // fp16 group: k-chunks of layer q (behind the 2 x CBS_MAXSEQ ints above)
 
 // One LDS-DMA instruction: every lane moves 16 bytes from (resource base + voff + soff) to lds + 16 * lane.
 // A NON-template wrapper on purpose: inside a kernel template the target builtin is a dependent call that the HOST
@@ -651,14 +654,30 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
     // item of its own and the reduce launch adds the slabs in chunk order; unsplit, one workgroup walks the whole
     // depth and folds its accumulators into a running sum at the chunk boundaries: the same additions in the
     // same order, so a sequence gets the same bits whether it runs alone (split) or beside others (unsplit).
-    // fp16 layers (HALF; one sequence per launch, so no batch invariance to keep): with few tiles the depth is cut into
-    // 8 or 16 chunks instead -- OpenPose's 7x7 layers on 128 channels at 46x81 recompute some 400 pixels, i.e. 14 tiles of
-    // 98 stages: 56 work items where there are 256 CUs (round 5).  p.maxChunks: 4, or up to 16 for HALF.
+    // fp16 layers (HALF): with few tiles the depth is cut into 8 or 16 chunks instead -- OpenPose's 7x7 layers on 128
+    // channels at 46x81 recompute some 400 pixels, i.e. 14 tiles of 98 stages: 56 work items where there are 256 CUs
+    // (round 5).  p.maxChunks: 4, or up to 16 for HALF.  The chunk count is chosen PER LAYER of a group from that layer's
+    // own tile count, by the rule a launch of the layer alone applies (round 6): a layer gets the same bits alone and
+    // beside the other branch of its stage.
     int CH = (p.nStages >= 48 && p.slabs) ? CBS_CHUNKS : 1;      // (the host refuses a deep layer without slabs)
-    if (HALF && CH > 1)
-        while (2 * CH <= min(p.maxChunks, 16) && TP * MT * 2 * CH <= (int)gridDim.x && TP * MT * 2 * CH <= p.slabCap &&
-               p.nStages >= 8 * CH)      // (at least four stages per chunk)
-            CH *= 2;
+    int chQ[HALF ? CBH_GROUP : 1], itemBase[HALF ? CBH_GROUP + 1 : 1];
+    int itemsSplit = 0, itemsWhole = 0;
+    if constexpr (HALF) {
+#pragma unroll
+        for (int u = 0; u < CBH_GROUP; ++u) {
+            int tu = 0, c = CH;
+            if (u < p.nSeq) {
+                tu = p.nSeq == 1 ? TP : __builtin_amdgcn_readfirstlane(s_seqTile[u + 1] - s_seqTile[u]);
+                if (CH > 1)
+                    while (2 * c <= min(p.maxChunks, 16) && tu * MT * 2 * c <= (int)gridDim.x &&
+                           tu * MT * 2 * c <= ext.slabCap1 && p.nStages >= 8 * c)      // (at least four stages per chunk)
+                        c *= 2;
+            }
+            chQ[u] = c;
+            itemBase[u] = tu;      // (tiles for now)
+            itemsSplit += tu * MT * c, itemsWhole += tu * MT;
+        }
+    }
     const int chShift = CH >= 16 ? 4 : (CH >= 8 ? 3 : 2);      // (CH is 1, 4, 8 or 16: the host clamps maxChunks to <= 16)
     int anyExact = 0;
     for (int q = 0; q < p.nSeq; ++q) anyExact |= s_exact[q];
@@ -666,11 +685,28 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
     int SK = 1;
     // (round 4: up to splitRounds = 2 work items per workgroup -- 65..128 tiles used to run unsplit, a quarter to a half of
     //  the CUs walking the whole depth while the others idled: 67 us where two rounds of quarter-depth items take 34)
-    if (TP > 0 && CH > 1 && TP * MT * CH <= p.splitRounds * (int)gridDim.x && TP * MT * CH <= p.slabCap && !anyExact)
-        SK = CH;
-    // (tests: 1 = unsplit, >= 4 = split -- but never more partial tiles than the workspace holds)
-    if (p.forceSK > 0 && CH > 1) SK = (p.forceSK >= CH && TP * MT * CH <= p.slabCap && !anyExact) ? CH : 1;
-    const int CMB = MT * SK, items = TP * CMB;
+    if constexpr (HALF) {
+        if (TP > 0 && CH > 1 && itemsSplit <= p.splitRounds * (int)gridDim.x && itemsSplit <= p.slabCap)
+            SK = max(chQ[0], chQ[CBH_GROUP - 1]);      // (> 1: split; each layer's own count is chQ[])
+    } else {
+        if (TP > 0 && CH > 1 && TP * MT * CH <= p.splitRounds * (int)gridDim.x && TP * MT * CH <= p.slabCap && !anyExact)
+            SK = CH;
+        // (tests: 1 = unsplit, >= 4 = split -- but never more partial tiles than the workspace holds)
+        if (p.forceSK > 0 && CH > 1) SK = (p.forceSK >= CH && TP * MT * CH <= p.slabCap && !anyExact) ? CH : 1;
+    }
+    const int CMB = MT * SK;
+    int items = TP * CMB;
+    if constexpr (HALF) {      // item ranges of the group's layers: [itemBase[u], itemBase[u + 1])
+        items = SK > 1 ? itemsSplit : itemsWhole;
+        int run = 0;
+#pragma unroll
+        for (int u = 0; u < CBH_GROUP; ++u) {
+            const int n = itemBase[u] * MT * (SK > 1 ? chQ[u] : 1);
+            itemBase[u] = run;
+            run += n;
+        }
+        itemBase[CBH_GROUP] = run;
+    }
     if (blockIdx.x == 0 && t == 0 && p.info) {
         p.info[CBS_INFO_SK] = SK;
         p.info[CBS_INFO_MT] = MT;
@@ -678,6 +714,10 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
         for (int q = 0; q < CBS_MAXSEQ; ++q) {
             p.info[CBS_INFO_TP + q] = q < p.nSeq ? s_seqTile[q + 1] - s_seqTile[q] : 0;
             p.info[CBS_INFO_TP + CBS_MAXSEQ + q] = q < p.nSeq ? s_seqN[q] : 0;
+        }
+        if constexpr (HALF) {
+#pragma unroll
+            for (int u = 0; u < CBH_GROUP; ++u) p.info[CBS_INFO_CH + u] = chQ[u];
         }
     }
 
@@ -718,10 +758,25 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
     for (int it = blockIdx.x; it < items; it += gridDim.x) {
         // it = (ptg * SK + slice) * MT + mt -- MT by its magic, SK (1 or CBS_CHUNKS, powers of two) by shifts: no
         // integer division by a run-time value on the way to the first DMA
-        const int d = cbs_div(it, p.magicMT), mt = it - d * MT;
-        const int slice = d & (SK - 1), ptg = SK == 1 ? d : d >> chShift;
+        int d = cbs_div(it, p.magicMT), mt = it - d * MT;
+        int slice = d & (SK - 1), ptg = SK == 1 ? d : d >> chShift;
         int q = 0, N = totAll, rb = 0, tile0 = 0;
-        if (p.nSeq > 1) {      // (one sequence: all of it known without LDS)
+        int CHi = CH, chShiftI = chShift;      // (fp16 group: the item's layer's own chunk count)
+        if constexpr (HALF) {
+            // the group's layers own item ranges of their own (their chunk counts differ); inside one:
+            // local = (tile * chunks + slice) * MT + mt
+            static_assert(CBH_GROUP == 2, "two item ranges");
+            q = (p.nSeq > 1 && it >= itemBase[1]) ? 1 : 0;
+            const int local = it - (q ? itemBase[1] : 0);
+            CHi = q ? chQ[CBH_GROUP - 1] : chQ[0];
+            chShiftI = CHi >= 16 ? 4 : (CHi >= 8 ? 3 : 2);
+            d = cbs_div(local, p.magicMT), mt = local - d * MT;
+            slice = SK == 1 ? 0 : d & (CHi - 1);
+            ptg = SK == 1 ? d : d >> chShiftI;      // (the tile inside its layer)
+            if (p.nSeq > 1) {
+                N = __builtin_amdgcn_readfirstlane(s_seqN[q]), rb = __builtin_amdgcn_readfirstlane(s_seqRank[q]);
+            }
+        } else if (p.nSeq > 1) {      // (one sequence: all of it known without LDS)
             for (int u = 1; u < p.nSeq; ++u)
                 if (ptg >= s_seqTile[u]) q = u;
             q = __builtin_amdgcn_readfirstlane(q);
@@ -746,9 +801,9 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
         // (bf16 triples: a step is a whole stage -- both register sets per stage --, so the boundaries need not be even:
         //  98 stages are 24 + 25 + 24 + 25 instead of 24 + 24 + 24 + 26, and the longest slice sets the launch's time)
         auto chunkBeg = [&](int c) {
-            return c >= CH ? p.nStages : (CH == 1 ? 0 : (X3 ? (p.nStages * c) >> chShift : 2 * ((P2 * c) >> chShift)));
+            return c >= CHi ? p.nStages : (CHi == 1 ? 0 : (X3 ? (p.nStages * c) >> chShiftI : 2 * ((P2 * c) >> chShiftI)));
         };
-        const int c0 = SK == 1 ? 0 : slice, c1 = SK == 1 ? CH : slice + 1;
+        const int c0 = SK == 1 ? 0 : slice, c1 = SK == 1 ? CHi : slice + 1;
         const int sBeg = chunkBeg(c0), sEnd = chunkBeg(c1);
         // (the first stage's tap offset: a scalar load whose round trip runs beside the pixel lookup below)
         int bNext = stageOff[sBeg];
@@ -1531,13 +1586,21 @@ __global__ __launch_bounds__(256) void cbs_reduce_kernel(CbsParams p, int BM, in
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void cbh_reduce_kernel(CbsParams p, CbhExt ext) {
     cb_touch_kernarg<sizeof(CbsParams) + sizeof(CbhExt)>();
-    const int SK = p.info[CBS_INFO_SK];
-    if (SK <= 1) return;
-    const int MT = p.info[CBS_INFO_MT], CMB = MT * SK, TILE4 = BM * BN / 4, HW = p.H * p.W;
-    int tilesBefore[CBH_GROUP + 1];
+    if (p.info[CBS_INFO_SK] <= 1) return;
+    const int MT = p.info[CBS_INFO_MT], TILE4 = BM * BN / 4, HW = p.H * p.W;
+    int tilesBefore[CBH_GROUP + 1], slabBase[CBH_GROUP], chQ[CBH_GROUP];
     tilesBefore[0] = 0;
+    {
+        int run = 0;      // (slab = work item index: the layers' item ranges follow each other, cbs_conv_kernel)
 #pragma unroll
-    for (int q = 0; q < CBH_GROUP; ++q) tilesBefore[q + 1] = tilesBefore[q] + p.info[CBS_INFO_TP + q];
+        for (int q = 0; q < CBH_GROUP; ++q) {
+            const int tq = p.info[CBS_INFO_TP + q];
+            chQ[q] = p.info[CBS_INFO_CH + q];
+            tilesBefore[q + 1] = tilesBefore[q] + tq;
+            slabBase[q] = run;
+            run += tq * MT * chQ[q];
+        }
+    }
     constexpr int PXG = 16, GP = BN / PXG;
     const int groups = tilesBefore[CBH_GROUP] * GP;
     const int t = threadIdx.x, px = t & 15;
@@ -1552,6 +1615,9 @@ __global__ __launch_bounds__(256) void cbh_reduce_kernel(CbsParams p, CbhExt ext
         const int n0 = (ptg - tilesBefore[q]) * BN + gi * PXG;
         const int N = p.info[CBS_INFO_TP + CBS_MAXSEQ + q];
         if (n0 >= N) continue;      // (uniform: a tile's last groups may be empty)
+        static_assert(CBH_GROUP == 2, "two layers");
+        const int SK = q ? chQ[1] : chQ[0], CMB = MT * SK;
+        const long tileSlab = (q ? slabBase[1] : slabBase[0]) + (long)(ptg - tilesBefore[q]) * CMB;
         const CbhLayer& L = ext.L[q];
         const int Kq = L.K, nNext = L.nNext;
         int pix = n0 + px < N ? p.seq[q].listOut[n0 + px] : -1;
@@ -1565,7 +1631,7 @@ __global__ __launch_bounds__(256) void cbh_reduce_kernel(CbsParams p, CbhExt ext
         bool chg[CBH_NEXT];
 #pragma unroll
         for (int c = 0; c < CBH_NEXT; ++c) chg[c] = false;
-        const float4* sl0 = slabs + (long)ptg * CMB * TILE4 + gi * PXG + px;
+        const float4* sl0 = slabs + tileSlab * TILE4 + gi * PXG + px;
         const int QT = MT * (BM / 4);      // channel quads of a pixel; thread: quads t >> 4, + 16, ... -- two per round
         const int nx2 = nNext > 1 ? 1 : 0;
         for (int cq0 = t >> 4; cq0 < QT; cq0 += 32) {
@@ -2668,8 +2734,10 @@ int cbinfer_hsplit_forward_group(const cbHalfLayer* layers, int nLayers, int poo
     }
     p.upstream = nLayers == 1 ? layers[0].upstreamCount : nullptr;
     p.arriveShards = (int)(MW / 16 < 8 ? MW / 16 : 8);
-    const long cap = cbs_slab_capacity(nLayers, H, W, K0);
+    const long cap = cbs_slab_capacity(nLayers, H, W, K0), cap1 = cbs_slab_capacity(1, H, W, K0);
     p.slabCap = (int)(cap > 0x7fffffffl ? 0x7fffffffl : cap);
+    x.slabCap1 = (int)(cap1 > 0x7fffffffl ? 0x7fffffffl : cap1);
+    x.pad_ = 0;
     const long E = (long)nLayers * MW;
     if (BM == 128) {
         if (E <= CBS_PRE_BIG) return cbs_launch_conv<128, 128, 4, 2, CBS_PRE_BIG, true, 4, 1>(p, 1, nullptr, s, x);

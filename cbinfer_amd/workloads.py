@@ -188,7 +188,7 @@ class OpenPoseModel(nn.Module):
     `model{t}_2` (19 confidence maps); stages t >= 2 see cat(branch1, branch2, features) = 185
     channels (PoseModel.py:122-137)."""
 
-    def __init__(self, T=2, seed=0, concurrentBranches=False, init='default'):
+    def __init__(self, T=2, seed=0, concurrentBranches=False, init='default', groupedBranches=False):
         """init='default': nn.Conv2d's own initialisation (kaiming_uniform with a = sqrt(5): activations shrink by ~0.4
         per layer, so on random weights a change dies out behind the fifth conv).  init='kaiming': variance-preserving
         kaiming_normal_(nonlinearity='relu') and zero biases -- activations keep their scale through all 36 layers, so
@@ -197,6 +197,8 @@ class OpenPoseModel(nn.Module):
         # the two branches of a stage are independent: with concurrentBranches they are enqueued on two
         # HIP streams (fork/join per stage), so that their per-launch fixed costs overlap
         self.concurrentBranches = concurrentBranches
+        # ... or (converted networks) walked in lockstep, every pair of layers ONE launch (pycbinfer.BranchGroup, round 6)
+        self.groupedBranches = groupedBranches
         state = torch.random.get_rng_state()
         torch.manual_seed(seed)
         self.T = T
@@ -219,8 +221,11 @@ class OpenPoseModel(nn.Module):
         cur = feat
         fork = getattr(self, 'concurrentBranches', False) and cur.is_cuda
         side = _side_stream(cur.device) if fork else None
+        grouped = getattr(self, 'groupedBranches', False) and cur.is_cuda and not fork
         for t in range(1, self.T + 1):
-            if fork:
+            if grouped:
+                outL, outS = self._branch_group(t)(cur)
+            elif fork:
                 main = torch.cuda.current_stream(cur.device)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
@@ -233,6 +238,15 @@ class OpenPoseModel(nn.Module):
             if t != self.T:
                 cur = torch.cat([outL, outS, feat], 1)
         return outL, outS
+
+    def _branch_group(self, t):
+        from .branches import BranchGroup
+        pair = (getattr(self, 'model%d_1' % t), getattr(self, 'model%d_2' % t))
+        groups = self.__dict__.setdefault('_branchGroups', {})
+        g = groups.get(t)
+        if g is None or g[0] is not pair[0] or g[1] is not pair[1]:      # (the sub-models may have been converted since)
+            g = groups[t] = (pair[0], pair[1], BranchGroup(pair))
+        return g[2]
 
     def submodelNames(self):
         return ['model0'] + ['model%d_%d' % (t, b) for t in range(1, self.T + 1) for b in (1, 2)]

@@ -132,3 +132,57 @@ def test_two_consumers_with_their_own_thresholds(pkg):
     assert folded[0] >= 5 and folded[1] >= 5, folded
     last = [m for m in A[0].modules() if type(m) is pkg.CBConv2d][-1]
     assert last._work['hsplit']['layer'][0].nNext == 2
+
+
+def test_branch_pairs_in_one_launch_are_bit_identical(pkg):
+    """pycbinfer.BranchGroup: two branches of one geometry (PoseModel.py:122-137: 38 and 19 output maps) walked in
+    lockstep, every layer pair ONE cbinfer_hsplit_forward_group call -- shallow 3x3, deep 7x7 (split along k: one reduce
+    launch for both), 1x1 layers, last layers of different channel counts (both pad to 64 rows) -- against the same
+    branches run one after the other: outputs, states and change lists bit-identical in every frame; the producers'
+    folded detections work across the grouped launches too."""
+    H, W = 46, 81
+
+    def build():
+        prod = chain(pkg, [(64, 128, 3), (128, 128, 3)], 5)
+        spec = [(128, 128, 3), (128, 128, 7), (128, 128, 7), (128, 128, 1)]
+        b1 = chain(pkg, spec + [(128, 38, 1)], 6, threshold=0.03)
+        b2 = chain(pkg, spec + [(128, 19, 1)], 7, threshold=0.06)
+        for seq in (prod, b1, b2):
+            pkg.fuseDetectionIntoProducer(seq)
+        last = [m for m in prod.modules() if type(m) is pkg.CBConv2d][-1]
+        pkg.linkConsumers(last, [next(iter(b1.children())), next(iter(b2.children()))])
+        return prod, b1, b2
+    A, B = build(), build()
+    group = pkg.BranchGroup([A[1], A[2]])
+    calls = []
+    from cbinfer_amd import _lib, branches
+    real = _lib.C.cbinfer_hsplit_forward_group
+
+    class Spy(object):      # (counts the grouped calls: the library object's attributes are read-only function pointers)
+        def __getattr__(self, name):
+            return getattr(_lib.C, name)
+
+        def cbinfer_hsplit_forward_group(self, layers, n, *a):
+            calls.append(n)
+            return real(layers, n, *a)
+    rng = np.random.default_rng(9)
+    frames = video(rng, 64, H, W, 9, [0.1, 0.1, 0.05, 1.0, 0.1, 0.0, 0.1, 0.1])
+    branches.C = Spy()
+    try:
+        with torch.no_grad():
+            for t, f in enumerate(frames):
+                x = torch.from_numpy(f).cuda()
+                ya = group(A[0](x))
+                fb = B[0](x)
+                yb = [B[1](fb), B[2](fb)]
+                torch.cuda.synchronize()
+                for k in (0, 1):
+                    assert torch.equal(ya[k], yb[k]), (t, k)
+                    for ma, mb in zip(A[1 + k].children(), B[1 + k].children()):
+                        assert torch.equal(ma.prevInput, mb.prevInput) and torch.equal(ma.prevOutput, mb.prevOutput), (t, k)
+                        assert torch.equal(ma.lastChangeIndexes().tensor(), mb.lastChangeIndexes().tensor()), (t, k)
+    finally:
+        branches.C = _lib.C
+    # from the second frame on (the first builds the call plans) every layer pair is one call of two layers
+    assert calls == [2] * (5 * (len(frames) - 1)), calls
+    assert all(m._work['hsplit']['layer'][0].detect == 0 for seq in (A[1], A[2]) for m in seq.children())

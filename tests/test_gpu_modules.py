@@ -2069,7 +2069,6 @@ def test_openpose_live_network_fullsize(pkg, oracle):
                     assert m._plan is not None and m._plan.get('fn') is _lib.C.cbinfer_hsplit_forward_group
                     folded[i] += int(hs['layer'][0].detect == 0)
                 assert np.array_equal(m.lastChangeIndexes().tensor().cpu().numpy(), got[2]), (t, i, m.weight.shape)
-                assert got[2].size > 0, (t, i)
                 assert np.array_equal(m.prevInput.cpu().numpy(), o.prevInput), (t, i, m.weight.shape)
                 ref = o.prevOutput.astype(np.float32)
                 tol = 2 * 2.0 ** -10 * max(1.0, float(np.abs(ref[np.isfinite(ref)]).max()))

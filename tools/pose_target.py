@@ -27,17 +27,19 @@ def main():
         return (f[:, :, :, :W] * (255.0 / 256.0) - 0.5).half().contiguous()
     init = os.environ.get("POSE_INIT", "kaiming")
     conc = os.environ.get("POSE_CONCURRENT", "0") == "1"      # the two branches of every stage on two HIP streams
-    test = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, init=init, concurrentBranches=conc).cuda().half(),
+    grp = os.environ.get("POSE_GROUPED", "1") == "1" and not conc      # ... or in lockstep, one launch per layer pair
+    test = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, init=init, concurrentBranches=conc,
+                                                             groupedBranches=grp).cuda().half(),
                                      threshold=float(os.environ.get("POSE_TH", "0.02")), feedbackLoop=feedback)
     if os.environ.get("POSE_NOFOLD", "0") != "1":      # (round 6: the consumers' detection inside the producers' launches)
         workloads.fuseOpenPoseDetections(test)
-    if os.environ.get("POSE_POOLS", "0") == "1":       # the three VGG pools change-based and folded into the detections
-        pycbinfer.insertCBPooling(test, cloneOutput=False)
-        pycbinfer.fusePoolingIntoDetection(test)
     base = workloads.OpenPoseModel(T=2, init=init, concurrentBranches=conc).cuda().half()
     if "POSE_TH" not in os.environ:
         # (calibrated on the running video; the timed walk continues it, so the network is in its steady state)
         workloads.calibrateChangeRatio(test, lambda: prep(vid.next()), target=float(os.environ.get("POSE_TARGET", "0.10")))
+    if os.environ.get("POSE_POOLS", "0") == "1":       # the three VGG pools change-based and folded into the detections
+        pycbinfer.insertCBPooling(test, cloneOutput=False)      # (behind the calibration: its hooks read tensor inputs)
+        pycbinfer.fusePoolingIntoDetection(test)
     frames = [prep(vid.frame)] + [prep(vid.next()) for _ in range(49)]
     frames, fresh = frames[:40], frames[40:]      # (the last ten: for the per-layer ratios, behind the timed walk)
     with torch.no_grad():

@@ -17,6 +17,7 @@ from .conv2d_cg import ChangeIndexes
 from .pipeline import FramePipeline
 from .batch import SequenceBatch
 from .branches import BranchGroup
+from .program import FrameProgram
 
 __version__ = "0.1.0"
 
@@ -323,7 +324,7 @@ def tuneThresholdParameters(vidSeqReader, evalSequences, numFramesPerSeq, target
         anchor = measure()
 
 
-__all__ = ['CBConv2d', 'CBPoolMax2d', 'CBTail1x1', 'ChangeIndexes', 'FramePipeline', 'SequenceBatch', 'BranchGroup', 'convert', 'convertRecur', 'subsitute',
+__all__ = ['CBConv2d', 'CBPoolMax2d', 'CBTail1x1', 'ChangeIndexes', 'FramePipeline', 'SequenceBatch', 'BranchGroup', 'FrameProgram', 'convert', 'convertRecur', 'subsitute',
            'mergeReLURecur', 'propChangeIndexesOf1x1', 'insertCBPooling', 'fusePoolingIntoDetection',
            'fuseDetectionIntoProducer', 'linkConsumers', 'fuseTail1x1',
            'clearMemory', 'getStateTensors',

@@ -218,7 +218,36 @@ def _load():
     return lib
 
 
-C = _load()
+class _Fn(object):
+    """One entry point of the library.  Calls go straight to the ctypes function; while a `FrameProgram` records
+    (cbinfer_amd/program.py) every call is also noted -- function and argument objects -- so that the frame's launch
+    sequence can be replayed later without the modules around it."""
+    __slots__ = ('raw', '__name__', 'launcher')
+
+    def __init__(self, raw, name, launcher):
+        # launcher: the function enqueues work on a stream (int status, last argument the stream) -- as opposed to the host
+        # helpers (sizes, capability queries), which a recorded frame does not need to repeat
+        self.raw, self.__name__, self.launcher = raw, name, launcher
+
+    def __call__(self, *args):
+        rec = _RECORDING[0]
+        if rec is not None and self.launcher:
+            rec.append((self, args))
+        return self.raw(*args)
+
+
+_RECORDING = [None]
+
+
+class _Lib(object):
+    def __init__(self, lib):
+        self._cdll = lib
+        for name in _SIGNATURES:
+            res, args = _SIGNATURES[name]
+            setattr(self, name, _Fn(getattr(lib, name), name, res is _i and bool(args) and args[-1] is _vp))
+
+
+C = _Lib(_load())
 
 
 class CBinferError(RuntimeError):

@@ -62,6 +62,22 @@ def main():
     n = len(frames) - 6
     print("OpenPose T=2 %dx%d fp16%s: change-based %.0f frames/s (%.1f us per frame), dense %.0f frames/s, eager"
           % (H, W, ", feedback mode" if feedback else "", n / dt, 1e6 * dt / n, n / dd))
+    if os.environ.get("POSE_GRAPH", "0") == "1":      # the same walk replayed from a hipGraph (one frame per graph)
+        import bench
+        more = [prep(vid.next()) for _ in range(40)]
+        r = bench.FrameRunner(test, more[0], "graph")
+        r.prime(more[:2])
+        for f in more[2:6]:
+            r.step(f)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for f in more[6:]:
+            r.step(f)
+        torch.cuda.synchronize()
+        dg = time.perf_counter() - t0
+        print("  replayed from a hipGraph: %.0f frames/s (%.1f us per frame)" % (34 / dg, 1e6 * dg / 34))
+        r.graph = None
+        fresh = [prep(vid.next()) for _ in range(10)]
     # per-layer change ratios: the mean over ten more frames of the walk (untimed: reading a list length is a sync)
     convs = [m for m in test.modules() if type(m) is pycbinfer.CBConv2d]
     counts = [0.0] * len(convs)

@@ -988,7 +988,32 @@ def openpose_config(args, measure):
     cbp = with_thresholds(converted())
     pycbinfer.insertCBPooling(cbp, cloneOutput=False)
     pycbinfer.fusePoolingIntoDetection(cbp)
-    cbpool = max(measure(cbp, frames, m, psteps, pwarm) for m in ("graph", "eager"))
+    cbpool_modes = {m: measure(cbp, frames, m, psteps, pwarm) for m in ("graph", "eager")}
+    # ... and, with the stage inputs concatenated by the library (pycbinfer.ChannelConcat instead of torch.cat), the frame
+    # consists of library calls only: replayed as a recorded launch program (pycbinfer.FrameProgram)
+    library_calls = None
+    try:
+        cbp.libraryConcat = True
+        with torch.no_grad():
+            for f in frames[:4]:
+                cbp(f)
+        prog = pycbinfer.FrameProgram(cbp)
+        prog.record(frames[4])
+        library_calls = len(prog.calls)
+        walk = frames[5:]
+        with torch.no_grad():
+            for f in walk[:pwarm]:
+                prog(f)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for f in walk[pwarm:pwarm + psteps]:
+                prog(f)
+            torch.cuda.synchronize()
+            cbpool_modes["program"] = len(walk[pwarm:pwarm + psteps]) / (time.perf_counter() - t0)
+        del prog
+    except Exception as e:      # (an add-on: never at the expense of the line)
+        cbpool_modes["program_error"] = repr(e)
+    cbpool = max(v for v in cbpool_modes.values() if isinstance(v, float))
     del cbp
     # the two branches of every stage (PoseModel.py:122-137: independent until the concat) on two HIP streams, fork / join
     # per stage -- an execution option of the MODEL, applied to the dense network as well
@@ -1033,7 +1058,8 @@ def openpose_config(args, measure):
         "feedback_mode_mean_ratio": sum(fratio) / max(1, len(fratio)), "feedback_mode_recomputed_gflop": fflops / 1e9,
         "feedback_mode_ratios": [round(r, 3) for r in fratio], "cb_unchained_fps": cbu,
         "unchained_speedup": cbu / dense, "cb_with_change_based_pools_fps": cbpool,
-        "change_based_pools_speedup": cbpool / dense,
+        "change_based_pools_speedup": cbpool / dense, "cb_with_change_based_pools_by_launch": cbpool_modes,
+        "library_calls_per_frame_in_the_program": library_calls,
         "concurrent_branches": {"cb_fps": cbconc, "dense_fps": densec, "speedup": cbconc / densec,
                                 "what": "the two branches of every stage on two HIP streams (eager), both networks"},
         "effective_gflops": cb * pose_ops / 1e9, "dense_ops_per_frame": pose_ops,
@@ -1107,7 +1133,20 @@ def secondary_configs(args):
                                      "fg_touched_ratio_per_layer": ratios(fg)})
         del base, cg, fg, frames
         torch.cuda.synchronize()
-    out["config4_openpose_fp16"] = openpose_config(args, measure)
+    c4 = out["config4_openpose_fp16"] = openpose_config(args, measure)
+    # (single figures for the compact line: the network in the reference's structure -- dense pools, torch.cat -- and with
+    #  the pools change-based + folded and the concatenation done by the library: library calls only, replayed program)
+    c4["value"] = c4["cb_fps"]
+    out["config4_openpose_library_only"] = {"value": c4["cb_with_change_based_pools_fps"], "unit": "frames/s",
+                                            "dense_fps": c4["dense_fps"],
+                                            "speedup": c4["cb_with_change_based_pools_fps"] / c4["dense_fps"]}
+    out["config4_dense"] = {"value": c4["dense_fps"], "unit": "frames/s"}
+    try:
+        mid = [r for r in out["config3_sweep"] if abs(r["input_change"] - 0.10) < 0.02][0]
+        out["config3_fg_cbpool_at_10pct"] = {"value": mid["fg_inplace_with_cbpoolmax2d_fps"], "unit": "frames/s",
+                                             "dense_fps": mid["dense_fps"]}
+    except Exception:
+        pass
     return out
 
 
@@ -1609,8 +1648,13 @@ def main():
     if steps_timed != args.steps and args.steps > 0:
         repeated = {"steps": steps_timed, "value": total_frames / elapsed, "ms_per_step": 1e3 * elapsed / steps_timed,
                     "timed_region_s": elapsed}
-        lt = timed_loop([q['runner'] for q in seqs], [q['frames'] for q in seqs], args.steps, barrier,
-                        start=seqs[0]['pos'])
+        # (the W warm-up steps once more, right in front: between the two regions the ranks exchange their results and the
+        #  GPU idles for milliseconds)
+        runners_, frames_ = [q['runner'] for q in seqs], [q['frames'] for q in seqs]
+        timed_loop(runners_, frames_, max(args.warmup, 1), lambda: None, start=seqs[0]['pos'])
+        for q in seqs:
+            q['pos'] += max(args.warmup, 1)
+        lt = timed_loop(runners_, frames_, args.steps, barrier, start=seqs[0]['pos'])
         for q in seqs:
             q['pos'] += args.steps
         total_frames, elapsed = shard.aggregate(args.steps * S, lt, device="cuda")

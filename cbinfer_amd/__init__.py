@@ -13,7 +13,7 @@ from . import _lib                      # loads libcbinfer_hip.so; raises Import
 from .conv2d import CBConv2d
 from .conv2d import CBPoolMax2d
 from .conv2d import CBTail1x1
-from .conv2d_cg import ChangeIndexes
+from .conv2d_cg import ChangeIndexes, ChannelConcat
 from .pipeline import FramePipeline
 from .batch import SequenceBatch
 from .branches import BranchGroup
@@ -324,7 +324,7 @@ def tuneThresholdParameters(vidSeqReader, evalSequences, numFramesPerSeq, target
         anchor = measure()
 
 
-__all__ = ['CBConv2d', 'CBPoolMax2d', 'CBTail1x1', 'ChangeIndexes', 'FramePipeline', 'SequenceBatch', 'BranchGroup', 'FrameProgram', 'convert', 'convertRecur', 'subsitute',
+__all__ = ['CBConv2d', 'CBPoolMax2d', 'CBTail1x1', 'ChangeIndexes', 'ChannelConcat', 'FramePipeline', 'SequenceBatch', 'BranchGroup', 'FrameProgram', 'convert', 'convertRecur', 'subsitute',
            'mergeReLURecur', 'propChangeIndexesOf1x1', 'insertCBPooling', 'fusePoolingIntoDetection',
            'fuseDetectionIntoProducer', 'linkConsumers', 'fuseTail1x1',
            'clearMemory', 'getStateTensors',

@@ -8,6 +8,8 @@ Additions the reference lacks: `matrixMult` (the contraction on MFMA; the refere
 matmul -> cuBLAS via matrixMult_python), `convChanged` (gather -> MFMA -> bias/ReLU -> scatter in one
 launch) and `ChangeIndexes` (a change list whose length stays on the device).
 """
+import ctypes
+
 import torch
 
 from ._lib import C, CBinferError, check, dtype_code, ptr, require_device, stream_ptr
@@ -374,3 +376,33 @@ def dilateChangeIndexes(changeIndexes, size, filtSize):
 __all__ = ['ChangeIndexes', 'MaskChangeIndexes', 'convWorkspace', 'newConvWorkspace', 'changeDetection', 'changePropagation', 'changeIndexesExtr',
            'changeIndexesExtrAsync', 'genXMatrix', 'prepWeights', 'matrixMult', 'matrixMult_python',
            'updateOutput', 'convChanged', 'maxPool2d', 'poolChangeIndexes', 'dilateChangeIndexes', 'CBinferError']
+
+
+class ChannelConcat(object):
+    """torch.cat(tensors, dim=1) of batch-1 [1,Ci,H,W] tensors (poseDetection/openPose/PoseModel.py:131) as ONE library launch
+    into a buffer this object keeps and reuses: the result has the same address every frame -- what a recorded launch
+    program (pycbinfer.FrameProgram) and a consumer's call plan want -- and is overwritten by the next call."""
+
+    def __init__(self):
+        self.out, self._key, self._srcs, self._chans = None, None, None, None
+
+    def __call__(self, tensors):
+        tensors = [t.detach() for t in tensors]
+        t0 = tensors[0]
+        require_device(*tensors)
+        n = len(tensors)
+        if not 1 <= n <= 4 or any(t.dim() != 4 or t.size(0) != 1 or t.shape[2:] != t0.shape[2:] or t.dtype != t0.dtype or
+                                  t.device != t0.device or not t.is_contiguous() for t in tensors):
+            raise CBinferError("ChannelConcat: 1..4 contiguous [1,Ci,H,W] tensors of one size, dtype and device")
+        key = (tuple(tuple(t.shape) for t in tensors), t0.dtype, t0.device)
+        if self._key != key:
+            C_ = sum(t.size(1) for t in tensors)
+            self.out = torch.empty((1, C_) + tuple(t0.shape[2:]), dtype=t0.dtype, device=t0.device)
+            self._srcs = (ctypes.c_void_p * n)()
+            self._chans = (ctypes.c_int32 * n)(*[t.size(1) for t in tensors])
+            self._key = key
+        for k, t in enumerate(tensors):
+            self._srcs[k] = t.data_ptr()
+        check(C.cbinfer_concat_channels(self._srcs, self._chans, n, ptr(self.out), t0.size(2) * t0.size(3),
+                                        dtype_code(t0), stream_ptr(t0)))
+        return self.out

@@ -140,11 +140,66 @@ __global__ __launch_bounds__(256) void cb_update_fg_kernel(const float* __restri
     }
 }
 
+// Channel concatenation of batch-1 tensors [Ci,H,W] (torch.cat(dim=1); poseDetection/openPose/PoseModel.py:131: the input
+// of a refinement stage is cat(branch 1, branch 2, features)): the sources are contiguous blocks that follow each other in
+// the destination -- one launch copies them all, in the widest unit every block boundary allows.
+struct CbConcatArgs {
+    const char* src[CBINFER_CONCAT_MAX];
+    long begin[CBINFER_CONCAT_MAX + 1];      // byte offsets of the blocks in the destination
+    int n;
+};
+template <typename U>
+__global__ __launch_bounds__(256) void cb_concat_kernel(CbConcatArgs a, char* __restrict__ dst) {
+    const long total = a.begin[a.n] / (long)sizeof(U);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i * (long)sizeof(U);
+        int k = 0;
+#pragma unroll
+        for (int u = 1; u < CBINFER_CONCAT_MAX; ++u)
+            if (u < a.n && b >= a.begin[u]) k = u;
+        ((U*)dst)[i] = *(const U*)(a.src[k] + (b - a.begin[k]));
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
 int cbinfer_abi_version(void) { return CBINFER_ABI_VERSION; }
+
+int cbinfer_concat_channels(const void* const* sources, const int32_t* channels, int n, void* output, long HW, int dtype,
+                            cbStream_t stream) {
+    CB_REQUIRE(sources && channels && output && n >= 1 && n <= CBINFER_CONCAT_MAX && HW > 0 &&
+               (dtype == CB_F32 || dtype == CB_F16));
+    const long es = dtype == CB_F32 ? 4 : 2;
+    CbConcatArgs a;
+    a.n = n;
+    a.begin[0] = 0;
+    unsigned long long align = (unsigned long long)(size_t)output;
+    for (int k = 0; k < CBINFER_CONCAT_MAX; ++k) {
+        a.src[k] = k < n ? (const char*)sources[k] : nullptr;
+        if (k < n) {
+            CB_REQUIRE(sources[k] && channels[k] > 0);
+            a.begin[k + 1] = a.begin[k] + (long)channels[k] * HW * es;
+            align |= (unsigned long long)(size_t)sources[k] | (unsigned long long)a.begin[k + 1];
+        } else {
+            a.begin[k + 1] = a.begin[k];
+        }
+    }
+    const long bytes = a.begin[n];
+    const int unit = (align & 15) == 0 ? 16 : ((align & 7) == 0 ? 8 : ((align & 3) == 0 ? 4 : 2));
+    const int blocks = (int)((bytes / unit + 255) / 256 > 4096 ? 4096 : (bytes / unit + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (unit == 16)
+        hipLaunchKernelGGL(cb_concat_kernel<uint4>, dim3(blocks), dim3(256), 0, s, a, (char*)output);
+    else if (unit == 8)
+        hipLaunchKernelGGL(cb_concat_kernel<uint2>, dim3(blocks), dim3(256), 0, s, a, (char*)output);
+    else if (unit == 4)
+        hipLaunchKernelGGL(cb_concat_kernel<unsigned>, dim3(blocks), dim3(256), 0, s, a, (char*)output);
+    else
+        hipLaunchKernelGGL(cb_concat_kernel<unsigned short>, dim3(blocks), dim3(256), 0, s, a, (char*)output);
+    return cb_launch_status();
+}
 
 const char* cbinfer_status_string(int status) {
     if (status == CB_OK) return "ok";

@@ -9,29 +9,51 @@ as plain stream launches -- the same kernels, the same order, the same arguments
 from a loop of a few ctypes calls.  The contract is a captured graph's: the network's buffers, flags and thresholds must not
 change between record and replay (the module-level decisions of the recorded frame are frozen), module bookkeeping
 (lastChangeIndexes, chain tags) is not advanced by a replay, and the network must consist of library calls only -- CBConv2d,
-lazily folded CBPoolMax2d, CBTail1x1 -- since a torch operator in between cannot be recorded (FrameProgram refuses such a
-network).  Re-record (`record(frame)`) after anything changed.  Outputs and states are those of the eager network, bit for
+lazily folded CBPoolMax2d, CBTail1x1, ChannelConcat -- since a torch operator in between cannot be recorded (the recording
+watches the operators that run, through a TorchDispatchMode, and refuses a frame that ran anything but views).  Re-record (`record(frame)`) after anything changed.  Outputs and states are those of the eager network, bit for
 bit (tests/test_gpu_modules.py, __graft_entry__.smoke())."""
 import ctypes
 
 import torch
 import torch.nn as nn
+from torch.utils._python_dispatch import TorchDispatchMode
 
 from . import _lib
 from ._lib import CBinferError, check
 from .conv2d import CBConv2d, CBPoolMax2d, CBTail1x1
 
 
+# torch operators a recorded frame may run: they launch nothing and allocate nothing (views and aliases of existing tensors)
+_HARMLESS = ('detach', 'alias', 'view', '_unsafe_view', 'reshape', 'slice', 'select', 'unsqueeze', 'squeeze', 'expand',
+             'as_strided', 'transpose', 't', 'permute', 'contiguous', '_reshape_alias', 'lift_fresh', 'is_same_size',
+             'sym_size', 'sym_stride', 'sym_numel', 'size', 'stride', 'numel', 'dim')
+
+
+class _OperatorWatch(TorchDispatchMode):
+    """Notes every torch operator that runs while a frame is recorded and is not a pure view: such an operator launches or
+    allocates, and a replay would not repeat it."""
+
+    def __init__(self):
+        super(_OperatorWatch, self).__init__()
+        self.seen = []
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = getattr(getattr(func, 'overloadpacket', func), '__name__', str(func))
+        if name not in _HARMLESS:
+            self.seen.append(name)
+        return func(*args, **(kwargs or {}))
+
+
 class FrameProgram(object):
     def __init__(self, model):
-        kids = list(model.children()) if isinstance(model, nn.Sequential) else None
-        if not kids or any(type(m) not in (CBConv2d, CBPoolMax2d, CBTail1x1) for m in kids) or \
-                any(type(m) is CBPoolMax2d and not getattr(m, 'lazy', False) for m in kids):
-            raise CBinferError("FrameProgram: the network must be an nn.Sequential of CBConv2d, lazily folded CBPoolMax2d "
-                               "(pycbinfer.fusePoolingIntoDetection) and CBTail1x1 modules -- library calls only")
+        """model: any callable of one frame whose forward, in the steady state, consists of library calls only -- an
+        nn.Sequential of CBConv2d / lazily folded CBPoolMax2d / CBTail1x1, or e.g. a converted OpenPose network with
+        change-based pools folded into the detections and pycbinfer.ChannelConcat between its stages.  Whether that holds
+        is checked when a frame is recorded."""
+        mods = list(model.modules()) if isinstance(model, nn.Module) else []
         if any(type(m) is CBConv2d and (m.syncIndexes or m.gatherComputationStats or m.saveChangeMap or
                                         (m.finegrained and not m.fgInPlace) or
-                                        not (m.feedbackLoop or m.copyInput or m.finegrained)) for m in kids):
+                                        not (m.feedbackLoop or m.copyInput or m.finegrained)) for m in mods):
             raise CBinferError("FrameProgram: every CBConv2d must run a sync-free frame on buffers of its own")
         self.model = model
         self.calls, self.patches, self.out, self.stream = None, None, None, None
@@ -41,14 +63,21 @@ class FrameProgram(object):
         if not (torch.is_tensor(frame) and frame.is_cuda and frame.is_contiguous()):
             raise CBinferError("FrameProgram: the frame must be a contiguous device tensor")
         calls = []
+        watch = _OperatorWatch()
         _lib._RECORDING[0] = calls
         try:
-            with torch.no_grad():
+            with torch.no_grad(), watch:
                 out = self.model(frame)
         finally:
             _lib._RECORDING[0] = None
         if not calls:
             raise CBinferError("FrameProgram: the frame made no library call")
+        if watch.seen:
+            raise CBinferError("FrameProgram: the frame ran torch operators a replay would not repeat (%s): the network "
+                               "must consist of library calls only -- CBConv2d, CBPoolMax2d folded into the detections "
+                               "(pycbinfer.insertCBPooling + fusePoolingIntoDetection), CBTail1x1, pycbinfer.ChannelConcat "
+                               "-- and be in its steady state (a first frame allocates)"
+                               % ", ".join(sorted(set(watch.seen))))
         # where the frame's address went: integer arguments, and pointer fields of argument structures
         addr, patches = frame.data_ptr(), []
         for ci, (fn, args) in enumerate(calls):

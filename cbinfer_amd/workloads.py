@@ -199,6 +199,7 @@ class OpenPoseModel(nn.Module):
         self.concurrentBranches = concurrentBranches
         # ... or (converted networks) walked in lockstep, every pair of layers ONE launch (pycbinfer.BranchGroup, round 6)
         self.groupedBranches = groupedBranches
+        self.libraryConcat = False      # (set by hand: the stage inputs concatenated by the library, see forward)
         state = torch.random.get_rng_state()
         torch.manual_seed(seed)
         self.T = T
@@ -236,7 +237,16 @@ class OpenPoseModel(nn.Module):
                 outL = getattr(self, 'model%d_1' % t)(cur)
                 outS = getattr(self, 'model%d_2' % t)(cur)
             if t != self.T:
-                cur = torch.cat([outL, outS, feat], 1)
+                if getattr(self, 'libraryConcat', False) and cur.is_cuda:
+                    # (one library launch into a buffer that keeps its address: pycbinfer.ChannelConcat -- with it a frame of
+                    #  the converted network makes library calls only and can be replayed by pycbinfer.FrameProgram)
+                    cc = self.__dict__.setdefault('_concats', {})
+                    if t not in cc:
+                        from . import ChannelConcat
+                        cc[t] = ChannelConcat()
+                    cur = cc[t]([outL, outS, feat])
+                else:
+                    cur = torch.cat([outL, outS, feat], 1)
         return outL, outS
 
     def _branch_group(self, t):

@@ -671,6 +671,15 @@ int cbinfer_cbconv2d_forward_rowpairs(const float* input, float* prevInput, floa
                                       int H, int W, int K, int kH, int kW, float threshold, int relu,
                                       const cbNextDetect* next, cbStream_t stream);
 
+/* ---- channel concatenation of batch-1 [Ci,H,W] tensors into [sum Ci,H,W] as ONE launch on the caller's stream
+ * (round 6).  The reference's pose network does torch.cat(dim=1) between its stages
+ * (poseDetection/openPose/PoseModel.py:131); with this entry point a frame of that network consists of library calls only
+ * and can be replayed from a recorded launch program (pycbinfer.FrameProgram).  sources / channels: n (<= 4) device
+ * pointers and channel counts (host arrays); output: [sum channels, H, W] of the same dtype; HW = H * W. */
+#define CBINFER_CONCAT_MAX 4
+int cbinfer_concat_channels(const void* const* sources, const int32_t* channels, int n, void* output, long HW, int dtype,
+                            cbStream_t stream);
+
 /* replaces conv2d_fg_cpu, cbconv2d_fg_backend.cu:81-112: HOST pointers, host code, race-free. */
 void cbinfer_conv2d_fg_cpu(const float* input, const float* prevInput, float* output,
                            const float* weight, float threshold, int no, int ni, int h, int w,

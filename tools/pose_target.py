@@ -62,6 +62,25 @@ def main():
     n = len(frames) - 6
     print("OpenPose T=2 %dx%d fp16%s: change-based %.0f frames/s (%.1f us per frame), dense %.0f frames/s, eager"
           % (H, W, ", feedback mode" if feedback else "", n / dt, 1e6 * dt / n, n / dd))
+    if os.environ.get("POSE_PROGRAM", "0") == "1":      # the frame as a recorded launch program (pycbinfer.FrameProgram)
+        test.libraryConcat = True
+        more = [prep(vid.next()) for _ in range(46)]
+        with torch.no_grad():
+            for f in more[:4]:
+                test(f)
+            prog = pycbinfer.FrameProgram(test)
+            prog.record(more[4])
+            for f in more[5:10]:
+                prog(f)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for f in more[10:]:
+                prog(f)
+            torch.cuda.synchronize()
+            dg = time.perf_counter() - t0
+        print("  recorded launch program (%d library calls per frame): %.0f frames/s (%.1f us per frame)"
+              % (len(prog.calls), 36 / dg, 1e6 * dg / 36))
+        fresh = [prep(vid.next()) for _ in range(10)]
     if os.environ.get("POSE_GRAPH", "0") == "1":      # the same walk replayed from a hipGraph (one frame per graph)
         import bench
         more = [prep(vid.next()) for _ in range(40)]

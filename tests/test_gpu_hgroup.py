@@ -186,3 +186,62 @@ def test_branch_pairs_in_one_launch_are_bit_identical(pkg):
     # from the second frame on (the first builds the call plans) every layer pair is one call of two layers
     assert calls == [2] * (5 * (len(frames) - 1)), calls
     assert all(m._work['hsplit']['layer'][0].detect == 0 for seq in (A[1], A[2]) for m in seq.children())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_channel_concat_is_torch_cat(pkg, dtype):
+    """pycbinfer.ChannelConcat (cbinfer_concat_channels: PoseModel.py:131's torch.cat(dim=1) as one library launch into a
+    buffer that keeps its address) against torch.cat: OpenPose's 38 + 19 + 128 channels at an odd map size (block
+    boundaries that are not 16-byte aligned), one source, four sources."""
+    cc = pkg.ChannelConcat()
+    for chans, (H, W) in (((38, 19, 128), (46, 81)), ((5,), (3, 7)), ((1, 2, 3, 4), (9, 5)), ((38, 19, 128), (46, 81))):
+        ts = [torch.randn(1, c, H, W, device="cuda").to(dtype) for c in chans]
+        out = cc(ts)
+        torch.cuda.synchronize()
+        assert torch.equal(out, torch.cat(ts, 1))
+    a = cc([torch.ones(1, 3, 4, 4, device="cuda", dtype=dtype)] * 2)
+    b = cc([torch.zeros(1, 3, 4, 4, device="cuda", dtype=dtype)] * 2)
+    assert a.data_ptr() == b.data_ptr()                      # (the buffer is kept: the address a recorded program replays)
+    with pytest.raises(Exception):
+        cc([torch.ones(1, 3, 4, 4, device="cuda"), torch.ones(1, 3, 4, 5, device="cuda")])
+
+
+def test_openpose_as_a_recorded_launch_program(pkg):
+    """A converted OpenPose T=2 network (fp16, 96x160) in the library-only execution form -- consumers' detection in the
+    producers' launches, branches grouped, the three pools change-based and folded into the detections, the stage inputs
+    concatenated by the library -- replayed from a recorded launch program (pycbinfer.FrameProgram) against the same network
+    run module by module: both outputs and every state tensor bit-identical over a walk with idle frames.  With dense
+    nn.MaxPool2d / torch.cat in the network the recording refuses."""
+    from cbinfer_amd import workloads
+    from cbinfer_amd._lib import CBinferError
+    H, W = 96, 160
+
+    def build():
+        net = workloads.convertOpenPose(workloads.OpenPoseModel(T=2, init='kaiming', groupedBranches=True).cuda().half(),
+                                        threshold=0.05)
+        return workloads.fuseOpenPoseDetections(net)
+    vid = workloads.SyntheticVideo(H=H, W=W, ratio=0.10, block=16, seed=21)
+    frames = [(f * (255.0 / 256.0) - 0.5).half().contiguous() for f in vid.frames(12)]
+    frames = frames[:8] + [frames[7], frames[7]] + frames[8:]
+    a, b = build(), build()
+    with torch.no_grad():
+        a(frames[0])
+        with pytest.raises(CBinferError):      # (dense pools and torch.cat: operators a replay would not repeat)
+            pkg.FrameProgram(a).record(frames[0])
+        a, b = build(), build()
+        for net in (a, b):
+            pkg.insertCBPooling(net, cloneOutput=False)
+            pkg.fusePoolingIntoDetection(net)
+            net.libraryConcat = True
+        for f in frames[:4]:
+            a(f), b(f)
+        prog = pkg.FrameProgram(a)
+        ya, yb = prog.record(frames[4]), b(frames[4])
+        assert len(prog.calls) <= 25
+        for t, f in enumerate(frames[5:]):
+            ya, yb = prog(f), b(f)
+            torch.cuda.synchronize()
+            assert all(torch.equal(u, v) for u, v in zip(ya, yb)), t
+    for ta, tb in zip(pkg.getStateTensors(a), pkg.getStateTensors(b)):
+        assert torch.equal(ta, tb)
+    assert sum(1 for m in a.modules() if type(m) is pkg.CBConv2d) == 36

@@ -50,11 +50,17 @@ echo "fg done"
 # OpenPose T=2 fp16 (config 4)
 run timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/pose_stats -o s --output-format csv -- \
     python3 $R/tools/pose_target.py > $O/pose_target.txt 2> $O/pose_stats.err || exit 1
+# (one steady-state frame of the same run, launch by launch)
+python3 $R/tools/pose_frame_table.py $O/pose_stats > $O/pose_frame.txt 2>/dev/null
+# the same network with every layer's own detection launch (round 5's form), and in the library-only form (change-based pools
+# folded, library concatenation) replayed as a recorded launch program -- un-profiled, for the frames/s
+export POSE_NOFOLD=1 POSE_GROUPED=0; run timeout -k 10 200 python3 $R/tools/pose_target.py 2>/dev/null | grep "change-based" | sed 's/^/own detection launches, branches one after the other: /' >> $O/pose_target.txt; unset POSE_NOFOLD POSE_GROUPED
+export POSE_POOLS=1 POSE_PROGRAM=1; run timeout -k 10 200 python3 $R/tools/pose_target.py 2>/dev/null | grep "change-based\|program\|producer" | sed 's/^/change-based pools folded + library concat: /' >> $O/pose_target.txt; unset POSE_POOLS POSE_PROGRAM
 echo "pose done"
 # keep the summaries, drop the bulky raw traces (gpurun merges at most 64 MiB back)
 mkdir -p $O/keep
 cp $O/bench.json $O/bench_under_rocprof.json $O/pmc_traffic.json $O/pmc_traffic.txt $O/fg_target.txt $O/keep/ 2>/dev/null
-cp $O/pose_target.txt $O/keep/ 2>/dev/null
+cp $O/pose_target.txt $O/pose_frame.txt $O/keep/ 2>/dev/null
 for d in stats fg_stats pose_stats; do
   f=$(find $O/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/keep/${d}_kernel_stats.csv
 done

@@ -1,24 +1,25 @@
 # copies what tools/collect_profiles.sh + tools/timeline_run.sh (eager and MODE=graph) left under gpurun_out/ into
-# profiles/r05_* (run in the build container after the gpurun call; the bench line itself -- profiles/r05_bench.json --
+# profiles/r06_* (run in the build container after the gpurun call; the bench line itself -- profiles/r06_bench.json --
 # is made by a bench run AFTER this, so that its roofline.traffic quotes these passes)
 set -e
 cd "$(git rev-parse --show-toplevel)"
 K=gpurun_out/prof/keep
-cp $K/pmc_traffic.txt profiles/r05_pmc_traffic_raw.txt
-cp $K/stats_kernel_stats.csv profiles/r05_bench_kernel_stats.csv
-cp $K/bench_under_rocprof.json profiles/r05_bench_under_rocprof.json
-cp $K/kernel_trace_summary.txt profiles/r05_bench_kernel_clusters.txt
-cp $K/fg_target.txt profiles/r05_fg_exp7_target.txt
-cp $K/fg_stats_kernel_stats.csv profiles/r05_fg_exp7_kernel_stats.csv
-cp $K/pose_target.txt profiles/r05_openpose_target.txt
-cp $K/pose_stats_kernel_stats.csv profiles/r05_openpose_kernel_stats.csv
+cp $K/pmc_traffic.txt profiles/r06_pmc_traffic_raw.txt
+cp $K/stats_kernel_stats.csv profiles/r06_bench_kernel_stats.csv
+cp $K/bench_under_rocprof.json profiles/r06_bench_under_rocprof.json
+cp $K/kernel_trace_summary.txt profiles/r06_bench_kernel_clusters.txt
+cp $K/fg_target.txt profiles/r06_fg_exp7_target.txt
+cp $K/fg_stats_kernel_stats.csv profiles/r06_fg_exp7_kernel_stats.csv
+cp $K/pose_target.txt profiles/r06_openpose_target.txt
+cp $K/pose_stats_kernel_stats.csv profiles/r06_openpose_kernel_stats.csv
+cp $K/pose_frame.txt profiles/r06_openpose_frame.txt
 python3 - <<'PY'
 import json, sys
 sys.path.insert(0, '.')
 import bench
 d = json.load(open('gpurun_out/prof/keep/pmc_traffic.json'))
 assert d['kernel_source_sha256'] == bench.kernel_source_hash(), "the passes ran on other kernel sources"
-json.dump(d, open('profiles/r05_pmc_traffic.json', 'w'), indent=1)
+json.dump(d, open('profiles/r06_pmc_traffic.json', 'w'), indent=1)
 print("pmc traffic of commit", d['commit'], "hash", d['kernel_source_sha256'])
 PY
 { echo "# eager stream (the launch form the bench runs): tools/timeline_run.sh, MI355X, commit $(git rev-parse --short HEAD)"
@@ -26,4 +27,4 @@ PY
   cat gpurun_out/doc/timeline_eager.txt
   echo
   echo "# the same network replayed from a hipGraph (MODE=graph tools/timeline_run.sh): idle time between the kernels of different library calls that the eager stream does not have"
-  cat gpurun_out/doc/timeline_graph.txt; } > profiles/r05_frame_timeline.txt
+  cat gpurun_out/doc/timeline_graph.txt; } > profiles/r06_frame_timeline.txt

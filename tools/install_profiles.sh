@@ -27,4 +27,7 @@ PY
   cat gpurun_out/doc/timeline_eager.txt
   echo
   echo "# the same network replayed from a hipGraph (MODE=graph tools/timeline_run.sh): idle time between the kernels of different library calls that the eager stream does not have"
-  cat gpurun_out/doc/timeline_graph.txt; } > profiles/r06_frame_timeline.txt
+  cat gpurun_out/doc/timeline_graph.txt
+  echo
+  echo "# the frame as a recorded launch program (MODE=program: pycbinfer.FrameProgram replays the library calls of one eager frame): the eager stream's kernels, four library calls per frame on the host"
+  cat gpurun_out/doc/timeline_program.txt; } > profiles/r06_frame_timeline.txt

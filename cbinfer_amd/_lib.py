@@ -196,6 +196,7 @@ _SIGNATURES = {
     "cbinfer_conv_changed_rowpairs_batched": (_i, [_psp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ndp, _vp]),
     "cbinfer_cbconv2d_forward_rowpairs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i,
                                                _ndp, _vp]),
+    "cbinfer_frame_mask_copy_offset": (_l, [_i, _i]),
     "cbinfer_concat_channels": (_i, [_vpp, ctypes.POINTER(ctypes.c_int32), _i, _vp, _l, _i, _vp]),
     "cbinfer_conv2d_fg_cpu": (None, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i]),
 }

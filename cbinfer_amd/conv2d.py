@@ -1202,6 +1202,12 @@ class CBConv2d(nn.Module):
         else:
             idx, count, cap = work['idx'], work['count'], H * W
             result = ChangeIndexes(idx, count, (H, W))
+            if work['selfc'] and not self.saveChangeMap:
+                # (round 6: the self-compacting contraction leaves a copy of the frame's change mask at a fixed address
+                #  inside the frame mask buffer -- a chained consumer's detection skips the segments this layer left alone)
+                off = C.cbinfer_frame_mask_copy_offset(H, W) // 8
+                result = MaskChangeIndexes(work['bits'][off:off + C.cbinfer_mask_words(H, W)], (H, W), idx, count,
+                                           made=True)
         if have and count is None:
             # exact host-side list: write its length where the kernels look for it
             count = torch.full((1,), cap, dtype=torch.int32, device=input.device)
@@ -1265,6 +1271,7 @@ class CBConv2d(nn.Module):
                     self._make_plan(False, input, C.cbinfer_cbconv2d_forward_after, cargs, 1)
                     if self._plan is not None:
                         self._plan['chain'] = True
+                        self._plan['indexes'] = result
                 else:
                     self._make_plan(False, input, C.cbinfer_cbconv2d_forward, args, 0)
             if work['selfc'] and not have:

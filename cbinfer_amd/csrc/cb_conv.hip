@@ -407,7 +407,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS)
         par = ctl[0];
         mask = p.frameMasks + (par ? p.maskWords : 0);
         unsigned long long* other = p.frameMasks + (par ? 0 : p.maskWords);
-        for (int i = blockIdx.x * NT + t; i < p.maskWords; i += gridDim.x * NT) other[i] = 0ull;
+        // (+ round 6: a copy of THIS frame's mask at a fixed address behind the two masks and the control words -- which
+        //  of the two masks is the frame's is a device-side matter (the parity); the copy is what a chained consumer's
+        //  detection reads as its producer mask: segments this layer did not rewrite are skipped)
+        unsigned long long* copy = p.frameMasks + 2 * (long)p.maskWords + 2;
+        for (int i = blockIdx.x * NT + t; i < p.maskWords; i += gridDim.x * NT) other[i] = 0ull, copy[i] = mask[i];
         // Exclusive prefix of the per-word popcounts.  Pass 1: coalesced, independent loads (word t,
         // t+NT, ...) -> counts in LDS; pass 2 (LDS only): thread t owns CH consecutive words.
         const int CH = (p.maskWords + NT - 1) / NT;
@@ -1205,7 +1209,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void cb_mfma_f16_kernel(ConvPara
         par = ctl[0];
         mask = p.frameMasks + (par ? p.maskWords : 0);
         unsigned long long* other = p.frameMasks + (par ? 0 : p.maskWords);
-        for (int i = blockIdx.x * NT + t; i < p.maskWords; i += gridDim.x * NT) other[i] = 0ull;
+        // (+ round 6: a copy of THIS frame's mask at a fixed address behind the two masks and the control words -- which
+        //  of the two masks is the frame's is a device-side matter (the parity); the copy is what a chained consumer's
+        //  detection reads as its producer mask: segments this layer did not rewrite are skipped)
+        unsigned long long* copy = p.frameMasks + 2 * (long)p.maskWords + 2;
+        for (int i = blockIdx.x * NT + t; i < p.maskWords; i += gridDim.x * NT) other[i] = 0ull, copy[i] = mask[i];
         // Exclusive prefix of the per-word popcounts.  Pass 1: coalesced, independent loads (word t,
         // t+NT, ...) -> counts in LDS; pass 2 (LDS only): thread t owns CH consecutive words.
         const int CH = (p.maskWords + NT - 1) / NT;
@@ -1985,7 +1993,10 @@ int cbinfer_conv_accumulate_from_mask(const float* delta, uint64_t* frameMasks, 
                              K, kH, kW, 0, workspace, dtype, stream, 1, reluOut);
 }
 
-long cbinfer_frame_mask_bytes(int H, int W) { return 2 * cbinfer_mask_words(H, W) * 8 + 16; }
+// two alternating masks, 16 bytes of control words, and (round 6) the copy of the current frame's mask the self-compacting
+// contractions leave at a fixed address (cbinfer_frame_mask_copy_offset)
+long cbinfer_frame_mask_bytes(int H, int W) { return 3 * cbinfer_mask_words(H, W) * 8 + 16; }
+long cbinfer_frame_mask_copy_offset(int H, int W) { return 2 * cbinfer_mask_words(H, W) * 8 + 16; }
 int cbinfer_frame_mask_max_words(void) { return CB_SELFC_MAXW; }
 
 }  // extern "C"

@@ -1606,7 +1606,14 @@ __global__ __launch_bounds__(256) void cbh_reduce_kernel(CbsParams p, CbhExt ext
     const int t = threadIdx.x, px = t & 15;
     __shared__ unsigned s_chg[CBH_NEXT];
     const float4* __restrict__ slabs = (const float4*)p.slabs;
-    for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    // work unit = (group of 16 changed pixels, chunk of 32 channel quads = 128 output channels): a layer of 512 output
+    // channels has four units per pixel group -- 1000 changed pixels of such a layer are 63 groups, too few workgroups for
+    // a launch whose every step is a round trip.  The any-channel OR of the consumers' predicate needs no meeting of the
+    // chunks: every unit ORs the pixels ITS channels found changed into the mask (atomic OR is idempotent).
+    const int QT = MT * (BM / 4);      // channel quads of a pixel
+    const int NCC = (QT + 31) / 32;
+    for (int unit = blockIdx.x; unit < groups * NCC; unit += gridDim.x) {
+        const int g = unit / NCC, cc = unit - g * NCC;
         const int ptg = g / GP, gi = g - ptg * GP;
         int q = 0;
 #pragma unroll
@@ -1632,9 +1639,9 @@ __global__ __launch_bounds__(256) void cbh_reduce_kernel(CbsParams p, CbhExt ext
 #pragma unroll
         for (int c = 0; c < CBH_NEXT; ++c) chg[c] = false;
         const float4* sl0 = slabs + tileSlab * TILE4 + gi * PXG + px;
-        const int QT = MT * (BM / 4);      // channel quads of a pixel; thread: quads t >> 4, + 16, ... -- two per round
         const int nx2 = nNext > 1 ? 1 : 0;
-        for (int cq0 = t >> 4; cq0 < QT; cq0 += 32) {
+        {
+            const int cq0 = cc * 32 + (t >> 4);      // this thread's two quads: cq0 and cq0 + 16
             // (one round trip per round: up to 2 x 8 slab float4 and the consumers' state values of both quads are
             //  requested together -- their addresses need the pixel index only; clamped addresses, predicated uses)
             float4 v[2][8];

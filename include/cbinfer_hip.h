@@ -187,6 +187,10 @@ int cbinfer_cbconv2d_forward(const void* input, void* prevInput, void* prevOutpu
  * fused kernel derives the change list from the mask by itself and still writes idx/countDev.
  * The two launches are also available on their own: */
 long cbinfer_frame_mask_bytes(int H, int W);
+/* byte offset, inside a frame mask buffer, of the COPY of the current frame's change mask (cbinfer_mask_words(H,W) words)
+ * that a self-compacting contraction (selfCompact = 1) leaves behind: the producerMask a chained consumer's detection takes
+ * (cbinfer_hsplit_forward[_group]); round 6 */
+long cbinfer_frame_mask_copy_offset(int H, int W);
 int cbinfer_frame_mask_max_words(void);
 int cbinfer_change_detection_frame(const void* input, void* state, uint64_t* frameMasks, int W, int H,
                                    int C, int kHHalf, int kWHalf, float threshold,

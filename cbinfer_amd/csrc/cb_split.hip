@@ -1259,6 +1259,27 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
             waitFrags(FNEXT);                                                              \
         } while (0)
 
+        // fp16, one column tile per wave (the 64 x 64 tile: every shallow layer of a pose network), consumers folded in: their
+        // state values at this item's pixels are requested HERE -- in front of the ring priming, so they are the wave's
+        // OLDEST vector loads (they retire in front of every DMA the hand-counted waits count) and their round trip runs
+        // under the whole stage loop -- and the outputs stay in registers for the comparison: the detection adds no round
+        // trip to the launch.  (Two column tiles per wave: the registers are not there -- the values are read back in the
+        // epilogue; a split item's detection is the reduce launch's.)
+        constexpr bool NEXT_REGS = HALF && TN == 1;
+        _Float16 hv16[NEXT_REGS ? 16 : 1], sv16[NEXT_REGS ? CBH_NEXT : 1][NEXT_REGS ? 16 : 1];
+        if constexpr (NEXT_REGS) {
+            if (nNext > 0 && SK == 1) {      // (uniform)
+                const int pixLd = max(s_tilePix[wn * 32 + l31], 0);
+                const int nx2 = nNext > 1 ? 1 : 0;
+                const int mb0 = m0 + wm * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long o = (long)min(mb0 + 8 * (r >> 2) + (r & 3), Kq - 1) * HW + pixLd;
+                    sv16[0][r] = ext.L[q].next[0].state[o];
+                    if (CBH_NEXT > 1) sv16[CBH_NEXT > 1 ? 1 : 0][r] = ext.L[q].next[nx2].state[o];
+                }
+            }
+        }
         Frags F0, F1;
         CBS_STAMP_AT(2);
 #pragma unroll
@@ -1343,25 +1364,6 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
             cbs_first = false;
 #endif
             continue;
-        }
-        // fp16, one column tile per wave (the 64 x 64 tile: every shallow layer of a pose network), consumers folded in: their
-        // state values are requested HERE, in front of the output arithmetic and stores, and the outputs stay in registers
-        // for the comparison -- the detection then adds no round trip of its own in front of its stores.  (Two column
-        // tiles: the registers are not there -- the values are read back, see below.)
-        constexpr bool NEXT_REGS = HALF && TN == 1;
-        _Float16 hv16[NEXT_REGS ? 16 : 1], sv16[NEXT_REGS ? CBH_NEXT : 1][NEXT_REGS ? 16 : 1];
-        if constexpr (NEXT_REGS) {
-            if (nNext > 0) {      // (uniform)
-                const int pixLd = max(s_tilePix[wn * 32 + l31], 0);
-                const int nx2 = nNext > 1 ? 1 : 0;
-                const int mb0 = m0 + wm * 32 + 4 * h;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long o = (long)min(mb0 + 8 * (r >> 2) + (r & 3), Kq - 1) * HW + pixLd;
-                    sv16[0][r] = ext.L[q].next[0].state[o];
-                    if (CBH_NEXT > 1) sv16[CBH_NEXT > 1 ? 1 : 0][r] = ext.L[q].next[nx2].state[o];
-                }
-            }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {

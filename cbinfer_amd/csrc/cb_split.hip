@@ -2424,10 +2424,17 @@ struct CbhDetArgs {
 // POOL: the value compared with (and written to) the states is the 2x2 max of `in`, computed on the fly with clamped
 // window coordinates (cb_detect_kernel<T, BITS, POOL>); a segment none of whose window pixels the producer rewrote is
 // not looked at (its pooled values are last frame's: nothing above the threshold, nothing to copy).
+// (round 6: the detections of BOTH layers of a group in one launch -- blockIdx.z = layer x channel group)
+struct CbhDetGroup {
+    CbhDetArgs a[CBH_GROUP];
+    int zPer;      // blockIdx.z values per layer
+};
 template <bool POOL>
-__global__ __launch_bounds__(512) void cbh_detect_kernel(CbhDetArgs a) {
+__global__ __launch_bounds__(512) void cbh_detect_kernel(CbhDetGroup grp) {
+    const int layer = (int)blockIdx.z / grp.zPer, zl = (int)blockIdx.z - layer * grp.zPer;
+    const CbhDetArgs& a = grp.a[layer];
     if (a.upstream && *a.upstream == 0) return;
-    cb_touch_kernarg<sizeof(CbhDetArgs)>();
+    cb_touch_kernarg<sizeof(CbhDetGroup)>();
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, t = threadIdx.x;
     const int tx = blockIdx.x, y = blockIdx.y;
     const int W = a.W, H = a.H, C = a.C;
@@ -2536,7 +2543,7 @@ __global__ __launch_bounds__(512) void cbh_detect_kernel(CbhDetArgs a) {
     // (copy-all form: the channel groups are independent -- each compares, copies and ORs its own finds into the mask
     //  -- and go to workgroups of their own, blockIdx.z: a 512-channel 46x81 layer took eight dependent rounds, 15 us)
     const int NG = (C + 63) >> 6;
-    const int cgBeg = a.copyAll ? (int)blockIdx.z : 0, cgEnd = a.copyAll ? cgBeg + 1 : NG;
+    const int cgBeg = a.copyAll ? zl : 0, cgEnd = a.copyAll ? cgBeg + 1 : NG;
     bool chg = false;
     for (int cg = cgBeg; cg < cgEnd; ++cg) group(cg, true, a.copyAll != 0, vm, chg);
     const unsigned long long b = __ballot(chg);
@@ -2669,23 +2676,33 @@ int cbinfer_hsplit_forward_group(const cbHalfLayer* layers, int nLayers, int poo
     }
     hipStream_t s = (hipStream_t)stream;
     const int wpr = cbinfer_mask_words_per_row(W);
-    for (int q = 0; q < nLayers; ++q) {
-        const cbHalfLayer& L = layers[q];
-        if (!L.detect) continue;
-        CbhDetArgs a;
-        a.in = (const _Float16*)L.input, a.state = (_Float16*)L.state, a.S = (char*)L.pixelState;
-        a.masks = (unsigned long long*)L.frameMasks;
-        a.W = W, a.H = H, a.C = C, a.kHH = (kH - 1) / 2, a.kWH = (kW - 1) / 2, a.wpr = wpr;
-        a.Wp = g.Wp, a.rec = g.rec, a.padY = g.padY, a.padXL = g.padXL, a.th = L.threshold;
-        a.copyAll = feedbackLoop ? 0 : 1;
-        a.upstream = nLayers == 1 ? L.upstreamCount : nullptr;
-        a.pH = pH, a.pW = pW, a.prodMask = (const unsigned long long*)L.producerMask;   // (pooled: at pH x pW; else at H x W)
-        if (pooled)
-            hipLaunchKernelGGL(cbh_detect_kernel<true>, dim3(wpr, H, a.copyAll ? g.C / 64 : 1), dim3(512), 0, s, a);
-        else
-            hipLaunchKernelGGL(cbh_detect_kernel<false>, dim3(wpr, H, a.copyAll ? g.C / 64 : 1), dim3(512), 0, s, a);
-        const int st = cb_launch_status();
-        if (st != CB_OK) return st;
+    {
+        // the detection launch: the layers of the group that run their own detection, in ONE launch
+        CbhDetGroup dg;
+        int nd = 0;
+        for (int q = 0; q < nLayers; ++q) {
+            const cbHalfLayer& L = layers[q];
+            if (!L.detect) continue;
+            CbhDetArgs& a = dg.a[nd++];
+            a.in = (const _Float16*)L.input, a.state = (_Float16*)L.state, a.S = (char*)L.pixelState;
+            a.masks = (unsigned long long*)L.frameMasks;
+            a.W = W, a.H = H, a.C = C, a.kHH = (kH - 1) / 2, a.kWH = (kW - 1) / 2, a.wpr = wpr;
+            a.Wp = g.Wp, a.rec = g.rec, a.padY = g.padY, a.padXL = g.padXL, a.th = L.threshold;
+            a.copyAll = feedbackLoop ? 0 : 1;
+            a.upstream = nLayers == 1 ? L.upstreamCount : nullptr;
+            a.pH = pH, a.pW = pW, a.prodMask = (const unsigned long long*)L.producerMask;   // (pooled: at pH x pW; else at H x W)
+        }
+        if (nd > 0) {
+            for (int q = nd; q < CBH_GROUP; ++q) dg.a[q] = dg.a[0];
+            dg.zPer = feedbackLoop ? 1 : g.C / 64;
+            const dim3 grid(wpr, H, dg.zPer * nd);
+            if (pooled)
+                hipLaunchKernelGGL(cbh_detect_kernel<true>, grid, dim3(512), 0, s, dg);
+            else
+                hipLaunchKernelGGL(cbh_detect_kernel<false>, grid, dim3(512), 0, s, dg);
+            const int st = cb_launch_status();
+            if (st != CB_OK) return st;
+        }
     }
 
     CbsParams p;

@@ -383,7 +383,20 @@ struct CbsParams {
                                       // the launch at once (cbinfer_cbconv2d_forward_after's contract)
     int dbg;                          // diagnostic ablations (builds with -DCBS_DBG only; CBINFER_SPLIT_DBG)
     int maxChunks;                    // k-chunks of a deep contraction: CBS_CHUNKS; fp16 layers: up to 16 (chosen on the device)
+#ifdef CBS_LAST_ARRIVER
+    int lastArrive;                   // experiment (builds with -DCBS_LAST_ARRIVER, CBINFER_SPLIT_LAST=1; x3, 128-row tile): the k-slices of a tile meet INSIDE
+                                      // the launch -- the last one to arrive sums the others' partial tiles and scatters
+    int* arriveTiles;                 // ... one arrival counter per (pixel tile, row tile), zero between launches
+#endif
 };
+// a wave-uniform pointer the compiler may not know to be uniform, into scalar registers (the "s" operand of the saddr
+// forms of global_load / global_store in inline asm)
+static __device__ __forceinline__ const void* cbs_uniform_ptr(const void* ptr) {
+    const unsigned long a = (unsigned long)ptr;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return (const void*)(((unsigned long)hi << 32) | lo);
+}
 // fp16 layers only (AR = 1; round 6): what differs between the layers of a GROUP -- the two branches of an OpenPose
 // stage issued as one persistent grid: CbsParams.seq[q] holds layer q's tensors, this its weights, bias, channel count
 // -- and the CONSUMERS of each layer's output whose change detection (copy mode: feedbackLoop = False, copyInput = True,
@@ -707,8 +720,15 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
         }
         itemBase[CBH_GROUP] = run;
     }
+    // (builds with -DCBS_LAST_ARRIVER only: compiled in but switched off, the form costs the 128-row kernel 0.85 us per
+    //  launch -- profiles/r06_ab_last_arriver.txt)
+#ifdef CBS_LAST_ARRIVER
+    const bool lastArr = X3 && BM == 128 && p.lastArrive && p.arriveTiles && SK > 1;
+#else
+    constexpr bool lastArr = false;
+#endif
     if (blockIdx.x == 0 && t == 0 && p.info) {
-        p.info[CBS_INFO_SK] = SK;
+        p.info[CBS_INFO_SK] = lastArr ? 1 : SK;      // (last-arriver form: the outputs are final when the launch ends)
         p.info[CBS_INFO_MT] = MT;
         p.info[2] = p.nSeq;
         for (int q = 0; q < CBS_MAXSEQ; ++q) {
@@ -1345,25 +1365,105 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
             reluPlane = accum ? pp->seq[q].reluOut : nullptr;
         }
         if (CBS_DBGBIT(32)) continue;
+        bool finishHere = false;      // (last-arriver experiment: this workgroup holds the tile's final sums in acc1)
         if (SK > 1) {
             // partial tile -> slab [BM/4][BN] float4 (four consecutive output channels of a pixel), plain stores:
             // the slices meet behind the launch boundary (cbs_reduce_kernel)
             float4* slab = (float4*)p.slabs + (long)it * (TILE / 4);
+#ifdef CBS_LAST_ARRIVER
+            if constexpr (X3 && BM == 128) {
+                if (lastArr) {
+                    // Experiment (VERDICT round 5, #2b): the slices meet inside the launch.  Partial tiles go out with
+                    // device-scope (sc1) stores; a counter per (pixel tile, row tile) tells the last slice to arrive, which
+                    // reads the other three with sc1 loads, sums all four in slice order -- its own from registers -- and
+                    // runs the ordinary epilogue; the second launch then finds final outputs (its unsplit path).
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    const float4* slabU = (const float4*)cbs_uniform_ptr(slab);
+                    asm volatile("s_nop 4" ::"s"(slabU));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nl = (wn * TN + j) * 32 + l31;
+                    for (int j = 0; j < TN; ++j) {
+                        const int nl = (wn * TN + j) * 32 + l31;
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int mq = wm * 8 + 2 * r4 + h;
-                    slab[mq * BN + nl] = make_float4(comb(j, 4 * r4), comb(j, 4 * r4 + 1), comb(j, 4 * r4 + 2),
-                                                     comb(j, 4 * r4 + 3));
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const int mq = wm * 8 + 2 * r4 + h;
+                            const f32x4 v = {comb(j, 4 * r4), comb(j, 4 * r4 + 1), comb(j, 4 * r4 + 2), comb(j, 4 * r4 + 3)};
+                            // (inline asm is opaque to the compiler's hazard recogniser: the wait states of a > 64-bit store before its
+                            //  data registers are written again, and of a VALU-written SGPR before VMEM reads it, are spelled out)
+                            asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"((mq * BN + nl) * 16), "v"(v), "s"(slabU) : "memory");
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __shared__ int s_arrived;
+                    __syncthreads();
+                    int* ctr = p.arriveTiles + (ptg * MT + mt);      // (one per (pixel tile, row tile))
+                    if (t == 0) {
+                        const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (old == SK - 1) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_arrived = old;
+                    }
+                    __syncthreads();
+                    if (s_arrived != SK - 1) continue;      // (uniform: not the last one)
+                    const float4* s0 = (const float4*)p.slabs + (long)(it - slice * MT) * (TILE / 4);      // slice 0 of the tile
+                    f32x4 o[3][TN * 4];
+                    const float4* sk[3];      // (the other three slices, in order; wave-uniform addresses in SGPRs)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        sk[k] = (const float4*)cbs_uniform_ptr(s0 + (long)(k < slice ? k : k + 1) * MT * (TILE / 4));
+                    }
+                    asm volatile("s_nop 4" ::"s"(sk[0]), "s"(sk[1]), "s"(sk[2]));      // (v_readfirstlane -> VMEM address: 5 wait states)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; ++r4) {
+                                const int nl = (wn * TN + j) * 32 + l31, mq = wm * 8 + 2 * r4 + h;
+                                asm volatile("global_load_dwordx4 %0, %1, %2 sc1"
+                                             : "=v"(o[k][j * 4 + r4])
+                                             : "v"((mq * BN + nl) * 16), "s"(sk[k])
+                                             : "memory");
+                            }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int i = 0; i < TN * 4; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(o[k][i])::"memory");
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float own = comb(j, i);
+                            float sum = 0.f;      // (cbs_reduce_tail_kernel's order: 0 + slice 0 + slice 1 + slice 2 + slice 3)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const int k = c < slice ? c : c - 1;
+                                const float ov = k == 0 ? o[0][j * 4 + (i >> 2)][i & 3]
+                                                        : (k == 1 ? o[1][j * 4 + (i >> 2)][i & 3] : o[2][j * 4 + (i >> 2)][i & 3]);
+                                sum += c == slice ? own : ov;
+                            }
+                            acc1[j][i] = sum, acc2[j][i] = 0.f;
+                        }
+                    finishHere = true;
                 }
             }
-            CBS_STAMP_AT(5);
-#ifdef CBS_STAMP
-            cbs_first = false;
 #endif
-            continue;
+            if (!finishHere) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int nl = (wn * TN + j) * 32 + l31;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int mq = wm * 8 + 2 * r4 + h;
+                        slab[mq * BN + nl] = make_float4(comb(j, 4 * r4), comb(j, 4 * r4 + 1), comb(j, 4 * r4 + 2),
+                                                         comb(j, 4 * r4 + 3));
+                    }
+                }
+                CBS_STAMP_AT(5);
+#ifdef CBS_STAMP
+                cbs_first = false;
+#endif
+                continue;
+            }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -1986,7 +2086,8 @@ long cbinfer_split_workspace_bytes(int nSeq, int C, int H, int W, int K, int kH,
     const CbsGeom g = cbs_geom(C, H, W, kH, kW);
     if (g.nStages < 48) return 0;
     const int bm = cbs_bm(K), bn = bm >= 128 ? 128 : 64;
-    return 256 + cbs_slab_capacity(nSeq, H, W, K) * bm * bn * 4;
+    // (+ one arrival counter per partial tile behind the slabs: the last-arriver experiment, CBINFER_SPLIT_LAST=1)
+    return 256 + cbs_slab_capacity(nSeq, H, W, K) * bm * bn * 4 + cbs_slab_capacity(nSeq, H, W, K) * 4;
 }
 
 int cbinfer_split_prep_weights(const float* weight, void* prepared, int K, int C, int kH, int kW, int H, int W,
@@ -2158,6 +2259,18 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
     p.arriveShards = (int)(MW / 16 < 8 ? MW / 16 : 8);
     p.dbg = 0;
     p.maxChunks = CBS_CHUNKS;
+#ifdef CBS_LAST_ARRIVER
+    {
+        static int last = -1;      // CBINFER_SPLIT_LAST=1: the last-arriver experiment (x3, 128-row tile, no accumulate form)
+        if (last < 0) {
+            const char* e = getenv("CBINFER_SPLIT_LAST");
+            last = e ? atoi(e) : 0;
+        }
+        p.lastArrive = (last && x3 && BM == 128 && !accumulate && workspace) ? 1 : 0;
+        p.arriveTiles = p.lastArrive ? (int*)((char*)workspace + 256 + cbs_slab_capacity(nSeq, H, W, K) * (long)BM * 128 * 4)
+                                     : nullptr;
+    }
+#endif
 #ifdef CBS_DBG
     if (const char* e = getenv("CBINFER_SPLIT_DBG")) p.dbg = atoi(e);
 #endif
@@ -2747,6 +2860,9 @@ int cbinfer_hsplit_forward_group(const cbHalfLayer* layers, int nLayers, int poo
     p.magicW = (1ull << 32) / (unsigned long long)W + 1ull;
     p.magicMT = (1ull << 32) / (unsigned long long)(KP / BM) + 1ull;
     p.forceSK = 0, p.accumulate = 0, p.halfOut = 1, p.splitRounds = 2, p.dbg = 0;
+#ifdef CBS_LAST_ARRIVER
+    p.lastArrive = 0, p.arriveTiles = nullptr;
+#endif
     {
         static int mc = -1;      // CBINFER_HSPLIT_MAXCHUNKS (A/B aid; default 16: the device picks 4, 8 or 16 by the tile count)
         if (mc < 0) {

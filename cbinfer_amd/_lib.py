@@ -173,6 +173,10 @@ _SIGNATURES = {
     "cbinfer_split_detect": (_i, [_sp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "cbinfer_split_conv": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp]),
     "cbinfer_split_forward": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _vp]),
+    "cbinfer_split_next_supported": (_i, [_i, _i, _i, _i, _i, _i, _ndp]),
+    "cbinfer_split_conv_next": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _ndp, _vp]),
+    "cbinfer_split_forward_next": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _ndp,
+                                        _vp]),
     "cbinfer_split_forward_fg": (_i, [_sp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     "cbinfer_hsplit_supported": (_i, [_i, _i, _i, _i]),
     "cbinfer_hsplit_max_mask_words": (_l, [_i]),
@@ -215,7 +219,7 @@ def _load():
         fn = getattr(lib, name)     # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.cbinfer_abi_version() != 9:
+    if lib.cbinfer_abi_version() != 10:
         raise ImportError("cbinfer_amd: libcbinfer_hip.so ABI version mismatch")
     return lib
 

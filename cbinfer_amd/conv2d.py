@@ -749,10 +749,24 @@ class CBConv2d(nn.Module):
         # launch has done already (cb_rowpair.hip; its change indexes carry this layer's token)
         cargs = [sp['seq'], 1, ptr(wp), ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(scale),
                  int(bool(self.withReLU)), ptr(sp['ws']), 0]
+        # round 6: with a split-state consumer behind a lazy pool (pycbinfer.fuseDetectionIntoProducer) the contraction runs
+        # in pooling-window order and is that consumer's pooled change detection as well (cbinfer_split_*_next), as the
+        # row-pair kernel is for its consumer
+        nxt, ntok, rawTok = None, None, None
+        nextEligible = tail is None and sp['arith'] == 'x3' and os.environ.get('CBINFER_NO_WINFOLD', '0') != '1'
+        if nextEligible:
+            nxt, ntok = self._next_detect(H, W)
+            rawTok = ntok
+            if nxt is not None and not C.cbinfer_split_next_supported(Cin, K, kH, kW, H, W, ctypes.pointer(nxt)):
+                nxt, ntok = None, None
         if tail is not None:
             fn, cfn = C.cbinfer_split_forward_tail, C.cbinfer_split_conv_tail
             args += [0, ctypes.pointer(sp['tail']), stream_ptr(src)]
             cargs += [ctypes.pointer(sp['tail']), stream_ptr(src)]
+        elif nxt is not None:
+            fn, cfn = C.cbinfer_split_forward_next, C.cbinfer_split_conv_next
+            args += [ctypes.pointer(nxt), stream_ptr(src)]
+            cargs = cargs[:-1] + [ctypes.pointer(nxt), stream_ptr(src)]      # (no forceSplit argument)
         else:
             fn, cfn = C.cbinfer_split_forward, C.cbinfer_split_conv
             args += [stream_ptr(src)]
@@ -766,6 +780,7 @@ class CBConv2d(nn.Module):
         self._inputIsLiveState = False
         self._lastIndexes = MaskChangeIndexes(sp['copy'], (H, W), work['idx'], work['count'], made=True)
         self._lastIndexes.tailDone = tail
+        self._lastIndexes.nextDetect = ntok
         w, b = self._parameters.get('weight'), self._parameters.get('bias')
         if (w is not None and b is not None and not self.gatherComputationStats and
                 os.environ.get('CBINFER_NO_FASTPATH', '0') != '1'):
@@ -778,7 +793,8 @@ class CBConv2d(nn.Module):
                 indexes=self._lastIndexes, fn=fn, tail=tail, tailKey=tail._fold_key() if tail is not None else None,
                 convFn=cfn, convArgs=cargs, tailBlocked=bool(self.__dict__.get('_noTailFold')),
                 detectToken=(id(self), prev.data_ptr(), sp['S'].data_ptr(), sp['bits'].data_ptr(),
-                             float(self.threshold), sp['arith']))
+                             float(self.threshold), sp['arith']),
+                nextEligible=nextEligible, nextToken=ntok, nextRaw=rawTok, keep=nxt, hw=(H, W))
         if self.propChangeIndexes:
             return 'changeIndexes', self.prevOutput, self._lastIndexes
         return self.prevOutput
@@ -813,6 +829,8 @@ class CBConv2d(nn.Module):
                                          os.environ.get('CBINFER_NO_TAILFOLD', '0') == '1' or
                                          plan['tail']._fold_key() != plan['tailKey']):
             return None
+        if plan['nextEligible'] and self._next_detect(*plan['hw'])[1] != plan['nextRaw']:
+            return None      # (the consumer's state or threshold is not the one this plan folds -- or it can fold now)
         plan['seq'].input = src.data_ptr()
         if plan['pooled'] and getattr(inp.indexes, 'nextDetect', None) == plan['detectToken']:
             status = plan['convFn'](*plan['convArgs'])      # (the producing layer's launch was this frame's detection)

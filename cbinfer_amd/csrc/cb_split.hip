@@ -425,6 +425,19 @@ struct CbhExt {
     int pad_;
 };
 struct CbsNoExt {};
+// AR = 3 ("x3" arithmetic + WINDOW order, round 6): the feedback-mode layer behind the 2x2 max pool that follows this
+// layer -- its pooled change detection (CBPoolMax2d, conv2d.py:49-78, + changeDetection with updateInputState,
+// cbconv2d_cg_backend.cu:40-81; what cbs_detect_kernel<POOL> does in a launch of its own) rides in this launch's epilogue,
+// as it does in cbp_rowpair_kernel's.  A second kernel argument of that one instance only.
+struct CbsWinExt {
+    float* nstate;                    // the consumer's prevInput [K, H2, W2]
+    char* nS;                         // its split state (pixel-major records)
+    unsigned long long* nmasks;       // its frame mask (the detection ORs into it)
+    int* nflag;                       // its range flag (f16 pairs) or null
+    int H2, W2, wpr2, kHH, kWH, Wp, rec, padY, padXL, planes;
+    float th;
+    unsigned long long magicW2;
+};
 template <int AR>
 struct CbsExtOf {
     typedef CbsNoExt type;
@@ -432,6 +445,10 @@ struct CbsExtOf {
 template <>
 struct CbsExtOf<1> {
     typedef CbhExt type;
+};
+template <>
+struct CbsExtOf<3> {
+    typedef CbsWinExt type;
 };
 
 // One pixel of a consumer's dilated change mask: rows y - kHH .. y + kHH, columns x - kWH .. x + kWH, clipped to the map
@@ -519,7 +536,7 @@ __device__ __forceinline__ int cbs_div(int x, unsigned long long magic) {
 // multiplied while (s + 1, 0) is read.
 template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING, int AR = 0>
 __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typename CbsExtOf<AR>::type ext) {
-    constexpr bool HALF = AR == 1, X3 = AR == 2;
+    constexpr bool HALF = AR == 1, X3 = AR == 2 || AR == 3, WIN = AR == 3;
     // (before anything else -- the burst over the kilobyte of arguments included: an idle frame is this one load)
     if (HALF && p.upstream && *p.upstream == 0) {      // (the detection in front returned the same way: the mask is empty)
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -528,7 +545,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
         }
         return;
     }
-    cb_touch_kernarg<sizeof(CbsParams) + (HALF ? sizeof(CbhExt) : 0)>();
+    cb_touch_kernarg<sizeof(CbsParams) + (HALF ? sizeof(CbhExt) : (WIN ? sizeof(CbsWinExt) : 0))>();
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TN = BN / WN / 32;
     static_assert(BM == 32 * WM, "one 32-row tile per wave");
@@ -551,6 +568,15 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
     __shared__ int s_tilePix[BN];
     __shared__ float s_bias[BM];
     __shared__ unsigned s_nchg[HALF ? CBH_NEXT * (BN / 32) : 1];      // fp16: a consumer's changed pixels of this tile
+    // WIN: window-count prefix over the (row pair, mask word) units; per tile: every slot's pixel whether it changed or
+    // not, the pooled pixel of each of the tile's BN / 4 windows, the windows whose
+    // pooled pixel changed
+    __shared__ int s_preW[WIN ? PRE_CAP / 2 + 2 : 1];
+    __shared__ int s_tileAny[WIN ? BN : 1];
+    __shared__ int s_winPos[WIN ? BN / 4 : 1];
+    __shared__ unsigned s_wchg;
+    __shared__ unsigned long long s_wsum64[WIN ? 64 * WM * WN / 64 : 1];
+    static_assert(!WIN || (BN / WN / 32 == 1 && MASK_LDS), "window order: one column tile per wave, the mask words in LDS");
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -585,65 +611,142 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
     // Thread t owns the CH consecutive words [t CH, (t+1) CH) of the concatenated masks: their popcounts stay in
     // registers, one wave scan + one exchange of the wave totals gives every thread its base, and the exclusive
     // prefix goes to LDS once -- two barriers, no serial section for a single sequence.
-    constexpr int CHMAX = (PRE_CAP + NT - 1) / NT;
-    const int CHW = (E + NT - 1) / NT, wb = t * CHW;
-    int cnt[CHMAX];
-    unsigned long long wordReg[MASK_LDS ? CHMAX : 1];
-    int loc = 0, totAll = 0;
+    int totAll = 0, nWin = 0;      // changed pixels of all sequences; WIN: touched 2x2 windows
+    if constexpr (WIN) {
+        // Window order (one sequence): the scan runs over the UNITS (row pair yo, mask word tx) instead of the words, with
+        // three counts per unit -- changed pixels of the upper row (A), of the lower row (B), touched windows (W) -- packed
+        // into one 64-bit value (20 bits each).  Exclusive prefixes: PA at s_pre[u], PB at s_pre[EU + 1 + u], PW at
+        // s_preW[u].  The row-major rank of a changed pixel -- its place in the change list, which keeps the reference's
+        // order -- is  PA[u] + PB[u0] + bits below  in the upper row and  PA[u0 + wpr] + PB[u] + bits below  in the lower
+        // one (u0 = yo wpr: the row pair's first unit).
+        const int HU = (p.H + 1) >> 1, EU = HU * p.wpr;
+        constexpr int CUMAX = (PRE_CAP / 2 + NT) / NT;
+        const int CHU = (EU + NT - 1) / NT, ub = t * CHU;
+        unsigned long long cntU[CUMAX], wA[CUMAX], wB[CUMAX];
+        unsigned long long locU = 0ull;
+        const unsigned long long* mk = s_maskPtr[0];
 #pragma unroll
-    for (int u = 0; u < CHMAX; ++u) {
-        const int i = wb + u;
-        cnt[u] = 0;
-        if (u < CHW && i < E) {
-            const int q = cbs_div(i, p.magicMW), w = i - q * MW;
-            const unsigned long long word = s_maskPtr[q][w];
-            cnt[u] = __popcll(word);
-            if (MASK_LDS) wordReg[u] = word;
+        for (int u = 0; u < CUMAX; ++u) {
+            const int i = ub + u;
+            cntU[u] = 0ull, wA[u] = 0ull, wB[u] = 0ull;
+            if (u < CHU && i < EU) {
+                const int yo = cbs_div(i, p.magicWpr), tx = i - yo * p.wpr, ya = 2 * yo;
+                const unsigned long long a = mk[ya * p.wpr + tx];
+                const unsigned long long b0 = mk[min(ya + 1, p.H - 1) * p.wpr + tx];      // (clamped, not predicated)
+                const unsigned long long b = ya + 1 < p.H ? b0 : 0ull;
+                const unsigned long long v = a | b;
+                wA[u] = a, wB[u] = b;
+                cntU[u] = (unsigned long long)__popcll(a) | ((unsigned long long)__popcll(b) << 20) |
+                          ((unsigned long long)__popcll((v | (v >> 1)) & 0x5555555555555555ull) << 40);
+            }
+            locU += cntU[u];
         }
-        loc += cnt[u];
-    }
-    for (int q = 0; q < p.nSeq; ++q) {      // this launch also leaves a copy of the frame's masks at a fixed address
-        unsigned long long* copy = p.seq[q].maskCopy;
-        if (copy)
-            for (int i = blockIdx.x * NT + t; i < MW; i += gridDim.x * NT) copy[i] = s_maskPtr[q][i];
-    }
-    {
-        int incl = loc;
+        {
+            unsigned long long* copy = p.seq[0].maskCopy;
+            if (copy)
+                for (int i = blockIdx.x * NT + t; i < MW; i += gridDim.x * NT) copy[i] = mk[i];
+        }
+        unsigned long long incl = locU;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
+            const unsigned long long v = __shfl_up(incl, o);
             if (lane >= o) incl += v;
         }
-        if (lane == 63) s_wsum[t >> 6] = incl;
+        if (lane == 63) s_wsum64[t >> 6] = incl;
         __syncthreads();
         CBS_STAMP_AT(8);
-        int base = 0, tot = 0;
+        unsigned long long base = 0ull, tot = 0ull;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            const int v = s_wsum[w];
-            base += w < (t >> 6) ? v : 0;
+            const unsigned long long v = s_wsum64[w];
+            base += w < (t >> 6) ? v : 0ull;
             tot += v;
         }
-        totAll = __builtin_amdgcn_readfirstlane(tot);
-        int run = base + incl - loc;
+        const int totA = (int)(tot & 0xfffffull), totB = (int)((tot >> 20) & 0xfffffull), totW = (int)(tot >> 40);
+        totAll = __builtin_amdgcn_readfirstlane(totA + totB);
+        nWin = __builtin_amdgcn_readfirstlane(totW);
+        unsigned long long run = base + incl - locU;
 #pragma unroll
+        for (int u = 0; u < CUMAX; ++u) {
+            const int i = ub + u;
+            if (u < CHU && i < EU) {
+                const int yo = cbs_div(i, p.magicWpr), tx = i - yo * p.wpr, ya = 2 * yo;
+                s_pre[i] = (int)(run & 0xfffffull);
+                s_pre[EU + 1 + i] = (int)((run >> 20) & 0xfffffull);
+                s_preW[i] = (int)(run >> 40);
+                s_mask[ya * p.wpr + tx] = wA[u];
+                if (ya + 1 < p.H) s_mask[(ya + 1) * p.wpr + tx] = wB[u];
+                run += cntU[u];
+            }
+        }
+        if (t == 0) {
+            s_pre[EU] = totA, s_pre[2 * EU + 1] = totB, s_preW[EU] = totW;
+            s_seqRank[0] = 0, s_seqN[0] = totA + totB, s_seqTile[0] = 0, s_seqTile[1] = (totW + BN / 4 - 1) / (BN / 4);
+            if (blockIdx.x == 0) p.seq[0].countOut[0] = totA + totB;
+        }
+        if (t < CBS_MAXSEQ) s_exact[t] = 0;
+        __syncthreads();
+    } else {
+        constexpr int CHMAX = (PRE_CAP + NT - 1) / NT;
+        const int CHW = (E + NT - 1) / NT, wb = t * CHW;
+        int cnt[CHMAX];
+        unsigned long long wordReg[MASK_LDS ? CHMAX : 1];
+        int loc = 0;
+    #pragma unroll
         for (int u = 0; u < CHMAX; ++u) {
             const int i = wb + u;
+            cnt[u] = 0;
             if (u < CHW && i < E) {
-                s_pre[i] = run;
-                if (MASK_LDS) s_mask[i] = wordReg[u];
-                run += cnt[u];
+                const int q = cbs_div(i, p.magicMW), w = i - q * MW;
+                const unsigned long long word = s_maskPtr[q][w];
+                cnt[u] = __popcll(word);
+                if (MASK_LDS) wordReg[u] = word;
             }
+            loc += cnt[u];
         }
-        if (t < CBS_MAXSEQ) s_exact[t] = flagv;
-        if (t == 0) {
-            s_pre[E] = tot;
-            if (p.nSeq == 1) {      // (one sequence: its tables need nothing from LDS)
-                s_seqRank[0] = 0, s_seqN[0] = tot, s_seqTile[0] = 0, s_seqTile[1] = (tot + BN - 1) / BN;
-                if (blockIdx.x == 0) p.seq[0].countOut[0] = tot;
+        for (int q = 0; q < p.nSeq; ++q) {      // this launch also leaves a copy of the frame's masks at a fixed address
+            unsigned long long* copy = p.seq[q].maskCopy;
+            if (copy)
+                for (int i = blockIdx.x * NT + t; i < MW; i += gridDim.x * NT) copy[i] = s_maskPtr[q][i];
+        }
+        {
+            int incl = loc;
+    #pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
             }
+            if (lane == 63) s_wsum[t >> 6] = incl;
+            __syncthreads();
+            CBS_STAMP_AT(8);
+            int base = 0, tot = 0;
+    #pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int v = s_wsum[w];
+                base += w < (t >> 6) ? v : 0;
+                tot += v;
+            }
+            totAll = __builtin_amdgcn_readfirstlane(tot);
+            int run = base + incl - loc;
+    #pragma unroll
+            for (int u = 0; u < CHMAX; ++u) {
+                const int i = wb + u;
+                if (u < CHW && i < E) {
+                    s_pre[i] = run;
+                    if (MASK_LDS) s_mask[i] = wordReg[u];
+                    run += cnt[u];
+                }
+            }
+            if (t < CBS_MAXSEQ) s_exact[t] = flagv;
+            if (t == 0) {
+                s_pre[E] = tot;
+                if (p.nSeq == 1) {      // (one sequence: its tables need nothing from LDS)
+                    s_seqRank[0] = 0, s_seqN[0] = tot, s_seqTile[0] = 0, s_seqTile[1] = (tot + BN - 1) / BN;
+                    if (blockIdx.x == 0) p.seq[0].countOut[0] = tot;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (p.nSeq > 1) {
         if (t == 0) {
@@ -659,8 +762,9 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
         __syncthreads();
     }
     CBS_STAMP_AT(1);
-    const int TP = p.nSeq == 1 ? (totAll + BN - 1) / BN                       // pixel tiles of all sequences
-                               : __builtin_amdgcn_readfirstlane(s_seqTile[p.nSeq]);
+    const int TP = WIN ? (nWin + BN / 4 - 1) / (BN / 4)                       // (tiles of BN / 4 whole windows)
+                       : (p.nSeq == 1 ? (totAll + BN - 1) / BN                // pixel tiles of all sequences
+                                      : __builtin_amdgcn_readfirstlane(s_seqTile[p.nSeq]));
     // Split along k while whole CUs would idle and the k-depth pays for the slab round trip -- WITHOUT letting the
     // partitioning into the arithmetic: a deep contraction (>= 48 stages) is always the sum, left to right, of
     // CBS_CHUNKS partial sums over fixed stage ranges, each accumulated from zero.  Split, every chunk is a work
@@ -833,7 +937,60 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
         // / last rank; then the waves expand the words in between, one word per wave and step, one bit per lane.
         __shared__ int s_wRange[2];
         __syncthreads();   // (s_tilePix and the ring of the previous item are no longer read)
-        {
+        if constexpr (WIN) {
+            // Window order: the tile is the BN / 4 touched windows of ranks [R0, R1]; slot 4 r + 2 dy + dx is pixel (dy, dx)
+            // of its r-th window.  s_tilePix holds the CHANGED pixels (the contraction computes those and nothing else),
+            // s_tileAny every pixel of the window inside the map, s_winPos the window's pooled pixel (-1: none -- the odd
+            // last row or column of a floor-mode pool).  One unit per wave and step, one column per lane.
+            const int EU = ((p.H + 1) >> 1) * p.wpr;
+            const int R0 = ptg * (BN / 4), R1 = min(R0 + BN / 4, nWin) - 1;
+            for (int i = t; i < EU; i += NT) {
+                const int a = s_preW[i], b = s_preW[i + 1];
+                if (a <= R0 && R0 < b) s_wRange[0] = i;
+                if (a <= R1 && R1 < b) s_wRange[1] = i;
+            }
+            if (t < BN) s_tilePix[t] = -1, s_tileAny[t] = -1;
+            if (t < BN / 4) s_winPos[t] = -1;
+            if (t == 0) s_wchg = 0u;
+            __syncthreads();
+            const int w0 = __builtin_amdgcn_readfirstlane(s_wRange[0]), w1 = __builtin_amdgcn_readfirstlane(s_wRange[1]);
+            int32_t* listOut = p.seq[0].listOut;
+            for (int i = w0 + wave; i <= w1; i += NW) {
+                const int yo = cbs_div(i, p.magicWpr), tx = i - yo * p.wpr, ya = 2 * yo, u0 = yo * p.wpr;
+                const bool hasB = ya + 1 < p.H;
+                const unsigned long long A = s_mask[ya * p.wpr + tx];
+                const unsigned long long B = hasB ? s_mask[(ya + 1) * p.wpr + tx] : 0ull;
+                const unsigned long long V = A | B, Wm = (V | (V >> 1)) & 0x5555555555555555ull;
+                if (Wm == 0ull) continue;
+                const int k2 = lane & ~1;      // bit of this lane's window in Wm
+                if ((Wm >> k2) & 1ull) {
+                    const int r = s_preW[i] + __popcll(Wm & ((1ull << k2) - 1ull)) - R0;
+                    if (r >= 0 && r < BN / 4) {
+                        const int x = tx * 64 + lane;
+                        const unsigned long long below = (1ull << lane) - 1ull;
+                        const int posA = ya * p.W + x, posB = posA + p.W, slotA = 4 * r + (lane & 1);
+                        if (x < p.W) {
+                            s_tileAny[slotA] = posA;
+                            if ((A >> lane) & 1ull) {
+                                s_tilePix[slotA] = posA;
+                                listOut[s_pre[i] + s_pre[EU + 1 + u0] + __popcll(A & below)] = posA;
+                            }
+                            if (hasB) {
+                                s_tileAny[slotA + 2] = posB;
+                                if ((B >> lane) & 1ull) {
+                                    s_tilePix[slotA + 2] = posB;
+                                    listOut[s_pre[u0 + p.wpr] + s_pre[EU + 1 + i] + __popcll(B & below)] = posB;
+                                }
+                            }
+                        }
+                        if ((lane & 1) == 0) {
+                            const int gx = tx * 32 + (lane >> 1);
+                            s_winPos[r] = (yo < ext.H2 && gx < ext.W2) ? yo * ext.W2 + gx : -1;
+                        }
+                    }
+                }
+            }
+        } else {
             const int R0 = rb + n0, R1 = rb + min(n0 + BN, N) - 1;
             for (int i = q * MW + t; i < (q + 1) * MW; i += NT) {
                 const int a = s_pre[i], b = s_pre[i + 1];
@@ -1300,6 +1457,37 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
                 }
             }
         }
+        // window order: what the pooled detection in the epilogue compares and falls back on is requested HERE, like the
+        // fp16 consumers' state above (the wave's oldest vector loads; their round trip runs under the stage loop): the
+        // consumer's state at the lane's window, and the OLD output of the lane's pixel -- a pixel of a touched window
+        // that did not change itself is not computed (its output would come out of other operand bits than the dense first
+        // frame's), its stored output takes part in the maximum.
+        float oldv[WIN ? 16 : 1], nsv[WIN ? 4 : 1];
+        int anyPos = -1, wPos = -1;
+        if constexpr (WIN) {
+            const int nl = wn * 32 + l31;
+            anyPos = s_tileAny[nl], wPos = s_winPos[nl >> 2];
+            const int aLd = max(anyPos, 0), wLd = max(wPos, 0);      // (clamped addresses, predicated uses)
+            const long H2W2 = (long)ext.H2 * ext.W2;
+            const float* oq = p.seq[0].out;
+            // (a wave none of whose windows holds an unchanged pixel -- the interior of a changed region -- skips the old
+            //  outputs' sixteen load instructions)
+            if (__builtin_amdgcn_ballot_w64(anyPos >= 0 && s_tilePix[nl] < 0) != 0ull) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = min(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, Kq - 1);
+                    oldv[r] = oq[(long)m * HW + aLd];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oldv[r] = 0.f;
+            }
+            // the consumer's state: the four lanes of a window share its channels -- lane k of the quad takes the four
+            // consecutive channels wm 32 + 8 k + 4 h + (0..3)
+            const int c0 = wm * 32 + 8 * (nl & 3) + 4 * h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) nsv[e] = ext.nstate[(long)min(c0 + e, Kq - 1) * H2W2 + wLd];
+        }
         Frags F0, F1;
         CBS_STAMP_AT(2);
 #pragma unroll
@@ -1481,12 +1669,96 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
                     if (pix >= 0 && m < Kq) ((_Float16*)out)[(long)m * HW + pix] = (_Float16)v;
                     continue;
                 }
+                if constexpr (WIN)      // (this pixel's value in the window's maximum: new, old, or none -- outside the map)
+                    oldv[WIN ? r : 0] = pix >= 0 ? v : (anyPos >= 0 ? oldv[WIN ? r : 0] : -__builtin_inff());
                 if (pix >= 0 && m < Kq) {
                     if (accum) {      // fine-grained: the sum of the products joins what the output holds
                         v += out[(long)m * HW + pix];
                         if (reluPlane) reluPlane[(long)m * HW + pix] = v <= 0.f ? 0.f : v;
                     }
                     out[(long)m * HW + pix] = v;
+                }
+            }
+        }
+        if constexpr (WIN) {
+            // The pooled change detection of the layer behind the 2x2 pool (cbs_detect_kernel<POOL>'s work, per window of
+            // this tile): the four pixels of a window sit in four consecutive lanes -- two DPP quad permutes give every lane
+            // the maximum (max(max(p00, p01), max(p10, p11)), the detection kernel's association) of its 16 channels --;
+            // strict > against the consumer's state over all channels (cbconv2d_cg_backend.cu:56), the window's verdict
+            // through LDS (channels live in both lane halves and both row-tile waves); feedback refresh of the f32 state
+            // and of its pixel-major split copy at the changed windows (.cu:74-80), their dilation into the frame mask.
+            const int nl = wn * 32 + l31, win = nl >> 2, kq = nl & 3;
+            const int c0 = wm * 32 + 8 * kq + 4 * h;      // this lane's four channels of the window (a whole quarter of a part)
+            float pv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = oldv[WIN ? r : 0];
+                x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true)));
+                x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true)));
+                // accumulator r holds channel wm 32 + (r & 3) + 8 (r >> 2) + 4 h: the lane keeps r = 4 kq + e
+                if ((r >> 2) == kq) pv[r & 3] = x;
+            }
+            const bool mine = wPos >= 0 && c0 < Kq;      // (K is a multiple of 16: a lane's four channels exist or do not)
+            bool chg = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) chg |= cb_changed(nsv[WIN ? e : 0], pv[e], ext.th);
+            if (chg && mine) atomicOr(&s_wchg, 1u << win);
+            __syncthreads();
+            const unsigned mW = __builtin_amdgcn_readfirstlane(s_wchg);
+            if (mW != 0u) {      // (uniform)
+                if (mine && ((mW >> win) & 1u)) {
+                    const long H2W2 = (long)ext.H2 * ext.W2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ext.nstate[(long)(c0 + e) * H2W2 + wPos] = pv[e];
+                    const int y2 = cbs_div(wPos, ext.magicW2), x2 = wPos - y2 * ext.W2;
+                    char* rec = ext.nS + CBS_SPAD + ((long)(y2 + ext.padY) * ext.Wp + (x2 + ext.padXL)) * ext.rec;
+                    const bool over = cbs_store_quarter(rec, c0 >> 4, (c0 >> 3) & 1, (c0 >> 2) & 1, ext.planes, pv);
+                    if (over && ext.nflag) *ext.nflag = 1;
+                }
+                // Dilation into the consumer's frame mask: the tile's changed windows are first united per mask word
+                // (lanes of the last wave: one window each, the lowest lane of every (row, word) key collects the bits),
+                // then each united word goes out dilated like cbs_detect_kernel's -- a few dozen atomics per tile.  (One
+                // atomic chain per WINDOW, the first form, was 22 000 atomics per frame on the ten cache lines of an 80 x 120
+                // mask: 25 us of this launch, served one after the other at the memory side.)
+                if (wave == NW - 1) {
+                    const int w = lane & (BN / 4 - 1);
+                    const bool on = lane < BN / 4 && ((mW >> w) & 1u);
+                    int key = -1 - lane, y2 = 0, wi = 0;
+                    unsigned long long bit = 0ull;
+                    if (on) {
+                        const int wp = s_winPos[w];
+                        y2 = cbs_div(wp, ext.magicW2);
+                        const int x2 = wp - y2 * ext.W2;
+                        wi = x2 >> 6, key = y2 * ext.wpr2 + wi, bit = 1ull << (x2 & 63);
+                    }
+                    unsigned long long acc = 0ull;
+                    bool leader = on;
+#pragma unroll
+                    for (int j = 0; j < BN / 4; ++j) {
+                        const int kj = __shfl(key, j);
+                        const unsigned long long bj = __shfl(bit, j);
+                        if (kj == key) {
+                            acc |= bj;
+                            if (j < lane) leader = false;
+                        }
+                    }
+                    if (leader) {
+                        unsigned long long D = acc, SR = 0ull, SL = 0ull;
+                        for (int d = 1; d <= ext.kWH; ++d) {
+                            D |= (acc << d) | (acc >> d);
+                            SR |= acc >> (64 - d);
+                            SL |= acc << (64 - d);
+                        }
+                        D &= cbs_valid_mask(ext.W2, wi);
+                        SR = (wi + 1 < ext.wpr2) ? (SR & cbs_valid_mask(ext.W2, wi + 1)) : 0ull;
+                        if (wi == 0) SL = 0ull;
+                        for (int yy = max(y2 - ext.kHH, 0); yy <= min(y2 + ext.kHH, ext.H2 - 1); ++yy) {
+                            unsigned long long* row = ext.nmasks + (long)yy * ext.wpr2 + wi;
+                            atomicOr(row, D);
+                            if (SR) atomicOr(row + 1, SR);
+                            if (SL) atomicOr(row - 1, SL);
+                        }
+                    }
                 }
             }
         }
@@ -2200,9 +2472,24 @@ int cbinfer_split_detect(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int
 // outScale = 1 / (weightScale * 2^-4).  forceSplit > 0 overrides the k-split decision (tests, tuning).
 // weightScale == 0 selects the bf16-TRIPLE form (x3: prepared weights of cbinfer_split3_prep_weights, split states of
 // cbinfer_split3_state_bytes; no scale anywhere, outScale = 1, no range flag).
+// Layers whose contraction launch can run in WINDOW order and carry the pooled detection of the layer behind the 2x2 pool
+// (AR = 3): all output channels in one 64-row tile (K <= 64, a multiple of 16), a shallow contraction (one item per tile:
+// no slabs), mask words and the three unit prefixes beside a five-stage ring; the consumer a split-state layer on K channels.
+static bool cbs_next_supported(int C, int K, int kH, int kW, int H, int W, const cbNextDetect* next) {
+    if (!next || !cbs_supported(C, K, kH, kW) || K > 64 || K % 16 != 0 || !cbs_supported(K, 1, next->kH, next->kW)) return false;
+    if (cbs_geom(C, H, W, kH, kW, 3).nStages >= 48) return false;
+    if (!((next->H == H / 2 || next->H == (H + 1) / 2) && (next->W == W / 2 || next->W == (W + 1) / 2))) return false;
+    if (next->arith != 0 && next->arith != 1) return false;
+    const long MW = cbinfer_mask_words(H, W), EU = (long)((H + 1) / 2) * cbinfer_mask_words_per_row(W);
+    if (MW > CBS_PRE_SMALL || 2 * EU + 2 > CBS_PRE_SMALL + 1 || EU + 1 > CBS_PRE_SMALL / 2 + 2) return false;
+    const CbsGeom g2 = cbs_geom(K, next->H, next->W, next->kH, next->kW, next->arith ? 3 : 2);
+    return (long)g2.Hp * g2.Wp * g2.rec < (1l << 31) && (long)H * W < (1l << 20);
+}
+
 static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
                           int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
-                          const CbsTailArgs* tail, cbStream_t stream, int accumulate = 0) {
+                          const CbsTailArgs* tail, cbStream_t stream, int accumulate = 0,
+                          const cbNextDetect* next = nullptr) {
     if (workspace == nullptr && cbs_supported(C, K, kH, kW) && cbs_geom(C, H, W, kH, kW).nStages >= 48)
         return CB_ERR_BADARG;      // a deep contraction needs its workspace (cbinfer_split_workspace_bytes)
     CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && prepared && H > 0 && W > 0 && weightScale >= 0.f);
@@ -2279,6 +2566,21 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
     // itself (items <= grid <= 2 CUs) always fits, a forced one (forceSplit: tests, tuning) is refused beyond it
     const long cap = cbs_slab_capacity(nSeq, H, W, K);
     p.slabCap = (int)(cap > 0x7fffffffl ? 0x7fffffffl : cap);
+    if (next) {
+        // window order + the pooled detection of the layer behind the 2x2 pool in this launch (AR = 3)
+        if (!cbs_next_supported(C, K, kH, kW, H, W, next) || nSeq != 1 || !x3 || accumulate || tail) return CB_ERR_UNSUPPORTED;
+        CB_REQUIRE(next->state && next->splitState && next->frameMasks);
+        const CbsGeom g2 = cbs_geom(K, next->H, next->W, next->kH, next->kW, next->arith ? 3 : 2);
+        CbsWinExt e;
+        e.nstate = next->state, e.nS = (char*)next->splitState, e.nmasks = (unsigned long long*)next->frameMasks;
+        e.nflag = next->arith ? nullptr : next->rangeFlag;      // (bf16 triples have f32's range)
+        e.H2 = next->H, e.W2 = next->W, e.wpr2 = cbinfer_mask_words_per_row(next->W);
+        e.kHH = (next->kH - 1) / 2, e.kWH = (next->kW - 1) / 2;
+        e.Wp = g2.Wp, e.rec = g2.rec, e.padY = g2.padY, e.padXL = g2.padXL, e.planes = g2.planes;
+        e.th = next->threshold;
+        e.magicW2 = (1ull << 32) / (unsigned long long)next->W + 1ull;
+        return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 5, 3>(p, 1, nullptr, s, e);
+    }
     if (x3) {
         // bf16 triples: 48 KB stages (128-row tile, three in the ring, the mask words in LDS while they and their prefix
         // fit beside it: six 80x120 sequences) / 24 KB stages (64-row tile: five alone on a CU, three when two
@@ -2407,6 +2709,33 @@ int cbinfer_split_forward_fg_tail(const cbSplitSeq* seqs, int nSeq, int pooled, 
 
 // One frame of a feedback-mode CBConv2d (conv2d.py:178-259) of every sequence: detection (+ pooling) + refresh of
 // both states, then the contraction.
+// The contraction in WINDOW order with the pooled change detection of the NEXT layer (behind a 2x2 / stride-2 max pool)
+// in its epilogue -- cbp_rowpair_kernel's arrangement for a split-state producer (round 6): one sequence, the bf16-triple
+// arithmetic (weightScale == 0), K <= 64 output channels, a shallow contraction.  `next`: the consumer's tensors, geometry
+// and threshold (cbNextDetect).  cbinfer_split_next_supported tells whether a layer pair is taken.
+int cbinfer_split_next_supported(int C, int K, int kH, int kW, int H, int W, const cbNextDetect* next) {
+    return cbs_next_supported(C, K, kH, kW, H, W, next) ? 1 : 0;
+}
+int cbinfer_split_conv_next(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
+                            int W, int K, int kH, int kW, float weightScale, int relu, void* workspace,
+                            const cbNextDetect* next, cbStream_t stream) {
+    CB_REQUIRE(next);
+    return cbs_split_conv(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace, 0, nullptr, stream,
+                          0, next);
+}
+int cbinfer_split_forward_next(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, const void* prepared,
+                               const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
+                               float weightScale, int relu, void* workspace, const cbNextDetect* next,
+                               cbStream_t stream) {
+    CB_REQUIRE(next);
+    if (!cbs_next_supported(C, K, kH, kW, H, W, next) || nSeq != 1 || weightScale != 0.f) return CB_ERR_UNSUPPORTED;
+    mode = (mode & ~CBINFER_SPLIT_X3) | CBINFER_SPLIT_X3;
+    const int st = cbinfer_split_detect(seqs, nSeq, mode, pH, pW, C, H, W, kH, kW, threshold, stream);
+    if (st != CB_OK) return st;
+    return cbinfer_split_conv_next(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace, next,
+                                   stream);
+}
+
 int cbinfer_split_forward(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, const void* prepared,
                           const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
                           float weightScale, int relu, void* workspace, cbStream_t stream) {

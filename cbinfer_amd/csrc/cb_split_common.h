@@ -123,4 +123,38 @@ __device__ __forceinline__ bool cbs_store_part(char* recBase, int grp, int half,
     return over;
 }
 
+// FOUR consecutive channels (quarter `sub` of half `half` of group `grp`) of a pixel's values into its record: the 8-byte
+// half of the part's 16-byte piece of every plane -- cbs_store_part's bytes, written by two lanes instead of one.
+__device__ __forceinline__ bool cbs_store_quarter(char* recBase, int grp, int half, int sub, int planes, const float* v) {
+    typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    char* dst = recBase + grp * 32 * planes + half * 16 + sub * 8;
+    bool over = false;
+    if (planes == 2) {
+        halfx4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = v[j] * CBS_XSCALE;
+            over |= !(fabsf(x) <= CBS_F16_MAX);
+            _Float16 h, l;
+            cbs_split(x, h, l);
+            hi[j] = h, lo[j] = l;
+        }
+        *(halfx4*)dst = hi;
+        *(halfx4*)(dst + 32) = lo;
+    } else {
+        bf16x4 t0, t1, t2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __bf16 a, b, c;
+            cbs_split3(v[j], a, b, c);
+            t0[j] = a, t1[j] = b, t2[j] = c;
+        }
+        *(bf16x4*)dst = t0;
+        *(bf16x4*)(dst + 32) = t1;
+        *(bf16x4*)(dst + 64) = t2;
+    }
+    return over;
+}
+
 }  // namespace cbs

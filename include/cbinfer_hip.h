@@ -58,8 +58,9 @@ typedef void* cbStream_t; /* hipStream_t */
  * 8: the f32-EQUIVALENT (bf16-triple) form of the split-state frame: cbinfer_split3_*, CBINFER_SPLIT_X3,
  * weightScale == 0, cbNextDetect.arith.  9: cbinfer_hsplit_forward_group (cbHalfLayer / cbHalfNext: two layers of one
  * geometry per launch, the consumers' change detection in the producing launch); cbinfer_hsplit_* take contractions
- * of a single k-stage and up (1x1 layers on >= 64 channels). */
-#define CBINFER_ABI_VERSION 9
+ * of a single k-stage and up (1x1 layers on >= 64 channels).  10: cbinfer_split_*_next (a split-state layer's contraction
+ * in window order carrying the pooled change detection of the layer behind the 2x2 pool). */
+#define CBINFER_ABI_VERSION 10
 
 int cbinfer_abi_version(void);
 const char* cbinfer_status_string(int status);
@@ -674,6 +675,27 @@ int cbinfer_cbconv2d_forward_rowpairs(const float* input, float* prevInput, floa
                                       int32_t* ctl, uint64_t* maskCopy, const void* prepared, const float* bias, int C,
                                       int H, int W, int K, int kH, int kW, float threshold, int relu,
                                       const cbNextDetect* next, cbStream_t stream);
+
+/* ---- round 6: the same folding for a split-state PRODUCER (the 16 -> 64 layer of the scene-labeling network in front of
+ * its second pool; replaces the consumer's cbinfer_split_detect launch, i.e. CBPoolMax2d conv2d.py:49-78 + changeDetection
+ * conv2d_cg.py:100-122 / cbconv2d_cg_backend.cu:40-81 of the NEXT layer).  The contraction's work list is ordered by 2x2
+ * pooling WINDOW (a tile = 16 windows touched by the change mask; only their changed pixels are computed, the others'
+ * stored outputs take part in the maximum), so the workgroup that recomputes a window also owns its pooled pixel: it
+ * compares the maximum with the next layer's state (strict >, all channels), refreshes that state and its split copy at the
+ * changed pooled pixels and ORs their dilation into the next layer's frame mask.  The change list the layer hands out
+ * (cbSplitSeq.idxOut) keeps the reference's row-major order.  Taken: one sequence, bf16-triple arithmetic (weightScale 0),
+ * K <= 64 output channels (a multiple of 16), fewer than 48 k-stages, a mask of at most 1280 words; next as for the
+ * row-pair kernel.  The caller falls back to the separate detection under the same conditions as there.
+ *   cbinfer_split_conv_next    : cbinfer_split_conv + next (this layer's own detection was its producer's business)
+ *   cbinfer_split_forward_next : cbinfer_split_forward + next */
+int cbinfer_split_next_supported(int C, int K, int kH, int kW, int H, int W, const cbNextDetect* next);
+int cbinfer_split_conv_next(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
+                            int W, int K, int kH, int kW, float weightScale, int relu, void* workspace,
+                            const cbNextDetect* next, cbStream_t stream);
+int cbinfer_split_forward_next(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, const void* prepared,
+                               const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,
+                               float weightScale, int relu, void* workspace, const cbNextDetect* next,
+                               cbStream_t stream);
 
 /* ---- channel concatenation of batch-1 [Ci,H,W] tensors into [sum Ci,H,W] as ONE launch on the caller's stream
  * (round 6).  The reference's pose network does torch.cat(dim=1) between its stages

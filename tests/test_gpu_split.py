@@ -568,3 +568,51 @@ def test_split_hostile_data_accuracy_fullsize(lib, oracle, C, K, H, W, capsys):
     # the f32-equivalent form: no worse than the f32 fma chain itself
     assert rel["x3 split-state (bf16 triples)"] <= rel["exact f32 MFMA"], rel
     assert res["x3 split-state (bf16 triples)"].max() <= res["exact f32 MFMA"].max() * 1.05 + 1e-30
+
+
+@pytest.mark.parametrize("H,W,K,k2,frac", [(45, 67, 64, 3, 0.1), (160, 240, 64, 7, 0.1), (38, 130, 32, 5, 0.3),
+                                            (64, 64, 16, 3, 0.02)])
+def test_split_next_detection_in_window_order(lib, oracle, H, W, K, k2, frac):
+    """cbinfer_split_conv_next (round 6): the producer's contraction in pooling-window order + the pooled change
+    detection of the layer behind the 2x2 pool in its epilogue, against the separate launches (cbinfer_split_conv, then
+    the consumer's cbinfer_split_detect with the pool folded in): the producer's outputs and change list (row-major, as
+    the reference orders it), the consumer's f32 state, its split copy, its list and its outputs -- all bit for bit."""
+    if ARITH != "x3":
+        pytest.skip("window order exists for the bf16-triple arithmetic")
+    C_ = lib.C
+    rng = np.random.default_rng(H * 7 + W + K)
+    Cin, K2 = 16, 48
+    H2, W2 = H // 2, W // 2
+    w1 = (rng.standard_normal((K, Cin, 7, 7)) / np.sqrt(Cin * 49)).astype(np.float32)
+    b1 = rng.standard_normal(K).astype(np.float32)
+    w2 = (rng.standard_normal((K2, K, k2, k2)) / np.sqrt(K * k2 * k2)).astype(np.float32)
+    b2 = rng.standard_normal(K2).astype(np.float32)
+    Pa, Pb = Layer(lib, w1, b1, H, W), Layer(lib, w1, b1, H, W)
+    Ca, Cb = Layer(lib, w2, b2, H2, W2, pooled=True), Layer(lib, w2, b2, H2, W2, pooled=True)
+    nd = lib.NextDetect()
+    nd.state, nd.splitState, nd.frameMasks = Cb.state[0].data_ptr(), Cb.S[0].data_ptr(), Cb.masks[0].data_ptr()
+    nd.rangeFlag, nd.H, nd.W, nd.kH, nd.kW, nd.threshold, nd.arith = Cb.flag.data_ptr(), H2, W2, k2, k2, 0.05, 1
+    import ctypes
+    assert C_.cbinfer_split_next_supported(Cin, K, 7, 7, H, W, ctypes.pointer(nd)) == 1
+    for t, x in enumerate(block_video(rng, Cin, H, W, 6, frac)):
+        xd = dev((x + rng.uniform(-0.03, 0.03, x.shape)).astype(np.float32))
+        # separate launches
+        Pa.frame([xd], 0.1, relu=True)
+        Ca.frame([Pa.out[0]], 0.05, relu=True)
+        # folded: the producer's detection, its contraction + the consumer's detection, the consumer's contraction alone
+        Pb.seqs[0].input, Pb.seqs[0].producerMask = xd.data_ptr(), None
+        lib.check(C_.cbinfer_split_detect(Pb.seqs, 1, 8, 0, 0, Cin, H, W, 7, 7, 0.1, None))
+        lib.check(C_.cbinfer_split_conv_next(Pb.seqs, 1, Pb.wp.data_ptr(), Pb.b.data_ptr(), Cin, H, W, K, 7, 7, 0.0, 1,
+                                             None, ctypes.pointer(nd), None))
+        Cb.seqs[0].input, Cb.seqs[0].producerMask = Pb.out[0].data_ptr(), None
+        lib.check(C_.cbinfer_split_conv(Cb.seqs, 1, Cb.wp.data_ptr(), Cb.b.data_ptr(), K, H2, W2, K2, k2, k2, 0.0, 1,
+                                        Cb.ws.data_ptr() if Cb.ws is not None else None, 0, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(Pa.list(), Pb.list()), t
+        assert torch.equal(Pa.out[0], Pb.out[0]) and torch.equal(Pa.state[0], Pb.state[0]), t
+        assert torch.equal(Pa.copy[0], Pb.copy[0]), t
+        assert np.array_equal(Ca.list(), Cb.list()), t
+        assert torch.equal(Ca.state[0], Cb.state[0]), t
+        assert torch.equal(Ca.S[0], Cb.S[0]), t
+        assert torch.equal(Ca.out[0], Cb.out[0]) and torch.equal(Ca.copy[0], Cb.copy[0]), t
+        assert len(Cb.list()) > 0 or t > 0

@@ -383,7 +383,7 @@ class ProgramRunner(object):
 
 
 def build_bench_model(experiment=6, threshold=0.05, fuse_tail=True, fuse_pool=True, pool_clone=False,
-                      device="cuda", fuse_detect=None):
+                      device="cuda", fuse_detect=None, window_order="auto"):
     """(dense baseline, change-based test network) exactly as the headline measurement runs them: the
     reference's experiment preset (sceneLabeling/modelLoader.py:41-87) on the scene-labeling CNN, then the two
     execution-level fusions (pycbinfer.fuseTail1x1, fusePoolingIntoDetection) and CBPoolMax2d.cloneOutput.
@@ -398,7 +398,8 @@ def build_bench_model(experiment=6, threshold=0.05, fuse_tail=True, fuse_pool=Tr
     pycbinfer.fuseTail1x1(test, enabled=fuse_tail)
     pycbinfer.fusePoolingIntoDetection(test, enabled=fuse_pool)
     # (a producer's launch doing the next layer's pooled detection: only where the pool is folded anyway)
-    pycbinfer.fuseDetectionIntoProducer(test, enabled=fuse_pool if fuse_detect is None else (fuse_detect and fuse_pool))
+    pycbinfer.fuseDetectionIntoProducer(test, enabled=fuse_pool if fuse_detect is None else (fuse_detect and fuse_pool),
+                                        windowOrder=window_order)
     return base, test
 
 
@@ -538,19 +539,31 @@ def inframe_layer_times(test, frames, start, reps=40):
                     bracket(which, (mi, 'detect'), empty, sink, lambda: check(lib.cbinfer_split_detect(
                         sp['seq'], 1, pooled, pH, pW, C, Hh, Ww, kH, kW, float(m.threshold), st)))
                 tail = m._folded_tail(sp, Hh, Ww, src.device)
+                # (round 6: the contraction in window order is the NEXT layer's pooled detection as well, as in the product path)
+                pl = m._plan if (m._plan and m._plan.get('split')) else None
+                wnext, wtok = (pl.get('keep'), pl.get('nextToken')) if pl is not None else (None, None)
+                if wnext is not None and m._next_detect(Hh, Ww)[1] != pl.get('nextRaw'):
+                    wnext, wtok = None, None
                 if tail is not None:
                     import ctypes
                     bracket(which, (mi, 'conv'), empty, sink, lambda: check(lib.cbinfer_split_conv_tail(
                         sp['seq'], 1, ptr(wp), ptr(m.bias.detach()), C, Hh, Ww, K, kH, kW, float(scale),
                         int(bool(m.withReLU)), ptr(sp['ws']), 0, ctypes.pointer(sp['tail']), st)))
+                elif wnext is not None:
+                    import ctypes
+                    bracket(which, (mi, 'conv'), empty, sink, lambda: check(lib.cbinfer_split_conv_next(
+                        sp['seq'], 1, ptr(wp), ptr(m.bias.detach()), C, Hh, Ww, K, kH, kW, float(scale),
+                        int(bool(m.withReLU)), ptr(sp['ws']), ctypes.pointer(wnext), st)))
                 else:
                     bracket(which, (mi, 'conv'), empty, sink, lambda: check(lib.cbinfer_split_conv(
                         sp['seq'], 1, ptr(wp), ptr(m.bias.detach()), C, Hh, Ww, K, kH, kW, float(scale),
                         int(bool(m.withReLU)), ptr(sp['ws']), 0, st)))
                 ci = MaskChangeIndexes(sp['copy'], (Hh, Ww), work['idx'], work['count'], made=True)
                 ci.tailDone = tail
-                kern = "cbs_conv_kernel (split-state, LDS-DMA, %s)" % (
-                    "bf16-triple products: f32-equivalent" if sp['arith'] == 'x3' else "f16-pair products") + \
+                ci.nextDetect = wtok
+                kern = "cbs_conv_kernel (split-state, LDS-DMA, %s%s)" % (
+                    "bf16-triple products: f32-equivalent" if sp['arith'] == 'x3' else "f16-pair products",
+                    "; window order + the next layer's pooled change detection" if wnext is not None else "") + \
                     (" + cbs_reduce_tail_kernel (second launch: sums the k-slices' partial tiles AND evaluates the "
                      "1x1 tail)" if tail is not None else " + cbs_reduce_kernel" if sp['ws'] is not None else "")
             else:
@@ -1120,6 +1133,13 @@ def secondary_configs(args):
         base, cg = build_bench_model(6, args.threshold)
         dense = max(measure(base, frames, m) for m in ("graph", "eager"))
         fcg = max(measure(cg, frames, m) for m in ("graph", "eager"))
+        # (the same network with the 16 -> 64 contraction forced into pixel order -- the 64 -> 256 layer's detection in a
+        #  launch of its own: round 5's frame -- and forced into window order: `cg` decides by itself, per sequence)
+        _, cgp = build_bench_model(6, args.threshold, window_order=False)
+        fcgp = max(measure(cgp, frames, m) for m in ("graph", "eager"))
+        _, cgw = build_bench_model(6, args.threshold, window_order=True)
+        fcgw = max(measure(cgw, frames, m) for m in ("graph", "eager"))
+        del cgp, cgw
         _, fg = workloads.sceneLabelingModels(experimentIdx=7, threshold=args.threshold)
         for m in fg.modules():
             if type(m) is pycbinfer.CBConv2d:
@@ -1137,6 +1157,7 @@ def secondary_configs(args):
         ffp = max(measure(fp, frames, m) for m in ("graph", "eager"))
         del fp
         out["config3_sweep"].append({"input_change": vid.ratio, "dense_fps": dense, "cg_exp6_fps": fcg,
+                                     "cg_exp6_pixel_order_fps": fcgp, "cg_exp6_window_order_fps": fcgw,
                                      "cg_speedup": fcg / dense, "cg_post_dilation_ratio_per_layer": ratios(cg),
                                      "fg_exp7_inplace_fps": ffg, "fg_speedup": ffg / dense,
                                      "fg_inplace_with_cbpoolmax2d_fps": ffp,

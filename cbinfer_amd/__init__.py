@@ -169,20 +169,29 @@ def fusePoolingIntoDetection(rootModule, enabled=True):
     return rootModule
 
 
-def fuseDetectionIntoProducer(rootModule, enabled=True):
+def fuseDetectionIntoProducer(rootModule, enabled=True, windowOrder='auto'):
     """Execution-level fusion (no change of results): inside every nn.Sequential a run  CBConv2d (producer) ->
     lazy CBPoolMax2d -> feedback-mode CBConv2d (consumer)  lets the PRODUCER's contraction launch also be the consumer's
     pooled change detection when the producer runs on the row-pair kernel (cb_rowpair.hip: a workgroup owns whole 2x2
     windows) and the consumer on the split-state kernels: one launch less per frame, and the freshly computed outputs
     are compared with the consumer's state while they are still in the workgroup's LDS.  Decided per frame
     (CBConv2d._next_detect): the first frames of a sequence, a frame after the consumer's state was restored or its
-    threshold changed run the separate detection.  Call after fusePoolingIntoDetection.  Returns rootModule."""
+    threshold changed run the separate detection.  Call after fusePoolingIntoDetection.  Returns rootModule.
+
+    Round 6: a producer that runs on the split-state kernels itself (<= 64 output channels, a shallow contraction -- the
+    16 -> 64 layer of the scene-labeling network) does the same with its contraction in pooling-WINDOW order
+    (cbinfer_split_conv_next).  `windowOrder`: True, False (such a producer stays in pixel order, the consumer's detection in
+    a launch of its own) or 'auto' (default): the window-order tile holds 16 whole windows -- the unchanged pixels of a
+    touched window cost slots -- and its prologue and epilogue are longer, which pays (measured at 160 x 240: 1.7-2.8 us per
+    frame from 2 to 35 % recomputed pixels) while its tiles fit ONE round of the grid and costs 2-3 us per round beyond; 'auto'
+    decides that when the layer's call plan is made, from the change count of the layer's last frame (CBConv2d._window_fold)."""
     for seq in _sequentials(rootModule):
         kids = list(seq.children())
         for prod, pool, cons in zip(kids[:-2], kids[1:-1], kids[2:]):
             if type(prod) == CBConv2d and type(pool) == CBPoolMax2d and type(cons) == CBConv2d:
                 if enabled and getattr(pool, 'lazy', False) and cons.feedbackLoop and prod.feedbackLoop:
                     prod.__dict__['_fusedNext'] = (pool, cons)      # (plain references, not children)
+                    prod.__dict__['_winFold'] = windowOrder
                 else:
                     prod.__dict__.pop('_fusedNext', None)
         # round 6: a CBConv2d directly behind another one (fp16 layers on the split-state machinery, the consumer in copy

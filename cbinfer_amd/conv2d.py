@@ -708,6 +708,44 @@ class CBConv2d(nn.Module):
         ev = sp['flagEvent'] = torch.cuda.Event()
         ev.record()
 
+    def _window_fold(self, sp, tail, H, W):
+        """Can this split-state layer's contraction run in pooling-window order and carry the pooled change detection of
+        the layer behind the following CBPoolMax2d (cbinfer_split_*_next, round 6)?  -> (eligible at all, cbNextDetect or
+        None, the token the consumer will look for or None, _next_detect's token before the library's own test).
+        pycbinfer.fuseDetectionIntoProducer(windowOrder=...) says whether: True, False, or 'auto' (default) -- decided when
+        the call plan is made (NOT per frame: the one place where the layer's last change count is read back, outside any
+        stream capture) from the tiles the window-order form would need: it pays while they fit one round of the grid
+        (DESIGN 5.8).  CBINFER_NO_WINFOLD=1 switches the form off."""
+        K, Cin, kH, kW = self.weight.size()
+        mode = self.__dict__.get('_winFold', 'auto')
+        eligible = (tail is None and sp['arith'] == 'x3' and mode is not False and
+                    os.environ.get('CBINFER_NO_WINFOLD', '0') != '1')
+        nxt, ntok, rawTok = None, None, None
+        if eligible:
+            nxt, ntok = self._next_detect(H, W)
+            rawTok = ntok
+            if nxt is not None and not C.cbinfer_split_next_supported(Cin, K, kH, kW, H, W, ctypes.pointer(nxt)):
+                nxt, ntok = None, None
+            if nxt is not None and mode == 'auto':
+                # decided ONCE per module, from the first frame that recomputed some but not all of the layer's pixels (the
+                # first frame of a sequence recomputes all of them, a repeated frame none): the tiles of 16 windows the form
+                # would need for that many pixels (a touched window's unchanged pixels cost slots: + ~20 %) -- beyond one
+                # round of the persistent grid its longer prologue and epilogue are paid once more per round, and its tile
+                # count crosses that line before pixel order's does.  Until then (at most four looks, each a read-back of
+                # the layer's change count while its call plan is made -- never inside a stream capture): the form is used.
+                st = self.__dict__.setdefault('_winAuto', {'fold': None, 'looks': 0})
+                if st['fold'] is None and not torch.cuda.is_current_stream_capturing():
+                    n = int(self._work['count'].item())
+                    st['looks'] += 1
+                    if 0 < n < H * W:
+                        cus = torch.cuda.get_device_properties(self.weight.device).multi_processor_count
+                        st['fold'] = (1.2 * n) / 64.0 <= cus
+                    elif st['looks'] >= 4:
+                        st['fold'] = True
+                if st['fold'] is False:
+                    nxt, ntok = None, None
+        return eligible, nxt, ntok, rawTok
+
     def _forward_split(self, src, lazy, work):
         """One frame on the split-state kernels: detection (+ pooling) + refresh of prevInput and of its pre-split
         copy, then the LDS-DMA contraction.  `src` is the layer input, or the pool's input when `lazy`."""
@@ -752,13 +790,7 @@ class CBConv2d(nn.Module):
         # round 6: with a split-state consumer behind a lazy pool (pycbinfer.fuseDetectionIntoProducer) the contraction runs
         # in pooling-window order and is that consumer's pooled change detection as well (cbinfer_split_*_next), as the
         # row-pair kernel is for its consumer
-        nxt, ntok, rawTok = None, None, None
-        nextEligible = tail is None and sp['arith'] == 'x3' and os.environ.get('CBINFER_NO_WINFOLD', '0') != '1'
-        if nextEligible:
-            nxt, ntok = self._next_detect(H, W)
-            rawTok = ntok
-            if nxt is not None and not C.cbinfer_split_next_supported(Cin, K, kH, kW, H, W, ctypes.pointer(nxt)):
-                nxt, ntok = None, None
+        nextEligible, nxt, ntok, rawTok = self._window_fold(sp, tail, H, W)
         if tail is not None:
             fn, cfn = C.cbinfer_split_forward_tail, C.cbinfer_split_conv_tail
             args += [0, ctypes.pointer(sp['tail']), stream_ptr(src)]
@@ -831,6 +863,9 @@ class CBConv2d(nn.Module):
             return None
         if plan['nextEligible'] and self._next_detect(*plan['hw'])[1] != plan['nextRaw']:
             return None      # (the consumer's state or threshold is not the one this plan folds -- or it can fold now)
+        if (plan['keep'] is not None and self.__dict__.get('_winFold', 'auto') == 'auto' and
+                self.__dict__.get('_winAuto', {}).get('fold') is None and not torch.cuda.is_current_stream_capturing()):
+            return None      # ('auto' has not seen a typical frame yet: the plan is made again, with another look)
         plan['seq'].input = src.data_ptr()
         if plan['pooled'] and getattr(inp.indexes, 'nextDetect', None) == plan['detectToken']:
             status = plan['convFn'](*plan['convArgs'])      # (the producing layer's launch was this frame's detection)

@@ -1687,6 +1687,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
             // strict > against the consumer's state over all channels (cbconv2d_cg_backend.cu:56), the window's verdict
             // through LDS (channels live in both lane halves and both row-tile waves); feedback refresh of the f32 state
             // and of its pixel-major split copy at the changed windows (.cu:74-80), their dilation into the frame mask.
+            CBS_STAMP_AT(12);
             const int nl = wn * 32 + l31, win = nl >> 2, kq = nl & 3;
             const int c0 = wm * 32 + 8 * kq + 4 * h;      // this lane's four channels of the window (a whole quarter of a part)
             float pv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1702,8 +1703,20 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
             bool chg = false;
 #pragma unroll
             for (int e = 0; e < 4; ++e) chg |= cb_changed(nsv[WIN ? e : 0], pv[e], ext.th);
-            if (chg && mine) atomicOr(&s_wchg, 1u << win);
+            {
+                // (the wave's eight windows' verdicts as one uniform value: one LDS atomic by one lane -- a per-lane atomicOr
+                //  with differing operands is compiled into a loop over the active lanes)
+                const unsigned long long bal = __ballot(chg && mine);
+                unsigned q4 = (unsigned)(bal | (bal >> 32));
+                q4 |= q4 >> 1;
+                q4 |= q4 >> 2;
+                unsigned m8 = 0u;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) m8 |= ((q4 >> (4 * w)) & 1u) << w;
+                if (lane == 0 && m8) atomicOr(&s_wchg, m8 << (wn * 8));
+            }
             __syncthreads();
+            CBS_STAMP_AT(13);
             const unsigned mW = __builtin_amdgcn_readfirstlane(s_wchg);
             if (mW != 0u) {      // (uniform)
                 if (mine && ((mW >> win) & 1u)) {
@@ -1715,6 +1728,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
                     const bool over = cbs_store_quarter(rec, c0 >> 4, (c0 >> 3) & 1, (c0 >> 2) & 1, ext.planes, pv);
                     if (over && ext.nflag) *ext.nflag = 1;
                 }
+                CBS_STAMP_AT(14);
                 // Dilation into the consumer's frame mask: the tile's changed windows are first united per mask word
                 // (lanes of the last wave: one window each, the lowest lane of every (row, word) key collects the bits),
                 // then each united word goes out dilated like cbs_detect_kernel's -- a few dozen atomics per tile.  (One

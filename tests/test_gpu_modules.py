@@ -1214,6 +1214,47 @@ def test_bench_inframe_pass_leaves_the_network_intact(pkg):
     assert len(iso) == 3 and all(r["conv_us"] > 0 for r in iso)
 
 
+def test_window_order_fold_in_the_bench_network(pkg):
+    """Round 6: the 16 -> 64 layer's contraction in pooling-window order with the 64 -> 256 layer's pooled detection in its
+    epilogue (pycbinfer.fuseDetectionIntoProducer(windowOrder=...), cbinfer_split_conv_next), at module level on the bench
+    network: forced on, forced off and 'auto' give the same outputs and the same state tensors, bit for bit, frame by
+    frame; forced on the form is what runs (the producer's plan holds the consumer's detection, the consumer's frame is its
+    contraction alone); 'auto' takes it at the bench's 10 % and declines it on a sequence that changes in most of its
+    pixels (the tiles would not fit one round of the grid)."""
+    import bench
+    import pycbinfer
+    nets = {w: bench.build_bench_model(window_order=w)[1] for w in (True, False, "auto")}
+    frames = bench.bench_video(91).frames(9)
+    with torch.no_grad():
+        for t, f in enumerate(frames):
+            ys = {w: n(f) for w, n in nets.items()}
+            torch.cuda.synchronize()
+            assert torch.equal(ys[True], ys[False]) and torch.equal(ys["auto"], ys[False]), t
+            for w in (True, "auto"):
+                for ta, tb in zip(pkg.getStateTensors(nets[w]), pkg.getStateTensors(nets[False])):
+                    assert torch.equal(ta, tb), (w, t)
+
+    def producer(net):
+        convs = [m for m in net.modules() if type(m) is pycbinfer.CBConv2d]
+        return convs[1], convs[2]
+    for w, want in ((True, True), (False, False), ("auto", True)):
+        p16, p64 = producer(nets[w])
+        plan = p16._plan
+        assert plan is not None and plan.get("split") and (plan.get("keep") is not None) == want, w
+        if want:      # (the consumer found its detection done: its library call of the last frame was the contraction alone)
+            assert p16.lastChangeIndexes().nextDetect == p64._plan["detectToken"]
+        # the change list the producer hands out keeps the reference's row-major order whatever order the tiles had
+        idx = p16.lastChangeIndexes().tensor().cpu().numpy()
+        assert np.all(np.diff(idx) > 0)
+    busy = bench.bench_video(92, ratio=0.6, block=16).frames(6)
+    _, auto = bench.build_bench_model(window_order="auto")
+    with torch.no_grad():
+        for f in busy:
+            auto(f)
+    torch.cuda.synchronize()
+    assert producer(auto)[0]._plan is not None and producer(auto)[0]._plan.get("keep") is None
+
+
 @pytest.mark.parametrize("name", ["seq_half", "seq_half_k3"])
 @pytest.mark.parametrize("sync", [False, True])
 def test_golden_sequences_half(pkg, golden_dir, name, sync):

@@ -14,7 +14,8 @@ import tools.bench_split as bs  # noqa: E402
 
 raw = ctypes.CDLL(_lib.LIB_PATH)
 NAMES = ['entry', 'list lengths known', 'item set up', 'ring primed', 'stage loop done', 'epilogue done']
-FINE = {8: 'mask words in LDS', 9: 'pixel lookup done (thread 0)', 10: 'lookup barrier passed', 11: 'DMA offsets ready'}
+FINE = {8: 'mask words in LDS', 9: 'pixel lookup done (thread 0)', 10: 'lookup barrier passed', 11: 'DMA offsets ready',
+        12: 'window order: outputs stored', 13: 'window order: verdicts known', 14: 'window order: states refreshed'}
 
 
 def report(clear=True):

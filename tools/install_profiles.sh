@@ -23,11 +23,11 @@ json.dump(d, open('profiles/r06_pmc_traffic.json', 'w'), indent=1)
 print("pmc traffic of commit", d['commit'], "hash", d['kernel_source_sha256'])
 PY
 { echo "# eager stream (the launch form the bench runs): tools/timeline_run.sh, MI355X, commit $(git rev-parse --short HEAD)"
-  echo "# the first group is the timed loop (6 launches per frame; under the profiler the host is the bottleneck, so the GAPS are the host's -- the un-profiled frame period equals the sum of the durations); the other groups are the bench's in-frame measurement passes (event records, on-demand compaction)"
+  echo "# the first group is the timed loop (5 launches per frame since the window-order fold, DESIGN 5.8; under the profiler the host is the bottleneck, so the GAPS are the host's -- the un-profiled frame period equals the sum of the durations); the other groups are the bench's in-frame measurement passes (event records, on-demand compaction)"
   cat gpurun_out/doc/timeline_eager.txt
   echo
   echo "# the same network replayed from a hipGraph (MODE=graph tools/timeline_run.sh): idle time between the kernels of different library calls that the eager stream does not have"
   cat gpurun_out/doc/timeline_graph.txt
   echo
-  echo "# the frame as a recorded launch program (MODE=program: pycbinfer.FrameProgram replays the library calls of one eager frame): the eager stream's kernels, four library calls per frame on the host"
+  echo "# the frame as a recorded launch program (MODE=program: pycbinfer.FrameProgram replays the library calls of one eager frame): the eager stream's kernels, three library calls per frame on the host"
   cat gpurun_out/doc/timeline_program.txt; } > profiles/r06_frame_timeline.txt

@@ -18,16 +18,30 @@ raw = ctypes.CDLL(LIB_PATH)
 
 
 def main():
+    S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     _, net = bench.build_bench_model()
-    frames = bench.bench_video(1234).frames(14)
-    with torch.no_grad():
-        for f in frames[:12]:
-            net(f)
-        torch.cuda.synchronize()
-        raw.cbinfer_debug_pair_stamps(None, 0, 1)
-        torch.cuda.synchronize()
-        net(frames[12])
-        torch.cuda.synchronize()
+    if S > 1:      # a SequenceBatch step of S sequences (usage: pair_stamps.py S)
+        import pycbinfer
+        sb = pycbinfer.SequenceBatch(net, S)
+        walk = [bench.bench_video(1234 + 7919 * q).frames(14) for q in range(S)]
+        with torch.no_grad():
+            for i in range(12):
+                sb([w[i] for w in walk])
+            torch.cuda.synchronize()
+            raw.cbinfer_debug_pair_stamps(None, 0, 1)
+            torch.cuda.synchronize()
+            sb([w[12] for w in walk])
+            torch.cuda.synchronize()
+    else:
+        frames = bench.bench_video(1234).frames(14)
+        with torch.no_grad():
+            for f in frames[:12]:
+                net(f)
+            torch.cuda.synchronize()
+            raw.cbinfer_debug_pair_stamps(None, 0, 1)
+            torch.cuda.synchronize()
+            net(frames[12])
+            torch.cuda.synchronize()
     buf = np.zeros(4096 * 8, dtype=np.uint64)
     raw.cbinfer_debug_pair_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(buf.nbytes), 0)
     st = buf.reshape(4096, 8).astype(np.int64)

@@ -1655,7 +1655,7 @@ def main():
                 del cseqs
             mode = max(calibration, key=calibration.get)
             # (within 1 % of the best, the recorded launch program is preferred: the steady state is GPU-bound for both, and
-            #  the program leaves the host four ctypes calls per frame instead of six modules' worth of Python -- what counts
+            #  the program leaves the host three ctypes calls per frame instead of six modules' worth of Python -- what counts
             #  when a short timed region starts on an empty launch queue, and for eight ranks sharing one host)
             if calibration.get("program", 0.0) >= 0.99 * calibration[mode]:
                 mode = "program"

@@ -493,6 +493,7 @@ def inframe_layer_times(test, frames, start, reps=40):
             sink.append((e0, e1))
 
     def run_frame(x, which, empty, sink):
+        side = [None]      # (round 6: a row-pair layer's state refresh waiting for the next contraction's idle workgroups)
         for mi, m in enumerate(mods):
             if type(m) is pycbinfer.CBTail1x1:
                 xin = x
@@ -551,6 +552,15 @@ def inframe_layer_times(test, frames, start, reps=40):
                     bracket(which, (mi, 'conv'), empty, sink, lambda: check(lib.cbinfer_split_conv_tail(
                         sp['seq'], 1, ptr(wp), ptr(m.bias.detach()), C, Hh, Ww, K, kH, kW, float(scale),
                         int(bool(m.withReLU)), ptr(sp['ws']), 0, ctypes.pointer(sp['tail']), st)))
+                elif wnext is not None and side[0] is not None and folded_detect:
+                    import ctypes
+                    from cbinfer_amd import _lib as _l
+                    sr = _l.SideRefresh()
+                    sr.frame, sr.state, sr.C, sr.H, sr.W, sr.threshold = side[0]
+                    side[0] = None
+                    bracket(which, (mi, 'conv'), empty, sink, lambda: check(lib.cbinfer_split_conv_next_refresh(
+                        sp['seq'], 1, ptr(wp), ptr(m.bias.detach()), C, Hh, Ww, K, kH, kW, float(scale),
+                        int(bool(m.withReLU)), ptr(sp['ws']), ctypes.pointer(wnext), ctypes.pointer(sr), st)))
                 elif wnext is not None:
                     import ctypes
                     bracket(which, (mi, 'conv'), empty, sink, lambda: check(lib.cbinfer_split_conv_next(
@@ -586,12 +596,26 @@ def inframe_layer_times(test, frames, start, reps=40):
                         lib.cbinfer_change_detection_frame
                     det = lambda: check(dfn(ptr(src), ptr(m.prevInput), ptr(bits), Ww, Hh, C, (kH - 1) // 2,
                                             (kW - 1) // 2, float(m.threshold), 1, dt, st))
-                bracket(which, (mi, 'detect'), empty, sink, det)
                 pairs_tok = None
+                own_det = False
                 if rows is not None and mpath == 'rows' and lazy is None and m._pairs_ok(Hh, Ww):
                     import ctypes
                     nxt, pairs_tok = m._next_detect(Hh, Ww)
                     nptr = ctypes.pointer(nxt) if nxt is not None else None
+                    own_det = m._pair_detect_ok(nxt, kH)      # (round 6: as the product path decides)
+                if own_det:
+                    folded_detect = True
+                    bracket(which, (mi, 'detect'), empty, sink, lambda: None)
+                    conv = lambda: check(lib.cbinfer_conv_rowpairs_detect(
+                        ptr(src), ptr(m.prevInput), ptr(m.prevOutput), ptr(rows['copy']), ptr(m._masked_call(mpath)[1]),
+                        ptr(m.bias.detach()), C, Hh, Ww, K, kH, kW, float(m.threshold), int(m.withReLU), nptr, st))
+                    side[0] = (src.data_ptr(), m.prevInput.data_ptr(), C, Hh, Ww, float(m.threshold))
+                    kern = "cbp_rowpair_kernel<DET> (row pairs + the layer's own change detection + the next layer's pooled one)"
+                else:
+                    bracket(which, (mi, 'detect'), empty, sink, det)
+                if own_det:
+                    pass
+                elif rows is not None and mpath == 'rows' and lazy is None and m._pairs_ok(Hh, Ww):
                     conv = lambda: check(lib.cbinfer_conv_changed_rowpairs(
                         ptr(m.prevInput), ptr(rows['bits']), ptr(rows['arrive']), ptr(rows['copy']),
                         ptr(m._masked_call(mpath)[1]), ptr(m.bias.detach()), ptr(m.prevOutput), C, Hh, Ww, K, kH, kW,
@@ -620,6 +644,9 @@ def inframe_layer_times(test, frames, start, reps=40):
                             HW=Hh * Ww, C=C, K=K, k=kH * kW, s=s_el, pooled=lazy is not None,
                             detect_folded=folded_detect)
             x = ('changeIndexes', m.prevOutput, ci) if m.propChangeIndexes else m.prevOutput
+        if side[0] is not None:      # (nobody carried the refresh: a launch of its own, as CBConv2d.forward does)
+            fr, stt, c_, h_, w_, th_ = side[0]
+            check(lib.cbinfer_refresh_state(fr, stt, c_, h_, w_, th_, st))
         return x
 
     times, counts = {}, {}

@@ -54,6 +54,15 @@ class NextDetect(ctypes.Structure):
 _ndp = ctypes.POINTER(NextDetect)
 
 
+class SideRefresh(ctypes.Structure):
+    """cbSideRefresh of include/cbinfer_hip.h: another layer's feedback refresh carried by a contraction launch."""
+    _fields_ = [("frame", ctypes.c_void_p), ("state", ctypes.c_void_p), ("C", ctypes.c_int), ("H", ctypes.c_int),
+                ("W", ctypes.c_int), ("threshold", ctypes.c_float)]
+
+
+_srp = ctypes.POINTER(SideRefresh)
+
+
 class PairSeq(ctypes.Structure):
     """cbPairSeq of include/cbinfer_hip.h."""
     _fields_ = [("state", _vp), ("output", _vp), ("bits", _vp), ("maskCopy", _vp), ("nextState", _vp),
@@ -175,6 +184,7 @@ _SIGNATURES = {
     "cbinfer_split_forward": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _vp]),
     "cbinfer_split_next_supported": (_i, [_i, _i, _i, _i, _i, _i, _ndp]),
     "cbinfer_split_conv_next": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _ndp, _vp]),
+    "cbinfer_split_conv_next_refresh": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _ndp, _srp, _vp]),
     "cbinfer_split_forward_next": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _ndp,
                                         _vp]),
     "cbinfer_split_forward_fg": (_i, [_sp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp]),
@@ -198,6 +208,8 @@ _SIGNATURES = {
     "cbinfer_rowpairs_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "cbinfer_conv_changed_rowpairs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ndp, _vp]),
     "cbinfer_conv_changed_rowpairs_batched": (_i, [_psp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _ndp, _vp]),
+    "cbinfer_conv_rowpairs_detect": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _ndp, _vp]),
+    "cbinfer_refresh_state": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "cbinfer_cbconv2d_forward_rowpairs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i,
                                                _ndp, _vp]),
     "cbinfer_frame_mask_copy_offset": (_l, [_i, _i]),
@@ -219,7 +231,7 @@ def _load():
         fn = getattr(lib, name)     # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
-    if lib.cbinfer_abi_version() != 10:
+    if lib.cbinfer_abi_version() != 11:
         raise ImportError("cbinfer_amd: libcbinfer_hip.so ABI version mismatch")
     return lib
 

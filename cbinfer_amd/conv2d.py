@@ -59,6 +59,12 @@ class _Produced(object):
         return None
 
 
+def _flush_side(pend):
+    """The feedback refresh of a row-pair layer's state as a launch of its own (pend: frame, state, C, H, W, threshold)."""
+    frame, state, Cn, H, W, th = pend
+    check(C.cbinfer_refresh_state(ptr(frame), ptr(state), Cn, H, W, float(th), stream_ptr(frame)))
+
+
 class LazyPool(object):
     """What a CBPoolMax2d with lazy=True hands to the next module instead of a pooled tensor: the pool's
     INPUT and the pooled size.  A feedback-mode CBConv2d folds the pooling into its change detection
@@ -310,6 +316,18 @@ class CBConv2d(nn.Module):
         K, Cin, kH, kW = self.weight.size()
         return (self.feedbackLoop and os.environ.get('CBINFER_NO_ROWPAIRS', '0') != '1' and
                 bool(C.cbinfer_rowpairs_supported(Cin, K, kH, kW, H, W)))
+
+    def _pair_detect_ok(self, nxt, kH):
+        """Does this row-pair layer run its own change detection inside its launch (cbinfer_conv_rowpairs_detect, round 6)?
+        Only while the consumer behind the pool takes the detection of ITS input from this launch (nxt) and ran its last
+        frame in window order -- its contraction then carries this layer's state refresh (cbinfer_split_conv_next_refresh).
+        CBINFER_NO_PAIRDET=1 switches the form off."""
+        if nxt is None or kH != 7 or os.environ.get('CBINFER_NO_PAIRDET', '0') == '1':
+            return False
+        link = self.__dict__.get('_fusedNext')
+        cons = link[1] if link is not None else None
+        cp = cons.__dict__.get('_plan') if cons is not None else None
+        return bool(cp is not None and cp.get('split') and cp.get('keep') is not None)
 
     def _detect_token(self):
         """What a producer that ran this layer's pooled detection inside its own launch must have seen: the identity of
@@ -806,7 +824,19 @@ class CBConv2d(nn.Module):
         myTok = None if rebuilt else self._detect_token_with(sp, prev)
         done = (lazy is not None and myTok is not None and
                 getattr(lazy.indexes, 'nextDetect', None) == myTok)
-        check(cfn(*cargs) if done else fn(*args))
+        # (round 6: the row-pair layer in front left its state refresh to this launch's idle workgroups)
+        side = sp.get('side')
+        if side is None:
+            side = sp['side'] = _lib.SideRefresh()
+        sargs = (cargs[:-1] + [ctypes.pointer(side), cargs[-1]]) if nxt is not None else None
+        pend = self.__dict__.get('_sidePending')
+        if pend is not None and done and sargs is not None:
+            self.__dict__.pop('_sidePending')
+            side.frame, side.state, side.C, side.H, side.W, side.threshold = (ptr(pend[0]), ptr(pend[1]), pend[2], pend[3],
+                                                                              pend[4], pend[5])
+            check(C.cbinfer_split_conv_next_refresh(*sargs))
+        else:
+            check(cfn(*cargs) if done else fn(*args))
         self._poll_range(sp)
         self.__dict__['_ranSplit'] = True
         self._inputIsLiveState = False
@@ -826,7 +856,8 @@ class CBConv2d(nn.Module):
                 convFn=cfn, convArgs=cargs, tailBlocked=bool(self.__dict__.get('_noTailFold')),
                 detectToken=(id(self), prev.data_ptr(), sp['S'].data_ptr(), sp['bits'].data_ptr(),
                              float(self.threshold), sp['arith']),
-                nextEligible=nextEligible, nextToken=ntok, nextRaw=rawTok, keep=nxt, hw=(H, W))
+                nextEligible=nextEligible, nextToken=ntok, nextRaw=rawTok, keep=nxt, hw=(H, W), side=side,
+                sideArgs=sargs)
         if self.propChangeIndexes:
             return 'changeIndexes', self.prevOutput, self._lastIndexes
         return self.prevOutput
@@ -868,7 +899,16 @@ class CBConv2d(nn.Module):
             return None      # ('auto' has not seen a typical frame yet: the plan is made again, with another look)
         plan['seq'].input = src.data_ptr()
         if plan['pooled'] and getattr(inp.indexes, 'nextDetect', None) == plan['detectToken']:
-            status = plan['convFn'](*plan['convArgs'])      # (the producing layer's launch was this frame's detection)
+            pend = self.__dict__.get('_sidePending')
+            if pend is not None and plan['sideArgs'] is not None:
+                # (the row-pair layer in front left its state refresh to this launch's idle workgroups)
+                self.__dict__.pop('_sidePending')
+                side = plan['side']
+                side.frame, side.state, side.C, side.H, side.W, side.threshold = (ptr(pend[0]), ptr(pend[1]), pend[2],
+                                                                                  pend[3], pend[4], pend[5])
+                status = C.cbinfer_split_conv_next_refresh(*plan['sideArgs'])
+            else:
+                status = plan['convFn'](*plan['convArgs'])      # (the producing layer's launch was this frame's detection)
         else:
             status = plan['fn'](*plan['args'])
         if status != 0:
@@ -1281,18 +1321,34 @@ class CBConv2d(nn.Module):
             rows = self._rows_workspace(work, H, W, input.device)
             _, wprep = self._masked_call(path)
             nxt, tok = self._next_detect(H, W)
-            fn = C.cbinfer_cbconv2d_forward_rowpairs
-            args = (ptr(input), ptr(prev), ptr(self.prevOutput), ptr(rows['bits']), ptr(rows['arrive']),
-                    ptr(rows['copy']), ptr(wprep), ptr(self.bias.detach()), Cin, H, W, K, kH, kW,
-                    float(self.threshold), int(bool(self.withReLU)),
-                    ctypes.pointer(nxt) if nxt is not None else None, stream_ptr(input))
-            check(fn(*args))
+            det = self._pair_detect_ok(nxt, kH)
+            if det:
+                # round 6: this layer's own detection inside the row-pair launch; the state is refreshed by the consumer's
+                # contraction (or, failing that, by a launch of its own behind the consumer's: CBConv2d.forward)
+                cons = self.__dict__['_fusedNext'][1]
+                old = cons.__dict__.pop('_sidePending', None)
+                if old is not None:      # (the consumer was not called last frame)
+                    _flush_side(old)
+                fn = C.cbinfer_conv_rowpairs_detect
+                args = (ptr(input), ptr(prev), ptr(self.prevOutput), ptr(rows['copy']), ptr(wprep),
+                        ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold), int(bool(self.withReLU)),
+                        ctypes.pointer(nxt), stream_ptr(input))
+                check(fn(*args))
+                cons.__dict__['_sidePending'] = (input, prev, Cin, H, W, float(self.threshold))
+            else:
+                fn = C.cbinfer_cbconv2d_forward_rowpairs
+                args = (ptr(input), ptr(prev), ptr(self.prevOutput), ptr(rows['bits']), ptr(rows['arrive']),
+                        ptr(rows['copy']), ptr(wprep), ptr(self.bias.detach()), Cin, H, W, K, kH, kW,
+                        float(self.threshold), int(bool(self.withReLU)),
+                        ctypes.pointer(nxt) if nxt is not None else None, stream_ptr(input))
+                check(fn(*args))
             result = MaskChangeIndexes(rows['copy'], (H, W), work['idx'], work['count'])
             result.nextDetect = tok
             if not self._inputIsLiveState:
                 self._make_plan(False, input, fn, args, 0, rows=True)
                 if self._plan is not None:
                     self._plan['pairs'], self._plan['nextToken'], self._plan['keep'] = True, tok, nxt
+                    self._plan['det'] = det
             cap = 0      # (done)
         elif path:
             rows = self._rows_workspace(work, H, W, input.device)
@@ -1452,6 +1508,15 @@ class CBConv2d(nn.Module):
             # the plan was made for (and starts to fold as soon as it can)
             if self._next_detect(plan['shape'][-2], plan['shape'][-1])[1] != plan['nextToken']:
                 return None
+            if plan.get('det') != self._pair_detect_ok(plan['keep'], self.weight.size(2)):
+                return None
+            if plan.get('det'):
+                cons = self.__dict__['_fusedNext'][1]
+                old = cons.__dict__.pop('_sidePending', None)
+                if old is not None:
+                    _flush_side(old)
+                cons.__dict__['_sidePending'] = (src, bufs['prevInput'], src.size(1), src.size(-2), src.size(-1),
+                                                 float(self.threshold))
         args = plan['args']
         if plan.get('fgSplit'):
             if plan['arith'] != os.environ.get('CBINFER_ARITH', 'x3'):
@@ -1566,6 +1631,16 @@ class CBConv2d(nn.Module):
         d['_upSeen'], d['_upNow'] = seen, now
 
     def forward(self, inp):
+        out = self._forward(inp)
+        # round 6: the row-pair layer in front detected its changes inside its own launch and left its state alone
+        # (cbinfer_conv_rowpairs_detect); this layer's contraction carries that refresh on its idle workgroups when it runs in
+        # window order (cbinfer_split_conv_next_refresh) -- and whenever it did not, the refresh is a launch of its own, here
+        pend = self.__dict__.pop('_sidePending', None)
+        if pend is not None:
+            _flush_side(pend)
+        return out
+
+    def _forward(self, inp):
         self._note_upstream(inp)
         if self.__dict__.get('_plan') is not None:
             out = self._run_plan(inp)

@@ -49,6 +49,7 @@ struct PairNext {                   // geometry of the next layer's detection (f
     int planes;                     // its records: 2 = f16 pairs, 3 = bf16 triples (cb_split_common.h)
 };
 struct PairSeq {                    // the tensors of ONE sequence (several sequences per launch: cbPairSeq)
+    const float* frame;             // DET: this frame's input [C,H,W] (the layer's change detection rides in the launch)
     const float* state;             // prevInput [C,H,W]: what the gather reads (conv2d.py:242)
     float* out;                     // prevOutput [K,H,W]
     unsigned long long* bits;       // change mask of this frame (every workgroup zeroes the words of its units)
@@ -62,6 +63,7 @@ struct PairParams {
     const float* wq;                // cbinfer_rowconv_prep_weights layout
     const float* bias;
     int C, H, W, K, relu, wpr, MW, units, nSeq;
+    float th;                       // DET: the layer's own threshold
     PairNext next;
     PairSeq seq[CBINFER_SPLIT_MAX_SEQUENCES];
 };
@@ -101,7 +103,14 @@ __device__ unsigned long long cbp_stamp_buf[4096 * 8];
 #define CBP_STAMP_AT(i)
 #endif
 
-template <int KH, int KW>
+// DET (round 6; one sequence, one unit per workgroup): the layer's OWN change detection in this launch as well.  The unit's
+// patch is what the detection of its two rows needs anyway -- rows ya - PH .. ya + 1 + PH, columns 64 tx - PW .. 64 tx + 63 + PW
+// --, so every workgroup loads it from the frame and from the state, compares (strict >, any channel: cbconv2d_cg_backend.cu:
+// 40-73), dilates the changed pixels of the patch into its own two mask words and, if they are not empty, multiplies the
+// REFRESHED values (frame where the pixel changed, state elsewhere: .cu:74-80).  It does not write the state: a neighbour
+// that starts later must still see the old one -- the refresh is left to a launch behind this one (cbs_conv_kernel's idle
+// workgroups: cbinfer_refresh_state's loop).  No global mask, no mask round trip in front of the patch's, no detection launch.
+template <int KH, int KW, bool DET = false>
 __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
     cb_touch_kernarg<sizeof(PairParams)>();
 #ifdef CBP_STAMP
@@ -115,6 +124,7 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
     __shared__ __attribute__((aligned(16))) float s_out[2 * 16 * 64];          // [row][channel][x]: the pair's outputs after this frame
     __shared__ float s_P[16 * 33];                // pooled values [channel][xo]
     __shared__ unsigned s_chg[CBP_NW];
+    __shared__ unsigned long long s_rb[DET ? 2 * (KH + 1) : 1];      // DET: changed pixels of the patch, [row][64 + KW - 1 bits]
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wpr = p.wpr, H = p.H, W = p.W, HW = H * W;
@@ -135,8 +145,47 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
     // ---- this workgroup's candidate units: blockIdx.x, + gridDim.x, ... (neighbouring units go to different
     //      workgroups); their mask words are requested in one burst and are the same for every lane ---------------
     unsigned long long cwA[CBP_MAXCAND], cwB[CBP_MAXCAND];
+    constexpr int PROWS = 4 * PR;                       // patch rows: plane x row
+    constexpr int PX4 = (PROWS * 16 + CBP_NT - 1) / CBP_NT, PED = (PROWS * (KW - 1) + CBP_NT - 1) / CBP_NT;
+    floatx4 xv4[DET ? PX4 : 1], sv4[DET ? PX4 : 1];
+    float xe[DET ? PED : 1], se[DET ? PED : 1];
+    if constexpr (DET) {
+        const int ul = blockIdx.x;
+        const int yo = ul / wpr, tx = ul - yo * wpr, ya = 2 * yo;
+        const __amdgpu_buffer_rsrc_t frsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)tab[0].frame, 0, (int)min((long)p.C * HW * 4, (long)0x7fffffff), 0x00020000);
+        const __amdgpu_buffer_rsrc_t srsrc0 =
+            __builtin_amdgcn_make_buffer_rsrc((void*)tab[0].state, 0, (int)min((long)p.C * HW * 4, (long)0x7fffffff), 0x00020000);
+        if (t < 2 * PR) s_rb[t] = 0ull;
+#pragma unroll
+        for (int i = 0; i < PX4; ++i) {
+            const int e = t + CBP_NT * i;
+            const int r = e >> 4, j4 = (e & 15) * 4;
+            const int c = r / PR, pr = r - c * PR;
+            const int yy = ya + pr - PH, xx = tx * 64 + j4;
+            const bool ok = (r < PROWS) & (c < p.C) & (yy >= 0) & (yy < H) & (xx < W);
+            const int off = ok ? ((c * H + yy) * W + xx) * 4 : (1 << 30);      // (out of range: the buffer load returns 0)
+            xv4[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(frsrc, off, 0, 0));
+            sv4[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(srsrc0, off, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < PED; ++i) {
+            const int e = t + CBP_NT * i;
+            const int r = e / (KW - 1), j = e - r * (KW - 1);
+            const int c = r / PR, pr = r - c * PR;
+            const int yy = ya + pr - PH, xx = j < PW ? tx * 64 - PW + j : tx * 64 + 64 + (j - PW);
+            const bool ok = (r < PROWS) & (c < p.C) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+            const int off = ok ? ((c * H + yy) * W + xx) * 4 : (1 << 30);
+            xe[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(frsrc, off, 0, 0));
+            se[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srsrc0, off, 0, 0));
+        }
+    }
 #pragma unroll
     for (int k = 0; k < CBP_MAXCAND; ++k) {
+        if constexpr (DET) {
+            cwA[k] = 0ull, cwB[k] = 0ull;
+            continue;
+        }
         const int u = blockIdx.x + k * gridDim.x;
         const int uc = min(u, units - 1);
         const int q = uc / unitsSeq, ul = uc - q * unitsSeq;
@@ -153,6 +202,62 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
                                                 wrsrc, min(t + CBP_NT * i, G * 64 - 1) * 16, 0, 0));
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[r] = p.bias ? p.bias[min(4 * (lane >> 4) + r, p.K - 1)] : 0.f;
+    if constexpr (DET) {
+        // (the weights to LDS right away -- held in registers through the detection they cost the kernel its occupancy)
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            if (t + CBP_NT * i < G * 64) *(floatx4*)(s_w + (t + CBP_NT * i) * 4) = wv[i];
+        // phase 1: the changed pixels of the patch (any channel) as bits of s_rb[patch row]: bit = patch column
+        const int ul = blockIdx.x;
+        const int yo = ul / wpr, tx = ul - yo * wpr, ya = 2 * yo;
+        __syncthreads();      // (s_rb is zero)
+#pragma unroll
+        for (int i = 0; i < PX4; ++i) {
+            const int e = t + CBP_NT * i;
+            const int r = e >> 4, j4 = (e & 15) * 4;
+            const int c = r / PR, pr = r - c * PR;
+            const int yy = ya + pr - PH, xx = tx * 64 + j4;
+            const bool ok = (r < PROWS) & (c < p.C) & (yy >= 0) & (yy < H);
+            unsigned b4 = 0u;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)      // (a piece cut by the map's right edge holds the next row's first pixels)
+                b4 |= (unsigned)(ok && xx + jj < W && cb_changed(sv4[i][jj], xv4[i][jj], p.th)) << jj;
+            if (b4) {
+                const int col = PW + j4;      // (<= 63 + PW: the four bits may straddle the first word's end)
+                atomicOr(&s_rb[2 * pr], (unsigned long long)b4 << col);
+                if (col + 3 >= 64) atomicOr(&s_rb[2 * pr + 1], (unsigned long long)b4 >> (64 - col));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PED; ++i) {
+            const int e = t + CBP_NT * i;
+            const int r = e / (KW - 1), j = e - r * (KW - 1);
+            const int c = r / PR, pr = r - c * PR;
+            const int yy = ya + pr - PH, xx = j < PW ? tx * 64 - PW + j : tx * 64 + 64 + (j - PW);
+            const bool ok = (r < PROWS) & (c < p.C) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+            const int col = j < PW ? j : 64 + j;
+            if (ok && cb_changed(se[i], xe[i], p.th)) {
+                if (col < 64) atomicOr(&s_rb[2 * pr], 1ull << col);
+                else atomicOr(&s_rb[2 * pr + 1], 1ull << (col - 64));
+            }
+        }
+        __syncthreads();
+        // the unit's two mask words: output pixel (row r, column x) <- patch rows r .. r + KH - 1, columns x .. x + KW - 1
+        unsigned long long w2[2] = {0ull, 0ull};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            unsigned long long lo = 0ull, hi = 0ull;
+#pragma unroll
+            for (int dr = 0; dr < KH; ++dr) lo |= s_rb[2 * (r + dr)], hi |= s_rb[2 * (r + dr) + 1];
+            unsigned long long D = 0ull;
+#pragma unroll
+            for (int dx = 0; dx < KW; ++dx) D |= dx ? ((lo >> dx) | (hi << (64 - dx))) : lo;
+            const int rem = W - tx * 64;
+            if (rem < 64) D &= (1ull << rem) - 1ull;
+            w2[r] = (ya + r < H) ? D : 0ull;
+        }
+        cwA[0] = w2[0], cwB[0] = w2[1];
+    }
     auto uniform64 = [](unsigned long long v) -> unsigned long long {
         return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
                (unsigned)__builtin_amdgcn_readfirstlane((int)v);
@@ -186,8 +291,8 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
                         mc[ya * wpr + tx] = cwA[k];
                         if (ya + 1 < H) mc[(ya + 1) * wpr + tx] = cwB[k];
                     }
-                    if (cwA[k]) bq[ya * wpr + tx] = 0ull;
-                    if (cwB[k]) bq[(ya + 1) * wpr + tx] = 0ull;
+                    if (!DET && cwA[k]) bq[ya * wpr + tx] = 0ull;
+                    if (!DET && cwB[k]) bq[(ya + 1) * wpr + tx] = 0ull;
                 }
             }
         }
@@ -199,10 +304,12 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
         CBP_STAMP_AT(7);
         return;
     }
+    if constexpr (!DET) {
 #pragma unroll
-    for (int i = 0; i < WPT; ++i)
-        if (t + CBP_NT * i < G * 64) *(floatx4*)(s_w + (t + CBP_NT * i) * 4) = wv[i];
-    // (visible to every wave behind the first barrier of the unit loop)
+        for (int i = 0; i < WPT; ++i)
+            if (t + CBP_NT * i < G * 64) *(floatx4*)(s_w + (t + CBP_NT * i) * 4) = wv[i];
+        // (visible to every wave behind the first barrier of the unit loop)
+    }
 
 #pragma unroll 1
     for (int k = 0; k < CBP_MAXCAND; ++k) {
@@ -227,12 +334,24 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
         //      lane wherever rows allow it (the 64 columns of the word; the kW - 1 columns beside them by dword): seven
         //      load instructions per thread instead of nineteen -- a CU takes in about 11 bytes per cycle however they
         //      are requested, but every instruction is a slot in its memory pipe.
-        constexpr int PROWS = 4 * PR;                       // patch rows: plane x row
-        constexpr int PX4 = (PROWS * 16 + CBP_NT - 1) / CBP_NT, PED = (PROWS * (KW - 1) + CBP_NT - 1) / CBP_NT;
         floatx4 pv4[PX4];
         float pe[PED];
 #pragma unroll
         for (int i = 0; i < PX4; ++i) {
+            if constexpr (DET) {      // (the refreshed value: the frame's where the pixel changed, the state's elsewhere)
+                const int e = t + CBP_NT * i;
+                const int r = e >> 4, j4 = (e & 15) * 4;
+                const int pr = r - (r / PR) * PR, col = PW + j4;
+                const unsigned long long rb0 = s_rb[2 * (pr % PR)], rb1 = s_rb[2 * (pr % PR) + 1];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int cc = col + jj;
+                    const bool ch = cc < 64 ? ((rb0 >> cc) & 1ull) != 0ull : ((rb1 >> (cc - 64)) & 1ull) != 0ull;
+                    // (columns beyond the map's right edge are the next row's first pixels, not padding)
+                    pv4[i][jj] = tx * 64 + j4 + jj >= W ? 0.f : (ch ? xv4[i][jj] : sv4[i][jj]);
+                }
+                continue;
+            }
             const int e = t + CBP_NT * i;
             const int r = e >> 4, j4 = (e & 15) * 4;
             const int c = r / PR, pr = r - c * PR;
@@ -252,6 +371,13 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
             const int e = t + CBP_NT * i;
             const int r = e / (KW - 1), j = e - r * (KW - 1);      // j < PW: left of the word, else right of it
             const int c = r / PR, pr = r - c * PR;
+            if constexpr (DET) {
+                const int col = j < PW ? j : 64 + j;
+                const bool ch = col < 64 ? ((s_rb[2 * (pr % PR)] >> col) & 1ull) != 0ull
+                                         : ((s_rb[2 * (pr % PR) + 1] >> (col - 64)) & 1ull) != 0ull;
+                pe[i] = ch ? xe[i] : se[i];
+                continue;
+            }
             const int yy = ya + pr - PH, xx = j < PW ? tx * 64 - PW + j : tx * 64 + 64 + (j - PW);
             const bool ok = (r < PROWS) & (c < p.C) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
             pe[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
@@ -272,6 +398,18 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
                 const bool ok = (yy < H) & (xx < W) & (m < p.K);
                 // (columns beyond the map's edge come back as the next row's pixels: no window of a valid pooled pixel
                 //  reads them -- cx1 below)
+                if constexpr (DET) {
+                    // straight into the LDS tile by LDS-DMA (lane t's 16 bytes land at s_out + 16 e): no registers held
+                    // through the multiplication, nothing waited for here -- they land while the unit is multiplied, and
+                    // the wait stands in front of the first store into the tile.  (Inline asm: a DMA the compiler knows of
+                    // it would wait for in front of the next LDS access.)
+                    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+                    const unsigned base = (unsigned)(size_t)(lds_ptr_t)(s_out + (wave * 64 + CBP_NT * i) * 4);
+                    const int voff = ok ? (m * HW + yy * W + xx) * 4 : (1 << 30);
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                                 ::"s"(base), "v"(voff), "s"(orsrc) : "memory", "m0");
+                    continue;
+                }
                 ov4[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
                                                          orsrc, ok ? (m * HW + yy * W + xx) * 4 : (1 << 30), 0, 0));
             }
@@ -299,7 +437,7 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
             const int c = r / PR, pr = r - c * PR;
             if (r < PROWS) s_patch[c * CS + pr * RS + (j < PW ? j : 64 + j)] = pe[i];
         }
-        if (fold) {
+        if (fold && !DET) {
 #pragma unroll
             for (int i = 0; i < OX4; ++i) *(floatx4*)(s_out + (t + CBP_NT * i) * 4) = ov4[i];
         }
@@ -311,9 +449,11 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
         const int row = wave >> 1, tile0 = 2 * (wave & 1);
         const unsigned long long word = row ? wordB : wordA;
         const int pc = __popcll(word);
+        const int n0 = tile0 * 16 + (lane & 15), n1 = n0 + 16;
+        int xl0 = 0, xl1 = 0;
+        floatx4 accA = {0.f, 0.f, 0.f, 0.f}, accB = accA;
         if (tile0 * 16 < pc) {
-            const int n0 = tile0 * 16 + (lane & 15), n1 = n0 + 16;
-            const int xl0 = cbp_nth_bit(word, n0 < pc ? n0 : 0), xl1 = cbp_nth_bit(word, n1 < pc ? n1 : 0);
+            xl0 = cbp_nth_bit(word, n0 < pc ? n0 : 0), xl1 = cbp_nth_bit(word, n1 < pc ? n1 : 0);
             const float* pl0 = s_patch + (lane >> 4) * CS + row * RS + xl0;
             const float* pl1 = s_patch + (lane >> 4) * CS + row * RS + xl1;
             // (the second tile is multiplied whether it exists or not -- its lanes then read the first changed pixel's
@@ -321,23 +461,37 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
             //  wait -> one matrix instruction -> branch, 98 times over: 5 of this kernel's first 18 us)
             floatx4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
             const floatx4* wl = (const floatx4*)s_w + lane;
-            floatx4 ag[G];
+            // (DET: the weight fragments of ONE filter row at a time, read with the B operands of that row -- all G of
+            //  them in registers, 52 for 7x7, do not fit beside the detection's patches)
+            constexpr int AR = (KW + 6) / 4 + 1;      // fragments a filter row can touch
+            floatx4 ag[DET ? 1 : G], arow[DET ? AR : 1], nrow[DET ? AR : 1];
+            if constexpr (!DET) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) ag[g] = wl[g * 64];
+                for (int g = 0; g < G; ++g) ag[g] = wl[g * 64];
+            } else {
+#pragma unroll
+                for (int j = 0; j < AR; ++j) arow[j] = wl[min(j, G - 1) * 64];
+            }
             // one filter row at a time: the B operands of row ky + 1 are read while row ky is multiplied
             float b0[KW], b1[KW], nb0[KW], nb1[KW];
 #pragma unroll
             for (int kx = 0; kx < KW; ++kx) b0[kx] = pl0[kx], b1[kx] = pl1[kx];
 #pragma unroll
             for (int ky = 0; ky < KH; ++ky) {
+                const int g0 = (ky * KW) >> 2;      // (compile-time: the loop is unrolled)
                 if (ky + 1 < KH) {
 #pragma unroll
                     for (int kx = 0; kx < KW; ++kx) nb0[kx] = pl0[(ky + 1) * RS + kx], nb1[kx] = pl1[(ky + 1) * RS + kx];
+                    if constexpr (DET) {
+                        const int gn = ((ky + 1) * KW) >> 2;
+#pragma unroll
+                        for (int j = 0; j < AR; ++j) nrow[j] = wl[min(gn + j, G - 1) * 64];
+                    }
                 }
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx) {
                     const int s = ky * KW + kx;
-                    const float av = ag[s >> 2][s & 3];
+                    const float av = DET ? arow[DET ? (s >> 2) - g0 : 0][s & 3] : ag[DET ? 0 : (s >> 2)][s & 3];
                     if (s & 1) {
                         acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0[kx], acc01, 0, 0, 0);
                         acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[kx], acc11, 0, 0, 0);
@@ -348,8 +502,22 @@ __global__ __launch_bounds__(CBP_NT, 4) void cbp_rowpair_kernel(PairParams p) {
                 }
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx) b0[kx] = nb0[kx], b1[kx] = nb1[kx];
+                if constexpr (DET) {
+#pragma unroll
+                    for (int j = 0; j < AR; ++j) arow[j] = nrow[j];
+                }
             }
-            const floatx4 accA = acc00 + acc01, accB = acc10 + acc11;
+            accA = acc00 + acc01, accB = acc10 + acc11;
+        }
+        if constexpr (DET) {
+            // (EVERY wave's DMA of the old outputs has landed in the LDS tile before anybody stores a new value over one of
+            //  them: each wave waits for its own, the barrier makes it everybody's)
+            if (fold) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+        if (tile0 * 16 < pc) {
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int n = h2 ? n1 : n0, xl = h2 ? xl1 : xl0;
@@ -494,7 +662,8 @@ int cbinfer_rowpairs_supported(int C, int K, int kH, int kW, int H, int W) {
 }
 
 static int cbp_launch(const cbPairSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H, int W,
-                      int K, int kH, int kW, int relu, const cbNextDetect* next, cbStream_t stream) {
+                      int K, int kH, int kW, int relu, const cbNextDetect* next, cbStream_t stream,
+                      const float* frame = nullptr, float threshold = 0.f) {
     CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBINFER_SPLIT_MAX_SEQUENCES && prepared);
     if (!cbinfer_rowpairs_supported(C, K, kH, kW, H, W)) return CB_ERR_UNSUPPORTED;
     PairParams p;
@@ -517,8 +686,10 @@ static int cbp_launch(const cbPairSeq* seqs, int nSeq, const void* prepared, con
         p.next.Wp = g.Wp, p.next.rec = g.rec, p.next.padY = g.padY, p.next.padXL = g.padXL;
         p.next.th = next->threshold;
     }
+    p.th = threshold;
     for (int q = 0; q < nSeq; ++q) {
-        CB_REQUIRE(seqs[q].state && seqs[q].output && seqs[q].bits);
+        CB_REQUIRE(seqs[q].state && seqs[q].output && (seqs[q].bits || frame));
+        p.seq[q].frame = frame;
         p.seq[q].state = seqs[q].state, p.seq[q].out = seqs[q].output;
         p.seq[q].bits = (unsigned long long*)seqs[q].bits, p.seq[q].maskCopy = (unsigned long long*)seqs[q].maskCopy;
         p.seq[q].nstate = nullptr, p.seq[q].nS = nullptr, p.seq[q].nmasks = nullptr, p.seq[q].nflag = nullptr;
@@ -530,6 +701,11 @@ static int cbp_launch(const cbPairSeq* seqs, int nSeq, const void* prepared, con
         }
     }
     const long total = (long)p.units * nSeq;
+    if (frame) {      // DET: one unit per workgroup, the layer's own detection inside (one sequence, 7x7)
+        if (nSeq != 1 || kH != 7) return CB_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((cbp_rowpair_kernel<7, 7, true>), dim3((unsigned)total), dim3(CBP_NT), 0, (hipStream_t)stream, p);
+        return cb_launch_status();
+    }
     // four workgroups of four waves per CU are resident (<= 128 registers, 32 KB of LDS each); a workgroup's units are
     // worked through one after the other (8 us each, mostly round trips to memory), so up to eight workgroups per CU
     // are started -- one candidate unit each at 480x320: the empty ones are gone after 1.8 us -- and at most
@@ -576,6 +752,47 @@ int cbinfer_conv_changed_rowpairs_batched(const cbPairSeq* seqs, int nSeq, const
                                           int C, int H, int W, int K, int kH, int kW, int relu,
                                           const cbNextDetect* next, cbStream_t stream) {
     return cbp_launch(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, relu, next, stream);
+}
+
+// The feedback refresh of a layer's state (cbconv2d_cg_backend.cu:74-80) as a launch of its own: every pixel of which some
+// channel differs from the state by more than the threshold takes the frame's values in all channels.  What
+// cbinfer_conv_rowpairs_detect leaves undone -- its workgroups must all see the OLD state --; the split-state contraction
+// behind it can carry this loop on its idle workgroups instead (cbSideRefresh).
+__global__ __launch_bounds__(256) void cbp_refresh_kernel(const float* __restrict__ frame, float* state, int C, long HW,
+                                                          float th) {
+    for (long i = blockIdx.x * 256l + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+        bool chg = false;
+        for (int c = 0; c < C; ++c) chg |= cb_changed(state[c * HW + i], frame[c * HW + i], th);
+        if (chg)
+            for (int c = 0; c < C; ++c) state[c * HW + i] = frame[c * HW + i];
+    }
+}
+int cbinfer_refresh_state(const float* frame, float* state, int C, int H, int W, float threshold, cbStream_t stream) {
+    CB_REQUIRE(frame && state && C >= 1 && H >= 1 && W >= 1);
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(cbp_refresh_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream, frame, state, C,
+                       HW, threshold);
+    return cb_launch_status();
+}
+
+// cbinfer_cbconv2d_forward_rowpairs WITHOUT its detection launch (round 6): the row-pair kernel detects the layer's changes
+// itself, from `input` and the UNTOUCHED prevInput, and multiplies the refreshed values; prevInput is refreshed by the
+// caller afterwards -- cbinfer_refresh_state, or the refresh loop of the next layer's contraction.  maskCopy takes the
+// frame's dilated change mask (there is no other mask).  One sequence, 7x7.
+int cbinfer_conv_rowpairs_detect(const float* input, const float* prevInput, float* prevOutput, uint64_t* maskCopy,
+                                 const void* prepared, const float* bias, int C, int H, int W, int K, int kH, int kW,
+                                 float threshold, int relu, const cbNextDetect* next, cbStream_t stream) {
+    CB_REQUIRE(input && prevInput && prevOutput && maskCopy);
+    cbPairSeq sq;
+    sq.state = prevInput, sq.output = prevOutput, sq.bits = nullptr, sq.maskCopy = maskCopy;
+    sq.nextState = nullptr, sq.nextSplitState = nullptr, sq.nextFrameMasks = nullptr, sq.nextRangeFlag = nullptr;
+    if (next && next->state) {
+        CB_REQUIRE(next->splitState && next->frameMasks);
+        sq.nextState = next->state, sq.nextSplitState = next->splitState;
+        sq.nextFrameMasks = next->frameMasks, sq.nextRangeFlag = next->rangeFlag;
+    }
+    return cbp_launch(&sq, 1, prepared, bias, C, H, W, K, kH, kW, relu, sq.nextState ? next : nullptr, stream, input,
+                      threshold);
 }
 
 // One frame of a feedback-mode CBConv2d (conv2d.py:178-259) on the row-pair kernel: detection with feedback refresh,

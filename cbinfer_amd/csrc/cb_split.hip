@@ -437,6 +437,13 @@ struct CbsWinExt {
     int H2, W2, wpr2, kHH, kWH, Wp, rec, padY, padXL, planes;
     float th;
     unsigned long long magicW2;
+    // a side job for workgroups without a work item (round 6): the feedback refresh of ANOTHER layer's state -- the
+    // row-pair layer in front, whose launch detected its changes itself and had to leave its state alone
+    // (cbinfer_conv_rowpairs_detect): state[:, p] = frame[:, p] wherever some channel differs by more than the threshold
+    const float* sideFrame;           // null: no side job
+    float* sideState;
+    int sideC, sideHW;
+    float sideTh;
 };
 template <int AR>
 struct CbsExtOf {
@@ -1868,6 +1875,28 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
 #endif
     }
 
+    if constexpr (WIN) {
+        if (ext.sideFrame) {      // (uniform)
+            // the side job: by the workgroups that had no item, if there are enough of them -- else by everybody, a slice each
+            const int busy = min(items, (int)gridDim.x), nIdle = (int)gridDim.x - busy;
+            const bool idleDo = nIdle >= 32;
+            const int parts = idleDo ? nIdle : (int)gridDim.x, part = idleDo ? (int)blockIdx.x - busy : (int)blockIdx.x;
+            if (part >= 0) {
+                const int per = (ext.sideHW + parts - 1) / parts;
+                const int i1 = min(ext.sideHW, (part + 1) * per);
+                for (int i = part * per + t; i < i1; i += NT) {
+                    bool chg = false;
+                    for (int c = 0; c < ext.sideC; ++c)
+                        chg |= cb_changed(ext.sideState[(long)c * ext.sideHW + i], ext.sideFrame[(long)c * ext.sideHW + i],
+                                          ext.sideTh);
+                    if (chg)
+                        for (int c = 0; c < ext.sideC; ++c)
+                            ext.sideState[(long)c * ext.sideHW + i] = ext.sideFrame[(long)c * ext.sideHW + i];
+                }
+            }
+        }
+    }
+
     // Last workgroup out zeroes the masks (every workgroup copied them into its LDS before its first barrier).  The
     // workgroups count themselves on SHARDED counters -- lines of their own in the unused second mask slot, a top
     // counter behind them: a returning atomic on ONE word is served every 11 ns, so a grid of 256-512 workgroups that
@@ -2503,7 +2532,7 @@ static bool cbs_next_supported(int C, int K, int kH, int kW, int H, int W, const
 static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
                           int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
                           const CbsTailArgs* tail, cbStream_t stream, int accumulate = 0,
-                          const cbNextDetect* next = nullptr) {
+                          const cbNextDetect* next = nullptr, const cbSideRefresh* side = nullptr) {
     if (workspace == nullptr && cbs_supported(C, K, kH, kW) && cbs_geom(C, H, W, kH, kW).nStages >= 48)
         return CB_ERR_BADARG;      // a deep contraction needs its workspace (cbinfer_split_workspace_bytes)
     CB_REQUIRE(seqs && nSeq >= 1 && nSeq <= CBS_MAXSEQ && prepared && H > 0 && W > 0 && weightScale >= 0.f);
@@ -2593,6 +2622,12 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
         e.Wp = g2.Wp, e.rec = g2.rec, e.padY = g2.padY, e.padXL = g2.padXL, e.planes = g2.planes;
         e.th = next->threshold;
         e.magicW2 = (1ull << 32) / (unsigned long long)next->W + 1ull;
+        e.sideFrame = nullptr, e.sideState = nullptr, e.sideC = 0, e.sideHW = 0, e.sideTh = 0.f;
+        if (side && side->frame) {
+            CB_REQUIRE(side->state && side->C >= 1 && side->H >= 1 && side->W >= 1 && (long)side->H * side->W < (1l << 30));
+            e.sideFrame = side->frame, e.sideState = side->state, e.sideC = side->C, e.sideHW = side->H * side->W;
+            e.sideTh = side->threshold;
+        }
         return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 5, 3>(p, 1, nullptr, s, e);
     }
     if (x3) {
@@ -2736,6 +2771,15 @@ int cbinfer_split_conv_next(const cbSplitSeq* seqs, int nSeq, const void* prepar
     CB_REQUIRE(next);
     return cbs_split_conv(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace, 0, nullptr, stream,
                           0, next);
+}
+// cbinfer_split_conv_next + the feedback refresh of ANOTHER layer's state on the launch's idle workgroups (`side`: what
+// cbinfer_refresh_state does in a launch of its own -- for the row-pair layer in front that ran cbinfer_conv_rowpairs_detect)
+int cbinfer_split_conv_next_refresh(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
+                                    int W, int K, int kH, int kW, float weightScale, int relu, void* workspace,
+                                    const cbNextDetect* next, const cbSideRefresh* side, cbStream_t stream) {
+    CB_REQUIRE(next && side);
+    return cbs_split_conv(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace, 0, nullptr, stream,
+                          0, next, side);
 }
 int cbinfer_split_forward_next(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, const void* prepared,
                                const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,

@@ -60,7 +60,7 @@ typedef void* cbStream_t; /* hipStream_t */
  * geometry per launch, the consumers' change detection in the producing launch); cbinfer_hsplit_* take contractions
  * of a single k-stage and up (1x1 layers on >= 64 channels).  10: cbinfer_split_*_next (a split-state layer's contraction
  * in window order carrying the pooled change detection of the layer behind the 2x2 pool). */
-#define CBINFER_ABI_VERSION 10
+#define CBINFER_ABI_VERSION 11
 
 int cbinfer_abi_version(void);
 const char* cbinfer_status_string(int status);
@@ -668,6 +668,16 @@ int cbinfer_rowpairs_supported(int C, int K, int kH, int kW, int H, int W);
 int cbinfer_conv_changed_rowpairs_batched(const cbPairSeq* seqs, int nSeq, const void* prepared, const float* bias,
                                           int C, int H, int W, int K, int kH, int kW, int relu,
                                           const cbNextDetect* next, cbStream_t stream);
+/* round 6 (ABI 11): the row-pair launch WITH the layer's own change detection (replaces changeDetection +
+ * updateInputState, conv2d_cg.py:100-122 / cbconv2d_cg_backend.cu:40-81, as a launch of its own in front of the contraction).
+ * Every workgroup compares the patch of its row pair in `input` and `prevInput`, dilates the changed pixels into its own two
+ * mask words (maskCopy takes them: there is no other mask) and multiplies the refreshed values.  prevInput is NOT written --
+ * every workgroup must see the old state -- : the caller refreshes it behind this launch (cbinfer_refresh_state).  One
+ * sequence, 7x7 filters; `next` as for cbinfer_conv_changed_rowpairs. */
+int cbinfer_conv_rowpairs_detect(const float* input, const float* prevInput, float* prevOutput, uint64_t* maskCopy,
+                                 const void* prepared, const float* bias, int C, int H, int W, int K, int kH, int kW,
+                                 float threshold, int relu, const cbNextDetect* next, cbStream_t stream);
+int cbinfer_refresh_state(const float* frame, float* state, int C, int H, int W, float threshold, cbStream_t stream);
 int cbinfer_conv_changed_rowpairs(const float* state, uint64_t* bits, int32_t* ctl, uint64_t* maskCopy,
                                   const void* prepared, const float* bias, float* output, int C, int H, int W, int K,
                                   int kH, int kW, int relu, const cbNextDetect* next, cbStream_t stream);
@@ -688,6 +698,17 @@ int cbinfer_cbconv2d_forward_rowpairs(const float* input, float* prevInput, floa
  * row-pair kernel.  The caller falls back to the separate detection under the same conditions as there.
  *   cbinfer_split_conv_next    : cbinfer_split_conv + next (this layer's own detection was its producer's business)
  *   cbinfer_split_forward_next : cbinfer_split_forward + next */
+/* (ABI 11) `side`: the feedback refresh of ANOTHER layer's state carried by this launch's workgroups without a work item --
+ * for the row-pair layer in front when it ran cbinfer_conv_rowpairs_detect (which leaves its state alone). */
+typedef struct {
+    const float* frame;       /* that layer's input of this frame [C, H, W] */
+    float* state;             /* its prevInput */
+    int C, H, W;
+    float threshold;
+} cbSideRefresh;
+int cbinfer_split_conv_next_refresh(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
+                                    int W, int K, int kH, int kW, float weightScale, int relu, void* workspace,
+                                    const cbNextDetect* next, const cbSideRefresh* side, cbStream_t stream);
 int cbinfer_split_next_supported(int C, int K, int kH, int kW, int H, int W, const cbNextDetect* next);
 int cbinfer_split_conv_next(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
                             int W, int K, int kH, int kW, float weightScale, int relu, void* workspace,

@@ -246,3 +246,67 @@ def test_rowpair_network_tracks_the_row_segment_kernel_over_many_frames(lib, mon
                 assert float((a.prevInput - r.prevInput).abs().max()) <= 2 * FP32_TOL, t
     assert convs["fold"][0]._plan.get('pairs') and convs["fold"][0]._plan.get('nextToken') is not None
     assert convs["rows"][0]._plan is not None and not convs["rows"][0]._plan.get('pairs')
+
+
+@pytest.mark.parametrize("H,W,th", [(64, 96, 0.05), (45, 67, 0.05), (90, 200, 0.2), (320, 480, 0.05), (33, 130, -1.0)])
+def test_rowpairs_with_their_own_detection(lib, H, W, th):
+    """cbinfer_conv_rowpairs_detect + cbinfer_refresh_state (round 6: the layer's own change detection inside the row-pair
+    launch, the state refreshed behind it) against cbinfer_cbconv2d_forward_rowpairs (detection launch + row pairs): outputs,
+    refreshed state, the frame's dilated mask and -- with the next layer's pooled detection folded in -- that layer's state,
+    split copy and frame mask, bit for bit over a sequence of frames; odd sizes, a map narrower than a mask word's multiple,
+    threshold -1 (every pixel changes)."""
+    C_ = lib.C
+    rng = np.random.default_rng(H * 3 + W)
+    C, K, k, k2 = 3, 16, 7, 7
+    H2, W2 = H // 2, W // 2
+    w = (rng.standard_normal((K, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    wp = torch.empty(C_.cbinfer_rowconv_prepared_bytes(C, K, k, k), dtype=torch.uint8, device="cuda")
+    lib.check(C_.cbinfer_rowconv_prep_weights(dev(w).data_ptr(), wp.data_ptr(), K, C, k, k, None))
+    bd = dev(b)
+    words = C_.cbinfer_mask_words(H, W)
+
+    class Side(object):
+        def __init__(self):
+            self.state = torch.zeros((1, C, H, W), device="cuda")
+            self.out = torch.zeros((1, K, H, W), device="cuda")
+            self.bits = torch.zeros(words, dtype=torch.int64, device="cuda")
+            self.ctl = torch.zeros(words, dtype=torch.int32, device="cuda")
+            self.copy = torch.zeros(words, dtype=torch.int64, device="cuda")
+            self.state2 = torch.zeros((1, K, H2, W2), device="cuda")
+            self.S2 = torch.empty(C_.cbinfer_split3_state_bytes(K, H2, W2, k2, k2), dtype=torch.uint8, device="cuda")
+            lib.check(C_.cbinfer_split3_state_init(self.S2.data_ptr(), K, H2, W2, k2, k2, None))
+            lib.check(C_.cbinfer_split3_state_rebuild(self.state2.data_ptr(), self.S2.data_ptr(), K, H2, W2, k2, k2, None))
+            self.mask2 = torch.zeros(C_.cbinfer_frame_mask_bytes(H2, W2) // 8, dtype=torch.int64, device="cuda")
+            self.nd = lib.NextDetect()
+            nd = self.nd
+            nd.state, nd.splitState, nd.frameMasks = self.state2.data_ptr(), self.S2.data_ptr(), self.mask2.data_ptr()
+            nd.rangeFlag, nd.H, nd.W, nd.kH, nd.kW, nd.threshold, nd.arith = None, H2, W2, k2, k2, 0.07, 1
+
+    a, d = Side(), Side()
+    x = rng.standard_normal((1, C, H, W)).astype(np.float32)
+    changed = 0
+    for t in range(6):
+        x = x.copy()
+        if t > 0:
+            for _ in range(max(1, H * W // 1500)):
+                y0, x0 = rng.integers(0, H - 4), rng.integers(0, W - 4)
+                x[0, :, y0:y0 + rng.integers(2, 9), x0:x0 + rng.integers(2, 30)] = rng.standard_normal((C, 1, 1))
+            x += rng.uniform(-0.02, 0.02, x.shape).astype(np.float32)      # (sub-threshold noise must not leak in)
+        xd = dev(x)
+        lib.check(C_.cbinfer_cbconv2d_forward_rowpairs(xd.data_ptr(), a.state.data_ptr(), a.out.data_ptr(),
+                                                       a.bits.data_ptr(), a.ctl.data_ptr(), a.copy.data_ptr(),
+                                                       wp.data_ptr(), bd.data_ptr(), C, H, W, K, k, k, th, 1,
+                                                       ctypes.pointer(a.nd), None))
+        lib.check(C_.cbinfer_conv_rowpairs_detect(xd.data_ptr(), d.state.data_ptr(), d.out.data_ptr(), d.copy.data_ptr(),
+                                                  wp.data_ptr(), bd.data_ptr(), C, H, W, K, k, k, th, 1,
+                                                  ctypes.pointer(d.nd), None))
+        lib.check(C_.cbinfer_refresh_state(xd.data_ptr(), d.state.data_ptr(), C, H, W, th, None))
+        torch.cuda.synchronize()
+        assert torch.equal(a.copy, d.copy), t
+        assert torch.equal(a.out, d.out), t
+        assert torch.equal(a.state, d.state), t
+        assert torch.equal(a.state2, d.state2) and torch.equal(a.S2, d.S2) and torch.equal(a.mask2, d.mask2), t
+        changed += int(torch.count_nonzero(d.copy).item())
+        a.mask2.zero_(), d.mask2.zero_()
+    assert changed > 0

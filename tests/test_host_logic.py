@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     from cbinfer_amd import _lib
     assert declared == set(_lib.EXPORTED_SYMBOLS)
-    assert lib.cbinfer_abi_version() == 10
+    assert lib.cbinfer_abi_version() == 11
     # split-state geometry helpers (host, pure): 64 ch 7x7 @80x120: (80 + 13) x (120 + 6) records of 256 B;
     # 16 ch 7x7: two x-adjacent taps per stage -> 7 x 4 stages, records of 64 B, one more column on the right
     lib.cbinfer_split_state_bytes.restype = ctypes.c_long

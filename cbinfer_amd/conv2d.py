@@ -355,6 +355,14 @@ class CBConv2d(nn.Module):
         if (link is None or self.__dict__.get('_noNextFold') or os.environ.get('CBINFER_NO_NEXTFOLD', '0') == '1'):
             return None, None
         pool, cons = link
+        # (per-frame fast path: the consumer's token and the flags the full test below looks at are what they were when the
+        #  structure was made -- this function runs once per frame and producer inside the call plans)
+        nd = self.__dict__.get('_nextStruct')
+        if nd is not None and type(cons) is CBConv2d:
+            flags = (getattr(pool, 'lazy', False), pool.propChangeIndexes, cons.feedbackLoop, cons.syncIndexes,
+                     cons.saveChangeMap, cons.gatherComputationStats, cons.finegrained, H, W)
+            if len(nd) > 2 and nd[2] == flags and nd[0] == cons._detect_token():
+                return nd[1], nd[0]
         K = self.weight.size(0)
         if (not getattr(pool, 'lazy', False) or pool.propChangeIndexes or type(cons) is not CBConv2d or
                 cons.in_channels != K or not cons.feedbackLoop or cons.syncIndexes or cons.saveChangeMap or
@@ -376,7 +384,10 @@ class CBConv2d(nn.Module):
             st.rangeFlag, st.H, st.W = sp['flag'].data_ptr(), H2, W2
             st.kH, st.kW, st.threshold = cons.weight.size(2), cons.weight.size(3), float(cons.threshold)
             st.arith = 1 if sp['arith'] == 'x3' else 0
-            nd = self.__dict__['_nextStruct'] = (tok, st)
+            nd = (tok, st)
+        flags = (getattr(pool, 'lazy', False), pool.propChangeIndexes, cons.feedbackLoop, cons.syncIndexes,
+                 cons.saveChangeMap, cons.gatherComputationStats, cons.finegrained, H, W)
+        nd = self.__dict__['_nextStruct'] = (nd[0], nd[1], flags)
         return nd[1], tok
 
     def _rows_workspace(self, work, H, W, dev):
@@ -904,8 +915,11 @@ class CBConv2d(nn.Module):
                 # (the row-pair layer in front left its state refresh to this launch's idle workgroups)
                 self.__dict__.pop('_sidePending')
                 side = plan['side']
-                side.frame, side.state, side.C, side.H, side.W, side.threshold = (ptr(pend[0]), ptr(pend[1]), pend[2],
-                                                                                  pend[3], pend[4], pend[5])
+                key = (pend[1].data_ptr(),) + pend[2:]
+                if plan.get('sideKey') != key:      # (everything but the frame's address stays from frame to frame)
+                    side.state, side.C, side.H, side.W, side.threshold = key
+                    plan['sideKey'] = key
+                side.frame = pend[0].data_ptr()
                 status = C.cbinfer_split_conv_next_refresh(*plan['sideArgs'])
             else:
                 status = plan['convFn'](*plan['convArgs'])      # (the producing layer's launch was this frame's detection)
@@ -1334,7 +1348,7 @@ class CBConv2d(nn.Module):
                         ptr(self.bias.detach()), Cin, H, W, K, kH, kW, float(self.threshold), int(bool(self.withReLU)),
                         ctypes.pointer(nxt), stream_ptr(input))
                 check(fn(*args))
-                cons.__dict__['_sidePending'] = (input, prev, Cin, H, W, float(self.threshold))
+                cons.__dict__['_sidePending'] = (input, prev, Cin, H, W, float(self.threshold))      # (tensors: kept alive)
             else:
                 fn = C.cbinfer_cbconv2d_forward_rowpairs
                 args = (ptr(input), ptr(prev), ptr(self.prevOutput), ptr(rows['bits']), ptr(rows['arrive']),

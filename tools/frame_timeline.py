@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Steady-state frames from a rocprofv3 --kernel-trace CSV of the bench: the dispatches are cut into frames (a
-frame starts with the detection in front of the first layer's row-segment contraction), frames are grouped by
+frame starts with the detection in front of the first layer's row-segment contraction, or with that contraction
+when it detects itself), frames are grouped by
 their sequence of kernel names -- the timed loop and the in-frame measurement passes issue different sequences --
 and for every common sequence the medians of durations and of the idle gaps between consecutive kernels are
 printed.  Under the profiler an eager run is host-bound (the gaps are the host's), so the durations are the
@@ -26,12 +27,13 @@ def short(n):
         "void cbs::", "cbs::").replace("void cbp::", "cbp::")
 
 
-starts = [i - 1 for i, r in enumerate(rows)
+# (round 6: a row-pair launch that detects the layer's changes itself -- cbp_rowpair_kernel<7, 7, true> -- IS the frame's first)
+starts = [(i if "cbp_rowpair_kernel<7, 7, true>" in r["Kernel_Name"] else i - 1) for i, r in enumerate(rows)
           if ("cb_rowconv_f32_kernel" in r["Kernel_Name"] or "cbp_rowpair_kernel" in r["Kernel_Name"]) and i > 0]
 groups = collections.defaultdict(list)
 for a, b in zip(starts[:-1], starts[1:]):
     fr = rows[a:b]
-    if 5 <= len(fr) <= 12:
+    if 4 <= len(fr) <= 12:
         groups[tuple(short(r["Kernel_Name"]).split("(")[0] for r in fr)].append(fr)
 for sig, frames in sorted(groups.items(), key=lambda kv: -len(kv[1]))[:3]:
     if len(frames) < 20:

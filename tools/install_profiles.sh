@@ -23,7 +23,7 @@ json.dump(d, open('profiles/r06_pmc_traffic.json', 'w'), indent=1)
 print("pmc traffic of commit", d['commit'], "hash", d['kernel_source_sha256'])
 PY
 { echo "# eager stream (the launch form the bench runs): tools/timeline_run.sh, MI355X, commit $(git rev-parse --short HEAD)"
-  echo "# the first group is the timed loop (5 launches per frame since the window-order fold, DESIGN 5.8; under the profiler the host is the bottleneck, so the GAPS are the host's -- the un-profiled frame period equals the sum of the durations); the other groups are the bench's in-frame measurement passes (event records, on-demand compaction)"
+  echo "# the first group is the timed loop (4 launches per frame: DESIGN 5.8, 5.9; under the profiler the host is the bottleneck, so the GAPS are the host's -- the un-profiled frame period equals the sum of the durations); the other groups are the bench's in-frame measurement passes (event records, on-demand compaction)"
   cat gpurun_out/doc/timeline_eager.txt
   echo
   echo "# the same network replayed from a hipGraph (MODE=graph tools/timeline_run.sh): idle time between the kernels of different library calls that the eager stream does not have"

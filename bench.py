@@ -566,6 +566,16 @@ def inframe_layer_times(test, frames, start, reps=40):
                     bracket(which, (mi, 'conv'), empty, sink, lambda: check(lib.cbinfer_split_conv_next(
                         sp['seq'], 1, ptr(wp), ptr(m.bias.detach()), C, Hh, Ww, K, kH, kW, float(scale),
                         int(bool(m.withReLU)), ptr(sp['ws']), ctypes.pointer(wnext), st)))
+                elif (side[0] is not None and folded_detect and sp['arith'] == 'x3' and
+                      lib.cbinfer_split_refresh_supported(C, K, kH, kW, Hh, Ww)):
+                    import ctypes
+                    from cbinfer_amd import _lib as _l
+                    sr = _l.SideRefresh()
+                    sr.frame, sr.state, sr.C, sr.H, sr.W, sr.threshold = side[0]
+                    side[0] = None
+                    bracket(which, (mi, 'conv'), empty, sink, lambda: check(lib.cbinfer_split_conv_refresh(
+                        sp['seq'], 1, ptr(wp), ptr(m.bias.detach()), C, Hh, Ww, K, kH, kW, float(scale),
+                        int(bool(m.withReLU)), ptr(sp['ws']), ctypes.pointer(sr), st)))
                 else:
                     bracket(which, (mi, 'conv'), empty, sink, lambda: check(lib.cbinfer_split_conv(
                         sp['seq'], 1, ptr(wp), ptr(m.bias.detach()), C, Hh, Ww, K, kH, kW, float(scale),

@@ -184,6 +184,8 @@ _SIGNATURES = {
     "cbinfer_split_forward": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _vp]),
     "cbinfer_split_next_supported": (_i, [_i, _i, _i, _i, _i, _i, _ndp]),
     "cbinfer_split_conv_next": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _ndp, _vp]),
+    "cbinfer_split_refresh_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "cbinfer_split_conv_refresh": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _srp, _vp]),
     "cbinfer_split_conv_next_refresh": (_i, [_sp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _ndp, _srp, _vp]),
     "cbinfer_split_forward_next": (_i, [_sp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _ndp,
                                         _vp]),

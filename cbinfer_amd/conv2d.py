@@ -319,15 +319,16 @@ class CBConv2d(nn.Module):
 
     def _pair_detect_ok(self, nxt, kH):
         """Does this row-pair layer run its own change detection inside its launch (cbinfer_conv_rowpairs_detect, round 6)?
-        Only while the consumer behind the pool takes the detection of ITS input from this launch (nxt) and ran its last
-        frame in window order -- its contraction then carries this layer's state refresh (cbinfer_split_conv_next_refresh).
+        Only while the consumer behind the pool takes the detection of ITS input from this launch (nxt) and its last frame
+        ran a contraction that can carry this layer's state refresh on its idle workgroups (cbinfer_split_conv_next_refresh
+        in window order, cbinfer_split_conv_refresh in pixel order).
         CBINFER_NO_PAIRDET=1 switches the form off."""
         if nxt is None or kH != 7 or os.environ.get('CBINFER_NO_PAIRDET', '0') == '1':
             return False
         link = self.__dict__.get('_fusedNext')
         cons = link[1] if link is not None else None
         cp = cons.__dict__.get('_plan') if cons is not None else None
-        return bool(cp is not None and cp.get('split') and cp.get('keep') is not None)
+        return bool(cp is not None and cp.get('split') and cp.get('sideArgs') is not None)
 
     def _detect_token(self):
         """What a producer that ran this layer's pooled detection inside its own launch must have seen: the identity of
@@ -839,13 +840,18 @@ class CBConv2d(nn.Module):
         side = sp.get('side')
         if side is None:
             side = sp['side'] = _lib.SideRefresh()
-        sargs = (cargs[:-1] + [ctypes.pointer(side), cargs[-1]]) if nxt is not None else None
+        sfn, sargs = None, None
+        if nxt is not None:
+            sfn, sargs = C.cbinfer_split_conv_next_refresh, cargs[:-1] + [ctypes.pointer(side), cargs[-1]]
+        elif (tail is None and sp['arith'] == 'x3' and
+              C.cbinfer_split_refresh_supported(Cin, K, kH, kW, H, W)):      # (pixel order: cbinfer_split_conv's arguments)
+            sfn, sargs = C.cbinfer_split_conv_refresh, cargs[:-2] + [ctypes.pointer(side), cargs[-1]]
         pend = self.__dict__.get('_sidePending')
         if pend is not None and done and sargs is not None:
             self.__dict__.pop('_sidePending')
             side.frame, side.state, side.C, side.H, side.W, side.threshold = (ptr(pend[0]), ptr(pend[1]), pend[2], pend[3],
                                                                               pend[4], pend[5])
-            check(C.cbinfer_split_conv_next_refresh(*sargs))
+            check(sfn(*sargs))
         else:
             check(cfn(*cargs) if done else fn(*args))
         self._poll_range(sp)
@@ -868,7 +874,7 @@ class CBConv2d(nn.Module):
                 detectToken=(id(self), prev.data_ptr(), sp['S'].data_ptr(), sp['bits'].data_ptr(),
                              float(self.threshold), sp['arith']),
                 nextEligible=nextEligible, nextToken=ntok, nextRaw=rawTok, keep=nxt, hw=(H, W), side=side,
-                sideArgs=sargs)
+                sideFn=sfn, sideArgs=sargs)
         if self.propChangeIndexes:
             return 'changeIndexes', self.prevOutput, self._lastIndexes
         return self.prevOutput
@@ -920,7 +926,7 @@ class CBConv2d(nn.Module):
                     side.state, side.C, side.H, side.W, side.threshold = key
                     plan['sideKey'] = key
                 side.frame = pend[0].data_ptr()
-                status = C.cbinfer_split_conv_next_refresh(*plan['sideArgs'])
+                status = plan['sideFn'](*plan['sideArgs'])
             else:
                 status = plan['convFn'](*plan['convArgs'])      # (the producing layer's launch was this frame's detection)
         else:

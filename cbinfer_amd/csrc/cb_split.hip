@@ -457,6 +457,18 @@ template <>
 struct CbsExtOf<3> {
     typedef CbsWinExt type;
 };
+// AR = 4: the bf16-triple arithmetic in PIXEL order + the side job alone (the consumer of a self-detecting row-pair layer
+// when it does not run in window order: section 5.9)
+struct CbsSideExt {
+    const float* sideFrame;
+    float* sideState;
+    int sideC, sideHW;
+    float sideTh;
+};
+template <>
+struct CbsExtOf<4> {
+    typedef CbsSideExt type;
+};
 
 // One pixel of a consumer's dilated change mask: rows y - kHH .. y + kHH, columns x - kWH .. x + kWH, clipped to the map
 // (what cbs_detect_kernel's word shifts produce for a single set bit)
@@ -543,7 +555,7 @@ __device__ __forceinline__ int cbs_div(int x, unsigned long long magic) {
 // multiplied while (s + 1, 0) is read.
 template <int BM, int BN, int WM, int WN, int PRE_CAP, bool MASK_LDS, int RING, int AR = 0>
 __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typename CbsExtOf<AR>::type ext) {
-    constexpr bool HALF = AR == 1, X3 = AR == 2 || AR == 3, WIN = AR == 3;
+    constexpr bool HALF = AR == 1, X3 = AR == 2 || AR == 3 || AR == 4, WIN = AR == 3, SIDE = AR == 3 || AR == 4;
     // (before anything else -- the burst over the kilobyte of arguments included: an idle frame is this one load)
     if (HALF && p.upstream && *p.upstream == 0) {      // (the detection in front returned the same way: the mask is empty)
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -552,7 +564,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
         }
         return;
     }
-    cb_touch_kernarg<sizeof(CbsParams) + (HALF ? sizeof(CbhExt) : (WIN ? sizeof(CbsWinExt) : 0))>();
+    cb_touch_kernarg<sizeof(CbsParams) + (HALF ? sizeof(CbhExt) : (WIN ? sizeof(CbsWinExt) : (SIDE ? sizeof(CbsSideExt) : 0)))>();
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TN = BN / WN / 32;
     static_assert(BM == 32 * WM, "one 32-row tile per wave");
@@ -1875,7 +1887,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cbs_conv_kernel(CbsParams p, typ
 #endif
     }
 
-    if constexpr (WIN) {
+    if constexpr (SIDE) {
         if (ext.sideFrame) {      // (uniform)
             // the side job: by the workgroups that had no item, if there are enough of them -- else by everybody, a slice each
             const int busy = min(items, (int)gridDim.x), nIdle = (int)gridDim.x - busy;
@@ -2529,6 +2541,13 @@ static bool cbs_next_supported(int C, int K, int kH, int kW, int H, int W, const
     return (long)g2.Hp * g2.Wp * g2.rec < (1l << 31) && (long)H * W < (1l << 20);
 }
 
+// Layers whose pixel-order contraction can carry a side refresh (AR = 4): the single-sequence 64-row instance with the mask
+// words in LDS, a shallow contraction (no second launch)
+static bool cbs_refresh_supported(int C, int K, int kH, int kW, int H, int W) {
+    return cbs_supported(C, K, kH, kW) && K <= 64 && cbs_geom(C, H, W, kH, kW, 3).nStages < 48 &&
+           cbinfer_mask_words(H, W) <= CBS_PRE_SMALL;
+}
+
 static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
                           int W, int K, int kH, int kW, float weightScale, int relu, void* workspace, int forceSplit,
                           const CbsTailArgs* tail, cbStream_t stream, int accumulate = 0,
@@ -2609,6 +2628,15 @@ static int cbs_split_conv(const cbSplitSeq* seqs, int nSeq, const void* prepared
     // itself (items <= grid <= 2 CUs) always fits, a forced one (forceSplit: tests, tuning) is refused beyond it
     const long cap = cbs_slab_capacity(nSeq, H, W, K);
     p.slabCap = (int)(cap > 0x7fffffffl ? 0x7fffffffl : cap);
+    if (side && side->frame && !next) {
+        // pixel order + another layer's state refresh on the idle workgroups (AR = 4)
+        if (!cbs_refresh_supported(C, K, kH, kW, H, W) || nSeq != 1 || !x3 || accumulate || tail) return CB_ERR_UNSUPPORTED;
+        CB_REQUIRE(side->state && side->C >= 1 && side->H >= 1 && side->W >= 1 && (long)side->H * side->W < (1l << 30));
+        CbsSideExt e;
+        e.sideFrame = side->frame, e.sideState = side->state, e.sideC = side->C, e.sideHW = side->H * side->W;
+        e.sideTh = side->threshold;
+        return cbs_launch_conv<64, 64, 2, 2, CBS_PRE_SMALL, true, 5, 4>(p, 1, nullptr, s, e);
+    }
     if (next) {
         // window order + the pooled detection of the layer behind the 2x2 pool in this launch (AR = 3)
         if (!cbs_next_supported(C, K, kH, kW, H, W, next) || nSeq != 1 || !x3 || accumulate || tail) return CB_ERR_UNSUPPORTED;
@@ -2780,6 +2808,18 @@ int cbinfer_split_conv_next_refresh(const cbSplitSeq* seqs, int nSeq, const void
     CB_REQUIRE(next && side);
     return cbs_split_conv(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace, 0, nullptr, stream,
                           0, next, side);
+}
+// cbinfer_split_conv (pixel order) + the side refresh: for the consumer of a self-detecting row-pair layer that does not run
+// in window order.  cbinfer_split_refresh_supported tells whether the layer's launch can carry it.
+int cbinfer_split_refresh_supported(int C, int K, int kH, int kW, int H, int W) {
+    return cbs_refresh_supported(C, K, kH, kW, H, W) ? 1 : 0;
+}
+int cbinfer_split_conv_refresh(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H, int W,
+                               int K, int kH, int kW, float weightScale, int relu, void* workspace,
+                               const cbSideRefresh* side, cbStream_t stream) {
+    CB_REQUIRE(side && side->frame);
+    return cbs_split_conv(seqs, nSeq, prepared, bias, C, H, W, K, kH, kW, weightScale, relu, workspace, 0, nullptr, stream,
+                          0, nullptr, side);
 }
 int cbinfer_split_forward_next(const cbSplitSeq* seqs, int nSeq, int mode, int pH, int pW, const void* prepared,
                                const float* bias, int C, int H, int W, int K, int kH, int kW, float threshold,

@@ -709,6 +709,12 @@ typedef struct {
 int cbinfer_split_conv_next_refresh(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
                                     int W, int K, int kH, int kW, float weightScale, int relu, void* workspace,
                                     const cbNextDetect* next, const cbSideRefresh* side, cbStream_t stream);
+/* ... and the same side job on a PIXEL-order contraction (the consumer does not run in window order): one sequence, the
+ * bf16-triple arithmetic, K <= 64, fewer than 48 k-stages, at most 1280 mask words. */
+int cbinfer_split_refresh_supported(int C, int K, int kH, int kW, int H, int W);
+int cbinfer_split_conv_refresh(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H, int W,
+                               int K, int kH, int kW, float weightScale, int relu, void* workspace,
+                               const cbSideRefresh* side, cbStream_t stream);
 int cbinfer_split_next_supported(int C, int K, int kH, int kW, int H, int W, const cbNextDetect* next);
 int cbinfer_split_conv_next(const cbSplitSeq* seqs, int nSeq, const void* prepared, const float* bias, int C, int H,
                             int W, int K, int kH, int kW, float weightScale, int relu, void* workspace,

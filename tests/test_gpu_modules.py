@@ -2208,3 +2208,40 @@ def test_chained_fp16_layers_skip_what_their_producer_left_alone(pkg, monkeypatc
         for part in range(4):
             for u, v in zip(a[part], b[part]):
                 assert torch.equal(u, v), (t, part)
+
+
+def test_first_layer_detects_in_its_own_launch(pkg):
+    """Round 6: the 3 -> 16 layer's change detection inside its row-pair launch, its state refresh carried by the
+    16 -> 64 layer's contraction -- in window order and in pixel order -- or, where nothing carries it, issued as a launch of
+    its own: against the network with the detection launch (CBINFER_NO_PAIRDET=1), outputs and every state tensor bit for
+    bit, frame by frame; the library calls of a steady-state frame are the three the form promises."""
+    import bench
+    import pycbinfer
+    from cbinfer_amd import _lib
+    frames = bench.bench_video(93).frames(9)
+    os.environ["CBINFER_NO_PAIRDET"] = "1"
+    try:
+        ref = bench.build_bench_model(window_order=False)[1]
+        want = []
+        with torch.no_grad():
+            for f in frames:
+                want.append((ref(f).clone(), [t.clone() for t in pkg.getStateTensors(ref)]))
+    finally:
+        os.environ.pop("CBINFER_NO_PAIRDET")
+    for wo, calls_want in ((True, ["cbinfer_conv_rowpairs_detect", "cbinfer_split_conv_next_refresh", "cbinfer_split_conv_tail"]),
+                           (False, ["cbinfer_conv_rowpairs_detect", "cbinfer_split_conv_refresh", "cbinfer_cbconv2d_forward" ])):
+        net = bench.build_bench_model(window_order=wo)[1]
+        with torch.no_grad():
+            for t, f in enumerate(frames):
+                rec = []
+                _lib._RECORDING[0] = rec
+                try:
+                    y = net(f)
+                finally:
+                    _lib._RECORDING[0] = None
+                torch.cuda.synchronize()
+                assert torch.equal(y, want[t][0]), (wo, t)
+                for a, b in zip(pkg.getStateTensors(net), want[t][1]):
+                    assert torch.equal(a, b), (wo, t)
+        names = [fn.__name__ for fn, _ in rec]
+        assert names[0] == calls_want[0] and names[1] == calls_want[1], (wo, names)

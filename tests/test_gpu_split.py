@@ -616,3 +616,60 @@ def test_split_next_detection_in_window_order(lib, oracle, H, W, K, k2, frac):
         assert torch.equal(Ca.S[0], Cb.S[0]), t
         assert torch.equal(Ca.out[0], Cb.out[0]) and torch.equal(Ca.copy[0], Cb.copy[0]), t
         assert len(Cb.list()) > 0 or t > 0
+
+
+@pytest.mark.parametrize("order", ["window", "pixel"])
+def test_split_contraction_carries_a_side_refresh(lib, oracle, order):
+    """cbinfer_split_conv_next_refresh / cbinfer_split_conv_refresh (round 6): the feedback refresh of ANOTHER layer's state on
+    the contraction's workgroups without a work item -- against cbinfer_refresh_state in a launch of its own, bit for bit, and
+    the contraction's own results untouched by it; a frame with few tiles (idle workgroups do it) and one with more tiles than
+    workgroups (everybody does a slice)."""
+    if ARITH != "x3":
+        pytest.skip("the side job rides on the bf16-triple instances")
+    import ctypes
+    C_ = lib.C
+    rng = np.random.default_rng(17)
+    Cin, K, K2, H, W, k2 = 16, 64, 32, 160, 240, 3
+    H2, W2 = H // 2, W // 2
+    w1 = (rng.standard_normal((K, Cin, 7, 7)) / np.sqrt(Cin * 49)).astype(np.float32)
+    b1 = rng.standard_normal(K).astype(np.float32)
+    w2 = (rng.standard_normal((K2, K, k2, k2)) / np.sqrt(K * k2 * k2)).astype(np.float32)
+    b2 = rng.standard_normal(K2).astype(np.float32)
+    Pa, Pb = Layer(lib, w1, b1, H, W), Layer(lib, w1, b1, H, W)
+    Cb = Layer(lib, w2, b2, H2, W2, pooled=True)
+    nd = lib.NextDetect()
+    nd.state, nd.splitState, nd.frameMasks = Cb.state[0].data_ptr(), Cb.S[0].data_ptr(), Cb.masks[0].data_ptr()
+    nd.rangeFlag, nd.H, nd.W, nd.kH, nd.kW, nd.threshold, nd.arith = Cb.flag.data_ptr(), H2, W2, k2, k2, 0.05, 1
+    sC, sH, sW = 3, 97, 131
+    sa = torch.zeros((sC, sH, sW), device="cuda")
+    sb = torch.zeros((sC, sH, sW), device="cuda")
+    side = lib.SideRefresh()
+    assert C_.cbinfer_split_refresh_supported(Cin, K, 7, 7, H, W) == 1
+    for t, (x, frac) in enumerate(zip(block_video(rng, Cin, H, W, 6, 0.1), (1.0, 0.1, 0.1, 0.9, 0.1, 0.05))):
+        if t == 3:
+            x = (x + rng.standard_normal(x.shape)).astype(np.float32)      # (every pixel changes: more tiles than workgroups)
+        xd = dev(x)
+        fr = dev((rng.standard_normal((sC, sH, sW)) * (rng.random((1, sH, sW)) < 0.3)).astype(np.float32))
+        for P in (Pa, Pb):
+            P.seqs[0].input, P.seqs[0].producerMask = xd.data_ptr(), None
+            lib.check(C_.cbinfer_split_detect(P.seqs, 1, 8, 0, 0, Cin, H, W, 7, 7, 0.1, None))
+        side.frame, side.state, side.C, side.H, side.W, side.threshold = fr.data_ptr(), sb.data_ptr(), sC, sH, sW, 0.25
+        if order == "window":
+            lib.check(C_.cbinfer_split_conv_next(Pa.seqs, 1, Pa.wp.data_ptr(), Pa.b.data_ptr(), Cin, H, W, K, 7, 7, 0.0, 1,
+                                                 None, ctypes.pointer(nd), None))
+            Cb.masks[0].zero_()
+            lib.check(C_.cbinfer_split_conv_next_refresh(Pb.seqs, 1, Pb.wp.data_ptr(), Pb.b.data_ptr(), Cin, H, W, K, 7, 7,
+                                                         0.0, 1, None, ctypes.pointer(nd), ctypes.pointer(side), None))
+            Cb.masks[0].zero_()
+        else:
+            lib.check(C_.cbinfer_split_conv(Pa.seqs, 1, Pa.wp.data_ptr(), Pa.b.data_ptr(), Cin, H, W, K, 7, 7, 0.0, 1, None,
+                                            0, None))
+            lib.check(C_.cbinfer_split_conv_refresh(Pb.seqs, 1, Pb.wp.data_ptr(), Pb.b.data_ptr(), Cin, H, W, K, 7, 7, 0.0,
+                                                    1, None, ctypes.pointer(side), None))
+        lib.check(C_.cbinfer_refresh_state(fr.data_ptr(), sa.data_ptr(), sC, sH, sW, 0.25, None))
+        torch.cuda.synchronize()
+        assert torch.equal(sa, sb), t
+        assert torch.equal(Pa.out[0], Pb.out[0]) and np.array_equal(Pa.list(), Pb.list()), t
+        # what the refresh means (cbconv2d_cg_backend.cu:74-80): a pixel of which some channel differs by more than the
+        # threshold holds the frame's values, every other pixel is within the threshold of them
+        assert float((sb - fr).abs().max()) <= 0.25

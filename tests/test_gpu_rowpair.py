@@ -248,7 +248,8 @@ def test_rowpair_network_tracks_the_row_segment_kernel_over_many_frames(lib, mon
     assert convs["rows"][0]._plan is not None and not convs["rows"][0]._plan.get('pairs')
 
 
-@pytest.mark.parametrize("H,W,th", [(64, 96, 0.05), (45, 67, 0.05), (90, 200, 0.2), (320, 480, 0.05), (33, 130, -1.0)])
+@pytest.mark.parametrize("H,W,th", [(64, 96, 0.05), (45, 67, 0.05), (90, 200, 0.2), (320, 480, 0.05), (33, 130, -1.0),
+                                    (8, 10, 0.05), (6, 70, 0.05)])
 def test_rowpairs_with_their_own_detection(lib, H, W, th):
     """cbinfer_conv_rowpairs_detect + cbinfer_refresh_state (round 6: the layer's own change detection inside the row-pair
     launch, the state refreshed behind it) against cbinfer_cbconv2d_forward_rowpairs (detection launch + row pairs): outputs,
